@@ -1,0 +1,476 @@
+"""CPU oracle: a plain-PyTorch restatement of UniDisc's denoising hot path.
+
+TEST INFRASTRUCTURE — not product code.  Only ``tests/``, ``__graft_entry__.smoke()`` and the
+``cpu_baseline`` leg of ``bench.py`` may import this module, and only as the checker.  The product
+(``unidisc_amd``) never routes through it and fails loudly when its HIP library is missing.
+
+Parity status: PINNED against golden vectors generated from the imported reference
+(``oracle/make_golden.py`` → ``tests/golden/*.npz``; ``tests/test_oracle_golden.py`` checks fp32
+equality to ≤1e-5 and bit-exact integer/boolean quantities).  The one exception is the Lumina
+2-D RoPE *table generator* (``oracle/cases.py::lumina_rope_2d``), which restates an un-vendored
+third-party function (diffusers 0.32.2) and is "parity unpinned"; the tables are inputs here.
+
+Every function cites the reference file:line (relative to /root/reference) it follows.
+All tensors are fp32 unless ``bf16=True`` is requested, in which case the rounding points of the
+reference's CUDA-autocast flow are emulated with explicit casts.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Dict, Optional
+
+import torch
+import torch.nn.functional as F
+
+NEG_INF = -1000000.0  # model_setup.py:269
+
+
+# ----------------------------------------------------------------------------------------------
+# configuration (only the keys the hot path reads)
+# ----------------------------------------------------------------------------------------------
+@dataclass
+class OracleConfig:
+    hidden_size: int
+    n_heads: int
+    cond_dim: int
+    n_blocks: int
+    txt_length: int
+    img_length: int
+    vocab_size: int
+    text_vocab_size: int
+    norm_type: str = "rms"
+    qk_norm: bool = True
+    sandwich_normalization: bool = True
+    modality_embed: bool = True
+    rope_2d: bool = False
+    linear_factor: float = 1.0
+    time_conditioning: bool = False
+    multimodal_batches: bool = True
+    force_argmax_valid_indices: bool = True
+    dropout: float = 0.0
+    # trainer-level
+    mask_entire_modality: Optional[float] = None
+    mask_txt_only: bool = False
+    softmin_snr: Optional[float] = None
+    text_loss_weight: Optional[float] = None
+    img_loss_weight: Optional[float] = None
+    force_full_attention_mask_loss_only: bool = False
+    force_full_attention_mask: bool = False
+    set_max_txt_loss_ratio: Optional[float] = None
+    antithetic_sampling: bool = True
+    sampling_eps: float = 1e-3
+    extra: dict = field(default_factory=dict)
+
+    @property
+    def length(self):
+        return self.txt_length + self.img_length
+
+    @property
+    def mask_index(self):
+        return self.text_vocab_size - 1  # asserted model.py:569
+
+    @property
+    def head_dim(self):
+        return self.hidden_size // self.n_heads
+
+    @classmethod
+    def from_case(cls, case: dict):
+        names = {f for f in cls.__dataclass_fields__}
+        kw = {k: v for k, v in case.items() if k in names and v is not None}
+        return cls(**kw)
+
+
+def _r(x, bf16):
+    """Rounding point: value is materialised as bf16 in the reference's autocast flow."""
+    return x.to(torch.bfloat16).to(torch.float32) if bf16 else x
+
+
+# ----------------------------------------------------------------------------------------------
+# small ops
+# ----------------------------------------------------------------------------------------------
+def rms_norm(x, w, eps=1e-6, bf16=False):
+    """models/dit.py:95-100 — ``_norm(x.float()).type_as(x) * weight``."""
+    y = x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + eps)
+    return y * w
+
+
+def rms_norm_lowp_input(x_bf16val, w, eps=1e-6, bf16=False):
+    """RMSNorm applied to a bf16 tensor (sandwich norms): normalised value is cast back to bf16
+    (``.type_as(x)``) *before* the fp32 weight multiply (dit.py:98-100; A5b items 6 and 8)."""
+    y = x_bf16val * torch.rsqrt(x_bf16val.pow(2).mean(-1, keepdim=True) + eps)
+    return _r(y, bf16) * w
+
+
+def layer_norm_nobias(x, w):
+    """models/dit.py:383-403 — F.layer_norm(x.float(), [dim]) * weight (eps 1e-5, no bias)."""
+    return F.layer_norm(x, [x.shape[-1]]) * w
+
+
+def get_norm(cfg: OracleConfig):
+    if cfg.norm_type == "rms":
+        return lambda x, w: rms_norm(x, w)
+    return layer_norm_nobias
+
+
+def linear(x, w, b=None, bf16=False):
+    """nn.Linear under autocast: bf16 operands, fp32 accumulate, bf16 result (A5b)."""
+    if bf16:
+        y = F.linear(_r(x, True), _r(w, True), None)
+        if b is not None:
+            y = y + _r(b, True)
+        return _r(y, True)
+    return F.linear(x, w, b)
+
+
+def gelu_tanh(x):
+    """nn.GELU(approximate='tanh') — models/dit.py:918."""
+    return F.gelu(x, approximate="tanh")
+
+
+def rotary_table_1d(seq_len, dim, base=10000.0):
+    """models/dit.py:307-330 ``Rotary`` + buffer slicing :1226-1239 → cos/sin fp32 [L, dim/2]."""
+    inv_freq = 1.0 / (base ** (torch.arange(0, dim, 2).float() / dim))
+    t = torch.arange(seq_len).type_as(inv_freq)
+    freqs = torch.einsum("i,j->ij", t, inv_freq)
+    return freqs.cos(), freqs.sin()
+
+
+def apply_rotary(x, cos, sin):
+    """models/standalone_rotary.py:14-31 (non-interleaved / NeoX half rotation).
+
+    x: [B, L, H', D]; cos/sin: [L, D/2] or [B, L, D/2].
+    """
+    cos = torch.cat([cos, cos], -1).unsqueeze(-2)
+    sin = torch.cat([sin, sin], -1).unsqueeze(-2)
+    x1, x2 = x.chunk(2, dim=-1)
+    rot = torch.cat((-x2, x1), dim=-1)
+    return x * cos + rot * sin
+
+
+def timestep_embedding(t, dim=256, max_period=10000):
+    """models/dit.py:428-444."""
+    half = dim // 2
+    freqs = torch.exp(-math.log(max_period) * torch.arange(0, half, dtype=torch.float32) / half)
+    args = t[:, None].float() * freqs[None]
+    return torch.cat([torch.cos(args), torch.sin(args)], dim=-1)
+
+
+def modulate(x, shift, scale, modality):
+    """models/dit.py:263-304 ``modulate_fused``: image-only when a modality map with any image token is given."""
+    if modality is not None and bool(modality.any()):
+        return torch.where(modality.unsqueeze(-1) == 1, x * (1 + scale) + shift, x)
+    return x * (1 + scale) + shift
+
+
+def bias_dropout_add_scale(x, scale, residual, modality):
+    """models/dit.py:229-253 with bias=None, dropout p=0 (parity runs use p=0).
+
+    With a modality map, text tokens receive the raw branch (no gate), image tokens the gated branch.
+    """
+    out = x
+    if scale is not None:
+        out = scale * out
+    if modality is not None:
+        out = torch.where((modality == 1).unsqueeze(-1), out, x)
+    return residual + out
+
+
+def attention_core(q, k, v, sample_ids=None):
+    """softmax(q kᵀ/√D) v, bidirectional (dit.py:826-829 SDPA ≡ :843 FA2); optional document mask
+    ``sid[q]==sid[kv] & sid[q]!=-1`` (model_utils.py:740-771).  q,k,v: [B, L, H, D] → [B, L, H*D]."""
+    B, L, H, D = q.shape
+    q, k, v = (t.transpose(1, 2) for t in (q, k, v))
+    s = (q @ k.transpose(-1, -2)) / math.sqrt(D)
+    if sample_ids is not None:
+        sid = sample_ids.clone()
+        allpad = (sid == -1).all(-1)
+        sid[allpad, 0] = 0
+        allow = (sid[:, :, None] == sid[:, None, :]) & (sid[:, :, None] != -1)
+        s = s.masked_fill(~allow[:, None], float("-inf"))
+    p = torch.softmax(s, dim=-1)
+    p = torch.nan_to_num(p, nan=0.0)
+    o = p @ v
+    return o.transpose(1, 2).reshape(B, L, H * D)
+
+
+# ----------------------------------------------------------------------------------------------
+# backbone (models/dit.py:1324-1500 with production flags; A5 of SURVEY.md)
+# ----------------------------------------------------------------------------------------------
+def select_rotary(cfg: OracleConfig, buffers: Dict[str, torch.Tensor], modality, L):
+    """models/dit.py:1413-1460 (non-interleaved branches)."""
+    if cfg.modality_embed and cfg.rope_2d and cfg.multimodal_batches:
+        ct, st = buffers["rotary_cos_emb_txt"], buffers["rotary_sin_emb_txt"]
+        ci, si = buffers["rotary_cos_emb_img"], buffers["rotary_sin_emb_img"]
+        if modality.shape[-1] != cfg.img_length:
+            pad = max(modality.shape[-1] - cfg.img_length, 0)
+            ci = torch.cat([torch.full((pad, ci.shape[-1]), float("nan")), ci], 0)
+            si = torch.cat([torch.full((pad, si.shape[-1]), float("nan")), si], 0)
+        sel = modality[:, :, None] == 0
+        return torch.where(sel, ct[None, :L], ci[None, :L]), torch.where(sel, st[None, :L], si[None, :L])
+    return buffers["rotary_cos_emb"][:L], buffers["rotary_sin_emb"][:L]
+
+
+def make_buffers(cfg: OracleConfig, lumina_fn=None):
+    """Non-persistent rotary buffers registered by DIT.__init__ (models/dit.py:1203-1239)."""
+    D = cfg.head_dim
+    out = {}
+    if cfg.rope_2d:
+        side = int(math.sqrt(cfg.img_length))
+        emb = lumina_fn(D, side, side, linear_factor=cfg.linear_factor, ntk_factor=1.0)
+        out["rotary_cos_emb_img"] = emb.flatten(0, 1).real.contiguous()
+        out["rotary_sin_emb_img"] = emb.flatten(0, 1).imag.contiguous()
+        n = cfg.length if cfg.multimodal_batches else cfg.txt_length
+        c, s = rotary_table_1d(n, D)
+        out["rotary_cos_emb_txt"], out["rotary_sin_emb_txt"] = c, s
+    else:
+        c, s = rotary_table_1d(cfg.length, D)
+        out["rotary_cos_emb"], out["rotary_sin_emb"] = c, s
+    return out
+
+
+def dit_block(cfg, P, pre, x, cos, sin, c, modality, sample_ids, bf16):
+    """models/dit.py:948-1033 ``DDiTBlock.forward`` + :616-887 ``Attention.forward`` (SDPA branch)."""
+    B, L, d = x.shape
+    H, D = cfg.n_heads, cfg.head_dim
+    norm = get_norm(cfg)
+    tc = cfg.time_conditioning
+    mod_map = modality if tc else None  # dit.py:884,1012
+    if tc:
+        ada = linear(c, P[pre + "adaLN_modulation.weight"], P[pre + "adaLN_modulation.bias"], bf16)[:, None, :]
+        sh1, sc1, g1, sh2, sc2, g2 = ada.chunk(6, dim=2)
+    x_skip = x
+    h = norm(x, P[pre + "norm1.weight"])
+    if tc:
+        h = modulate(h, sh1, sc1, modality)
+    qkv = linear(h, P[pre + "attention.attn_qkv.weight"], None, bf16)
+    q, k, v = qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:]
+    if cfg.qk_norm:  # dit.py:680-682: LayerNorm over the full hidden dim, written back in place (bf16)
+        q = _r(F.layer_norm(q, [d], P[pre + "attention.q_norm.weight"], P[pre + "attention.q_norm.bias"], 1e-5), bf16)
+        k = _r(F.layer_norm(k, [d], P[pre + "attention.k_norm.weight"], P[pre + "attention.k_norm.bias"], 1e-5), bf16)
+    qk = torch.stack([q, k], 2).reshape(B, L, 2 * H, D)  # "b s (three h d)" → q heads then k heads
+    qk = _r(apply_rotary(qk, cos, sin), bf16)  # dit.py:723-726
+    q, k = qk[:, :, :H], qk[:, :, H:]
+    a = _r(attention_core(q, k, v.reshape(B, L, H, D), sample_ids), bf16)
+    a = linear(a, P[pre + "attention.attn_out.weight"], None, bf16)
+    if cfg.sandwich_normalization:  # dit.py:993-994 (gate_msa unused, :983)
+        x = x_skip + (rms_norm_lowp_input(a, P[pre + "pre_residual_norm.weight"], bf16=bf16) if cfg.norm_type == "rms"
+                      else norm(a, P[pre + "pre_residual_norm.weight"]))
+    else:  # dit.py:877-885.  Attention.time_conditioning is never set by DDiTBlock (ctor default False, dit.py:533;
+        # DIT passes the flag to the block only, :1267-1290), so the attention branch is gated on ALL tokens.
+        x = bias_dropout_add_scale(a, g1 if tc else None, x_skip, None)
+    h = norm(x, P[pre + "norm2.weight"])
+    if tc:
+        h = modulate(h, sh2, sc2, modality)
+    u = linear(h, P[pre + "mlp.0.weight"], P[pre + "mlp.0.bias"], bf16)
+    u = _r(gelu_tanh(u), bf16)
+    u = linear(u, P[pre + "mlp.2.weight"], P[pre + "mlp.2.bias"], bf16)
+    if cfg.sandwich_normalization:
+        u = (rms_norm_lowp_input(u, P[pre + "post_ff_norm.weight"], bf16=bf16) if cfg.norm_type == "rms"
+             else norm(u, P[pre + "post_ff_norm.weight"]))
+    return bias_dropout_add_scale(u, g2 if tc else None, x, mod_map)  # dit.py:1015-1031
+
+
+def dit_forward(cfg: OracleConfig, P: Dict[str, torch.Tensor], buffers, indices, sigma=None, modality=None,
+                sample_ids=None, bf16=False, return_hidden=False):
+    """models/dit.py:1324-1500 ``DIT.forward`` → logits [B, L, V]."""
+    B, L = indices.shape
+    x = P["vocab_embed.embedding"][indices]  # :1375
+    c = None
+    if cfg.time_conditioning:  # :1377-1379
+        te = timestep_embedding(sigma, 256)
+        hdn = F.silu(linear(te, P["sigma_map.mlp.0.weight"], P["sigma_map.mlp.0.bias"], bf16))
+        c = F.silu(linear(hdn, P["sigma_map.mlp.2.weight"], P["sigma_map.mlp.2.bias"], bf16))
+    if cfg.modality_embed:  # :1402-1411
+        Em = P["modality_embed.embedding"]
+        if cfg.multimodal_batches:
+            x = x + torch.where((modality == 0).unsqueeze(-1), Em[0][None, None], Em[1][None, None])
+        else:
+            x = torch.cat([x[:, :cfg.txt_length] + Em[0], x[:, cfg.txt_length:] + Em[1]], 1)
+    cos, sin = select_rotary(cfg, buffers, modality, L)
+    for i in range(cfg.n_blocks):
+        x = dit_block(cfg, P, f"blocks.{i}.", x, cos, sin, c, modality, sample_ids, bf16)
+    norm = get_norm(cfg)
+    h = norm(x, P["output_layer.norm_final.weight"])  # :1083-1092
+    if cfg.time_conditioning:
+        ada = linear(c, P["output_layer.adaLN_modulation.weight"], P["output_layer.adaLN_modulation.bias"], bf16)[:, None, :]
+        sh, sc = ada.chunk(2, dim=2)
+        h = modulate(h, sh, sc, modality)
+    logits = linear(h, P["output_layer.linear.weight"], P["output_layer.linear.bias"], bf16)
+    return (logits, x) if return_hidden else logits
+
+
+# ----------------------------------------------------------------------------------------------
+# trainer-level pieces (model.py)
+# ----------------------------------------------------------------------------------------------
+def update_batch(cfg: OracleConfig, batch: dict):
+    """model.py:183-212, 296-348 — token-dataset branch."""
+    b = dict(batch)
+    if "img_input_ids" in b:
+        img = b.pop("img_input_ids").to(torch.int64)
+        ids, am = img, torch.ones_like(img).to(torch.bool)
+        if "txt_input_ids" in b:
+            txt = b["txt_input_ids"].to(torch.int64)
+            ids = torch.cat([txt, ids + cfg.text_vocab_size], -1)
+            am = torch.cat([b["txt_attention_mask"], am], -1)
+        b["input_ids"] = ids.to(torch.int64)
+        b["attention_mask"] = am
+        if "modality" not in b:
+            mod = torch.zeros_like(ids)
+            mod[:, -img.shape[-1]:] = 1
+            b["modality"] = mod
+    if "modality" in b:
+        b["modality"] = b["modality"].to(torch.int64)
+        b["modality"][b["modality"] == -1] = 0
+        b["modality_mask"] = F.one_hot(b["modality"], num_classes=2).to(torch.bool)
+        b["batch_contains_img"] = (b["modality"] == 1).any(-1)
+        b["txt_sl"] = b["modality_mask"][..., 0]
+        b["img_sl"] = b["modality_mask"][..., 1]
+    if cfg.force_full_attention_mask:
+        b["attention_mask"] = torch.ones_like(b["attention_mask"], dtype=torch.bool)
+    b["attention_mask"] = b["attention_mask"].to(torch.bool)
+    return b
+
+
+def sample_t(cfg: OracleConfig, n, generator=None):
+    """model.py:589-619."""
+    u = torch.rand(n, generator=generator)
+    if cfg.antithetic_sampling:
+        u = (u / n + torch.arange(n) / n) % 1
+    return ((1 - cfg.sampling_eps) * u + cfg.sampling_eps).to(torch.float32)
+
+
+def loglinear_noise(t, eps=1e-3):
+    """models/noise_schedule.py:142-150 → (total σ, rate σ')."""
+    return -torch.log1p(-(1 - eps) * t), (1 - eps) / (1 - (1 - eps) * t)
+
+
+def q_xt(cfg: OracleConfig, x0, move_chance, batch, training=True, generator=None):
+    """model.py:439, 468-539 (non-interleaved), 579."""
+    B, L = x0.shape
+    move = torch.rand(B, L, generator=generator) < move_chance
+    ignore = smt = smi = None
+    pm = cfg.mask_entire_modality
+    if pm is not None and training:
+        if cfg.mask_txt_only:
+            smt = torch.rand(B, 1, generator=generator) < pm
+            smi = torch.zeros_like(smt)
+        else:
+            smt = torch.rand(B, 1, generator=generator) < pm / 2
+            smi = torch.rand(B, 1, generator=generator) < pm / 2
+        both = smt & smi
+        smt, smi = smt & ~both, smi & ~both
+        if cfg.multimodal_batches:
+            move = torch.where(smt, batch["modality_mask"][..., 0], move)
+            move = torch.where(smi, batch["modality_mask"][..., 1], move)
+        else:
+            smi = smi & ~batch["txt_sl"].all(-1, keepdim=True)
+            move[:, :cfg.txt_length] |= smt
+            move[:, L - cfg.img_length:] |= smi
+        ignore = smi | smt
+    xt = torch.where(move, cfg.mask_index, x0)
+    return xt, ignore, smt, smi, move
+
+
+def subs_parameterization(cfg: OracleConfig, logits, xt, modality=None, batch=None, bf16=False):
+    """model.py:621-658 (training: not allow_slicing)."""
+    z = logits.clone()
+    m, Vt = cfg.mask_index, cfg.text_vocab_size
+    z[..., m] = _r(z[..., m] + NEG_INF, bf16)
+    if cfg.force_argmax_valid_indices:
+        if cfg.multimodal_batches:
+            txt = batch["txt_sl"] if modality is None else modality == 0
+            img = batch["img_sl"] if modality is None else modality == 1
+            z[..., Vt:] = torch.where(txt[..., None], NEG_INF, z[..., Vt:])
+            z[..., :Vt] = torch.where(img[..., None], NEG_INF, z[..., :Vt])
+        else:
+            z[:, :cfg.txt_length, Vt:] = NEG_INF
+            z[:, z.shape[1] - cfg.img_length:, :Vt] = NEG_INF
+    z = _r(z, bf16)
+    z = _r(z - _r(torch.logsumexp(z, -1, keepdim=True), bf16), bf16)
+    unmasked = xt != m
+    z = torch.where(unmasked[..., None], torch.full_like(z, NEG_INF), z)
+    onehot = torch.arange(z.shape[-1]) == xt[..., None]
+    z = torch.where(unmasked[..., None] & onehot, torch.zeros_like(z), z)
+    return _r(z, bf16)
+
+
+@dataclass
+class OracleLoss:
+    loss: torch.Tensor
+    img_loss: object = 0
+    txt_loss: object = 0
+    nlls: torch.Tensor = None
+    token_mask: torch.Tensor = None
+    txt_nlls: object = 0
+    img_nlls: object = 0
+    extra_losses: dict = None
+    modality_mask: torch.Tensor = None
+    aux: dict = None
+
+
+def reduce_loss(cfg: OracleConfig, log_p, sigma, dsigma, attention_mask, modality_mask, ignore_batch):
+    """model.py:967-1161 — weighting, reduction, Loss record."""
+    std_w = (dsigma / torch.expm1(sigma))[:, None]
+    loss = -log_p * std_w
+    if cfg.softmin_snr is not None:
+        loss = -log_p * (dsigma / (torch.expm1(sigma) + 1 / cfg.softmin_snr))[:, None]
+    std_loss = (-log_p * std_w).detach()
+    rec = dict(extra_losses={})
+    if modality_mask is not None:
+        rec["txt_nlls"] = std_loss * modality_mask[..., 0] * attention_mask
+        rec["img_nlls"] = std_loss * modality_mask[..., 1] * attention_mask
+    weighted = cfg.text_loss_weight is not None and cfg.img_loss_weight is not None
+    if cfg.multimodal_batches or weighted:
+        tm = modality_mask[..., 0] & attention_mask
+        im = modality_mask[..., 1] & attention_mask
+        tc, ic = tm.sum(), im.sum()
+        tot = tc + ic
+        tf, imf = tc / tot, ic / tot
+        rec["extra_losses"]["trainer/img_frac"] = imf
+        rec["extra_losses"]["trainer/txt_frac"] = tf
+        rec["extra_losses"]["trainer/attention_mask_valid_frac"] = attention_mask.sum() / attention_mask.numel()
+        if ignore_batch is not None:
+            ib = ignore_batch.squeeze(-1)
+            rec["extra_losses"]["trainer/ignore_batch_metrics_frac"] = ib.sum() / ib.numel()
+    if weighted:
+        loss = loss * attention_mask
+        txt_loss = (loss[tm].sum() / tc) * tf * cfg.text_loss_weight
+        img_loss = (loss[im].sum() / ic) * imf * cfg.img_loss_weight
+        r = cfg.set_max_txt_loss_ratio
+        if r is not None and not (torch.isnan(img_loss).any() or torch.isnan(txt_loss).any()):
+            scale = torch.minimum(torch.tensor(1.0), (r * img_loss.detach()) / (txt_loss.detach() + 1e-8))
+            txt_loss = txt_loss * scale
+        txt_loss = torch.nan_to_num(txt_loss, nan=0.0)
+        img_loss = torch.nan_to_num(img_loss, nan=0.0)
+        total = txt_loss + img_loss
+        rec.update(txt_loss=txt_loss.detach().clone(), img_loss=img_loss.detach().clone())
+    else:
+        am = torch.ones_like(attention_mask) if cfg.force_full_attention_mask_loss_only else attention_mask
+        total = torch.nan_to_num((loss * am).sum() / am.sum(), nan=0.0)
+    nlls = std_loss * attention_mask
+    token_mask = attention_mask
+    if ignore_batch is not None:
+        token_mask = torch.where(ignore_batch.squeeze(-1)[:, None].repeat(1, attention_mask.shape[-1]),
+                                 torch.full_like(attention_mask, False), attention_mask)
+    return OracleLoss(loss=total, img_loss=rec.get("img_loss", 0), txt_loss=rec.get("txt_loss", 0), nlls=nlls,
+                      token_mask=token_mask, txt_nlls=rec.get("txt_nlls", 0), img_nlls=rec.get("img_nlls", 0),
+                      extra_losses=rec["extra_losses"], modality_mask=modality_mask)
+
+
+def compute_loss(cfg: OracleConfig, P, buffers, batch, generator=None, bf16=False, training=True):
+    """model.py:797-1173, SUBS / continuous-time / absorbing branch.  ``batch`` must come from update_batch."""
+    x0, am = batch["input_ids"], batch["attention_mask"]
+    modality_mask = batch.get("modality_mask")
+    t = sample_t(cfg, x0.shape[0], generator)
+    sigma, dsigma = loglinear_noise(t)
+    move_chance = 1 - torch.exp(-sigma[:, None])
+    xt, ignore, smt, smi, move = q_xt(cfg, x0, move_chance, batch, training, generator)
+    modality = batch["modality"] if cfg.multimodal_batches else None
+    logits = dit_forward(cfg, P, buffers, xt, sigma, modality, None, bf16)
+    lp = subs_parameterization(cfg, logits, xt, modality, batch, bf16).float()
+    log_p = torch.gather(lp, -1, x0[:, :, None]).squeeze(-1)
+    out = reduce_loss(cfg, log_p, sigma, dsigma, am, modality_mask, ignore)
+    out.aux = dict(t=t, sigma=sigma, dsigma=dsigma, xt=xt, move_indices=move, logits=logits, log_probs=lp,
+                   ignore_batch_mask=ignore, should_mask_txt=smt, should_mask_img=smi, log_p=log_p)
+    return out
