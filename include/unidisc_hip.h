@@ -1,0 +1,115 @@
+/* unidisc_hip.h — C ABI of the MI355X (gfx950) kernel library behind UniDisc's denoising hot path.
+ *
+ * The reference (alexanderswerdlow/unidisc) is pure Python/PyTorch and has NO native interface of its
+ * own; each entry point below therefore replaces a torch / third-party-kernel call
+ * site of the reference, cited as file:line relative to the reference root.  The binding a maintainer adds
+ * on the reference side is a ctypes stub; `unidisc_amd/_lib.py` is that stub.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every buffer is caller-allocated DEVICE memory (PyTorch tensors in
+ *     practice), the library never allocates, frees or synchronises;
+ *   - bf16 tensors are `void*` to raw 16-bit words, row-major, 16-byte aligned, row strides in ELEMENTS;
+ *   - all kernels are enqueued on `stream` and return immediately;
+ *   - return value 0 = enqueued; non-zero = nothing enqueued (2: bad argument, 1: launch failure) and
+ *     udm_last_error() holds a message; no exception or exit crosses the ABI;
+ *   - thread-safety: entry points may be called from any host thread (forward on the main thread,
+ *     backward on the autograd thread); the error string is thread-local.
+ */
+#ifndef UNIDISC_HIP_H
+#define UNIDISC_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#ifndef __HIP__
+typedef struct ihipStream_t* hipStream_t;
+#endif
+
+#define UDM_ABI_VERSION 1
+
+/* GEMM epilogues */
+#define UDM_EPI_NONE 0      /* C = A·Bᵀ                                                   */
+#define UDM_EPI_BIAS 1      /* C = A·Bᵀ + bias[n]                                          */
+#define UDM_EPI_BIAS_GELU 2 /* aux = bf16(A·Bᵀ + bias); C = gelu_tanh(aux)   (mlp.0 + GELU) */
+#define UDM_EPI_DGELU 3     /* C = (A·Bᵀ) ⊙ gelu_tanh'(aux)                  (GELU backward) */
+
+const char* udm_last_error(void);
+int udm_abi_version(void);
+
+/* ---- GEMM family: nn.Linear forward / dgrad / wgrad under bf16 autocast -------------------------
+ * replaces: models/dit.py:642 (attn_qkv), :877-887 (attn_out), :917-919 + :1016/1025 (mlp), :1091 (head),
+ *           :966-967, :1084 (adaLN_modulation), :447 (sigma_map) and their autograd backward.
+ * C[M,N] = A[M,K] · B[N,K]ᵀ, A/B bf16 K-contiguous; C bf16 or fp32; beta accumulates into an fp32 C.   */
+int udm_gemm_nt_bf16(const void* A, const void* B, void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int out_f32,
+                     int epilogue, const float* bias, void* aux, int64_t ldaux, float beta, hipStream_t stream);
+/* out[C,R] = in[R,C]ᵀ (bf16); optional colsum[c] += Σ_r in[r,c] (bias gradient).  Feeds the wgrad GEMMs. */
+int udm_transpose_bf16(const void* in, void* out, int64_t R, int64_t C, int64_t ld_in, int64_t ld_out, float* colsum, hipStream_t stream);
+/* fp32 master weights -> bf16 shadow (and Kᵀ-major shadow for dgrad): the per-forward autocast weight cast. */
+int udm_cast_transpose_f32_bf16(const float* in, void* out, void* out_t, int64_t R, int64_t C, int64_t ld_in, int64_t ld_out, int64_t ld_t,
+                                hipStream_t stream);
+int udm_cast_f32_bf16(const float* x, void* y, int64_t n, float scale, hipStream_t stream); /* DDP bf16 compress hook, main.py:645 */
+int udm_cast_bf16_f32(const void* x, float* y, int64_t n, float scale, hipStream_t stream); /* ... and decompress */
+
+/* ---- norms: RMSNorm models/dit.py:77-100, LayerNorm(no bias) :383-403, modulate_fused :263-304 -----
+ * y(bf16) = modulate(norm(x) * w).  norm_type 0 = RMS (eps 1e-6), 1 = LayerNorm (eps 1e-5).
+ * shift/scale: bf16 [B, mod_stride] slices of the adaLN output or NULL; `modality` [M] + `any_img` device
+ * flag select the reference's image-token-only modulation.  L = rows per batch element.              */
+int udm_norm_fwd(const float* x, void* y, float* rstd, float* mean, const float* w, const void* shift, const void* scale, int64_t mod_stride,
+                 const int64_t* modality, const int* any_img, int64_t M, int64_t d, int64_t L, int norm_type, float eps, hipStream_t stream);
+int udm_norm_bwd(const void* dy, const float* x, const float* rstd, const float* mean, const float* w, const void* shift, const void* scale,
+                 int64_t mod_stride, const int64_t* modality, const int* any_img, float* dx, float* dw, float* dshift, float* dscale, int64_t M,
+                 int64_t d, int64_t L, int norm_type, int accumulate, hipStream_t stream);
+
+/* ---- residual branch: bias_dropout_add_scale models/dit.py:229-253 and the sandwich adds :993-994, :1015-1031
+ * x_out = x_in + gate ⊙ dropout_p(sandwich_norm(branch; w_b)); every stage optional (NULL / p = 0).       */
+int udm_residual_fwd(const float* x_in, const void* branch, float* x_out, const float* w_b, float* rstd_b, float* mean_b, const void* gate,
+                     int64_t mod_stride, const int64_t* modality, int64_t M, int64_t d, int64_t L, int norm_type, float eps, float p_drop, uint64_t seed,
+                     hipStream_t stream);
+int udm_residual_bwd(const float* dx, const void* branch, void* dbranch, const float* w_b, const float* rstd_b, const float* mean_b, const void* gate,
+                     int64_t mod_stride, const int64_t* modality, float* dw_b, float* dgate, int64_t M, int64_t d, int64_t L, int norm_type, float p_drop,
+                     uint64_t seed, hipStream_t stream);
+
+/* ---- QK LayerNorm (models/dit.py:569-572, 680-682) + rotary (models/standalone_rotary.py:14-31, call dit.py:723-726)
+ * qkv bf16 [M,3d] -> qkr bf16 [M,2d] (normalised, rotated q | k).  cos/sin fp32 [L,D/2] or per-sample [M,D/2]. */
+int udm_qknorm_rope_fwd(const void* qkv, void* qkr, const float* gq, const float* bq, const float* gk, const float* bk, float* stats, const float* cos_t,
+                        const float* sin_t, int rope_per_sample, int64_t M, int64_t d, int64_t L, int64_t D, float eps, hipStream_t stream);
+int udm_qknorm_rope_bwd(const void* dqkr, const void* qkv, void* dqkv, const float* gq, const float* gk, const float* stats, const float* cos_t,
+                        const float* sin_t, int rope_per_sample, float* dgq, float* dbq, float* dgk, float* dbk, int64_t M, int64_t d, int64_t L, int64_t D,
+                        hipStream_t stream);
+
+/* ---- attention core: flash_attn_qkvpacked_func models/dit.py:843 / SDPA :826-829 / FlexAttention doc mask :784-812
+ * bidirectional softmax(QKᵀ/√D)V; element (b,l,h,:) of a tensor lives at base + (b*L+l)*stride + h*D.
+ * sample_ids [B,L] (or NULL): attend iff ids equal and != -1 (model_utils.py:740-771).  lse/delta fp32 [B,H,L]. */
+int udm_attention_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const int64_t* sample_ids, int64_t B, int64_t H, int64_t L, int64_t D,
+                      int64_t q_stride, int64_t k_stride, int64_t v_stride, int64_t o_stride, hipStream_t stream);
+int udm_attention_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse, float* delta, void* dq, void* dk,
+                      void* dv, const int64_t* sample_ids, int64_t B, int64_t H, int64_t L, int64_t D, int64_t q_stride, int64_t k_stride, int64_t v_stride,
+                      int64_t o_stride, int64_t do_stride, int64_t dq_stride, int64_t dk_stride, int64_t dv_stride, hipStream_t stream);
+int udm_attention_set_tr_read(int enable); /* diagnostics: 0 = gather Vᵀ fragments with scalar LDS reads */
+
+/* ---- embeddings: EmbeddingLayer models/dit.py:1036-1043 (+modality embedding :1402-1411) ------------- */
+int udm_embedding_fwd(const int64_t* ids, const float* E, const int64_t* modality, const float* Em, float* x, int64_t M, int64_t d, int64_t V,
+                      hipStream_t stream);
+int udm_embedding_bwd(const int64_t* ids, const int64_t* modality, const float* dx, float* dE, float* dEm, int64_t M, int64_t d, int64_t V, int64_t hot_id,
+                      hipStream_t stream);
+
+/* ---- SUBS cross-entropy: Diffusion._subs_parameterization model.py:621-658 + gather :967 -------------- */
+int udm_subs_ce_fwd(const void* logits, int64_t ld, const int64_t* x0, const int64_t* xt, const int64_t* modality, float* log_p, float* lse, int64_t M,
+                    int64_t V, int64_t Vt, int64_t mask_id, int restrict_modality, hipStream_t stream);
+int udm_subs_ce_bwd(void* logits, int64_t ld, const int64_t* x0, const int64_t* xt, const int64_t* modality, const float* lse, const float* g, int64_t M,
+                    int64_t V, int64_t Vt, int64_t mask_id, int restrict_modality, hipStream_t stream);
+int udm_subs_logprobs(const void* logits, int64_t ld, const int64_t* xt, const int64_t* modality, void* out, int64_t ld_out, int out_f32, int64_t M, int64_t V,
+                      int64_t Vt, int64_t mask_id, int restrict_modality, hipStream_t stream);
+
+/* ---- adaLN-Zero helpers: TimestepEmbedder models/dit.py:415-449, F.silu :1379 ------------------------- */
+int udm_timestep_embedding(const float* sigma, void* out, int64_t B, int64_t dim, hipStream_t stream);
+int udm_silu_fwd(const void* x, void* y, int64_t n, hipStream_t stream);
+int udm_silu_bwd(const void* x, const void* dy, void* dx, int64_t n, hipStream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UNIDISC_HIP_H */

@@ -1,0 +1,320 @@
+"""CPU stand-ins for ``unidisc_amd.kernels`` used ONLY by tests/test_engine_orchestration.py.
+
+They let the hand-scheduled forward/backward engine in ``unidisc_amd/dit.py`` (buffer plumbing, gradient
+bookkeeping, adaLN chunk indexing, callbacks) be exercised in the GPU-less container.  They are test doubles:
+nothing in the product imports them, and the product has no CPU path.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_DGELU = 0, 1, 2, 3
+NORM_RMS, NORM_LN = 0, 1
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+def require_gpu(t):
+    return None
+
+
+def norm_id(norm_type):
+    return NORM_RMS if norm_type == "rms" else NORM_LN
+
+
+@torch.enable_grad()
+def gemm_nt(a, b, out=None, *, out_dtype=BF16, M=None, N=None, K=None, lda=None, ldb=None, ldc=None, epilogue=EPI_NONE, bias=None, aux=None, ldaux=None,
+            beta=0.0):
+    M = a.shape[0] if M is None else M
+    K = a.shape[1] if K is None else K
+    N = b.shape[0] if N is None else N
+    acc = a[:M, :K].float() @ b[:N, :K].float().t()
+    if epilogue in (EPI_BIAS, EPI_BIAS_GELU):
+        acc = acc + bias[:N].float()
+    if epilogue == EPI_BIAS_GELU:
+        pre = acc.bfloat16()
+        aux[:M, :N] = pre
+        acc = F.gelu(pre.float(), approximate="tanh")
+    if epilogue == EPI_DGELU:
+        u = aux[:M, :N].float().requires_grad_()
+        (gr,) = torch.autograd.grad(F.gelu(u, approximate="tanh").sum(), u)
+        acc = acc * gr
+    if out is None:
+        out = torch.empty((M, N), dtype=out_dtype)
+    if beta != 0.0:
+        acc = acc + beta * out[:M, :N].float()
+    out[:M, :N] = acc.to(out.dtype)
+    return out
+
+
+def transpose(x, out=None, colsum=None, R=None, C=None):
+    if colsum is not None:
+        colsum += x.float().sum(0)
+    t = x.t().contiguous()
+    if out is not None:
+        out.copy_(t)
+        return out
+    return t
+
+
+def cast_transpose(w, out, out_t):
+    R, C = w.shape
+    if out is not None:
+        out[:R, :C] = w.bfloat16()
+    if out_t is not None:
+        out_t[:C, :R] = w.t().bfloat16()
+
+
+def cast_f32_bf16(x, y, scale=1.0):
+    y.copy_((x.bfloat16().float() * scale).bfloat16())
+    return y
+
+
+def cast_bf16_f32(x, y, scale=1.0):
+    y.copy_(x.float() * scale)
+    return y
+
+
+def _rows_to_batch(M, L):
+    return torch.arange(M) // L
+
+
+def _modulated(n, mod, idx, modality, any_img, L):
+    if mod is None:
+        return n
+    d = n.shape[1]
+    b = _rows_to_batch(n.shape[0], L)
+    sh, sc = mod[b, idx[0] * d:(idx[0] + 1) * d], mod[b, idx[1] * d:(idx[1] + 1) * d]
+    out = n * (1 + sc) + sh
+    if modality is not None and (any_img is None or int(any_img) != 0):
+        out = torch.where((modality == 1)[:, None], out, n)
+    return out
+
+
+def _norm(x, w, nt):
+    if nt == NORM_RMS:
+        rstd = torch.rsqrt(x.pow(2).mean(-1) + 1e-6)
+        return x * rstd[:, None] * w, rstd, None
+    mean = x.mean(-1)
+    rstd = torch.rsqrt(x.var(-1, unbiased=False) + 1e-5)
+    return (x - mean[:, None]) * rstd[:, None] * w, rstd, mean
+
+
+def norm_fwd(x, w, norm_type, L, *, mod=None, mod_idx=(0, 1), modality=None, any_img=None):
+    n, rstd, mean = _norm(x, w, norm_type)
+    y = _modulated(n, mod.float() if mod is not None else None, mod_idx, modality, any_img, L)
+    return y.bfloat16(), rstd, mean
+
+
+@torch.enable_grad()
+def norm_bwd(dy, x, rstd, mean, w, norm_type, L, dx, dw, *, accumulate=True, mod=None, dmod=None, mod_idx=(0, 1), modality=None, any_img=None):
+    x_, w_ = x.clone().requires_grad_(), w.clone().requires_grad_()
+    mod_ = mod.float().clone().requires_grad_() if mod is not None else None
+    n, _, _ = _norm(x_, w_, norm_type)
+    y = _modulated(n, mod_, mod_idx, modality, any_img, L)
+    y.backward(dy.float())
+    dx.copy_(x_.grad + (dx if accumulate else 0))
+    dw += w_.grad
+    if mod is not None:
+        dmod += mod_.grad
+
+
+def _branch(x_in, br, L, w_b, norm_type, mod, gate_idx, modality):
+    n = br
+    rstd = mean = None
+    if w_b is not None:
+        if norm_type == NORM_RMS:
+            rstd = torch.rsqrt(br.pow(2).mean(-1) + 1e-6)
+            nh = br * rstd[:, None]
+            n = (nh + (nh.detach().bfloat16().float() - nh.detach())) * w_b  # straight-through bf16 rounding
+        else:
+            n, rstd, mean = _norm(br, w_b, norm_type)
+    out = n
+    if mod is not None and gate_idx is not None:
+        d = br.shape[1]
+        g = mod[_rows_to_batch(br.shape[0], L), gate_idx * d:(gate_idx + 1) * d]
+        out = g * n
+        if modality is not None:
+            out = torch.where((modality == 1)[:, None], out, n)
+    return x_in + out, rstd, mean
+
+
+def residual_fwd(x_in, branch, L, *, w_b=None, norm_type=NORM_RMS, mod=None, gate_idx=None, modality=None, p_drop=0.0, seed=0):
+    assert p_drop == 0.0, "fake kernels: dropout not emulated"
+    out, rstd, mean = _branch(x_in, branch.float(), L, w_b, norm_type, mod.float() if mod is not None else None, gate_idx, modality)
+    return out, rstd, mean
+
+
+@torch.enable_grad()
+def residual_bwd(dx, branch, L, *, w_b=None, rstd=None, mean=None, norm_type=NORM_RMS, mod=None, dmod=None, gate_idx=None, modality=None, dw_b=None,
+                 p_drop=0.0, seed=0):
+    br = branch.float().clone().requires_grad_()
+    w_ = w_b.clone().requires_grad_() if w_b is not None else None
+    mod_ = mod.float().clone().requires_grad_() if (mod is not None and gate_idx is not None) else None
+    out, _, _ = _branch(torch.zeros_like(dx), br, L, w_, norm_type, mod_, gate_idx, modality)
+    out.backward(dx)
+    if w_b is not None:
+        dw_b += w_.grad
+    if mod_ is not None:
+        dmod += mod_.grad
+    return br.grad.bfloat16()
+
+
+def _qk(qkv, cos, sin, L, D, gq, bq, gk, bk):
+    M, d3 = qkv.shape
+    d = d3 // 3
+    H = d // D
+    q, k = qkv[:, :d], qkv[:, d:2 * d]
+    if gq is not None:
+        q = F.layer_norm(q, [d], gq, bq, 1e-5)
+        k = F.layer_norm(k, [d], gk, bk, 1e-5)
+        q = q + (q.detach().bfloat16().float() - q.detach())
+        k = k + (k.detach().bfloat16().float() - k.detach())
+    qk = torch.stack([q, k], 1).reshape(M, 2 * H, D)
+    if cos.dim() == 3:
+        c, s = cos.reshape(M, -1), sin.reshape(M, -1)
+    else:
+        idx = torch.arange(M) % L
+        c, s = cos[idx], sin[idx]
+    c, s = torch.cat([c, c], -1)[:, None], torch.cat([s, s], -1)[:, None]
+    x1, x2 = qk.chunk(2, -1)
+    out = qk * c + torch.cat([-x2, x1], -1) * s
+    return out.reshape(M, 2 * d)
+
+
+def qknorm_rope_fwd(qkv, cos, sin, L, D, *, gq=None, bq=None, gk=None, bk=None):
+    out = _qk(qkv.float(), cos, sin, L, D, gq, bq, gk, bk)
+    return out.bfloat16(), (torch.zeros(qkv.shape[0], 4) if gq is not None else None)
+
+
+_saved_qk = {}
+
+
+@torch.enable_grad()
+def qknorm_rope_bwd(dqkr, qkv, dqkv, cos, sin, L, D, *, gq=None, gk=None, stats=None, dgq=None, dbq=None, dgk=None, dbk=None, bq=None, bk=None):
+    d = qkv.shape[1] // 3
+    x = qkv.float().clone().requires_grad_()
+    p = [t.clone().requires_grad_() if t is not None else None for t in (gq, gk)]
+    zeros = torch.zeros(d)
+    out = _qk(x, cos, sin, L, D, p[0], zeros if gq is not None else None, p[1], zeros if gq is not None else None)
+    out.backward(dqkr.float())
+    dqkv[:, :2 * d] = x.grad[:, :2 * d].bfloat16()
+    if gq is not None:
+        dgq += p[0].grad
+        dgk += p[1].grad
+        # d beta = column sums of the gradient w.r.t. the LayerNorm output = grad through the rotation
+        g = dqkr.float().reshape(qkv.shape[0], -1, D)
+        M = qkv.shape[0]
+        if cos.dim() == 3:
+            c, s = cos.reshape(M, -1), sin.reshape(M, -1)
+        else:
+            idx = torch.arange(M) % L
+            c, s = cos[idx], sin[idx]
+        c, s = c[:, None], s[:, None]
+        g1, g2 = g.chunk(2, -1)
+        gl = g1 * c + g2 * s
+        gh = g2 * c - g1 * s
+        gb = torch.cat([gl, gh], -1).reshape(M, 2 * d)
+        dbq += gb[:, :d].sum(0)
+        dbk += gb[:, d:].sum(0)
+
+
+def _attn(q, k, v, B, L, H, D, sid):
+    q, k, v = (t.reshape(B, L, H, D).transpose(1, 2) for t in (q, k, v))
+    s = q @ k.transpose(-1, -2) / math.sqrt(D)
+    if sid is not None:
+        allow = (sid[:, :, None] == sid[:, None, :]) & (sid[:, :, None] >= 0)
+        s = s.masked_fill(~allow[:, None], float("-inf"))
+    p = torch.nan_to_num(torch.softmax(s, -1), nan=0.0)
+    return (p @ v).transpose(1, 2).reshape(B * L, H * D)
+
+
+def attention_fwd(qkr, qkv, B, L, H, D, sample_ids=None):
+    d = H * D
+    o = _attn(qkr[:, :d].float(), qkr[:, d:].float(), qkv[:, 2 * d:].float(), B, L, H, D, sample_ids)
+    return o.bfloat16(), torch.zeros(B, H, L)
+
+
+@torch.enable_grad()
+def attention_bwd(qkr, qkv, o, do, lse, dqkr, dqkv, B, L, H, D, sample_ids=None):
+    d = H * D
+    q, k, v = (t.float().clone().requires_grad_() for t in (qkr[:, :d], qkr[:, d:], qkv[:, 2 * d:]))
+    _attn(q, k, v, B, L, H, D, sample_ids).backward(do.float())
+    dqkr[:, :d], dqkr[:, d:], dqkv[:, 2 * d:] = q.grad.bfloat16(), k.grad.bfloat16(), v.grad.bfloat16()
+
+
+def embedding_fwd(ids, E, modality=None, Em=None):
+    x = E[ids]
+    if Em is not None:
+        x = x + Em[(modality != 0).long()]
+    return x
+
+
+def embedding_bwd(ids, dx, dE, hot_id, modality=None, dEm=None):
+    dE.index_add_(0, ids, dx)
+    if dEm is not None:
+        dEm.index_add_(0, (modality != 0).long(), dx)
+
+
+def _valid(M, V, Vt, mask_id, modality, restrict):
+    v = torch.ones(M, V, dtype=torch.bool)
+    if restrict:
+        img = (modality == 1)[:, None]
+        ar = torch.arange(V)[None]
+        v = torch.where(img, ar >= Vt, ar < Vt)
+    v[:, mask_id] = False
+    return v
+
+
+def subs_ce_fwd(logits, x0, xt, modality, V, Vt, mask_id, restrict):
+    M = logits.shape[0]
+    z = logits[:, :V].float().masked_fill(~_valid(M, V, Vt, mask_id, modality, restrict), float("-inf"))
+    lse = torch.logsumexp(z, -1)
+    zx = z.gather(1, x0[:, None])[:, 0]
+    zx = torch.where(torch.isinf(zx), torch.full_like(zx, -1e6), zx)
+    masked = xt == mask_id
+    log_p = torch.where(masked, zx - lse, torch.where(x0 == xt, torch.zeros_like(lse), torch.full_like(lse, -1e6)))
+    return log_p, torch.where(masked, lse, torch.zeros_like(lse))
+
+
+def subs_ce_bwd(logits, x0, xt, modality, lse, g, V, Vt, mask_id, restrict):
+    M = logits.shape[0]
+    valid = _valid(M, V, Vt, mask_id, modality, restrict)
+    z = logits[:, :V].float()
+    p = torch.where(valid, torch.exp(z - lse[:, None]), torch.zeros_like(z))
+    onehot = F.one_hot(x0, V).float() * valid
+    dl = g[:, None] * (onehot - p)
+    dl = torch.where((xt == mask_id)[:, None], dl, torch.zeros_like(dl))
+    logits.zero_()
+    logits[:, :V] = dl.bfloat16()
+
+
+def timestep_embedding(sigma, out, B, dim=256):
+    half = dim // 2
+    freqs = torch.exp(-math.log(10000) * torch.arange(0, half, dtype=torch.float32) / half)
+    args = sigma[:, None].float() * freqs[None]
+    out[:B] = torch.cat([torch.cos(args), torch.sin(args)], -1).bfloat16()
+
+
+def silu_fwd(x, n=None):
+    return F.silu(x.float()).bfloat16()
+
+
+@torch.enable_grad()
+def silu_bwd(x, dy):
+    xf = x.float().requires_grad_()
+    F.silu(xf).backward(dy.float())
+    return xf.grad.bfloat16()
+
+
+def subs_logprobs(logits, xt, modality, V, Vt, mask_id, restrict, out_dtype=BF16):
+    M = logits.shape[0]
+    valid = _valid(M, V, Vt, mask_id, modality, restrict)
+    z = logits[:, :V].float().masked_fill(~valid, float("-inf"))
+    out = z - torch.logsumexp(z, -1, keepdim=True)
+    out = torch.where(valid, out, torch.full_like(out, -1e6))
+    if xt is not None:
+        un = (xt != mask_id)[:, None]
+        onehot = F.one_hot(xt.clamp(0, V - 1), V).bool()
+        out = torch.where(un, torch.where(onehot, torch.zeros_like(out), torch.full_like(out, -1e6)), out)
+    return out.to(out_dtype)

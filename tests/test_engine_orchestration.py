@@ -1,0 +1,65 @@
+"""CPU check of the hand-scheduled engine's orchestration with kernel test doubles (tests/fake_kernels.py).
+
+The real numerics tests are the `-m gpu` ones; this one catches plumbing mistakes (buffer shapes, adaLN chunk
+indices, gradient bookkeeping, callback order) without a GPU by swapping `unidisc_amd.dit.K` for torch stand-ins.
+"""
+import pytest
+import torch
+
+import fake_kernels
+from golden_utils import CASE_NAMES, Golden, rel_err
+from product_utils import build_product
+
+
+@pytest.fixture()
+def fake_k(monkeypatch):
+    import unidisc_amd.dit as dit_mod
+    import unidisc_amd.diffusion as diff_mod
+
+    monkeypatch.setattr(dit_mod, "K", fake_kernels)
+    monkeypatch.setattr(diff_mod, "K", fake_kernels)
+    return fake_kernels
+
+
+@pytest.mark.parametrize("name", CASE_NAMES)
+def test_compute_loss_and_grads_match_golden(name, fake_k):
+    g = Golden(name)
+    diff = build_product(g, device="cpu")
+    diff.rng_device = "cpu"
+    ready = []
+    diff.backbone.grad_ready_callback = lambda ps: ready.append(len(ps))
+    torch.manual_seed(g.case["step_seed"])
+    out = diff.training_step(g.batch(), 1)
+    assert torch.equal(diff._last["xt"], g.t("fp32/xt"))
+    assert torch.equal(diff._last["move_indices"], g.t("fp32/move_indices"))
+    assert torch.equal(out.token_mask, g.t("fp32/token_mask"))
+    l32, l16 = float(g.t("fp32/loss")), float(g.t("bf16/loss"))
+    assert abs(float(out.loss) - l32) <= 3 * abs(l16 - l32) + 5e-3 * abs(l32), (float(out.loss), l32, l16)
+    assert torch.allclose(out.nlls, g.t("fp32/nlls"), atol=0.15, rtol=0.05)
+    out.loss.backward()
+    assert sum(ready) == sum(1 for _ in diff.backbone.parameters())
+    gref = g.grads("fp32")
+    gb16 = g.grads("bf16")
+    named = dict(diff.backbone.named_parameters())
+    assert set(gref) == {k for k, p in named.items() if p.grad is not None}
+    for k, gr in gref.items():
+        budget = rel_err(gb16[k], gr)
+        e = rel_err(named[k].grad, gr)
+        assert e <= 3 * budget + 0.03, (k, e, budget)
+
+
+def test_logits_path_and_state_dict(fake_k):
+    g = Golden("c_large")
+    diff = build_product(g, device="cpu")
+    xt, sigma = g.t("fp32/xt"), None
+    with torch.no_grad():
+        logits = diff.backbone(xt, sigma, modality=g.t("fp32/modality"))
+    assert logits.shape == g.t("fp32/logits").shape and logits.dtype == torch.bfloat16
+    truth = g.t("fp32/logits")
+    assert rel_err(logits.float(), truth) <= 3 * rel_err(g.t("bf16/logits"), truth) + 5e-3
+    with torch.no_grad():
+        lp = diff.forward(xt, sigma, batch=None, modality=g.t("fp32/modality"))
+    ref = g.t("fp32/log_probs")
+    finite = ref > -1e5
+    assert torch.equal(lp.float() > -1e5, finite)
+    assert torch.allclose(lp.float()[finite], ref[finite], atol=0.1, rtol=0.05)

@@ -1,0 +1,350 @@
+"""Per-kernel parity tests on a real MI355X (pytest -m gpu): every HIP kernel vs a plain-PyTorch fp32 reference
+of the same op (tests/fake_kernels.py, evaluated on CPU copies), called through the C ABI."""
+import math
+
+import pytest
+import torch
+
+import fake_kernels as R
+from golden_utils import rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def K():
+    from unidisc_amd import kernels
+
+    return kernels
+
+
+def rnd(*shape, dtype=torch.float32, scale=1.0, seed=0):
+    g = torch.Generator().manual_seed(seed + sum(shape))
+    return (torch.randn(*shape, generator=g) * scale).to(dtype)
+
+
+def bf(x):
+    return x.to(torch.bfloat16)
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("M,N,K_", [(128, 128, 64), (256, 384, 128), (200, 136, 72), (1024, 2048, 512), (136, 1001, 256), (8, 384, 32), (40, 64, 2056)])
+@pytest.mark.parametrize("out_f32", [False, True])
+def test_gemm_nt_plain(K, M, N, K_, out_f32):
+    a, b = bf(rnd(M, K_, seed=1)), bf(rnd(N, K_, seed=2))
+    ref = a.float() @ b.float().t()
+    out = K.gemm_nt(a.to(DEV), b.to(DEV), out_dtype=torch.float32 if out_f32 else torch.bfloat16)
+    torch.cuda.synchronize()
+    tol = 1e-5 if out_f32 else 4e-3
+    assert rel_err(out.float().cpu(), ref) < tol
+    # transpose-detecting spot check on an asymmetric corner
+    assert torch.allclose(out.float().cpu()[0, :4], ref[0, :4], atol=0.05 * ref.abs().max().item())
+    assert torch.allclose(out.float().cpu()[:4, 0], ref[:4, 0], atol=0.05 * ref.abs().max().item())
+
+
+def test_gemm_identity_asymmetric(K):
+    # A = I (padded), B asymmetric: catches swapped row/col fragment maps
+    n = 128
+    a = bf(torch.eye(n))
+    b = bf(torch.arange(n * n, dtype=torch.float32).reshape(n, n) % 251 - 100)
+    out = K.gemm_nt(a.to(DEV), b.to(DEV), out_dtype=torch.float32).cpu()
+    assert torch.equal(out, b.float().t())
+
+
+def test_gemm_epilogues(K):
+    M, N, K_ = 264, 520, 192
+    a, b, bias = bf(rnd(M, K_, seed=3, scale=0.5)), bf(rnd(N, K_, seed=4, scale=0.2)), rnd(N, seed=5)
+    acc = a.float() @ b.float().t()
+    out = K.gemm_nt(a.to(DEV), b.to(DEV), epilogue=K.EPI_BIAS, bias=bias.to(DEV)).float().cpu()
+    assert rel_err(out, acc + bias) < 4e-3
+    aux = torch.empty((M, N), dtype=torch.bfloat16, device=DEV)
+    g = K.gemm_nt(a.to(DEV), b.to(DEV), epilogue=K.EPI_BIAS_GELU, bias=bias.to(DEV), aux=aux).float().cpu()
+    pre = (acc + bias).bfloat16()
+    assert rel_err(aux.float().cpu(), pre.float()) < 4e-3
+    assert rel_err(g, torch.nn.functional.gelu(aux.float().cpu(), approximate="tanh")) < 4e-3
+    u = aux.float().cpu().requires_grad_()
+    (gp,) = torch.autograd.grad(torch.nn.functional.gelu(u, approximate="tanh").sum(), u)
+    dg = K.gemm_nt(a.to(DEV), b.to(DEV), epilogue=K.EPI_DGELU, aux=aux).float().cpu()
+    assert rel_err(dg, acc * gp) < 5e-3
+    c0 = rnd(M, N, seed=6)
+    c = c0.clone().to(DEV)
+    K.gemm_nt(a.to(DEV), b.to(DEV), out=c, beta=1.0)
+    assert rel_err(c.cpu(), acc + c0) < 1e-5
+
+
+def test_gemm_strided_views_and_partial_rows(K):
+    # wgrad-style call: A = dY^T [N, M] using only the first `rows` rows, fp32 output into a view
+    M, N, Kin, rows = 256, 200, 128, 193
+    dyt, xt = bf(rnd(N, M, seed=7)), bf(rnd(Kin, M, seed=8))
+    out = torch.zeros((rows, Kin), dtype=torch.float32, device=DEV)
+    K.gemm_nt(dyt.to(DEV), xt.to(DEV), out=out, M=rows, N=Kin, K=M)
+    assert rel_err(out.cpu(), dyt[:rows].float() @ xt.float().t()) < 1e-5
+
+
+@pytest.mark.parametrize("R_,C", [(64, 64), (256, 136), (1280, 2048), (8, 192), (200, 72)])
+def test_transpose_and_colsum(K, R_, C):
+    x = bf(rnd(R_, C, seed=9))
+    cs = torch.zeros(C, dtype=torch.float32, device=DEV)
+    out = K.transpose(x.to(DEV), colsum=cs)
+    assert torch.equal(out.cpu(), x.t().contiguous())
+    assert torch.allclose(cs.cpu(), x.float().sum(0), atol=1e-3, rtol=1e-4)
+
+
+@pytest.mark.parametrize("R_,C", [(192, 64), (65, 64), (1001, 256), (256, 32)])
+def test_cast_transpose(K, R_, C):
+    w = rnd(R_, C, seed=10)
+    Rp = (R_ + 127) // 128 * 128
+    o = torch.zeros((Rp, C), dtype=torch.bfloat16, device=DEV)
+    ot = torch.zeros((C, Rp), dtype=torch.bfloat16, device=DEV)
+    K.cast_transpose(w.to(DEV), o, ot)
+    assert torch.equal(o.cpu()[:R_], w.bfloat16()) and torch.all(o.cpu()[R_:] == 0)
+    assert torch.equal(ot.cpu()[:, :R_], w.t().bfloat16()) and torch.all(ot.cpu()[:, R_:] == 0)
+
+
+def test_cast_roundtrip(K):
+    x = rnd(4099, seed=11)
+    y = torch.empty(4099, dtype=torch.bfloat16, device=DEV)
+    K.cast_f32_bf16(x.to(DEV), y)
+    assert torch.equal(y.cpu(), x.bfloat16())
+    K.cast_f32_bf16(x.to(DEV), y, scale=0.125)
+    assert torch.equal(y.cpu(), (x.bfloat16().float() * 0.125).bfloat16())
+    z = torch.empty(4099, dtype=torch.float32, device=DEV)
+    K.cast_bf16_f32(y, z, scale=2.0)
+    assert torch.equal(z.cpu(), y.cpu().float() * 2.0)
+
+
+# ------------------------------------------------------------------------------------------------ norms / residual
+def _mod_inputs(B, d, n, seed):
+    Bp = (B + 7) // 8 * 8
+    mod = torch.zeros(Bp, n * d)
+    mod[:B] = rnd(B, n * d, seed=seed, scale=0.3)
+    return bf(mod)
+
+
+@pytest.mark.parametrize("d", [64, 768, 2048])
+@pytest.mark.parametrize("nt", [0, 1])
+@pytest.mark.parametrize("mode", ["plain", "mod_all", "mod_img"])
+def test_norm_fwd_bwd(K, d, nt, mode):
+    B, L = 3, 40
+    M = B * L
+    x, w, dy = rnd(M, d, seed=12, scale=2.0) + 0.3, 1 + 0.1 * rnd(d, seed=13), bf(rnd(M, d, seed=14))
+    mod = _mod_inputs(B, d, 6, 15) if mode != "plain" else None
+    modality = (torch.arange(M) % L >= L // 2).long() if mode == "mod_img" else None
+    any_img = torch.ones(1, dtype=torch.int32) if mode == "mod_img" else None
+    idx = (3, 4)
+    yr, rstd_r, mean_r = R.norm_fwd(x, w, nt, L, mod=mod, mod_idx=idx, modality=modality, any_img=any_img)
+    g = lambda t: t.to(DEV) if t is not None else None
+    y, rstd, mean = K.norm_fwd(g(x), g(w), nt, L, mod=g(mod), mod_idx=idx, modality=g(modality), any_img=g(any_img))
+    assert rel_err(y.float().cpu(), yr.float()) < 4e-3
+    assert torch.allclose(rstd.cpu(), rstd_r, rtol=1e-5)
+    dx0 = rnd(M, d, seed=16)
+    dx_r, dw_r = dx0.clone(), torch.zeros(d)
+    dmod_r = torch.zeros(mod.shape) if mod is not None else None
+    R.norm_bwd(dy, x, rstd_r, mean_r, w, nt, L, dx_r, dw_r, accumulate=True, mod=mod, dmod=dmod_r, mod_idx=idx, modality=modality, any_img=any_img)
+    dx, dw = g(dx0.clone()), torch.zeros(d, device=DEV)
+    dmod = torch.zeros(mod.shape, device=DEV) if mod is not None else None
+    K.norm_bwd(g(dy), g(x), rstd, mean, g(w), nt, L, dx, dw, accumulate=True, mod=g(mod), dmod=dmod, mod_idx=idx, modality=g(modality), any_img=g(any_img))
+    assert rel_err(dx.cpu(), dx_r) < 1e-4
+    assert rel_err(dw.cpu(), dw_r) < 1e-3
+    if mod is not None:
+        assert rel_err(dmod.cpu(), dmod_r) < 1e-3
+
+
+@pytest.mark.parametrize("d", [64, 768, 2048])
+@pytest.mark.parametrize("variant", ["plain", "sandwich_rms", "sandwich_ln", "gate_all", "gate_img"])
+def test_residual_fwd_bwd(K, d, variant):
+    B, L = 2, 24
+    M = B * L
+    x_in, br, dx = rnd(M, d, seed=17), bf(rnd(M, d, seed=18, scale=1.5)), rnd(M, d, seed=19)
+    w_b = 1 + 0.1 * rnd(d, seed=20) if variant.startswith("sandwich") else None
+    nt = 1 if variant == "sandwich_ln" else 0
+    mod = _mod_inputs(B, d, 6, 21) if variant.startswith("gate") else None
+    gi = 5 if mod is not None else None
+    modality = (torch.arange(M) % L >= L // 3).long() if variant == "gate_img" else None
+    g = lambda t: t.to(DEV) if t is not None else None
+    xr, rstd_r, mean_r = R.residual_fwd(x_in, br, L, w_b=w_b, norm_type=nt, mod=mod, gate_idx=gi, modality=modality)
+    xo, rstd, mean = K.residual_fwd(g(x_in), g(br), L, w_b=g(w_b), norm_type=nt, mod=g(mod), gate_idx=gi, modality=g(modality))
+    assert rel_err(xo.cpu(), xr) < 2e-3  # bf16 rounding of the normalised branch can flip an ulp
+    dw_r = torch.zeros(d) if w_b is not None else None
+    dmod_r = torch.zeros(mod.shape) if mod is not None else None
+    db_r = R.residual_bwd(dx, br, L, w_b=w_b, rstd=rstd_r, mean=mean_r, norm_type=nt, mod=mod, dmod=dmod_r, gate_idx=gi, modality=modality, dw_b=dw_r)
+    dw = torch.zeros(d, device=DEV) if w_b is not None else None
+    dmod = torch.zeros(mod.shape, device=DEV) if mod is not None else None
+    db = K.residual_bwd(g(dx), g(br), L, w_b=g(w_b), rstd=rstd, mean=mean, norm_type=nt, mod=g(mod), dmod=dmod, gate_idx=gi, modality=g(modality), dw_b=dw)
+    assert rel_err(db.float().cpu(), db_r.float()) < 6e-3
+    if w_b is not None:
+        assert rel_err(dw.cpu(), dw_r) < 5e-3
+    if mod is not None:
+        assert rel_err(dmod.cpu(), dmod_r) < 5e-3
+
+
+def test_residual_dropout_mask_consistent(K):
+    M, d, L, p = 64, 256, 32, 0.25
+    x_in, br, dx = torch.zeros(M, d), bf(torch.ones(M, d)), torch.ones(M, d)
+    xo, _, _ = K.residual_fwd(x_in.to(DEV), br.to(DEV), L, p_drop=p, seed=1234)
+    xo = xo.cpu()
+    keep = xo != 0
+    assert abs(keep.float().mean().item() - (1 - p)) < 0.02
+    assert torch.allclose(xo[keep], torch.full_like(xo[keep], 1 / (1 - p)), rtol=1e-6)
+    db = K.residual_bwd(dx.to(DEV), br.to(DEV), L, p_drop=p, seed=1234).float().cpu()
+    assert torch.equal(db != 0, keep)
+    xo2, _, _ = K.residual_fwd(x_in.to(DEV), br.to(DEV), L, p_drop=p, seed=1235)
+    assert not torch.equal(xo2.cpu() != 0, keep)
+
+
+# ------------------------------------------------------------------------------------------------ qk-norm + rope
+@pytest.mark.parametrize("d,D", [(64, 32), (768, 64), (2048, 128), (256, 64)])
+@pytest.mark.parametrize("qk_norm", [True, False])
+@pytest.mark.parametrize("per_sample", [False, True])
+def test_qknorm_rope(K, d, D, qk_norm, per_sample):
+    B, L = 2, 20
+    M = B * L
+    qkv, dqkr = bf(rnd(M, 3 * d, seed=22)), bf(rnd(M, 2 * d, seed=23))
+    if per_sample:
+        ang = rnd(B, L, D // 2, seed=24)
+    else:
+        ang = rnd(L, D // 2, seed=24)
+    cos, sin = ang.cos().contiguous(), ang.sin().contiguous()
+    gq, bq, gk, bk = (1 + 0.1 * rnd(d, seed=25), 0.1 * rnd(d, seed=26), 1 + 0.1 * rnd(d, seed=27), 0.1 * rnd(d, seed=28)) if qk_norm else (None,) * 4
+    g = lambda t: t.to(DEV) if t is not None else None
+    ref, _ = R.qknorm_rope_fwd(qkv, cos, sin, L, D, gq=gq, bq=bq, gk=gk, bk=bk)
+    out, stats = K.qknorm_rope_fwd(g(qkv), g(cos), g(sin), L, D, gq=g(gq), bq=g(bq), gk=g(gk), bk=g(bk))
+    assert rel_err(out.float().cpu(), ref.float()) < 6e-3
+    dqkv_r = torch.zeros(M, 3 * d, dtype=torch.bfloat16)
+    grads_r = [torch.zeros(d) for _ in range(4)] if qk_norm else [None] * 4
+    R.qknorm_rope_bwd(dqkr, qkv, dqkv_r, cos, sin, L, D, gq=gq, gk=gk, dgq=grads_r[0], dbq=grads_r[1], dgk=grads_r[2], dbk=grads_r[3])
+    dqkv = torch.zeros(M, 3 * d, dtype=torch.bfloat16, device=DEV)
+    grads = [torch.zeros(d, device=DEV) for _ in range(4)] if qk_norm else [None] * 4
+    K.qknorm_rope_bwd(g(dqkr), g(qkv), dqkv, g(cos), g(sin), L, D, gq=g(gq), gk=g(gk), stats=stats, dgq=grads[0], dbq=grads[1], dgk=grads[2], dbk=grads[3])
+    assert rel_err(dqkv.float().cpu()[:, :2 * d], dqkv_r.float()[:, :2 * d]) < 8e-3
+    assert torch.all(dqkv.cpu()[:, 2 * d:] == 0)
+    if qk_norm:
+        for a, b in zip(grads, grads_r):
+            assert rel_err(a.cpu(), b) < 5e-3
+
+
+# ------------------------------------------------------------------------------------------------ attention
+def _attn_ref(q, k, v, B, L, H, D, sid, do):
+    q, k, v = (t.float().clone().requires_grad_() for t in (q, k, v))
+    with torch.enable_grad():
+        o = R._attn(q, k, v, B, L, H, D, sid)
+        o.backward(do.float())
+    return o.detach(), q.grad, k.grad, v.grad
+
+
+@pytest.mark.parametrize("tr", [True, False])
+@pytest.mark.parametrize("D,H", [(32, 2), (64, 3), (128, 2)])
+@pytest.mark.parametrize("L", [32, 100, 384])
+@pytest.mark.parametrize("use_sid", [False, True])
+def test_attention_fwd_bwd(K, tr, D, H, L, use_sid):
+    B = 2
+    d = H * D
+    M = B * L
+    q, k, v, do = (bf(rnd(M, d, seed=s)) for s in (30, 31, 32, 33))
+    sid = None
+    if use_sid:
+        sid = torch.zeros(B, L, dtype=torch.int64)
+        sid[:, L // 3:] = 1
+        sid[:, (2 * L) // 3:] = 2
+        sid[1, -5:] = -1  # padding tail
+    K.set_tr_read(tr)
+    try:
+        o_r, dq_r, dk_r, dv_r = _attn_ref(q, k, v, B, L, H, D, sid, do)
+        g = lambda t: t.to(DEV) if t is not None else None
+        o, lse = K.attention_fwd_generic(g(q), g(k), g(v), B, L, H, D, g(sid))
+        assert rel_err(o.float().cpu(), o_r) < 1e-2
+        dq, dk, dv = K.attention_bwd_generic(g(q), g(k), g(v), o, g(do), lse, B, L, H, D, g(sid))
+        assert rel_err(dv.float().cpu(), dv_r) < 1.5e-2
+        assert rel_err(dq.float().cpu(), dq_r) < 1.5e-2
+        assert rel_err(dk.float().cpu(), dk_r) < 1.5e-2
+        # LSE: natural-log LSE of scaled scores = lse2 * ln2
+        if not use_sid:
+            s = (q.float().reshape(B, L, H, D).transpose(1, 2) @ k.float().reshape(B, L, H, D).transpose(1, 2).transpose(-1, -2)) / math.sqrt(D)
+            assert torch.allclose(lse.cpu() * math.log(2.0), torch.logsumexp(s, -1), atol=2e-2, rtol=1e-3)
+    finally:
+        K.set_tr_read(True)
+
+
+def test_attention_online_softmax_rescale_branch(K):
+    # a key far above the others late in the sequence forces the running max to jump (rule: test the rare branch)
+    B, H, L, D = 1, 1, 256, 64
+    q, k, v, do = (bf(rnd(L, D, seed=s)) for s in (40, 41, 42, 43))
+    k[200] = k[200] * 12
+    q[7] = bf(k[200].float() / 4)
+    o_r, dq_r, dk_r, dv_r = _attn_ref(q, k, v, B, L, H, D, None, do)
+    o, lse = K.attention_fwd_generic(q.to(DEV), k.to(DEV), v.to(DEV), B, L, H, D)
+    assert rel_err(o.float().cpu(), o_r) < 1e-2
+    assert torch.allclose(o.float().cpu()[7], o_r[7], atol=3e-2)
+    dq, dk, dv = K.attention_bwd_generic(q.to(DEV), k.to(DEV), v.to(DEV), o, do.to(DEV), lse, B, L, H, D)
+    assert rel_err(dq.float().cpu(), dq_r) < 2e-2 and rel_err(dk.float().cpu(), dk_r) < 2e-2 and rel_err(dv.float().cpu(), dv_r) < 2e-2
+
+
+# ------------------------------------------------------------------------------------------------ embedding / CE / small ops
+def test_embedding_fwd_bwd(K):
+    V, d, M, hot = 97, 192, 512, 40
+    E, Em = rnd(V, d, seed=50), rnd(2, d, seed=51)
+    ids = torch.randint(0, V, (M,), generator=torch.Generator().manual_seed(1))
+    ids[::2] = hot
+    mod = (torch.arange(M) % 7 > 2).long()
+    x = K.embedding_fwd(ids.to(DEV), E.to(DEV), mod.to(DEV), Em.to(DEV)).cpu()
+    assert torch.equal(x, R.embedding_fwd(ids, E, mod, Em))
+    dx = rnd(M, d, seed=52)
+    dE, dEm = torch.zeros(V, d, device=DEV), torch.zeros(2, d, device=DEV)
+    K.embedding_bwd(ids.to(DEV), dx.to(DEV), dE, hot, modality=mod.to(DEV), dEm=dEm)
+    dE_r, dEm_r = torch.zeros(V, d), torch.zeros(2, d)
+    R.embedding_bwd(ids, dx, dE_r, hot, modality=mod, dEm=dEm_r)
+    assert torch.allclose(dE.cpu(), dE_r, atol=1e-4, rtol=1e-5) and torch.allclose(dEm.cpu(), dEm_r, atol=1e-3, rtol=1e-5)
+
+
+@pytest.mark.parametrize("V,Vt", [(65, 41), (1001, 1001), (40193, 32001)])
+@pytest.mark.parametrize("restrict", [True, False])
+def test_subs_ce(K, V, Vt, restrict):
+    if restrict and V == Vt:
+        pytest.skip("text-only vocabulary has nothing to restrict")
+    M = 48
+    mask_id = Vt - 1
+    Vp = (V + 127) // 128 * 128
+    logits = torch.zeros(M, Vp, dtype=torch.bfloat16)
+    logits[:, :V] = bf(rnd(M, V, seed=60, scale=2.0))
+    modality = (torch.arange(M) % 4 >= 2).long() if V > Vt else torch.zeros(M, dtype=torch.long)
+    gen = torch.Generator().manual_seed(3)
+    x0 = torch.where(modality == 1, torch.randint(Vt, max(V, Vt + 1), (M,), generator=gen), torch.randint(0, Vt - 1, (M,), generator=gen))
+    xt = x0.clone()
+    xt[::2] = mask_id
+    g_up = rnd(M, seed=61)
+    lp_r, lse_r = R.subs_ce_fwd(logits, x0, xt, modality, V, Vt, mask_id, restrict)
+    gl = logits.clone().to(DEV)
+    lp, lse = K.subs_ce_fwd(gl, x0.to(DEV), xt.to(DEV), modality.to(DEV), V, Vt, mask_id, restrict)
+    assert torch.allclose(lp.cpu(), lp_r, atol=2e-4, rtol=1e-5)
+    assert torch.all(lp.cpu()[1::2] == 0)
+    full = K.subs_logprobs(gl, xt.to(DEV), modality.to(DEV), V, Vt, mask_id, restrict, out_dtype=torch.float32).cpu()
+    full_r = R.subs_logprobs(logits, xt, modality, V, Vt, mask_id, restrict, out_dtype=torch.float32)
+    assert torch.allclose(full, full_r, atol=2e-4, rtol=1e-5)
+    assert torch.allclose(full.gather(1, x0[:, None])[:, 0], lp.cpu(), atol=2e-4)
+    ref = logits.clone()
+    R.subs_ce_bwd(ref, x0, xt, modality, lse_r, g_up, V, Vt, mask_id, restrict)
+    K.subs_ce_bwd(gl, x0.to(DEV), xt.to(DEV), modality.to(DEV), lse, g_up.to(DEV), V, Vt, mask_id, restrict)
+    assert rel_err(gl.float().cpu(), ref.float()) < 6e-3
+    assert torch.all(gl.cpu()[:, V:] == 0) and torch.all(gl.cpu()[1::2] == 0)
+
+
+def test_small_ops(K):
+    B, Bp = 5, 8
+    sigma = torch.rand(B, generator=torch.Generator().manual_seed(5)) * 3
+    te = torch.zeros(Bp, 256, dtype=torch.bfloat16, device=DEV)
+    K.timestep_embedding(sigma.to(DEV), te, B, 256)
+    ref = torch.zeros(Bp, 256, dtype=torch.bfloat16)
+    R.timestep_embedding(sigma, ref, B, 256)
+    assert torch.allclose(te.float().cpu(), ref.float(), atol=1e-2)
+    x, dy = bf(rnd(Bp, 128, seed=70)), bf(rnd(Bp, 128, seed=71))
+    assert rel_err(K.silu_fwd(x.to(DEV)).float().cpu(), R.silu_fwd(x).float()) < 4e-3
+    assert rel_err(K.silu_bwd(x.to(DEV), dy.to(DEV)).float().cpu(), R.silu_bwd(x, dy).float()) < 6e-3
+
+
+def test_error_reporting(K):
+    a = torch.zeros(8, 12, dtype=torch.bfloat16, device=DEV)  # K = 12 is not a multiple of 8
+    with pytest.raises(RuntimeError, match="multiples of 8"):
+        K.gemm_nt(a, a)
+    with pytest.raises(RuntimeError, match="GPU tensors"):
+        K.gemm_nt(torch.zeros(8, 8, dtype=torch.bfloat16), torch.zeros(8, 8, dtype=torch.bfloat16))

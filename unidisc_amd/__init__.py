@@ -1,0 +1,12 @@
+"""unidisc_amd — MI355X-native (gfx950) implementation of UniDisc's discrete-diffusion denoising hot path.
+
+Drop-in boundary: :class:`unidisc_amd.dit.DIT` for ``models/dit.py::DIT`` and
+:class:`unidisc_amd.diffusion.Diffusion` for the hot-path methods of ``model.py::Diffusion``.
+Compute runs in hand-written HIP kernels behind the C ABI in ``include/unidisc_hip.h``; there is no CPU fallback.
+"""
+from .config import Cfg, make_config, MODEL_PRESETS  # noqa: F401
+from .dit import DIT  # noqa: F401
+from .diffusion import Diffusion, Loss  # noqa: F401
+from .noise_schedule import LogLinearNoise  # noqa: F401
+
+__all__ = ["DIT", "Diffusion", "Loss", "LogLinearNoise", "Cfg", "make_config", "MODEL_PRESETS"]

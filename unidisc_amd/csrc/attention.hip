@@ -1,0 +1,540 @@
+// Bidirectional flash attention (forward, dQ, dK/dV) on gfx950 MFMA, bf16 in / fp32 accumulate.
+//
+// Replaces flash_attn_qkvpacked_func / SDPA / FlexAttention-with-document-mask in the reference
+// (models/dit.py:826-829, :843, :784-812; mask semantics model_utils.py:740-771).
+//
+// Layout idea (wave64, v_mfma_f32_32x32x16_bf16): scores are computed TRANSPOSED, S^T = K·Q^T, so that a
+// lane owns ONE query column (lane & 31) and its 16 accumulator registers walk the key rows.  Softmax
+// statistics are then lane-local (one __shfl_xor with lane^32 joins the two half-waves), the rescale of
+// O^T is lane-local, and P^T feeds the second MFMA as its B operand straight from registers: for a
+// 16-key chunk the accumulator registers 8c..8c+7 of a lane are, in order, exactly the 8 k-slots the B
+// operand wants once the A operand (V^T) is gathered with the same key permutation
+//      k-slot (half h, j) -> key 4h + j (j < 4), 8 + 4h + (j - 4) (j >= 4),
+// which is what two ds_read_b64_tr_b16 transposing LDS reads of a row-major V tile deliver.
+// K/V (or Q/dO) tiles are staged global -> registers -> XOR-swizzled LDS with the next tile's loads in
+// flight under the current tile's MFMAs.  The same swizzle is conflict-free for the ds_read_b128
+// fragment reads and for the transposing reads.
+#include "common.h"
+#include "../../include/unidisc_hip.h"
+
+namespace {
+using namespace udm;
+
+template <int D>
+__device__ __forceinline__ int swz(int row) {
+  if (D == 128) return (row & 15) ^ ((row & 3) << 2);
+  if (D == 64) { int x = row >> 1; return (x & 7) ^ ((x & 1) << 2); }
+  return (row >> 2) & 3;  // D == 32
+}
+// byte offset of 16-byte slot `slot` of row `row` in a [rows][D] bf16 tile
+template <int D>
+__device__ __forceinline__ int tile_off(int row, int slot) { return row * (2 * D) + ((slot ^ swz<D>(row)) << 4); }
+
+__device__ __forceinline__ bf16x8_t lds_frag(const char* base, int off) { return *reinterpret_cast<const bf16x8_t*>(base + off); }
+
+// A-operand fragment of X^T for the permuted 16-row chunk starting at row r0 (rows = contraction index),
+// 32 columns starting at c0:  element j of lane (col = lane&31, half h = lane>>5) is
+//   X[r0 + 4h + j][c0 + col] (j<4),  X[r0 + 8 + 4h + (j-4)][c0 + col] (j>=4).
+template <int D, bool USE_TR>
+__device__ __forceinline__ bf16x8_t lds_frag_T(const char* tile, int r0, int c0, int lane) {
+  const int hi = lane >> 5;
+  if (USE_TR) {
+    const int g1 = (lane >> 4) & 1, p = lane & 15;
+    const int row = r0 + 4 * hi + (p >> 2);
+    const int col = c0 + g1 * 16 + (p & 3) * 4;
+    const int o1 = tile_off<D>(row, col >> 3) + (col & 7) * 2;
+    const int o2 = tile_off<D>(row + 8, col >> 3) + (col & 7) * 2;
+    s16x4_t a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((UDM_LDS s16x4_t*)(tile + o1));
+    s16x4_t b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((UDM_LDS s16x4_t*)(tile + o2));
+    s16x8_t r = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8_t, r);
+  } else {
+    const int col = c0 + (lane & 31);
+    s16x8_t r;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int row = r0 + (j < 4 ? 4 * hi + j : 8 + 4 * hi + (j - 4));
+      r[j] = *reinterpret_cast<const short*>(tile + tile_off<D>(row, col >> 3) + (col & 7) * 2);
+    }
+    return __builtin_bit_cast(bf16x8_t, r);
+  }
+}
+
+__device__ __forceinline__ bf16x8_t pack8(const float* p) {
+  uint4 u = make_uint4(pack2bf(p[0], p[1]), pack2bf(p[2], p[3]), pack2bf(p[4], p[5]), pack2bf(p[6], p[7]));
+  return __builtin_bit_cast(bf16x8_t, u);
+}
+__device__ __forceinline__ bf16x8_t load_frag_global(const bf16_t* p, bool ok) {
+  uint4 u = ok ? *reinterpret_cast<const uint4*>(p) : make_uint4(0, 0, 0, 0);
+  return __builtin_bit_cast(bf16x8_t, u);
+}
+
+struct AttnArgs {
+  const bf16_t* q; const bf16_t* k; const bf16_t* v; const bf16_t* o; const bf16_t* dout;
+  bf16_t* out;          // fwd: O;            bwd-dq: dQ
+  bf16_t* out2;         // bwd-dkv: dK
+  bf16_t* out3;         // bwd-dkv: dV
+  float* lse;           // [B,H,L] log2-domain log-sum-exp of scaled scores
+  const float* delta;   // [B,H,L] rowsum(dO * O)
+  const int64_t* sample_ids;  // [B,L] or null
+  long q_stride, k_stride, v_stride, o_stride, do_stride, out_stride, out2_stride, out3_stride;
+  int B, H, L;
+  float scale_log2;     // log2(e) / sqrt(D)
+  float scale;          // 1 / sqrt(D)
+};
+
+// stage a [ROWS][D] tile: registers <- global (predicated on row < L), then registers -> swizzled LDS
+template <int D, int ROWS>
+struct TileStager {
+  static constexpr int CPR = D / 8;                   // 16-byte chunks per row
+  static constexpr int CPT = ROWS * CPR / 256;        // chunks per thread
+  static_assert(CPT >= 1, "tile too small for 256 threads");
+  uint4 r[CPT];
+  __device__ __forceinline__ void load(const bf16_t* base, long stride, int row0, int L, int tid) {
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {
+      const int c = tid + i * 256, row = c / CPR, s = c % CPR;
+      r[i] = (row0 + row < L) ? *reinterpret_cast<const uint4*>(base + (long)(row0 + row) * stride + s * 8) : make_uint4(0, 0, 0, 0);
+    }
+  }
+  __device__ __forceinline__ void store(char* tile, int tid) const {
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {
+      const int c = tid + i * 256, row = c / CPR, s = c % CPR;
+      *reinterpret_cast<uint4*>(tile + tile_off<D>(row, s)) = r[i];
+    }
+  }
+};
+
+constexpr int BQ = 128;   // query rows per block (4 waves x 32)
+constexpr int BKV = 64;   // keys per tile
+
+// ------------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------------
+template <int D, bool HAS_SID, bool USE_TR>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
+  __shared__ __attribute__((aligned(16))) char Ks[BKV * D * 2];
+  __shared__ __attribute__((aligned(16))) char Vs[BKV * D * 2];
+  __shared__ long sidk[BKV];
+  constexpr int KS = D / 16, DB = D / 32;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int qi = blockIdx.x * BQ + wave * 32 + l31;
+  const bool q_ok = qi < a.L;
+  const long rowbase = (long)b * a.L;
+
+  bf16x8_t qf[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) qf[ks] = load_frag_global(a.q + (rowbase + qi) * a.q_stride + h * D + ks * 16 + hi * 8, q_ok);
+  long sid_q = 0;
+  if (HAS_SID) sid_q = q_ok ? a.sample_ids[rowbase + qi] : -1;
+
+  f32x16_t oT[DB];
+#pragma unroll
+  for (int i = 0; i < DB; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oT[i][r] = 0.f;
+  float m = -INFINITY, lsum = 0.f;
+  const float c = a.scale_log2;
+
+  const bf16_t* kbase = a.k + rowbase * a.k_stride + h * D;
+  const bf16_t* vbase = a.v + rowbase * a.v_stride + h * D;
+  TileStager<D, BKV> sk, sv;
+  const int nkv = (a.L + BKV - 1) / BKV;
+  sk.load(kbase, a.k_stride, 0, a.L, tid);
+  sv.load(vbase, a.v_stride, 0, a.L, tid);
+  for (int t = 0; t < nkv; ++t) {
+    const int kv0 = t * BKV;
+    __syncthreads();
+    sk.store(Ks, tid);
+    sv.store(Vs, tid);
+    if (HAS_SID && tid < BKV) sidk[tid] = (kv0 + tid < a.L) ? a.sample_ids[rowbase + kv0 + tid] : -2;
+    __syncthreads();
+    if (t + 1 < nkv) {
+      sk.load(kbase, a.k_stride, kv0 + BKV, a.L, tid);
+      sv.load(vbase, a.v_stride, kv0 + BKV, a.L, tid);
+    }
+    // S^T = K Q^T : [64 keys] x [32 queries per wave]
+    f32x16_t sT[2];
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sT[f][r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        bf16x8_t kfr = lds_frag(Ks, tile_off<D>(f * 32 + l31, ks * 2 + hi));
+        sT[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr, qf[ks], sT[f], 0, 0, 0);
+      }
+    }
+    if (HAS_SID || kv0 + BKV > a.L) {
+#pragma unroll
+      for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int kl = f * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          bool ok = kv0 + kl < a.L;
+          if (HAS_SID) ok = ok && (sidk[kl] == sid_q) && (sid_q >= 0);
+          if (!ok) sT[f][r] = -INFINITY;
+        }
+    }
+    float mloc = -INFINITY;
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, sT[f][r]);
+    mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+    const float m_new = fmaxf(m, mloc);
+    const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+    const float alpha = __builtin_amdgcn_exp2f((m - m_use) * c);
+    float psum = 0.f;
+    float p[2][16];
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        p[f][r] = __builtin_amdgcn_exp2f(sT[f][r] * c - m_use * c);
+        psum += p[f][r];
+      }
+    lsum = lsum * alpha + psum;
+    m = m_new;
+#pragma unroll
+    for (int i = 0; i < DB; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oT[i][r] *= alpha;
+    // O^T += V^T P^T
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc) {
+      bf16x8_t pb = pack8(&p[cc >> 1][8 * (cc & 1)]);
+#pragma unroll
+      for (int i = 0; i < DB; ++i) {
+        bf16x8_t vt = lds_frag_T<D, USE_TR>(Vs, cc * 16, i * 32, lane);
+        oT[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vt, pb, oT[i], 0, 0, 0);
+      }
+    }
+  }
+  const float ltot = lsum + __shfl_xor(lsum, 32, 64);
+  const float inv = ltot > 0.f ? 1.f / ltot : 0.f;
+  if (q_ok) {
+    bf16_t* op = a.out + (rowbase + qi) * a.out_stride + h * D;
+#pragma unroll
+    for (int i = 0; i < DB; ++i)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const int d0 = i * 32 + 8 * rg + 4 * hi;
+        *reinterpret_cast<uint2*>(op + d0) = make_uint2(pack2bf(oT[i][rg * 4] * inv, oT[i][rg * 4 + 1] * inv), pack2bf(oT[i][rg * 4 + 2] * inv, oT[i][rg * 4 + 3] * inv));
+      }
+    if (hi == 0) a.lse[((long)b * a.H + h) * a.L + qi] = ltot > 0.f ? m * c + log2f(ltot) : INFINITY;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// delta[b,h,q] = sum_d dO[b,q,h,d] * O[b,q,h,d]
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout, float* __restrict__ delta, long o_stride,
+                                                        long do_stride, int B, int H, int L, int D) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lph = D / 8;  // lanes per head
+  const int d = H * D;
+  const long M = (long)B * L;
+  for (long row = (long)blockIdx.x * 4 + wave; row < M; row += (long)gridDim.x * 4) {
+    const int b = (int)(row / L), l = (int)(row % L);
+    for (int t = lane; t < d / 8; t += 64) {
+      uint4 uo = *reinterpret_cast<const uint4*>(o + row * o_stride + t * 8);
+      uint4 ud = *reinterpret_cast<const uint4*>(dout + row * do_stride + t * 8);
+      const uint32_t wo[4] = {uo.x, uo.y, uo.z, uo.w}, wd[4] = {ud.x, ud.y, ud.z, ud.w};
+      float s = 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        s += __uint_as_float(wo[k] << 16) * __uint_as_float(wd[k] << 16);
+        s += __uint_as_float(wo[k] & 0xffff0000u) * __uint_as_float(wd[k] & 0xffff0000u);
+      }
+      for (int off = 1; off < lph; off <<= 1) s += __shfl_xor(s, off, 64);
+      if ((lane & (lph - 1)) == 0) delta[((long)b * H + t / lph) * L + l] = s;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward, dQ: block owns 128 queries, walks key tiles.  dQ^T = K^T dS^T (lane owns a query column).
+// ------------------------------------------------------------------------------------------------
+template <int D, bool HAS_SID, bool USE_TR>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
+  __shared__ __attribute__((aligned(16))) char Ks[BKV * D * 2];
+  __shared__ __attribute__((aligned(16))) char Vs[BKV * D * 2];
+  __shared__ long sidk[BKV];
+  constexpr int KS = D / 16, DB = D / 32;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int qi = blockIdx.x * BQ + wave * 32 + l31;
+  const bool q_ok = qi < a.L;
+  const long rowbase = (long)b * a.L;
+
+  bf16x8_t qf[KS], dof[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    qf[ks] = load_frag_global(a.q + (rowbase + qi) * a.q_stride + h * D + ks * 16 + hi * 8, q_ok);
+    dof[ks] = load_frag_global(a.dout + (rowbase + qi) * a.do_stride + h * D + ks * 16 + hi * 8, q_ok);
+  }
+  long sid_q = 0;
+  if (HAS_SID) sid_q = q_ok ? a.sample_ids[rowbase + qi] : -1;
+  const long sidx = ((long)b * a.H + h) * a.L + qi;
+  const float lse_q = q_ok ? a.lse[sidx] : INFINITY;
+  const float delta_q = q_ok ? a.delta[sidx] : 0.f;
+  const float c = a.scale_log2;
+
+  f32x16_t dqT[DB];
+#pragma unroll
+  for (int i = 0; i < DB; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dqT[i][r] = 0.f;
+
+  const bf16_t* kbase = a.k + rowbase * a.k_stride + h * D;
+  const bf16_t* vbase = a.v + rowbase * a.v_stride + h * D;
+  TileStager<D, BKV> sk, sv;
+  const int nkv = (a.L + BKV - 1) / BKV;
+  sk.load(kbase, a.k_stride, 0, a.L, tid);
+  sv.load(vbase, a.v_stride, 0, a.L, tid);
+  for (int t = 0; t < nkv; ++t) {
+    const int kv0 = t * BKV;
+    __syncthreads();
+    sk.store(Ks, tid);
+    sv.store(Vs, tid);
+    if (HAS_SID && tid < BKV) sidk[tid] = (kv0 + tid < a.L) ? a.sample_ids[rowbase + kv0 + tid] : -2;
+    __syncthreads();
+    if (t + 1 < nkv) {
+      sk.load(kbase, a.k_stride, kv0 + BKV, a.L, tid);
+      sv.load(vbase, a.v_stride, kv0 + BKV, a.L, tid);
+    }
+    float ds[2][16];
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+      f32x16_t sT, dpT;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { sT[r] = 0.f; dpT[r] = 0.f; }
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const int off = tile_off<D>(f * 32 + l31, ks * 2 + hi);
+        sT = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag(Ks, off), qf[ks], sT, 0, 0, 0);
+        dpT = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag(Vs, off), dof[ks], dpT, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int kl = f * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        bool ok = (kv0 + kl < a.L) && q_ok;
+        if (HAS_SID) ok = ok && (sidk[kl] == sid_q) && (sid_q >= 0);
+        const float pv = ok ? __builtin_amdgcn_exp2f(sT[r] * c - lse_q) : 0.f;
+        ds[f][r] = pv * (dpT[r] - delta_q);
+      }
+    }
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc) {
+      bf16x8_t dsb = pack8(&ds[cc >> 1][8 * (cc & 1)]);
+#pragma unroll
+      for (int i = 0; i < DB; ++i) {
+        bf16x8_t kt = lds_frag_T<D, USE_TR>(Ks, cc * 16, i * 32, lane);
+        dqT[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kt, dsb, dqT[i], 0, 0, 0);
+      }
+    }
+  }
+  if (q_ok) {
+    bf16_t* op = a.out + (rowbase + qi) * a.out_stride + h * D;
+#pragma unroll
+    for (int i = 0; i < DB; ++i)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const int d0 = i * 32 + 8 * rg + 4 * hi;
+        *reinterpret_cast<uint2*>(op + d0) = make_uint2(pack2bf(dqT[i][rg * 4] * a.scale, dqT[i][rg * 4 + 1] * a.scale),
+                                                        pack2bf(dqT[i][rg * 4 + 2] * a.scale, dqT[i][rg * 4 + 3] * a.scale));
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward, dK/dV: block owns 128 keys (lane owns a key column), walks 64-query tiles.
+//   S = Q K^T (regs walk queries), dP = dO V^T, dV^T += dO^T P, dK^T += Q^T dS
+// ------------------------------------------------------------------------------------------------
+constexpr int BQT = 64;
+template <int D, bool HAS_SID, bool USE_TR>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
+  __shared__ __attribute__((aligned(16))) char Qs[BQT * D * 2];
+  __shared__ __attribute__((aligned(16))) char Os[BQT * D * 2];
+  __shared__ __attribute__((aligned(16))) float lse_s[BQT];
+  __shared__ __attribute__((aligned(16))) float delta_s[BQT];
+  __shared__ long sidq[BQT];
+  constexpr int KS = D / 16, DB = D / 32;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int ki = blockIdx.x * 128 + wave * 32 + l31;
+  const bool k_ok = ki < a.L;
+  const long rowbase = (long)b * a.L;
+
+  bf16x8_t kf[KS], vf[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    kf[ks] = load_frag_global(a.k + (rowbase + ki) * a.k_stride + h * D + ks * 16 + hi * 8, k_ok);
+    vf[ks] = load_frag_global(a.v + (rowbase + ki) * a.v_stride + h * D + ks * 16 + hi * 8, k_ok);
+  }
+  long sid_k = 0;
+  if (HAS_SID) sid_k = k_ok ? a.sample_ids[rowbase + ki] : -2;
+  const float c = a.scale_log2;
+
+  f32x16_t dkT[DB], dvT[DB];
+#pragma unroll
+  for (int i = 0; i < DB; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dkT[i][r] = 0.f; dvT[i][r] = 0.f; }
+
+  const bf16_t* qbase = a.q + rowbase * a.q_stride + h * D;
+  const bf16_t* dobase = a.dout + rowbase * a.do_stride + h * D;
+  const long sbase = ((long)b * a.H + h) * a.L;
+  TileStager<D, BQT> sq, so;
+  const int nq = (a.L + BQT - 1) / BQT;
+  sq.load(qbase, a.q_stride, 0, a.L, tid);
+  so.load(dobase, a.do_stride, 0, a.L, tid);
+  for (int t = 0; t < nq; ++t) {
+    const int q0 = t * BQT;
+    __syncthreads();
+    sq.store(Qs, tid);
+    so.store(Os, tid);
+    if (tid < BQT) {
+      const bool ok = q0 + tid < a.L;
+      lse_s[tid] = ok ? a.lse[sbase + q0 + tid] : INFINITY;
+      delta_s[tid] = ok ? a.delta[sbase + q0 + tid] : 0.f;
+      if (HAS_SID) sidq[tid] = ok ? a.sample_ids[rowbase + q0 + tid] : -1;
+    }
+    __syncthreads();
+    if (t + 1 < nq) {
+      sq.load(qbase, a.q_stride, q0 + BQT, a.L, tid);
+      so.load(dobase, a.do_stride, q0 + BQT, a.L, tid);
+    }
+#pragma unroll
+    for (int qs = 0; qs < 2; ++qs) {
+      f32x16_t s, dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const int off = tile_off<D>(qs * 32 + l31, ks * 2 + hi);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag(Qs, off), kf[ks], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag(Os, off), vf[ks], dp, 0, 0, 0);
+      }
+      float p[16], ds[16];
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const int ql0 = qs * 32 + 8 * rg + 4 * hi;
+        const float4 l4 = *reinterpret_cast<const float4*>(lse_s + ql0);
+        const float4 d4 = *reinterpret_cast<const float4*>(delta_s + ql0);
+        const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dv[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = rg * 4 + e;
+          bool ok = k_ok && (q0 + ql0 + e < a.L);
+          if (HAS_SID) ok = ok && (sidq[ql0 + e] == sid_k) && (sid_k >= 0);
+          p[r] = ok ? __builtin_amdgcn_exp2f(s[r] * c - lv[e]) : 0.f;
+          ds[r] = p[r] * (dp[r] - dv[e]);
+        }
+      }
+#pragma unroll
+      for (int c2 = 0; c2 < 2; ++c2) {
+        bf16x8_t pb = pack8(&p[8 * c2]);
+        bf16x8_t dsb = pack8(&ds[8 * c2]);
+#pragma unroll
+        for (int i = 0; i < DB; ++i) {
+          bf16x8_t dot = lds_frag_T<D, USE_TR>(Os, qs * 32 + c2 * 16, i * 32, lane);
+          dvT[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dot, pb, dvT[i], 0, 0, 0);
+          bf16x8_t qt = lds_frag_T<D, USE_TR>(Qs, qs * 32 + c2 * 16, i * 32, lane);
+          dkT[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qt, dsb, dkT[i], 0, 0, 0);
+        }
+      }
+    }
+  }
+  if (k_ok) {
+    bf16_t* kp = a.out2 + (rowbase + ki) * a.out2_stride + h * D;
+    bf16_t* vp = a.out3 + (rowbase + ki) * a.out3_stride + h * D;
+#pragma unroll
+    for (int i = 0; i < DB; ++i)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const int d0 = i * 32 + 8 * rg + 4 * hi;
+        *reinterpret_cast<uint2*>(kp + d0) = make_uint2(pack2bf(dkT[i][rg * 4] * a.scale, dkT[i][rg * 4 + 1] * a.scale),
+                                                        pack2bf(dkT[i][rg * 4 + 2] * a.scale, dkT[i][rg * 4 + 3] * a.scale));
+        *reinterpret_cast<uint2*>(vp + d0) = make_uint2(pack2bf(dvT[i][rg * 4], dvT[i][rg * 4 + 1]), pack2bf(dvT[i][rg * 4 + 2], dvT[i][rg * 4 + 3]));
+      }
+  }
+}
+
+template <int D, bool SID, bool TR>
+void launch_fwd(const AttnArgs& a, hipStream_t s) {
+  dim3 grid((a.L + BQ - 1) / BQ, a.H, a.B);
+  hipLaunchKernelGGL((attn_fwd_kernel<D, SID, TR>), grid, dim3(256), 0, s, a);
+}
+template <int D, bool SID, bool TR>
+void launch_bwd(const AttnArgs& a, hipStream_t s) {
+  dim3 gq((a.L + BQ - 1) / BQ, a.H, a.B), gk((a.L + 127) / 128, a.H, a.B);
+  hipLaunchKernelGGL((attn_bwd_dq_kernel<D, SID, TR>), gq, dim3(256), 0, s, a);
+  hipLaunchKernelGGL((attn_bwd_dkv_kernel<D, SID, TR>), gk, dim3(256), 0, s, a);
+}
+
+#define ATTN_DISPATCH(FN, a, D, sid, tr, s)                                    \
+  do {                                                                         \
+    if (D == 128) { if (sid) { if (tr) FN<128, true, true>(a, s); else FN<128, true, false>(a, s); } else { if (tr) FN<128, false, true>(a, s); else FN<128, false, false>(a, s); } } \
+    else if (D == 64) { if (sid) { if (tr) FN<64, true, true>(a, s); else FN<64, true, false>(a, s); } else { if (tr) FN<64, false, true>(a, s); else FN<64, false, false>(a, s); } } \
+    else { if (sid) { if (tr) FN<32, true, true>(a, s); else FN<32, true, false>(a, s); } else { if (tr) FN<32, false, true>(a, s); else FN<32, false, false>(a, s); } } \
+  } while (0)
+
+int g_use_tr = 1;
+
+int check_common(const char* name, int64_t B, int64_t H, int64_t L, int64_t D, int64_t qs, int64_t ks, int64_t vs) {
+  UDM_CHECK_ARG(B > 0 && H > 0 && L > 0, "%s: empty problem", name);
+  UDM_CHECK_ARG(D == 32 || D == 64 || D == 128, "%s: head_dim %ld unsupported (32, 64, 128)", name, (long)D);
+  UDM_CHECK_ARG(qs % 8 == 0 && ks % 8 == 0 && vs % 8 == 0, "%s: row strides must be multiples of 8 elements", name);
+  UDM_CHECK_ARG(B <= 65535 && H <= 65535, "%s: grid too large", name);
+  return 0;
+}
+}  // namespace
+
+extern "C" int udm_attention_set_tr_read(int enable) {
+  g_use_tr = enable ? 1 : 0;
+  return 0;
+}
+
+extern "C" int udm_attention_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const int64_t* sample_ids, int64_t B, int64_t H, int64_t L,
+                                 int64_t D, int64_t q_stride, int64_t k_stride, int64_t v_stride, int64_t o_stride, hipStream_t stream) {
+  UDM_CHECK_ARG(q && k && v && o && lse, "udm_attention_fwd: null pointer");
+  if (int rc = check_common("udm_attention_fwd", B, H, L, D, q_stride, k_stride, v_stride)) return rc;
+  UDM_CHECK_ARG(o_stride % 4 == 0, "udm_attention_fwd: o_stride must be a multiple of 4");
+  AttnArgs a{};
+  a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.out = (bf16_t*)o; a.lse = lse; a.sample_ids = sample_ids;
+  a.q_stride = q_stride; a.k_stride = k_stride; a.v_stride = v_stride; a.out_stride = o_stride;
+  a.B = (int)B; a.H = (int)H; a.L = (int)L;
+  a.scale = 1.0f / sqrtf((float)D);
+  a.scale_log2 = a.scale * 1.4426950408889634f;
+  ATTN_DISPATCH(launch_fwd, a, D, sample_ids != nullptr, g_use_tr, stream);
+  UDM_CHECK_LAUNCH("udm_attention_fwd");
+  return 0;
+}
+
+extern "C" int udm_attention_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse, float* delta, void* dq, void* dk,
+                                 void* dv, const int64_t* sample_ids, int64_t B, int64_t H, int64_t L, int64_t D, int64_t q_stride, int64_t k_stride,
+                                 int64_t v_stride, int64_t o_stride, int64_t do_stride, int64_t dq_stride, int64_t dk_stride, int64_t dv_stride,
+                                 hipStream_t stream) {
+  UDM_CHECK_ARG(q && k && v && o && dout && lse && delta && dq && dk && dv, "udm_attention_bwd: null pointer");
+  if (int rc = check_common("udm_attention_bwd", B, H, L, D, q_stride, k_stride, v_stride)) return rc;
+  UDM_CHECK_ARG(o_stride % 8 == 0 && do_stride % 8 == 0 && dq_stride % 4 == 0 && dk_stride % 4 == 0 && dv_stride % 4 == 0, "udm_attention_bwd: bad strides");
+  AttnArgs a{};
+  a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.o = (const bf16_t*)o; a.dout = (const bf16_t*)dout;
+  a.out = (bf16_t*)dq; a.out2 = (bf16_t*)dk; a.out3 = (bf16_t*)dv; a.lse = const_cast<float*>(lse); a.delta = delta; a.sample_ids = sample_ids;
+  a.q_stride = q_stride; a.k_stride = k_stride; a.v_stride = v_stride; a.o_stride = o_stride; a.do_stride = do_stride;
+  a.out_stride = dq_stride; a.out2_stride = dk_stride; a.out3_stride = dv_stride;
+  a.B = (int)B; a.H = (int)H; a.L = (int)L;
+  a.scale = 1.0f / sqrtf((float)D);
+  a.scale_log2 = a.scale * 1.4426950408889634f;
+  const long M = (long)B * L;
+  const int grid = (int)((M + 3) / 4 < 2048 ? (M + 3) / 4 : 2048);
+  hipLaunchKernelGGL(attn_delta_kernel, dim3(grid), dim3(256), 0, stream, a.o, a.dout, delta, (long)o_stride, (long)do_stride, (int)B, (int)H, (int)L, (int)D);
+  UDM_CHECK_LAUNCH("udm_attention_bwd(delta)");
+  ATTN_DISPATCH(launch_bwd, a, D, sample_ids != nullptr, g_use_tr, stream);
+  UDM_CHECK_LAUNCH("udm_attention_bwd");
+  return 0;
+}

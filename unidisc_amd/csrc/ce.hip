@@ -1,0 +1,215 @@
+// SUBS-parameterised cross-entropy over the joint text+image vocabulary, on materialised bf16 logits.
+//
+// Replaces Diffusion._subs_parameterization + the fp32 cast + gather of the reference (model.py:621-658,
+// :924-925, :967): ~10 full [M,V] passes and 3-4 full-size temporaries there; here one read of the
+// logits row per MASKED token (unmasked tokens have log p = 0 by construction and are never read), fp32
+// online log-sum-exp over the ids that are valid for the token's modality, and the gather of logit[x0].
+// The backward overwrites the logits buffer in place with d logits = g * (onehot - softmax_valid).
+#include "common.h"
+#include "../../include/unidisc_hip.h"
+
+namespace {
+using namespace udm;
+constexpr float NEG = -1000000.0f;  // reference neg_infinity (model_setup.py:269): finite on purpose
+
+struct CeArgs {
+  bf16_t* logits;      // [M, ld] (ld >= V, multiple of 8); backward writes in place
+  long ld;
+  const int64_t* x0;
+  const int64_t* xt;
+  const int64_t* modality;  // nullable
+  float* log_p;        // [M]
+  float* lse;          // [M] natural-log LSE over valid ids (masked rows)
+  const float* g;      // [M] upstream d loss / d log_p (backward)
+  int M, V, Vt, mask_id, restrict_modality;
+};
+
+__device__ __forceinline__ void valid_range(const CeArgs& a, long row, int& lo, int& hi) {
+  // valid ids = [lo, hi) minus mask_id.  force_argmax_valid_indices (model.py:627-635): text rows keep text ids,
+  // image rows keep image ids.
+  lo = 0; hi = a.V;
+  if (a.restrict_modality) {
+    const bool img = a.modality && a.modality[row] == 1;
+    if (img) lo = a.Vt; else hi = a.Vt;
+  }
+}
+
+__device__ __forceinline__ void block_reduce_ms(float& m, float& s, float* sm, float* ss) {
+  // combine (max, sum-exp) pairs over the block
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    const float m2 = __shfl_xor(m, o, 64), s2 = __shfl_xor(s, o, 64);
+    const float mn = fmaxf(m, m2);
+    s = (m == -INFINITY ? 0.f : s * __expf(m - mn)) + (m2 == -INFINITY ? 0.f : s2 * __expf(m2 - mn));
+    m = mn;
+  }
+  if (lane == 0) { sm[wave] = m; ss[wave] = s; }
+  __syncthreads();
+  float M = sm[0], S = ss[0];
+#pragma unroll
+  for (int w = 1; w < 4; ++w) {
+    const float m2 = sm[w], s2 = ss[w];
+    const float mn = fmaxf(M, m2);
+    S = (M == -INFINITY ? 0.f : S * __expf(M - mn)) + (m2 == -INFINITY ? 0.f : s2 * __expf(m2 - mn));
+    M = mn;
+  }
+  m = M; s = S;
+}
+
+__global__ __launch_bounds__(256) void subs_ce_fwd_kernel(CeArgs a) {
+  __shared__ float sm[4], ss[4];
+  const long row = blockIdx.x;
+  const int tid = threadIdx.x;
+  const long x0 = a.x0[row], xt = a.xt[row];
+  if (xt != a.mask_id) {  // unmasked token: one-hot log-prob (model.py:646-656)
+    if (tid == 0) { a.log_p[row] = (x0 == xt) ? 0.f : NEG; a.lse[row] = 0.f; }
+    return;
+  }
+  int lo, hi;
+  valid_range(a, row, lo, hi);
+  const bf16_t* z = a.logits + row * a.ld;
+  float m = -INFINITY, s = 0.f;
+  const int c_begin = (lo / 8) * 8;
+  for (int c = c_begin + tid * 8; c < hi; c += 256 * 8) {
+    uint4 u = *reinterpret_cast<const uint4*>(z + c);
+    const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+    float v[8];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { v[2 * k] = __uint_as_float(w[k] << 16); v[2 * k + 1] = __uint_as_float(w[k] & 0xffff0000u); }
+    float cm = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int id = c + k;
+      const bool ok = id >= lo && id < hi && id != a.mask_id;
+      v[k] = ok ? v[k] : -INFINITY;
+      cm = fmaxf(cm, v[k]);
+    }
+    if (cm > m) { s = (m == -INFINITY) ? 0.f : s * __expf(m - cm); m = cm; }
+    if (m != -INFINITY) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) s += __expf(v[k] - m);
+    }
+  }
+  block_reduce_ms(m, s, sm, ss);
+  if (tid == 0) {
+    const float lse = m + __logf(s);
+    const bool x0_ok = x0 >= lo && x0 < hi && x0 != a.mask_id && x0 >= 0 && x0 < a.V;
+    const float zx = x0_ok ? bf2f(z[x0]) : NEG;
+    a.lse[row] = lse;
+    a.log_p[row] = zx - lse;
+  }
+}
+
+__global__ __launch_bounds__(256) void subs_ce_bwd_kernel(CeArgs a) {
+  const long row = blockIdx.x;
+  const int tid = threadIdx.x;
+  bf16_t* z = a.logits + row * a.ld;
+  const long xt = a.xt[row];
+  const float g = a.g[row];
+  if (xt != a.mask_id || g == 0.f) {
+    for (int c = tid * 8; c < a.ld; c += 256 * 8) *reinterpret_cast<uint4*>(z + c) = make_uint4(0, 0, 0, 0);
+    return;
+  }
+  int lo, hi;
+  valid_range(a, row, lo, hi);
+  const long x0 = a.x0[row];
+  const float lse = a.lse[row];
+  for (int c = tid * 8; c < a.ld; c += 256 * 8) {
+    uint4 u = *reinterpret_cast<const uint4*>(z + c);
+    const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+    float v[8];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { v[2 * k] = __uint_as_float(w[k] << 16); v[2 * k + 1] = __uint_as_float(w[k] & 0xffff0000u); }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int id = c + k;
+      const bool ok = id >= lo && id < hi && id != a.mask_id;
+      v[k] = ok ? g * ((id == x0 ? 1.f : 0.f) - __expf(v[k] - lse)) : 0.f;
+    }
+    *reinterpret_cast<uint4*>(z + c) = make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
+  }
+}
+
+// full SUBS log-probabilities [M, V] (samplers / Diffusion.forward contract, model.py:621-658)
+template <bool OUT_F32>
+__global__ __launch_bounds__(256) void subs_logprobs_kernel(CeArgs a, void* out, long ld_out) {
+  __shared__ float sm[4], ss[4];
+  const long row = blockIdx.x;
+  const int tid = threadIdx.x;
+  const bf16_t* z = a.logits + row * a.ld;
+  const long xt = a.xt ? a.xt[row] : a.mask_id;
+  const bool masked = xt == a.mask_id;
+  int lo, hi;
+  valid_range(a, row, lo, hi);
+  float lse = 0.f;
+  if (masked) {
+    float m = -INFINITY, s = 0.f;
+    for (int c = tid; c < a.V; c += 256) {
+      const bool ok = c >= lo && c < hi && c != a.mask_id;
+      if (ok) {
+        const float v = bf2f(z[c]);
+        if (v > m) { s = (m == -INFINITY) ? 0.f : s * __expf(m - v); m = v; }
+        s += __expf(v - m);
+      }
+    }
+    block_reduce_ms(m, s, sm, ss);
+    lse = m + __logf(s);
+  }
+  for (int c = tid; c < a.V; c += 256) {
+    float o;
+    if (masked) {
+      const bool ok = c >= lo && c < hi && c != a.mask_id;
+      o = ok ? bf2f(z[c]) - lse : NEG;
+    } else {
+      o = (c == xt) ? 0.f : NEG;
+    }
+    if (OUT_F32) reinterpret_cast<float*>(out)[row * ld_out + c] = o;
+    else reinterpret_cast<bf16_t*>(out)[row * ld_out + c] = f2bf(o);
+  }
+}
+
+int check(const char* name, const void* logits, int64_t M, int64_t V, int64_t ld, int64_t Vt, int64_t mask_id) {
+  UDM_CHECK_ARG(logits, "%s: null logits", name);
+  UDM_CHECK_ARG(M > 0 && V > 0 && ld >= V && ld % 8 == 0, "%s: bad shape M=%ld V=%ld ld=%ld (ld must be a multiple of 8)", name, (long)M, (long)V, (long)ld);
+  UDM_CHECK_ARG(Vt > 0 && Vt <= V && mask_id >= 0 && mask_id < V, "%s: bad vocabulary split", name);
+  UDM_CHECK_ARG(((uintptr_t)logits % 16) == 0, "%s: logits must be 16-byte aligned", name);
+  return 0;
+}
+}  // namespace
+
+extern "C" int udm_subs_ce_fwd(const void* logits, int64_t ld, const int64_t* x0, const int64_t* xt, const int64_t* modality, float* log_p, float* lse,
+                               int64_t M, int64_t V, int64_t Vt, int64_t mask_id, int restrict_modality, hipStream_t stream) {
+  if (int rc = check("udm_subs_ce_fwd", logits, M, V, ld, Vt, mask_id)) return rc;
+  UDM_CHECK_ARG(x0 && xt && log_p && lse, "udm_subs_ce_fwd: null pointer");
+  UDM_CHECK_ARG(!restrict_modality || modality, "udm_subs_ce_fwd: restrict_modality needs the modality map");
+  CeArgs a{(bf16_t*)logits, (long)ld, x0, xt, modality, log_p, lse, nullptr, (int)M, (int)V, (int)Vt, (int)mask_id, restrict_modality};
+  hipLaunchKernelGGL(subs_ce_fwd_kernel, dim3((unsigned)M), dim3(256), 0, stream, a);
+  UDM_CHECK_LAUNCH("udm_subs_ce_fwd");
+  return 0;
+}
+
+extern "C" int udm_subs_ce_bwd(void* logits, int64_t ld, const int64_t* x0, const int64_t* xt, const int64_t* modality, const float* lse, const float* g,
+                               int64_t M, int64_t V, int64_t Vt, int64_t mask_id, int restrict_modality, hipStream_t stream) {
+  if (int rc = check("udm_subs_ce_bwd", logits, M, V, ld, Vt, mask_id)) return rc;
+  UDM_CHECK_ARG(x0 && xt && lse && g, "udm_subs_ce_bwd: null pointer");
+  UDM_CHECK_ARG(!restrict_modality || modality, "udm_subs_ce_bwd: restrict_modality needs the modality map");
+  CeArgs a{(bf16_t*)logits, (long)ld, x0, xt, modality, nullptr, const_cast<float*>(lse), g, (int)M, (int)V, (int)Vt, (int)mask_id, restrict_modality};
+  hipLaunchKernelGGL(subs_ce_bwd_kernel, dim3((unsigned)M), dim3(256), 0, stream, a);
+  UDM_CHECK_LAUNCH("udm_subs_ce_bwd");
+  return 0;
+}
+
+extern "C" int udm_subs_logprobs(const void* logits, int64_t ld, const int64_t* xt, const int64_t* modality, void* out, int64_t ld_out, int out_f32, int64_t M,
+                                 int64_t V, int64_t Vt, int64_t mask_id, int restrict_modality, hipStream_t stream) {
+  if (int rc = check("udm_subs_logprobs", logits, M, V, ld, Vt, mask_id)) return rc;
+  UDM_CHECK_ARG(out && ld_out >= V, "udm_subs_logprobs: bad output");
+  UDM_CHECK_ARG(!restrict_modality || modality, "udm_subs_logprobs: restrict_modality needs the modality map");
+  CeArgs a{(bf16_t*)logits, (long)ld, nullptr, xt, modality, nullptr, nullptr, nullptr, (int)M, (int)V, (int)Vt, (int)mask_id, restrict_modality};
+  if (out_f32)
+    hipLaunchKernelGGL(subs_logprobs_kernel<true>, dim3((unsigned)M), dim3(256), 0, stream, a, out, (long)ld_out);
+  else
+    hipLaunchKernelGGL(subs_logprobs_kernel<false>, dim3((unsigned)M), dim3(256), 0, stream, a, out, (long)ld_out);
+  UDM_CHECK_LAUNCH("udm_subs_logprobs");
+  return 0;
+}

@@ -1,0 +1,99 @@
+// Shared device helpers for the UniDisc MI355X (gfx950 / CDNA4) kernels.
+// wave = 64 lanes everywhere; bf16 is carried as raw uint16 (RNE conversions below).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef unsigned short bf16_t;  // raw bits
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;   // MFMA A/B operand (4 VGPRs)
+typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;   // 32x32 MFMA accumulator
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+#define UDM_LDS __attribute__((address_space(3)))
+
+namespace udm {
+
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+
+__device__ __forceinline__ bf16_t f2bf(float f) {  // round-to-nearest-even, NaN preserved
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40u);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+
+__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// tanh-approximate GELU and its derivative (nn.GELU(approximate="tanh"), reference models/dit.py:918)
+__device__ __forceinline__ float gelu_tanh(float x) {
+  const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+  float u = k0 * (x + k1 * x * x * x);
+  float t = 1.0f - 2.0f / (1.0f + __expf(2.0f * u));  // tanh(u)
+  return 0.5f * x * (1.0f + t);
+}
+__device__ __forceinline__ float gelu_tanh_grad(float x) {
+  const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+  float x2 = x * x;
+  float u = k0 * (x + k1 * x * x2);
+  float t = 1.0f - 2.0f / (1.0f + __expf(2.0f * u));
+  float du = k0 * (1.0f + 3.0f * k1 * x2);
+  return 0.5f * (1.0f + t) + 0.5f * x * (1.0f - t * t) * du;
+}
+
+// Philox4x32-10 counter RNG for dropout masks: (seed, 64-bit element-group counter) -> 4 uniform uint32.
+__device__ __forceinline__ uint4 philox4x32(uint64_t seed, uint64_t ctr) {
+  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+  uint32_t c0 = (uint32_t)ctr, c1 = (uint32_t)(ctr >> 32), c2 = 0x5bd1e995u, c3 = 0x27d4eb2fu;
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+    uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+    c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  return make_uint4(c0, c1, c2, c3);
+}
+
+// XCD-aware block remap (8 XCDs, block b is dispatched to XCD b % 8): give each XCD a contiguous
+// chunk of the logical tile order so neighbouring tiles share one L2.  Bijective for any nwg.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int nx = 8;
+  int xcd = bid % nx, loc = bid / nx;
+  int q = nwg / nx, r = nwg % nx;
+  int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + loc;
+}
+
+}  // namespace udm
+
+// ---- host-side error plumbing (no exceptions cross the C ABI) -----------------------------------
+void udm_set_error(const char* fmt, ...);
+#define UDM_CHECK_ARG(cond, ...)            \
+  do {                                      \
+    if (!(cond)) {                          \
+      udm_set_error(__VA_ARGS__);           \
+      return 2;                             \
+    }                                       \
+  } while (0)
+#define UDM_CHECK_LAUNCH(name)                                                   \
+  do {                                                                           \
+    hipError_t e__ = hipGetLastError();                                          \
+    if (e__ != hipSuccess) {                                                     \
+      udm_set_error("%s: launch failed: %s", name, hipGetErrorString(e__));      \
+      return 1;                                                                  \
+    }                                                                            \
+  } while (0)

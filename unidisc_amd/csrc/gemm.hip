@@ -1,0 +1,364 @@
+// bf16 MFMA GEMM for gfx950:  C[M,N] (op)= A[M,K] · B[N,K]^T   ("NT": both operands K-contiguous)
+//
+// Replaces every nn.Linear on the hot path (reference models/dit.py:562,567,917-919,1068 — cuBLAS bf16
+// GEMMs under autocast), the dgrad GEMMs (with a transposed bf16 weight shadow) and the wgrad GEMMs
+// (with transposed activations, see transpose_bf16 below).
+//
+// Structure (round-1): 128x128x64 block tile, 256 threads = 4 waves in 2x2, each wave 64x64 as 2x2
+// v_mfma_f32_32x32x16_bf16 fragments; register-staged global->LDS copy with the next tile's loads
+// issued before the current tile's MFMAs (one barrier per K tile, two LDS buffers); XOR-swizzled LDS
+// rows so every ds_read_b128 fragment read is bank-conflict free; fp32 accumulator tile staged
+// through LDS so the epilogue (bias / GELU / GELU' / accumulate) runs on coalesced 16-byte rows.
+// Tile order is XCD-aware (8 private L2s) with a grouped-M sweep.
+#include "common.h"
+#include "../../include/unidisc_hip.h"
+
+namespace {
+using namespace udm;
+
+constexpr int BM = 128, BN = 128, BK = 64, NTHREADS = 256;
+constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand tile
+constexpr int GROUP_M = 8;
+
+struct GemmArgs {
+  const bf16_t* A;
+  const bf16_t* B;
+  void* C;
+  const float* bias;
+  bf16_t* aux;
+  long lda, ldb, ldc, ldaux;
+  int M, N, K;
+  int tiles_m, tiles_n;
+  float beta;
+};
+
+template <int EPI, bool OUT_F32>
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(GemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 x (A tile + B tile) = 64 KiB
+
+  // ---- tile mapping: XCD-contiguous chunks, grouped along M for L2 reuse of the B panel ----
+  const int nwg = p.tiles_m * p.tiles_n;
+  int pid = xcd_remap(blockIdx.x, nwg);
+  const int per_group = GROUP_M * p.tiles_n;
+  const int group = pid / per_group;
+  const int first_m = group * GROUP_M;
+  const int gsz = min(p.tiles_m - first_m, GROUP_M);
+  const int tm = first_m + (pid % per_group) % gsz;
+  const int tn = (pid % per_group) / gsz;
+  const int row0 = tm * BM, col0 = tn * BN;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, hi = lane >> 5;
+
+  // ---- global->register staging: thread owns rows ld_row + 32*i, 16-byte slot ld_slot ----
+  const int ld_row = tid >> 3, ld_slot = tid & 7;
+  const bf16_t* a_ptr[4];
+  const bf16_t* b_ptr[4];
+  bool a_ok[4], b_ok[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int ra = row0 + ld_row + 32 * i, rb = col0 + ld_row + 32 * i;
+    a_ok[i] = ra < p.M;
+    b_ok[i] = rb < p.N;
+    a_ptr[i] = p.A + (long)(a_ok[i] ? ra : 0) * p.lda + ld_slot * 8;
+    b_ptr[i] = p.B + (long)(b_ok[i] ? rb : 0) * p.ldb + ld_slot * 8;
+  }
+  const int st_off = ld_row * 128 + ((ld_slot ^ ((ld_row >> 1) & 7)) << 4);  // + i*32*128
+
+  uint4 ra[4], rb[4];
+  auto gload = [&](int kt) {
+    const int k = kt * BK;
+    const bool kok = (k + ld_slot * 8) < p.K;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      ra[i] = (a_ok[i] && kok) ? *reinterpret_cast<const uint4*>(a_ptr[i] + k) : make_uint4(0, 0, 0, 0);
+      rb[i] = (b_ok[i] && kok) ? *reinterpret_cast<const uint4*>(b_ptr[i] + k) : make_uint4(0, 0, 0, 0);
+    }
+  };
+  auto lstore = [&](int buf) {
+    char* As = smem + buf * 2 * TILE_BYTES;
+    char* Bs = As + TILE_BYTES;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      *reinterpret_cast<uint4*>(As + st_off + i * 32 * 128) = ra[i];
+      *reinterpret_cast<uint4*>(Bs + st_off + i * 32 * 128) = rb[i];
+    }
+  };
+
+  // ---- fragment read offsets (row = lane&31 within a 32-row fragment, k-slot = 2*kk + lane>>5) ----
+  const int sw = (l31 >> 1) & 7;
+  int a_off[2], b_off[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    a_off[i] = (wm * 64 + i * 32 + l31) * 128;
+    b_off[i] = (wn * 64 + i * 32 + l31) * 128;
+  }
+
+  f32x16_t acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk = (p.K + BK - 1) / BK;
+  gload(0);
+  lstore(0);
+  __syncthreads();
+  int cur = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) gload(kt + 1);  // in flight under the MFMAs below
+    const char* As = smem + cur * 2 * TILE_BYTES;
+    const char* Bs = As + TILE_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const int so = ((kk * 2 + hi) ^ sw) << 4;
+      bf16x8_t a[2], b[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        a[i] = *reinterpret_cast<const bf16x8_t*>(As + a_off[i] + so);
+        b[i] = *reinterpret_cast<const bf16x8_t*>(Bs + b_off[i] + so);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < nk) lstore(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // ---- epilogue: accumulators -> LDS (fp32 [128][128]) -> coalesced rows ----
+  float* Cs = reinterpret_cast<float*>(smem);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        int m = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        int n = wn * 64 + j * 32 + l31;
+        Cs[m * BN + n] = acc[i][j][r];
+      }
+  __syncthreads();
+
+  const bool n_vec_ok = (p.ldc % 4 == 0);
+#pragma unroll 4
+  for (int it = 0; it < 16; ++it) {
+    const int idx = tid + it * NTHREADS;
+    const int r = idx >> 5, c4 = (idx & 31) * 4;
+    const int gm = row0 + r, gn = col0 + c4;
+    if (gm >= p.M || gn >= p.N) continue;
+    float4 v = *reinterpret_cast<const float4*>(Cs + r * BN + c4);
+    float x[4] = {v.x, v.y, v.z, v.w};
+    const int nvalid = min(4, p.N - gn);
+    if (EPI == UDM_EPI_BIAS || EPI == UDM_EPI_BIAS_GELU) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (e < nvalid) x[e] += p.bias[gn + e];
+    }
+    if (EPI == UDM_EPI_BIAS_GELU) {
+      // pre-activation is materialised in bf16 (as the reference's mlp.0 output is), GELU evaluated on it
+      bf16_t pre[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        pre[e] = f2bf(x[e]);
+        x[e] = gelu_tanh(bf2f(pre[e]));
+      }
+      bf16_t* ap = p.aux + (long)gm * p.ldaux + gn;
+      if (nvalid == 4 && (p.ldaux % 4 == 0)) {
+        *reinterpret_cast<uint2*>(ap) = make_uint2((uint32_t)pre[0] | ((uint32_t)pre[1] << 16), (uint32_t)pre[2] | ((uint32_t)pre[3] << 16));
+      } else {
+        for (int e = 0; e < nvalid; ++e) ap[e] = pre[e];
+      }
+    }
+    if (EPI == UDM_EPI_DGELU) {
+      const bf16_t* ap = p.aux + (long)gm * p.ldaux + gn;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (e < nvalid) x[e] *= gelu_tanh_grad(bf2f(ap[e]));
+    }
+    if (OUT_F32) {
+      float* cp = reinterpret_cast<float*>(p.C) + (long)gm * p.ldc + gn;
+      if (p.beta != 0.f) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (e < nvalid) x[e] += p.beta * cp[e];
+      }
+      if (nvalid == 4 && n_vec_ok) {
+        *reinterpret_cast<float4*>(cp) = make_float4(x[0], x[1], x[2], x[3]);
+      } else {
+        for (int e = 0; e < nvalid; ++e) cp[e] = x[e];
+      }
+    } else {
+      bf16_t* cp = reinterpret_cast<bf16_t*>(p.C) + (long)gm * p.ldc + gn;
+      if (nvalid == 4 && n_vec_ok) {
+        *reinterpret_cast<uint2*>(cp) = make_uint2(pack2bf(x[0], x[1]), pack2bf(x[2], x[3]));
+      } else {
+        for (int e = 0; e < nvalid; ++e) cp[e] = f2bf(x[e]);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// bf16 transpose [R,C] -> [C,R] with optional fused column sums (bias gradient: db[c] += sum_r in[r,c]).
+// 64x64 tiles through LDS; 16-byte global accesses on both sides.
+// ---------------------------------------------------------------------------------------------
+constexpr int TT = 64, TPAD = 8;
+__global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out, int R, int C,
+                                                            long ld_in, long ld_out, float* __restrict__ colsum) {
+  __shared__ __attribute__((aligned(16))) bf16_t tile[TT][TT + TPAD];
+  const int r0 = blockIdx.y * TT, c0 = blockIdx.x * TT;
+  const int tid = threadIdx.x;
+  const int cs = (tid & 7) * 8;
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    const int r = (tid >> 3) + pass * 32;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (r0 + r < R && c0 + cs < C) v = *reinterpret_cast<const uint4*>(in + (long)(r0 + r) * ld_in + c0 + cs);
+    const bf16_t* e = reinterpret_cast<const bf16_t*>(&v);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) tile[cs + k][r] = e[k];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    const int c = (tid >> 3) + pass * 32;
+    const int rs = (tid & 7) * 8;
+    uint4 v = *reinterpret_cast<const uint4*>(&tile[c][rs]);
+    const bool ok = (c0 + c < C) && (r0 + rs < R);
+    if (ok && out) *reinterpret_cast<uint4*>(out + (long)(c0 + c) * ld_out + r0 + rs) = v;
+    if (colsum) {
+      const bf16_t* e = reinterpret_cast<const bf16_t*>(&v);
+      float s = 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) s += bf2f(e[k]);  // rows beyond R were zero-filled
+      s += __shfl_xor(s, 1, 64);
+      s += __shfl_xor(s, 2, 64);
+      s += __shfl_xor(s, 4, 64);
+      if ((tid & 7) == 0 && c0 + c < C) atomicAdd(colsum + c0 + c, s);
+    }
+  }
+}
+
+// fp32 [R,C] -> bf16 [R,C] (ld_out) and/or bf16 transposed [C,R] (ld_t): the per-step weight shadow that
+// autocast makes in the reference (cast of fp32 master weights), plus the K-major copy used by dgrad.
+__global__ __launch_bounds__(256) void cast_transpose_kernel(const float* __restrict__ in, bf16_t* __restrict__ out, bf16_t* __restrict__ out_t,
+                                                            int R, int C, long ld_in, long ld_out, long ld_t) {
+  __shared__ __attribute__((aligned(16))) bf16_t tile[TT][TT + TPAD];
+  const int r0 = blockIdx.y * TT, c0 = blockIdx.x * TT;
+  const int tid = threadIdx.x;
+  const int cs = (tid & 15) * 4;
+#pragma unroll
+  for (int pass = 0; pass < 4; ++pass) {
+    const int r = (tid >> 4) + pass * 16;
+    float x[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool rok = r0 + r < R;
+    if (rok) {
+      const float* ip = in + (long)(r0 + r) * ld_in + c0 + cs;
+      if (c0 + cs + 3 < C && (ld_in % 4 == 0)) {
+        float4 v = *reinterpret_cast<const float4*>(ip);
+        x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w;
+      } else {
+        for (int k = 0; k < 4; ++k)
+          if (c0 + cs + k < C) x[k] = ip[k];
+      }
+    }
+    bf16_t b[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) b[k] = f2bf(x[k]);
+    if (out && rok) {
+      bf16_t* op = out + (long)(r0 + r) * ld_out + c0 + cs;
+      if (c0 + cs + 3 < C && (ld_out % 4 == 0)) {
+        *reinterpret_cast<uint2*>(op) = make_uint2((uint32_t)b[0] | ((uint32_t)b[1] << 16), (uint32_t)b[2] | ((uint32_t)b[3] << 16));
+      } else {
+        for (int k = 0; k < 4; ++k)
+          if (c0 + cs + k < C) op[k] = b[k];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) tile[cs + k][r] = b[k];
+  }
+  if (!out_t) return;
+  __syncthreads();
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    const int c = (tid >> 3) + pass * 32;
+    const int rs = (tid & 7) * 8;
+    if (c0 + c >= C || r0 + rs >= R) continue;
+    bf16_t* op = out_t + (long)(c0 + c) * ld_t + r0 + rs;
+    if (r0 + rs + 7 < R && (ld_t % 8 == 0)) {
+      *reinterpret_cast<uint4*>(op) = *reinterpret_cast<const uint4*>(&tile[c][rs]);
+    } else {
+      for (int k = 0; k < 8; ++k)
+        if (r0 + rs + k < R) op[k] = tile[c][rs + k];
+    }
+  }
+}
+
+template <int EPI>
+int launch_gemm(const GemmArgs& a, int out_f32, hipStream_t stream) {
+  dim3 grid(a.tiles_m * a.tiles_n), block(NTHREADS);
+  const size_t lds = 4 * TILE_BYTES;
+  if (out_f32)
+    hipLaunchKernelGGL((gemm_nt_kernel<EPI, true>), grid, block, lds, stream, a);
+  else
+    hipLaunchKernelGGL((gemm_nt_kernel<EPI, false>), grid, block, lds, stream, a);
+  UDM_CHECK_LAUNCH("udm_gemm_nt_bf16");
+  return 0;
+}
+}  // namespace
+
+extern "C" int udm_gemm_nt_bf16(const void* A, const void* B, void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc,
+                                int out_f32, int epilogue, const float* bias, void* aux, int64_t ldaux, float beta, hipStream_t stream) {
+  UDM_CHECK_ARG(A && B && C, "udm_gemm_nt_bf16: null operand");
+  UDM_CHECK_ARG(M > 0 && N > 0 && K > 0, "udm_gemm_nt_bf16: empty problem M=%ld N=%ld K=%ld", (long)M, (long)N, (long)K);
+  UDM_CHECK_ARG(K % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0, "udm_gemm_nt_bf16: K, lda, ldb must be multiples of 8 (16-byte rows); K=%ld lda=%ld ldb=%ld",
+                (long)K, (long)lda, (long)ldb);
+  UDM_CHECK_ARG(((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0) && ((uintptr_t)C % 16 == 0), "udm_gemm_nt_bf16: operands must be 16-byte aligned");
+  UDM_CHECK_ARG(beta == 0.f || out_f32, "udm_gemm_nt_bf16: beta accumulate needs fp32 output");
+  UDM_CHECK_ARG(M < (1 << 30) && N < (1 << 30) && K < (1 << 30), "udm_gemm_nt_bf16: dimension too large");
+  GemmArgs a;
+  a.A = (const bf16_t*)A; a.B = (const bf16_t*)B; a.C = C; a.bias = bias; a.aux = (bf16_t*)aux;
+  a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ldaux = ldaux;
+  a.M = (int)M; a.N = (int)N; a.K = (int)K;
+  a.tiles_m = (int)((M + BM - 1) / BM); a.tiles_n = (int)((N + BN - 1) / BN);
+  a.beta = beta;
+  switch (epilogue) {
+    case UDM_EPI_NONE: return launch_gemm<UDM_EPI_NONE>(a, out_f32, stream);
+    case UDM_EPI_BIAS:
+      UDM_CHECK_ARG(bias, "udm_gemm_nt_bf16: EPI_BIAS without bias");
+      return launch_gemm<UDM_EPI_BIAS>(a, out_f32, stream);
+    case UDM_EPI_BIAS_GELU:
+      UDM_CHECK_ARG(bias && aux && !out_f32, "udm_gemm_nt_bf16: EPI_BIAS_GELU needs bias, aux and bf16 output");
+      return launch_gemm<UDM_EPI_BIAS_GELU>(a, out_f32, stream);
+    case UDM_EPI_DGELU:
+      UDM_CHECK_ARG(aux, "udm_gemm_nt_bf16: EPI_DGELU needs aux (saved pre-activation)");
+      return launch_gemm<UDM_EPI_DGELU>(a, out_f32, stream);
+    default: udm_set_error("udm_gemm_nt_bf16: unknown epilogue %d", epilogue); return 2;
+  }
+}
+
+extern "C" int udm_transpose_bf16(const void* in, void* out, int64_t R, int64_t C, int64_t ld_in, int64_t ld_out, float* colsum, hipStream_t stream) {
+  UDM_CHECK_ARG(in && (out || colsum), "udm_transpose_bf16: null pointer");
+  UDM_CHECK_ARG(R > 0 && C > 0, "udm_transpose_bf16: empty");
+  UDM_CHECK_ARG(R % 8 == 0 && C % 8 == 0 && ld_in % 8 == 0 && (!out || ld_out % 8 == 0), "udm_transpose_bf16: R, C and strides must be multiples of 8");
+  dim3 grid((unsigned)((C + TT - 1) / TT), (unsigned)((R + TT - 1) / TT));
+  hipLaunchKernelGGL(transpose_bf16_kernel, grid, dim3(256), 0, stream, (const bf16_t*)in, (bf16_t*)out, (int)R, (int)C, (long)ld_in, (long)ld_out, colsum);
+  UDM_CHECK_LAUNCH("udm_transpose_bf16");
+  return 0;
+}
+
+extern "C" int udm_cast_transpose_f32_bf16(const float* in, void* out, void* out_t, int64_t R, int64_t C, int64_t ld_in, int64_t ld_out, int64_t ld_t,
+                                           hipStream_t stream) {
+  UDM_CHECK_ARG(in && (out || out_t), "udm_cast_transpose_f32_bf16: null pointer");
+  UDM_CHECK_ARG(R > 0 && C > 0, "udm_cast_transpose_f32_bf16: empty");
+  dim3 grid((unsigned)((C + TT - 1) / TT), (unsigned)((R + TT - 1) / TT));
+  hipLaunchKernelGGL(cast_transpose_kernel, grid, dim3(256), 0, stream, in, (bf16_t*)out, (bf16_t*)out_t, (int)R, (int)C, (long)ld_in, (long)ld_out, (long)ld_t);
+  UDM_CHECK_LAUNCH("udm_cast_transpose_f32_bf16");
+  return 0;
+}

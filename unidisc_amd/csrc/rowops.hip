@@ -1,0 +1,957 @@
+// Row-wise (HBM-bound) kernels of the DiT block: RMSNorm / LayerNorm (+adaLN modulate), the residual
+// branch update (sandwich norm, gate, dropout), QK-LayerNorm + rotary, token embedding, small adaLN helpers.
+//
+// One 64-lane wave owns one row: the row lives in registers (16-byte vector loads, lane-contiguous =
+// fully coalesced), row statistics are wavefront-shuffle reductions, nothing is re-read from HBM.
+// Reference ops replaced: models/dit.py:77-100 (RMSNorm), :383-403 (LayerNorm), :229-253
+// (bias_dropout_add_scale), :263-304 (modulate_fused), :680-682 (qk LayerNorm), models/standalone_rotary.py:14-31
+// (rotary), :1036-1043 + :1402-1411 (embedding + modality embedding), :415-449 (timestep embedding).
+#include "common.h"
+#include "../../include/unidisc_hip.h"
+
+namespace {
+using namespace udm;
+
+constexpr int ROWS_PER_BLOCK = 4;  // 256 threads = 4 waves = 4 rows in flight per block
+
+__device__ __forceinline__ void load8_f32(const float* p, float (&v)[8]) {
+  float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+__device__ __forceinline__ void store8_f32(float* p, const float (&v)[8]) {
+  *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+  *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+}
+__device__ __forceinline__ void load8_bf16(const bf16_t* p, float (&v)[8]) {
+  uint4 u = *reinterpret_cast<const uint4*>(p);
+  const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    v[2 * k] = __uint_as_float(w[k] << 16);
+    v[2 * k + 1] = __uint_as_float(w[k] & 0xffff0000u);
+  }
+}
+__device__ __forceinline__ void store8_bf16(bf16_t* p, const float (&v)[8]) {
+  *reinterpret_cast<uint4*>(p) = make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
+}
+__device__ __forceinline__ float rbf(float x) { return bf2f(f2bf(x)); }
+
+// dropout keep-mask for 8 consecutive elements starting at flat element index e0 (multiple of 8)
+__device__ __forceinline__ void dropout_keep8(uint64_t seed, uint64_t e0, float p, bool (&keep)[8]) {
+  const uint32_t thr = (uint32_t)(p * 4294967296.0f);
+  uint4 r0 = philox4x32(seed, e0 >> 2), r1 = philox4x32(seed, (e0 >> 2) + 1);
+  keep[0] = r0.x >= thr; keep[1] = r0.y >= thr; keep[2] = r0.z >= thr; keep[3] = r0.w >= thr;
+  keep[4] = r1.x >= thr; keep[5] = r1.y >= thr; keep[6] = r1.z >= thr; keep[7] = r1.w >= thr;
+}
+
+struct NormArgs {
+  const float* x;        // [M,d] fp32 residual stream
+  bf16_t* y;             // [M,d] bf16 (GEMM input)
+  float* rstd;           // [M]
+  float* mean;           // [M] (LayerNorm only)
+  const float* w;        // [d]
+  const bf16_t* shift;   // adaLN: [B, mod_stride] slices, nullable
+  const bf16_t* scale;
+  const int64_t* modality;  // [M], nullable
+  const int* any_img;       // device flag: modality.any() (reference dit.py:266-268), nullable
+  long mod_stride;
+  int M, d, L;
+  int norm_type;         // 0 rms, 1 layernorm (no bias)
+  float eps;
+};
+
+template <int NCH>
+__global__ __launch_bounds__(256) void norm_fwd_kernel(NormArgs a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const bool img_only = a.modality && (!a.any_img || *a.any_img != 0);
+  for (long row = (long)blockIdx.x * ROWS_PER_BLOCK + wave; row < a.M; row += (long)gridDim.x * ROWS_PER_BLOCK) {
+    float v[NCH][8];
+    float s1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = (i * 64 + lane) * 8;
+      if (c < a.d) {
+        load8_f32(a.x + row * a.d + c, v[i]);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s1 += (a.norm_type == 0) ? v[i][k] * v[i][k] : v[i][k];
+      } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[i][k] = 0.f;
+      }
+    }
+    s1 = wave_sum(s1);
+    float mu = 0.f, rs;
+    if (a.norm_type == 0) {
+      rs = rsqrtf(s1 / a.d + a.eps);
+    } else {
+      mu = s1 / a.d;
+      float s2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) {
+        const int c = (i * 64 + lane) * 8;
+        if (c < a.d) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) { float t = v[i][k] - mu; s2 += t * t; }
+        }
+      }
+      rs = rsqrtf(wave_sum(s2) / a.d + a.eps);
+    }
+    if (lane == 0) {
+      a.rstd[row] = rs;
+      if (a.mean) a.mean[row] = mu;
+    }
+    const int b = (int)(row / a.L);
+    const bool modulate = a.shift && (!img_only || a.modality[row] == 1);
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = (i * 64 + lane) * 8;
+      if (c >= a.d) continue;
+      float w8[8], o[8];
+      load8_f32(a.w + c, w8);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) o[k] = (v[i][k] - mu) * rs * w8[k];
+      if (modulate) {
+        float sh[8], sc[8];
+        load8_bf16(a.shift + (long)b * a.mod_stride + c, sh);
+        load8_bf16(a.scale + (long)b * a.mod_stride + c, sc);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[k] = o[k] * (1.f + sc[k]) + sh[k];
+      }
+      store8_bf16(a.y + row * a.d + c, o);
+    }
+  }
+}
+
+struct NormBwdArgs {
+  const bf16_t* dy;   // [M,d] grad wrt the (modulated) norm output
+  const float* x;     // [M,d]
+  const float* rstd;
+  const float* mean;  // LN only
+  const float* w;
+  const bf16_t* shift;
+  const bf16_t* scale;
+  const int64_t* modality;
+  const int* any_img;
+  float* dx;          // [M,d] fp32, accumulated into (dx += ...) when accumulate != 0
+  float* dw;          // [d] fp32 atomics
+  float* dshift;      // [B, mod_stride] fp32 atomics (nullable)
+  float* dscale;
+  long mod_stride;
+  int M, d, L, norm_type, accumulate;
+};
+
+template <int NCH>
+__global__ __launch_bounds__(256) void norm_bwd_kernel(NormBwdArgs a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const bool img_only = a.modality && (!a.any_img || *a.any_img != 0);
+  float dw_acc[NCH][8];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) dw_acc[i][k] = 0.f;
+  for (long row = (long)blockIdx.x * ROWS_PER_BLOCK + wave; row < a.M; row += (long)gridDim.x * ROWS_PER_BLOCK) {
+    const float rs = a.rstd[row];
+    const float mu = a.norm_type ? a.mean[row] : 0.f;
+    const int b = (int)(row / a.L);
+    const bool modulate = a.shift && (!img_only || a.modality[row] == 1);
+    float xh[NCH][8], g[NCH][8];
+    float s_g = 0.f, s_gx = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = (i * 64 + lane) * 8;
+      if (c < a.d) {
+        float x8[8], dy8[8], w8[8];
+        load8_f32(a.x + row * a.d + c, x8);
+        load8_bf16(a.dy + row * a.d + c, dy8);
+        load8_f32(a.w + c, w8);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) xh[i][k] = (x8[k] - mu) * rs;
+        if (modulate) {
+          float sc[8];
+          load8_bf16(a.scale + (long)b * a.mod_stride + c, sc);
+          float dsh[8], dsc[8];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            dsh[k] = dy8[k];
+            dsc[k] = dy8[k] * xh[i][k] * w8[k];
+            dy8[k] *= (1.f + sc[k]);
+          }
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            atomicAdd(a.dshift + (long)b * a.mod_stride + c + k, dsh[k]);
+            atomicAdd(a.dscale + (long)b * a.mod_stride + c + k, dsc[k]);
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          dw_acc[i][k] += dy8[k] * xh[i][k];
+          g[i][k] = dy8[k] * w8[k];
+          s_g += g[i][k];
+          s_gx += g[i][k] * xh[i][k];
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { xh[i][k] = 0.f; g[i][k] = 0.f; }
+      }
+    }
+    s_gx = wave_sum(s_gx) / a.d;
+    s_g = a.norm_type ? wave_sum(s_g) / a.d : 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = (i * 64 + lane) * 8;
+      if (c >= a.d) continue;
+      float o[8];
+      if (a.accumulate) load8_f32(a.dx + row * a.d + c, o);
+      else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[k] = 0.f;
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) o[k] += rs * (g[i][k] - s_g - xh[i][k] * s_gx);
+      store8_f32(a.dx + row * a.d + c, o);
+    }
+  }
+  // cross-wave reduction of dw through LDS, then one atomic per column per block
+  __shared__ float red[ROWS_PER_BLOCK][64 * 8 + 8];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 8; ++k) red[wave][lane * 8 + k] = dw_acc[i][k];
+    __syncthreads();
+    for (int t = threadIdx.x; t < 512; t += 256) {
+      const int c = i * 512 + t;
+      if (c < a.d) {
+        float s = red[0][t] + red[1][t] + red[2][t] + red[3][t];
+        atomicAdd(a.dw + c, s);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// residual branch:  x_out = x_in + T(branch)
+//   T = [sandwich norm(branch; w_b)] -> dropout(p) -> * gate      (gate / dropout skipped on text rows when a
+//   modality map is given: reference bias_dropout_add_scale, models/dit.py:239-251)
+// ---------------------------------------------------------------------------------------------
+struct ResidArgs {
+  const float* x_in;
+  const bf16_t* branch;
+  float* x_out;
+  const float* w_b;     // sandwich norm weight, nullable
+  float* rstd_b;        // [M] saved (sandwich)
+  float* mean_b;        // LN sandwich only
+  const bf16_t* gate;   // [B, mod_stride], nullable
+  const int64_t* modality;  // nullable: when set, gate+dropout apply to rows with modality==1 only
+  long mod_stride;
+  int M, d, L, norm_type;
+  float eps, p_drop;
+  uint64_t seed;
+};
+
+template <int NCH>
+__global__ __launch_bounds__(256) void residual_fwd_kernel(ResidArgs a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (long row = (long)blockIdx.x * ROWS_PER_BLOCK + wave; row < a.M; row += (long)gridDim.x * ROWS_PER_BLOCK) {
+    float v[NCH][8];
+    float s1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = (i * 64 + lane) * 8;
+      if (c < a.d) {
+        load8_bf16(a.branch + row * a.d + c, v[i]);
+        if (a.w_b) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) s1 += (a.norm_type == 0) ? v[i][k] * v[i][k] : v[i][k];
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[i][k] = 0.f;
+      }
+    }
+    float mu = 0.f, rs = 1.f;
+    if (a.w_b) {
+      s1 = wave_sum(s1);
+      if (a.norm_type == 0) {
+        rs = rsqrtf(s1 / a.d + a.eps);
+      } else {
+        mu = s1 / a.d;
+        float s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+          const int c = (i * 64 + lane) * 8;
+          if (c < a.d) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { float t = v[i][k] - mu; s2 += t * t; }
+          }
+        }
+        rs = rsqrtf(wave_sum(s2) / a.d + a.eps);
+      }
+      if (lane == 0) {
+        a.rstd_b[row] = rs;
+        if (a.mean_b) a.mean_b[row] = mu;
+      }
+    }
+    const int b = (int)(row / a.L);
+    const bool special = !a.modality || a.modality[row] == 1;  // row receives gate + dropout
+    const float keep_scale = 1.f / (1.f - a.p_drop);
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = (i * 64 + lane) * 8;
+      if (c >= a.d) continue;
+      float o[8], xi[8];
+      if (a.w_b) {
+        float w8[8];
+        load8_f32(a.w_b + c, w8);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          float n = (v[i][k] - mu) * rs;
+          if (a.norm_type == 0) n = rbf(n);  // RMSNorm: `.type_as(x)` on a bf16 input (dit.py:98-100)
+          o[k] = n * w8[k];
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[k] = v[i][k];
+      }
+      if (special) {
+        if (a.p_drop > 0.f) {
+          bool keep[8];
+          dropout_keep8(a.seed, (uint64_t)row * a.d + c, a.p_drop, keep);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) o[k] = keep[k] ? o[k] * keep_scale : 0.f;
+        }
+        if (a.gate) {
+          float g8[8];
+          load8_bf16(a.gate + (long)b * a.mod_stride + c, g8);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) o[k] *= g8[k];
+        }
+      }
+      load8_f32(a.x_in + row * a.d + c, xi);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) o[k] += xi[k];
+      store8_f32(a.x_out + row * a.d + c, o);
+    }
+  }
+}
+
+struct ResidBwdArgs {
+  const float* dx;        // [M,d] grad wrt x_out (== grad wrt x_in: passes through untouched)
+  const bf16_t* branch;   // saved branch output
+  bf16_t* dbranch;        // [M,d] out
+  const float* w_b;
+  const float* rstd_b;
+  const float* mean_b;
+  const bf16_t* gate;
+  const int64_t* modality;
+  float* dw_b;            // [d] atomics
+  float* dgate;           // [B, mod_stride] atomics
+  long mod_stride;
+  int M, d, L, norm_type;
+  float p_drop;
+  uint64_t seed;
+};
+
+template <int NCH>
+__global__ __launch_bounds__(256) void residual_bwd_kernel(ResidBwdArgs a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float dw_acc[NCH][8];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) dw_acc[i][k] = 0.f;
+  const float keep_scale = 1.f / (1.f - a.p_drop);
+  for (long row = (long)blockIdx.x * ROWS_PER_BLOCK + wave; row < a.M; row += (long)gridDim.x * ROWS_PER_BLOCK) {
+    const int b = (int)(row / a.L);
+    const bool special = !a.modality || a.modality[row] == 1;
+    const float rs = a.w_b ? a.rstd_b[row] : 1.f;
+    const float mu = (a.w_b && a.norm_type) ? a.mean_b[row] : 0.f;
+    float nh[NCH][8], g[NCH][8];
+    float s_g = 0.f, s_gx = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = (i * 64 + lane) * 8;
+      if (c < a.d) {
+        float br[8], dn[8], w8[8];
+        load8_bf16(a.branch + row * a.d + c, br);
+        load8_f32(a.dx + row * a.d + c, dn);
+        if (a.w_b) load8_f32(a.w_b + c, w8);
+        // recompute T's intermediate n (post-norm, pre-dropout) for dgate / dw_b
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          float n = (br[k] - mu) * rs;
+          nh[i][k] = n;
+        }
+        if (special) {
+          float g8[8];
+          if (a.gate) load8_bf16(a.gate + (long)b * a.mod_stride + c, g8);
+          bool keep[8];
+          if (a.p_drop > 0.f) dropout_keep8(a.seed, (uint64_t)row * a.d + c, a.p_drop, keep);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const float dm = (a.p_drop > 0.f) ? (keep[k] ? keep_scale : 0.f) : 1.f;
+            if (a.gate) {
+              float nn = a.w_b ? ((a.norm_type == 0 ? rbf(nh[i][k]) : nh[i][k]) * w8[k]) : br[k];
+              atomicAdd(a.dgate + (long)b * a.mod_stride + c + k, dn[k] * nn * dm);
+              dn[k] *= g8[k];
+            }
+            dn[k] *= dm;
+          }
+        }
+        if (a.w_b) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const float nr = (a.norm_type == 0) ? rbf(nh[i][k]) : nh[i][k];
+            dw_acc[i][k] += dn[k] * nr;
+            g[i][k] = dn[k] * w8[k];
+            s_g += g[i][k];
+            s_gx += g[i][k] * nh[i][k];
+          }
+        } else {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) g[i][k] = dn[k];
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { nh[i][k] = 0.f; g[i][k] = 0.f; }
+      }
+    }
+    if (a.w_b) {
+      s_gx = wave_sum(s_gx) / a.d;
+      s_g = a.norm_type ? wave_sum(s_g) / a.d : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = (i * 64 + lane) * 8;
+      if (c >= a.d) continue;
+      float o[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) o[k] = a.w_b ? rs * (g[i][k] - s_g - nh[i][k] * s_gx) : g[i][k];
+      store8_bf16(a.dbranch + row * a.d + c, o);
+    }
+  }
+  if (!a.w_b) return;
+  __shared__ float red[ROWS_PER_BLOCK][64 * 8 + 8];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 8; ++k) red[wave][lane * 8 + k] = dw_acc[i][k];
+    __syncthreads();
+    for (int t = threadIdx.x; t < 512; t += 256) {
+      const int c = i * 512 + t;
+      if (c < a.d) atomicAdd(a.dw_b + c, red[0][t] + red[1][t] + red[2][t] + red[3][t]);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// QK LayerNorm (over the full hidden dim, affine, eps 1e-5) + NeoX rotary on q and k.
+// Lane item t -> (part, head, j): columns c_lo = part*d + head*D + 4j .. +3 and c_hi = c_lo + D/2 (the
+// rotation partners live in the same lane, so no cross-lane traffic).  NIT items per lane.
+// ---------------------------------------------------------------------------------------------
+struct QkArgs {
+  const bf16_t* qkv;   // [M, 3d]
+  bf16_t* qkr;         // [M, 2d] normalised + rotated q | k
+  const float* gq; const float* bq; const float* gk; const float* bk;  // [d] each, nullable (qk_norm off)
+  float* stats;        // [M, 4] = mean_q, rstd_q, mean_k, rstd_k
+  const float* cos_t;  // [L, D/2] or [B*L, D/2]
+  const float* sin_t;
+  int M, d, L, D, rope_per_sample;
+  float eps;
+};
+
+__device__ __forceinline__ void load4_bf16(const bf16_t* p, float (&v)[4]) {
+  uint2 u = *reinterpret_cast<const uint2*>(p);
+  v[0] = __uint_as_float(u.x << 16); v[1] = __uint_as_float(u.x & 0xffff0000u);
+  v[2] = __uint_as_float(u.y << 16); v[3] = __uint_as_float(u.y & 0xffff0000u);
+}
+__device__ __forceinline__ void store4_bf16(bf16_t* p, const float (&v)[4]) {
+  *reinterpret_cast<uint2*>(p) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+}
+__device__ __forceinline__ void load4_f32(const float* p, float (&v)[4]) {
+  float4 a = *reinterpret_cast<const float4*>(p);
+  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+}
+
+template <int NIT>
+__global__ __launch_bounds__(256) void qknorm_rope_fwd_kernel(QkArgs a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int half = a.D / 2, per_head = a.D / 8, per_part = a.d / 8;
+  const bool do_norm = a.gq != nullptr;
+  for (long row = (long)blockIdx.x * ROWS_PER_BLOCK + wave; row < a.M; row += (long)gridDim.x * ROWS_PER_BLOCK) {
+    float lo[NIT][4], hi[NIT][4];
+    float sq = 0.f, sk = 0.f;
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+      const int t = i * 64 + lane;
+      if (t < 2 * per_part) {
+        const int part = t / per_part, r = t % per_part;
+        const int c = part * a.d + (r / per_head) * a.D + (r % per_head) * 4;
+        load4_bf16(a.qkv + row * 3 * a.d + c, lo[i]);
+        load4_bf16(a.qkv + row * 3 * a.d + c + half, hi[i]);
+        float s = lo[i][0] + lo[i][1] + lo[i][2] + lo[i][3] + hi[i][0] + hi[i][1] + hi[i][2] + hi[i][3];
+        if (part == 0) sq += s; else sk += s;
+      }
+    }
+    float mq = 0.f, mk = 0.f, rq = 1.f, rk = 1.f;
+    if (do_norm) {
+      mq = wave_sum(sq) / a.d;
+      mk = wave_sum(sk) / a.d;
+      float vq = 0.f, vk = 0.f;
+#pragma unroll
+      for (int i = 0; i < NIT; ++i) {
+        const int t = i * 64 + lane;
+        if (t < 2 * per_part) {
+          const int part = t / per_part;
+          const float m = part ? mk : mq;
+          float s = 0.f;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) { float u = lo[i][k] - m, w = hi[i][k] - m; s += u * u + w * w; }
+          if (part == 0) vq += s; else vk += s;
+        }
+      }
+      rq = rsqrtf(wave_sum(vq) / a.d + a.eps);
+      rk = rsqrtf(wave_sum(vk) / a.d + a.eps);
+      if (lane == 0) {
+        a.stats[row * 4 + 0] = mq; a.stats[row * 4 + 1] = rq; a.stats[row * 4 + 2] = mk; a.stats[row * 4 + 3] = rk;
+      }
+    }
+    const long trow = a.rope_per_sample ? row : (row % a.L);
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+      const int t = i * 64 + lane;
+      if (t >= 2 * per_part) continue;
+      const int part = t / per_part, r = t % per_part;
+      const int hc = (r / per_head) * a.D + (r % per_head) * 4;  // column within the part
+      float xl[4], xh[4];
+      if (do_norm) {
+        const float* g = part ? a.gk : a.gq;
+        const float* bb = part ? a.bk : a.bq;
+        const float m = part ? mk : mq, rs = part ? rk : rq;
+        float g0[4], g1[4], b0[4], b1[4];
+        load4_f32(g + hc, g0); load4_f32(g + hc + half, g1); load4_f32(bb + hc, b0); load4_f32(bb + hc + half, b1);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          xl[k] = rbf((lo[i][k] - m) * rs * g0[k] + b0[k]);  // LayerNorm result is written back in bf16 (dit.py:681-682)
+          xh[k] = rbf((hi[i][k] - m) * rs * g1[k] + b1[k]);
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { xl[k] = lo[i][k]; xh[k] = hi[i][k]; }
+      }
+      float cs[4], sn[4], ol[4], oh[4];
+      const int pc = (r % per_head) * 4;
+      load4_f32(a.cos_t + trow * half + pc, cs);
+      load4_f32(a.sin_t + trow * half + pc, sn);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        ol[k] = xl[k] * cs[k] - xh[k] * sn[k];
+        oh[k] = xh[k] * cs[k] + xl[k] * sn[k];
+      }
+      store4_bf16(a.qkr + row * 2 * a.d + part * a.d + hc, ol);
+      store4_bf16(a.qkr + row * 2 * a.d + part * a.d + hc + half, oh);
+    }
+  }
+}
+
+struct QkBwdArgs {
+  const bf16_t* dqkr;  // [M, 2d] grads wrt rotated q|k
+  const bf16_t* qkv;   // [M, 3d] saved raw projections
+  bf16_t* dqkv;        // [M, 3d]: columns [0,2d) written here (v columns are written by the attention backward)
+  const float* gq; const float* gk;
+  const float* stats;
+  const float* cos_t; const float* sin_t;
+  float* dgq; float* dbq; float* dgk; float* dbk;  // [d] atomics
+  int M, d, L, D, rope_per_sample;
+};
+
+template <int NIT>
+__global__ __launch_bounds__(256) void qknorm_rope_bwd_kernel(QkBwdArgs a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int half = a.D / 2, per_head = a.D / 8, per_part = a.d / 8;
+  const bool do_norm = a.gq != nullptr;
+  float dg_acc[NIT][8], db_acc[NIT][8];
+#pragma unroll
+  for (int i = 0; i < NIT; ++i)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { dg_acc[i][k] = 0.f; db_acc[i][k] = 0.f; }
+  for (long row = (long)blockIdx.x * ROWS_PER_BLOCK + wave; row < a.M; row += (long)gridDim.x * ROWS_PER_BLOCK) {
+    const long trow = a.rope_per_sample ? row : (row % a.L);
+    float mq = 0.f, rq = 1.f, mk = 0.f, rk = 1.f;
+    if (do_norm) {
+      mq = a.stats[row * 4 + 0]; rq = a.stats[row * 4 + 1]; mk = a.stats[row * 4 + 2]; rk = a.stats[row * 4 + 3];
+    }
+    float gl[NIT][4], gh[NIT][4], xl[NIT][4], xh[NIT][4];
+    float sgq = 0.f, sgxq = 0.f, sgk = 0.f, sgxk = 0.f;
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+      const int t = i * 64 + lane;
+      if (t < 2 * per_part) {
+        const int part = t / per_part, r = t % per_part;
+        const int hc = (r / per_head) * a.D + (r % per_head) * 4;
+        const int pc = (r % per_head) * 4;
+        float dl[4], dh[4], cs[4], sn[4];
+        load4_bf16(a.dqkr + row * 2 * a.d + part * a.d + hc, dl);
+        load4_bf16(a.dqkr + row * 2 * a.d + part * a.d + hc + half, dh);
+        load4_f32(a.cos_t + trow * half + pc, cs);
+        load4_f32(a.sin_t + trow * half + pc, sn);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {  // transpose of the rotation
+          gl[i][k] = dl[k] * cs[k] + dh[k] * sn[k];
+          gh[i][k] = dh[k] * cs[k] - dl[k] * sn[k];
+        }
+        if (do_norm) {
+          const float* g = part ? a.gk : a.gq;
+          const float m = part ? mk : mq, rs = part ? rk : rq;
+          float g0[4], g1[4], r0[4], r1[4];
+          load4_f32(g + hc, g0); load4_f32(g + hc + half, g1);
+          load4_bf16(a.qkv + row * 3 * a.d + part * a.d + hc, r0);
+          load4_bf16(a.qkv + row * 3 * a.d + part * a.d + hc + half, r1);
+          float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            xl[i][k] = (r0[k] - m) * rs;
+            xh[i][k] = (r1[k] - m) * rs;
+            dg_acc[i][k] += gl[i][k] * xl[i][k];
+            dg_acc[i][k + 4] += gh[i][k] * xh[i][k];
+            db_acc[i][k] += gl[i][k];
+            db_acc[i][k + 4] += gh[i][k];
+            gl[i][k] *= g0[k];
+            gh[i][k] *= g1[k];
+            s1 += gl[i][k] + gh[i][k];
+            s2 += gl[i][k] * xl[i][k] + gh[i][k] * xh[i][k];
+          }
+          if (part == 0) { sgq += s1; sgxq += s2; } else { sgk += s1; sgxk += s2; }
+        }
+      }
+    }
+    if (do_norm) {
+      sgq = wave_sum(sgq) / a.d; sgxq = wave_sum(sgxq) / a.d;
+      sgk = wave_sum(sgk) / a.d; sgxk = wave_sum(sgxk) / a.d;
+    }
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+      const int t = i * 64 + lane;
+      if (t >= 2 * per_part) continue;
+      const int part = t / per_part, r = t % per_part;
+      const int hc = (r / per_head) * a.D + (r % per_head) * 4;
+      float ol[4], oh[4];
+      if (do_norm) {
+        const float rs = part ? rk : rq, sg = part ? sgk : sgq, sgx = part ? sgxk : sgxq;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          ol[k] = rs * (gl[i][k] - sg - xl[i][k] * sgx);
+          oh[k] = rs * (gh[i][k] - sg - xh[i][k] * sgx);
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { ol[k] = gl[i][k]; oh[k] = gh[i][k]; }
+      }
+      store4_bf16(a.dqkv + row * 3 * a.d + part * a.d + hc, ol);
+      store4_bf16(a.dqkv + row * 3 * a.d + part * a.d + hc + half, oh);
+    }
+  }
+  if (!do_norm) return;
+  // reduce dgamma/dbeta over the block's 4 waves via LDS, then atomics
+  __shared__ float red[ROWS_PER_BLOCK][64 * 8 + 8];
+  for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < 8; ++k) red[wave][lane * 8 + k] = pass ? db_acc[i][k] : dg_acc[i][k];
+      __syncthreads();
+      for (int u = threadIdx.x; u < 512; u += 256) {
+        const int ln = u >> 3, k = u & 7;
+        const int t = i * 64 + ln;
+        if (t < 2 * per_part) {
+          const int part = t / per_part, r = t % per_part;
+          const int hc = (r / per_head) * a.D + (r % per_head) * 4 + (k & 3) + (k >> 2) * half;
+          float s = red[0][u] + red[1][u] + red[2][u] + red[3][u];
+          float* dst = pass ? (part ? a.dbk : a.dbq) : (part ? a.dgk : a.dgq);
+          atomicAdd(dst + hc, s);
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// token embedding gather (+ modality embedding) and its scatter-add backward
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void embedding_fwd_kernel(const int64_t* __restrict__ ids, const float* __restrict__ E, const int64_t* __restrict__ modality,
+                                                           const float* __restrict__ Em, float* __restrict__ x, long M, int d, long V) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (long row = (long)blockIdx.x * ROWS_PER_BLOCK + wave; row < M; row += (long)gridDim.x * ROWS_PER_BLOCK) {
+    long id = ids[row];
+    id = id < 0 ? 0 : (id >= V ? V - 1 : id);
+    const float* e = E + id * d;
+    const float* em = Em ? Em + (modality[row] == 0 ? 0 : d) : nullptr;
+    for (int c = lane * 4; c < d; c += 256) {
+      float4 v = *reinterpret_cast<const float4*>(e + c);
+      if (em) {
+        float4 m = *reinterpret_cast<const float4*>(em + c);
+        v.x += m.x; v.y += m.y; v.z += m.z; v.w += m.w;
+      }
+      *reinterpret_cast<float4*>(x + row * d + c) = v;
+    }
+  }
+}
+
+// Each block owns a contiguous chunk of rows; a thread owns columns.  Rows whose id is `hot_id` (the [MASK]
+// token: about half of all rows under the absorbing schedule) are summed in registers and leave the block as
+// ONE atomic per column; other rows scatter with atomics directly.
+__global__ __launch_bounds__(256) void embedding_bwd_kernel(const int64_t* __restrict__ ids, const int64_t* __restrict__ modality, const float* __restrict__ dx,
+                                                           float* __restrict__ dE, float* __restrict__ dEm, long M, int d, long V, long hot_id,
+                                                           int rows_per_block) {
+  const long r0 = (long)blockIdx.x * rows_per_block;
+  const long r1 = min(M, r0 + rows_per_block);
+  for (int c = threadIdx.x; c < d; c += 256) {
+    float hot = 0.f, m0 = 0.f, m1 = 0.f;
+    for (long row = r0; row < r1; ++row) {
+      const float g = dx[row * d + c];
+      const long id = ids[row];
+      if (id == hot_id) hot += g;
+      else if (id >= 0 && id < V) atomicAdd(dE + id * d + c, g);
+      if (dEm) { if (modality[row] == 0) m0 += g; else m1 += g; }
+    }
+    if (hot != 0.f) atomicAdd(dE + hot_id * d + c, hot);
+    if (dEm) { atomicAdd(dEm + c, m0); atomicAdd(dEm + d + c, m1); }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// small adaLN helpers
+// ---------------------------------------------------------------------------------------------
+// sinusoidal timestep features (reference TimestepEmbedder.timestep_embedding, dit.py:428-444) -> bf16 [B, dim]
+__global__ void timestep_embedding_kernel(const float* __restrict__ sigma, bf16_t* __restrict__ out, int B, int dim) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int half = dim / 2;
+  if (i >= B * dim) return;
+  const int b = i / dim, j = i % dim;
+  float v = 0.f;
+  if (j < 2 * half) {
+    const int jj = j < half ? j : j - half;
+    const float f = expf(-logf(10000.f) * (float)jj / (float)half);
+    const float arg = sigma[b] * f;
+    v = j < half ? cosf(arg) : sinf(arg);
+  }
+  out[i] = f2bf(v);
+}
+
+__global__ void silu_fwd_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float v = bf2f(x[i]);
+  y[i] = f2bf(v / (1.f + __expf(-v)));
+}
+__global__ void silu_bwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy, bf16_t* __restrict__ dx, long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float v = bf2f(x[i]);
+  const float s = 1.f / (1.f + __expf(-v));
+  dx[i] = f2bf(bf2f(dy[i]) * (s + v * s * (1.f - s)));
+}
+__global__ void cast_f32_bf16_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, long n) {
+  const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i + 3 < n) {
+    float4 v = *reinterpret_cast<const float4*>(x + i);
+    *reinterpret_cast<uint2*>(y + i) = make_uint2(pack2bf(v.x, v.y), pack2bf(v.z, v.w));
+  } else {
+    for (long k = i; k < n; ++k) y[k] = f2bf(x[k]);
+  }
+}
+// bf16 -> fp32 with scale; used by the gradient-bucket decompress (reference DDP bf16 compress hook, main.py:645)
+__global__ void cast_bf16_f32_kernel(const bf16_t* __restrict__ x, float* __restrict__ y, long n, float scale) {
+  const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i + 3 < n) {
+    uint2 u = *reinterpret_cast<const uint2*>(x + i);
+    *reinterpret_cast<float4*>(y + i) = make_float4(__uint_as_float(u.x << 16) * scale, __uint_as_float(u.x & 0xffff0000u) * scale,
+                                                   __uint_as_float(u.y << 16) * scale, __uint_as_float(u.y & 0xffff0000u) * scale);
+  } else {
+    for (long k = i; k < n; ++k) y[k] = bf2f(x[k]) * scale;
+  }
+}
+__global__ void scale_cast_f32_bf16_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, long n, float scale) {
+  const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i + 3 < n) {
+    float4 v = *reinterpret_cast<const float4*>(x + i);
+    // reference order: cast to bf16 first, then divide by world size in bf16 (torch _compress_hook)
+    *reinterpret_cast<uint2*>(y + i) = make_uint2(pack2bf(rbf(v.x) * scale, rbf(v.y) * scale), pack2bf(rbf(v.z) * scale, rbf(v.w) * scale));
+  } else {
+    for (long k = i; k < n; ++k) y[k] = f2bf(rbf(x[k]) * scale);
+  }
+}
+
+inline int grid_rows(long M) {
+  long g = (M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
+  return (int)(g < 2048 ? (g < 1 ? 1 : g) : 2048);
+}
+inline int nch_for(long d) { return (int)((d + 511) / 512); }
+
+#define DISPATCH_NCH(nch, KERNEL, grid, stream, args)                                          \
+  switch (nch) {                                                                               \
+    case 1: hipLaunchKernelGGL((KERNEL<1>), dim3(grid), dim3(256), 0, stream, args); break;   \
+    case 2: hipLaunchKernelGGL((KERNEL<2>), dim3(grid), dim3(256), 0, stream, args); break;   \
+    case 3: hipLaunchKernelGGL((KERNEL<3>), dim3(grid), dim3(256), 0, stream, args); break;   \
+    case 4: hipLaunchKernelGGL((KERNEL<4>), dim3(grid), dim3(256), 0, stream, args); break;   \
+    case 8: hipLaunchKernelGGL((KERNEL<8>), dim3(grid), dim3(256), 0, stream, args); break;   \
+    default: udm_set_error(#KERNEL ": unsupported hidden size (d <= 2048 or d == 4096, d %% 8 == 0)"); return 2; \
+  }
+}  // namespace
+
+extern "C" int udm_norm_fwd(const float* x, void* y, float* rstd, float* mean, const float* w, const void* shift, const void* scale, int64_t mod_stride,
+                            const int64_t* modality, const int* any_img, int64_t M, int64_t d, int64_t L, int norm_type, float eps, hipStream_t stream) {
+  UDM_CHECK_ARG(x && y && rstd && w, "udm_norm_fwd: null pointer");
+  UDM_CHECK_ARG(M > 0 && d > 0 && d % 8 == 0 && L > 0, "udm_norm_fwd: bad shape M=%ld d=%ld L=%ld", (long)M, (long)d, (long)L);
+  UDM_CHECK_ARG(norm_type == 0 || mean, "udm_norm_fwd: LayerNorm needs a mean buffer");
+  UDM_CHECK_ARG((shift == nullptr) == (scale == nullptr), "udm_norm_fwd: shift and scale go together");
+  NormArgs a{x, (bf16_t*)y, rstd, norm_type ? mean : nullptr, w, (const bf16_t*)shift, (const bf16_t*)scale, modality, any_img, (long)mod_stride,
+             (int)M, (int)d, (int)L, norm_type, eps};
+  int nch = nch_for(d); if (nch > 4) nch = 8;
+  DISPATCH_NCH(nch, norm_fwd_kernel, grid_rows(M), stream, a);
+  UDM_CHECK_LAUNCH("udm_norm_fwd");
+  return 0;
+}
+
+extern "C" int udm_norm_bwd(const void* dy, const float* x, const float* rstd, const float* mean, const float* w, const void* shift, const void* scale,
+                            int64_t mod_stride, const int64_t* modality, const int* any_img, float* dx, float* dw, float* dshift, float* dscale,
+                            int64_t M, int64_t d, int64_t L, int norm_type, int accumulate, hipStream_t stream) {
+  UDM_CHECK_ARG(dy && x && rstd && w && dx && dw, "udm_norm_bwd: null pointer");
+  UDM_CHECK_ARG(M > 0 && d > 0 && d % 8 == 0 && L > 0, "udm_norm_bwd: bad shape");
+  UDM_CHECK_ARG(!shift || (scale && dshift && dscale), "udm_norm_bwd: modulated norm needs scale, dshift, dscale");
+  NormBwdArgs a{(const bf16_t*)dy, x, rstd, mean, w, (const bf16_t*)shift, (const bf16_t*)scale, modality, any_img, dx, dw, dshift, dscale,
+                (long)mod_stride, (int)M, (int)d, (int)L, norm_type, accumulate};
+  int nch = nch_for(d); if (nch > 4) nch = 8;
+  const int grid = min(grid_rows(M), 512);
+  DISPATCH_NCH(nch, norm_bwd_kernel, grid, stream, a);
+  UDM_CHECK_LAUNCH("udm_norm_bwd");
+  return 0;
+}
+
+extern "C" int udm_residual_fwd(const float* x_in, const void* branch, float* x_out, const float* w_b, float* rstd_b, float* mean_b, const void* gate,
+                                int64_t mod_stride, const int64_t* modality, int64_t M, int64_t d, int64_t L, int norm_type, float eps, float p_drop,
+                                uint64_t seed, hipStream_t stream) {
+  UDM_CHECK_ARG(x_in && branch && x_out, "udm_residual_fwd: null pointer");
+  UDM_CHECK_ARG(M > 0 && d > 0 && d % 8 == 0 && L > 0, "udm_residual_fwd: bad shape");
+  UDM_CHECK_ARG(!w_b || rstd_b, "udm_residual_fwd: sandwich norm needs rstd buffer");
+  UDM_CHECK_ARG(!(w_b && norm_type) || mean_b, "udm_residual_fwd: sandwich LayerNorm needs mean buffer");
+  UDM_CHECK_ARG(p_drop >= 0.f && p_drop < 1.f, "udm_residual_fwd: dropout p out of range");
+  ResidArgs a{x_in, (const bf16_t*)branch, x_out, w_b, rstd_b, (w_b && norm_type) ? mean_b : nullptr, (const bf16_t*)gate, modality, (long)mod_stride,
+              (int)M, (int)d, (int)L, norm_type, eps, p_drop, seed};
+  int nch = nch_for(d); if (nch > 4) nch = 8;
+  DISPATCH_NCH(nch, residual_fwd_kernel, grid_rows(M), stream, a);
+  UDM_CHECK_LAUNCH("udm_residual_fwd");
+  return 0;
+}
+
+extern "C" int udm_residual_bwd(const float* dx, const void* branch, void* dbranch, const float* w_b, const float* rstd_b, const float* mean_b,
+                                const void* gate, int64_t mod_stride, const int64_t* modality, float* dw_b, float* dgate, int64_t M, int64_t d, int64_t L,
+                                int norm_type, float p_drop, uint64_t seed, hipStream_t stream) {
+  UDM_CHECK_ARG(dx && branch && dbranch, "udm_residual_bwd: null pointer");
+  UDM_CHECK_ARG(M > 0 && d > 0 && d % 8 == 0 && L > 0, "udm_residual_bwd: bad shape");
+  UDM_CHECK_ARG(!w_b || (rstd_b && dw_b), "udm_residual_bwd: sandwich norm needs rstd and dw");
+  UDM_CHECK_ARG(!gate || dgate, "udm_residual_bwd: gate needs dgate");
+  ResidBwdArgs a{dx, (const bf16_t*)branch, (bf16_t*)dbranch, w_b, rstd_b, mean_b, (const bf16_t*)gate, modality, dw_b, dgate, (long)mod_stride,
+                 (int)M, (int)d, (int)L, norm_type, p_drop, seed};
+  int nch = nch_for(d); if (nch > 4) nch = 8;
+  const int grid = min(grid_rows(M), 512);
+  DISPATCH_NCH(nch, residual_bwd_kernel, grid, stream, a);
+  UDM_CHECK_LAUNCH("udm_residual_bwd");
+  return 0;
+}
+
+extern "C" int udm_qknorm_rope_fwd(const void* qkv, void* qkr, const float* gq, const float* bq, const float* gk, const float* bk, float* stats,
+                                   const float* cos_t, const float* sin_t, int rope_per_sample, int64_t M, int64_t d, int64_t L, int64_t D, float eps,
+                                   hipStream_t stream) {
+  UDM_CHECK_ARG(qkv && qkr && cos_t && sin_t, "udm_qknorm_rope_fwd: null pointer");
+  UDM_CHECK_ARG(M > 0 && d > 0 && D > 0 && d % D == 0 && D % 8 == 0, "udm_qknorm_rope_fwd: bad shape d=%ld D=%ld", (long)d, (long)D);
+  UDM_CHECK_ARG(!gq || (bq && gk && bk && stats), "udm_qknorm_rope_fwd: qk-norm needs all four affine vectors and stats");
+  QkArgs a{(const bf16_t*)qkv, (bf16_t*)qkr, gq, bq, gk, bk, stats, cos_t, sin_t, (int)M, (int)d, (int)L, (int)D, rope_per_sample, eps};
+  int nit = (int)((2 * (d / 8) + 63) / 64);
+  int nch = nit <= 4 ? (nit == 3 ? 3 : (nit <= 1 ? 1 : (nit == 2 ? 2 : 4))) : 8;
+  UDM_CHECK_ARG(nit <= 8, "udm_qknorm_rope_fwd: hidden size too large");
+  DISPATCH_NCH(nch, qknorm_rope_fwd_kernel, grid_rows(M), stream, a);
+  UDM_CHECK_LAUNCH("udm_qknorm_rope_fwd");
+  return 0;
+}
+
+extern "C" int udm_qknorm_rope_bwd(const void* dqkr, const void* qkv, void* dqkv, const float* gq, const float* gk, const float* stats, const float* cos_t,
+                                   const float* sin_t, int rope_per_sample, float* dgq, float* dbq, float* dgk, float* dbk, int64_t M, int64_t d, int64_t L,
+                                   int64_t D, hipStream_t stream) {
+  UDM_CHECK_ARG(dqkr && qkv && dqkv && cos_t && sin_t, "udm_qknorm_rope_bwd: null pointer");
+  UDM_CHECK_ARG(M > 0 && d > 0 && D > 0 && d % D == 0 && D % 8 == 0, "udm_qknorm_rope_bwd: bad shape");
+  UDM_CHECK_ARG(!gq || (gk && stats && dgq && dbq && dgk && dbk), "udm_qknorm_rope_bwd: qk-norm needs gk, stats and the four gradient vectors");
+  QkBwdArgs a{(const bf16_t*)dqkr, (const bf16_t*)qkv, (bf16_t*)dqkv, gq, gk, stats, cos_t, sin_t, dgq, dbq, dgk, dbk, (int)M, (int)d, (int)L, (int)D,
+              rope_per_sample};
+  int nit = (int)((2 * (d / 8) + 63) / 64);
+  UDM_CHECK_ARG(nit <= 8, "udm_qknorm_rope_bwd: hidden size too large");
+  int nch = nit <= 4 ? (nit == 3 ? 3 : (nit <= 1 ? 1 : (nit == 2 ? 2 : 4))) : 8;
+  const int grid = min(grid_rows(M), 512);
+  DISPATCH_NCH(nch, qknorm_rope_bwd_kernel, grid, stream, a);
+  UDM_CHECK_LAUNCH("udm_qknorm_rope_bwd");
+  return 0;
+}
+
+extern "C" int udm_embedding_fwd(const int64_t* ids, const float* E, const int64_t* modality, const float* Em, float* x, int64_t M, int64_t d, int64_t V,
+                                 hipStream_t stream) {
+  UDM_CHECK_ARG(ids && E && x, "udm_embedding_fwd: null pointer");
+  UDM_CHECK_ARG(M > 0 && d > 0 && d % 4 == 0 && V > 0, "udm_embedding_fwd: bad shape");
+  UDM_CHECK_ARG(!Em || modality, "udm_embedding_fwd: modality embedding needs the modality map");
+  hipLaunchKernelGGL(embedding_fwd_kernel, dim3(grid_rows(M)), dim3(256), 0, stream, ids, E, modality, Em, x, (long)M, (int)d, (long)V);
+  UDM_CHECK_LAUNCH("udm_embedding_fwd");
+  return 0;
+}
+
+extern "C" int udm_embedding_bwd(const int64_t* ids, const int64_t* modality, const float* dx, float* dE, float* dEm, int64_t M, int64_t d, int64_t V,
+                                 int64_t hot_id, hipStream_t stream) {
+  UDM_CHECK_ARG(ids && dx && dE, "udm_embedding_bwd: null pointer");
+  UDM_CHECK_ARG(M > 0 && d > 0 && V > 0, "udm_embedding_bwd: bad shape");
+  UDM_CHECK_ARG(!dEm || modality, "udm_embedding_bwd: modality embedding grad needs the modality map");
+  const int rows_per_block = 32;
+  const int grid = (int)((M + rows_per_block - 1) / rows_per_block);
+  hipLaunchKernelGGL(embedding_bwd_kernel, dim3(grid), dim3(256), 0, stream, ids, modality, dx, dE, dEm, (long)M, (int)d, (long)V, (long)hot_id,
+                     rows_per_block);
+  UDM_CHECK_LAUNCH("udm_embedding_bwd");
+  return 0;
+}
+
+extern "C" int udm_timestep_embedding(const float* sigma, void* out, int64_t B, int64_t dim, hipStream_t stream) {
+  UDM_CHECK_ARG(sigma && out && B > 0 && dim > 0, "udm_timestep_embedding: bad argument");
+  const long n = B * dim;
+  hipLaunchKernelGGL(timestep_embedding_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, sigma, (bf16_t*)out, (int)B, (int)dim);
+  UDM_CHECK_LAUNCH("udm_timestep_embedding");
+  return 0;
+}
+extern "C" int udm_silu_fwd(const void* x, void* y, int64_t n, hipStream_t stream) {
+  UDM_CHECK_ARG(x && y && n > 0, "udm_silu_fwd: bad argument");
+  hipLaunchKernelGGL(silu_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (const bf16_t*)x, (bf16_t*)y, (long)n);
+  UDM_CHECK_LAUNCH("udm_silu_fwd");
+  return 0;
+}
+extern "C" int udm_silu_bwd(const void* x, const void* dy, void* dx, int64_t n, hipStream_t stream) {
+  UDM_CHECK_ARG(x && dy && dx && n > 0, "udm_silu_bwd: bad argument");
+  hipLaunchKernelGGL(silu_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (const bf16_t*)x, (const bf16_t*)dy, (bf16_t*)dx, (long)n);
+  UDM_CHECK_LAUNCH("udm_silu_bwd");
+  return 0;
+}
+extern "C" int udm_cast_f32_bf16(const float* x, void* y, int64_t n, float scale, hipStream_t stream) {
+  UDM_CHECK_ARG(x && y && n > 0, "udm_cast_f32_bf16: bad argument");
+  UDM_CHECK_ARG(((uintptr_t)x % 16 == 0) && ((uintptr_t)y % 8 == 0), "udm_cast_f32_bf16: misaligned");
+  const unsigned grid = (unsigned)((n / 4 + 256) / 256);
+  if (scale == 1.f)
+    hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(grid), dim3(256), 0, stream, x, (bf16_t*)y, (long)n);
+  else
+    hipLaunchKernelGGL(scale_cast_f32_bf16_kernel, dim3(grid), dim3(256), 0, stream, x, (bf16_t*)y, (long)n, scale);
+  UDM_CHECK_LAUNCH("udm_cast_f32_bf16");
+  return 0;
+}
+extern "C" int udm_cast_bf16_f32(const void* x, float* y, int64_t n, float scale, hipStream_t stream) {
+  UDM_CHECK_ARG(x && y && n > 0, "udm_cast_bf16_f32: bad argument");
+  UDM_CHECK_ARG(((uintptr_t)y % 16 == 0) && ((uintptr_t)x % 8 == 0), "udm_cast_bf16_f32: misaligned");
+  const unsigned grid = (unsigned)((n / 4 + 256) / 256);
+  hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3(grid), dim3(256), 0, stream, (const bf16_t*)x, y, (long)n, scale);
+  UDM_CHECK_LAUNCH("udm_cast_bf16_f32");
+  return 0;
+}

@@ -1,0 +1,400 @@
+"""Trainer-level hot path: the reference's ``model.py::Diffusion`` methods that run every training step.
+
+Mirrors, with the same names / argument meaning / error behaviour:
+  ``update_batch`` (model.py:157-395, token-dataset branch), ``get_cond_dict`` (:397-418), ``training_step`` (:420-422),
+  ``q_xt`` (:424-587), ``_sample_t`` (:589-619), ``_subs_parameterization`` (:621-658), ``_process_sigma`` (:660-672),
+  ``forward`` (:674-795), ``compute_loss`` (:797-1173) and the ``Loss`` record (model_utils.py:110-120).
+
+Host logic (RNG draws, masks, weights, reductions on [B] / [B,L] tensors) is plain torch on the device — the
+reference's draw order ``rand(B)`` → ``rand(B,L)`` → ``rand(B,1)``×2 is preserved so masks are bit-exact for a
+given generator state.  All O(B·L·d) and O(B·L·V) work goes through ``unidisc_amd.DIT`` (HIP kernels).
+``compute_loss`` uses the fused path ``backbone.forward_logp`` and never materialises [B,L,V] log-probs;
+``forward`` still returns full SUBS log-probs (or logits) for samplers.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+import torch.nn.functional as F
+
+from . import kernels as K
+from .dit import DIT, cfg_get
+from .noise_schedule import get_noise
+
+
+@dataclass
+class Loss:  # model_utils.py:110-120
+    loss: torch.FloatTensor
+    img_loss: torch.FloatTensor = None
+    txt_loss: torch.FloatTensor = None
+    nlls: torch.FloatTensor = None
+    token_mask: torch.FloatTensor = None
+    txt_nlls: torch.FloatTensor = None
+    img_nlls: torch.FloatTensor = None
+    extra_losses: dict = None
+    modality_mask: torch.FloatTensor = None
+
+
+class Diffusion:
+    def __init__(self, config, tokenizer, device, disable_init=False, backbone: Optional[torch.nn.Module] = None):
+        self.config, self.tokenizer, self.device = config, tokenizer, torch.device(device)
+        if disable_init:
+            return
+        self.init(config, tokenizer, device, backbone)
+
+    # ---- model_setup.init (model_setup.py:47-327), hot-path subset
+    def init(self, config, tokenizer, device, backbone=None):
+        m, tr = cfg_get(config, "model"), cfg_get(config, "trainer")
+        self.global_step = 0
+        self.current_run_fwd_bwd_pass = 0
+        prec = str(cfg_get(tr, "precision", "bf16"))
+        self.dtype = torch.float32 if ("fp32" in prec or "no" in prec) else (torch.bfloat16 if "bf16" in prec else torch.float16)
+        if self.dtype != torch.bfloat16:
+            raise NotImplementedError(f"unidisc_amd: trainer.precision={prec}; only bf16 (the reference's training precision) is implemented in HIP")
+        self.image_model = bool(cfg_get(m, "image_model", False))
+        self.unified_model = bool(cfg_get(m, "unified_model", False))
+        self.antithetic_sampling = cfg_get(tr, "antithetic_sampling", True)
+        self.importance_sampling = cfg_get(tr, "importance_sampling", False)
+        self.change_of_variables = cfg_get(tr, "change_of_variables", False)
+        if self.importance_sampling or self.change_of_variables:
+            raise NotImplementedError("unidisc_amd: importance_sampling / change_of_variables are off in every shipped config and not implemented")
+        if self.image_model is False or self.unified_model:  # model_setup.py:89-98
+            forced = cfg_get(m, "force_text_vocab_size", None)
+            self.vocab_size = forced if forced is not None else len(tokenizer)
+            if tokenizer is None or getattr(tokenizer, "mask_token", None) is None:
+                self.mask_index = self.vocab_size
+                self.vocab_size += 1
+            else:
+                self.mask_index = tokenizer.mask_token_id
+        if self.image_model:  # :99-113
+            if self.unified_model:
+                self.text_vocab_size = self.vocab_size
+                self.vocab_size += cfg_get(m, "image_vocab_size")
+                self.image_vocab_size = cfg_get(m, "image_vocab_size")
+            else:
+                self.vocab_size = cfg_get(m, "image_vocab_size") + 1
+                self.mask_index = self.vocab_size - 1
+                self.text_vocab_size = 0
+        else:
+            self.text_vocab_size = self.vocab_size
+        self.parameterization = cfg_get(config, "parameterization", "subs")
+        if self.parameterization != "subs":
+            raise NotImplementedError(f"unidisc_amd: parameterization={self.parameterization}; only SUBS is on the denoising hot path")
+        if cfg_get(config, "backbone", "dit") != "dit":
+            raise NotImplementedError("unidisc_amd: only backbone=dit is implemented")
+        self.static_txt_sl = slice(None, cfg_get(m, "txt_length"))
+        self.static_img_sl = slice(-cfg_get(m, "img_length"), None) if cfg_get(m, "img_length", 0) else slice(0, 0)
+        if backbone is None:  # model_setup.py:148-161
+            backbone = DIT(config, vocab_size=self.vocab_size, text_vocab_size=self.text_vocab_size, mask_index=self.mask_index, autocast_dtype=self.dtype,
+                           device=device, static_img_sl=self.static_img_sl, static_txt_sl=self.static_txt_sl)
+        self.backbone = backbone
+        self.T = cfg_get(config, "T", 0)
+        if self.T:
+            raise NotImplementedError("unidisc_amd: discrete-time T>0 (D3PM loss) is not on the denoising hot path")
+        self.noise = get_noise(config)
+        self.sampling_eps = cfg_get(tr, "sampling_eps", 1e-3)
+        self.time_conditioning = cfg_get(config, "time_conditioning", False)
+        self.neg_infinity = -1000000.0  # model_setup.py:269
+
+    rng_device = None  # set to "cpu" to draw t / masks from the CPU generator (bit-reproducible across devices)
+
+    def _rand(self, *shape, device):
+        if self.rng_device is None:
+            return torch.rand(*shape, device=device)
+        return torch.rand(*shape, device=self.rng_device).to(device)
+
+    @property
+    def training(self):
+        return self.backbone.training
+
+    @property
+    def allow_slicing(self):  # model.py:1283-1285
+        return not self.backbone.training
+
+    def txt_sl(self, batch=None):
+        return batch["modality_mask"][..., 0]
+
+    def img_sl(self, batch=None):
+        return batch["modality_mask"][..., 1]
+
+    # ---- model.py:157-395
+    def update_batch(self, batch):
+        cfg, tr, m = self.config, cfg_get(self.config, "trainer"), cfg_get(self.config, "model")
+        if batch is None:
+            return batch
+        batch = dict(batch.items()) if not isinstance(batch, dict) else dict(batch)
+        if self.image_model or cfg_get(cfg_get(cfg, "data"), "force_image_dataset", False):
+            if "txt_input_ids" in batch or "img_input_ids" in batch:  # :183-212
+                for key in ("img_input_ids", "txt_input_ids", "sample_ids"):
+                    if key in batch:
+                        if isinstance(batch[key], list):
+                            batch[key] = torch.stack(batch[key], dim=0)
+                        batch[key] = batch[key].to(torch.int64)
+                img_input_ids = batch.pop("img_input_ids")
+                batch["input_ids"] = img_input_ids
+                batch["attention_mask"] = torch.ones_like(img_input_ids).to(torch.bool)
+                if "txt_input_ids" in batch:
+                    batch["input_ids"] = torch.cat([batch["txt_input_ids"], batch["input_ids"] + self.text_vocab_size], dim=-1)
+                    batch["attention_mask"] = torch.cat([batch["txt_attention_mask"], batch["attention_mask"]], dim=-1)
+                batch["input_ids"] = batch["input_ids"].to(torch.int64)
+                if "modality" not in batch:
+                    if cfg_get(tr, "ignore_text_in_unified", False):
+                        modality = torch.ones_like(batch["input_ids"], dtype=torch.int64)
+                    else:
+                        assert cfg_get(m, "txt_length") > 0 and cfg_get(m, "img_length") > 0
+                        modality = torch.zeros_like(batch["input_ids"], dtype=torch.int64)
+                        modality[:, -img_input_ids.shape[-1]:] = 1
+                    batch["modality"] = modality
+            elif cfg_get(tr, "multimodal_batches", False):  # :214-250 (pre-tokenised multimodal batches)
+                if "img" in batch:
+                    raise NotImplementedError("unidisc_amd: raw-image batches need the VQ tokenizer, which is outside the denoising hot path")
+                batch["input_ids"] = batch["input_ids"].to(torch.int64)
+                if "sample_ids" in batch:
+                    batch["sample_ids"] = batch["sample_ids"].to(torch.int64)
+                if cfg_get(tr, "force_shift_image_batches", False):
+                    batch["input_ids"] = torch.where(batch["modality"] == 1, batch["input_ids"] + self.text_vocab_size, batch["input_ids"])
+            else:
+                raise NotImplementedError("unidisc_amd: raw-image batches need the VQ tokenizer, which is outside the denoising hot path")
+            if batch["input_ids"].shape[1] != cfg_get(m, "length") and not cfg_get(tr, "ar_inpainting", False):
+                assert False, f"input ids are not the correct length input ids shape: {batch['input_ids'].shape}, model length: {cfg_get(m, 'length')}"
+        if "modality" in batch:  # :296-304
+            batch["modality"] = batch["modality"].to(torch.int64)
+            if cfg_get(tr, "multimodal_batches", False) and batch["modality"].ndim == 2 and batch["modality"].shape[-1] == 1:
+                batch["modality"] = batch["modality"].repeat(1, cfg_get(m, "length"))
+        else:
+            if self.image_model and not cfg_get(tr, "multimodal_batches", False):
+                modality = torch.zeros_like(batch["input_ids"], dtype=torch.int64)
+                modality[:, self.static_img_sl] = 1
+                batch["modality"] = modality
+            elif cfg_get(cfg_get(cfg, "data"), "txt_only", False):
+                batch["modality"] = torch.zeros_like(batch["input_ids"], dtype=torch.int64)
+        if "modality" in batch:  # :309-315
+            batch["modality"][batch["modality"] == -1] = 0
+            assert batch["modality"].min() == 0 and batch["modality"].max() == 1
+            batch["modality_mask"] = F.one_hot(batch["modality"], num_classes=2).to(torch.bool)
+            batch["batch_contains_img"] = (batch["modality"] == 1).any(dim=-1)
+            batch["txt_sl"] = self.txt_sl(batch)
+            batch["img_sl"] = self.img_sl(batch)
+        for key in list(batch.keys()):  # :337-343
+            if isinstance(batch[key], torch.Tensor):
+                batch[key] = batch[key].to(self.device)
+        if cfg_get(tr, "force_full_attention_mask", False):
+            batch["attention_mask"] = torch.ones_like(batch["attention_mask"], dtype=torch.bool)
+        batch["attention_mask"] = batch["attention_mask"].to(torch.bool)
+        if cfg_get(cfg_get(cfg, "data"), "require_sample_ids", False):  # :349-353
+            assert "sample_ids" in batch
+            batch["sample_ids"][~(batch["attention_mask"].bool())] = -1
+            batch["attention_mask"][batch["sample_ids"] == -1] = False
+        if cfg_get(tr, "interleaved", False) and "sample_ids" not in batch:
+            batch["sample_ids"] = torch.zeros_like(batch["modality"], dtype=torch.int64)
+        return batch
+
+    def get_cond_dict(self, batch):  # model.py:397-418
+        ret = dict()
+        if "cond_input_ids" in batch or "img_label" in batch:
+            raise NotImplementedError("unidisc_amd: image / label conditioning is outside the denoising hot path")
+        if cfg_get(cfg_get(self.config, "model"), "use_attention_mask", False):
+            raise NotImplementedError("unidisc_amd: model.use_attention_mask (SDPA padding mask) is not implemented; shipped configs leave it off")
+        if cfg_get(cfg_get(self.config, "trainer"), "multimodal_batches", False):
+            ret["modality"] = batch["modality"]
+        return ret
+
+    def training_step(self, batch, batch_idx):  # model.py:420-422
+        batch = self.update_batch(batch)
+        return self.compute_loss(batch, prefix="train", batch_idx=batch_idx)
+
+    # ---- model.py:424-587 (absorbing state, non-interleaved)
+    def q_xt(self, x, move_chance, allow_move_mask=None, return_ignore_batch_mask_for_metrics=False, mask_image_square=False, mask_text_region=False,
+             batch=None):
+        tr = cfg_get(self.config, "trainer")
+        if mask_image_square or mask_text_region:
+            raise NotImplementedError("unidisc_amd: square / region masking are evaluation-time options outside the hot path")
+        move_indices = self._rand(*x.shape, device=x.device) < move_chance
+        ignore_batch_mask_for_metrics = None
+        should_mask_txt, should_mask_img = None, None
+        mask_prob = cfg_get(tr, "mask_entire_modality", None)
+        if mask_prob is not None and self.backbone.training:
+            assert batch is not None
+            batch_size, seq_len = x.shape
+            if cfg_get(tr, "mask_txt_only", False):
+                should_mask_txt = self._rand(batch_size, 1, device=x.device) < mask_prob
+                should_mask_img = torch.zeros_like(should_mask_txt, device=x.device)
+            else:
+                should_mask_txt = self._rand(batch_size, 1, device=x.device) < mask_prob / 2
+                should_mask_img = self._rand(batch_size, 1, device=x.device) < mask_prob / 2
+            if cfg_get(tr, "multimodal_batches", False):
+                if cfg_get(tr, "interleaved", False):
+                    raise NotImplementedError("unidisc_amd: per-block modality masking for interleaved batches (SURVEY §8 row a19) is not built yet")
+                both_mask = should_mask_txt & should_mask_img
+                should_mask_txt = torch.where(both_mask, False, should_mask_txt)
+                should_mask_img = torch.where(both_mask, False, should_mask_img)
+                move_indices = torch.where(should_mask_txt, batch["modality_mask"][..., 0], move_indices)
+                move_indices = torch.where(should_mask_img, batch["modality_mask"][..., 1], move_indices)
+                ignore_batch_mask_for_metrics = should_mask_img | should_mask_txt
+            else:
+                both_mask = should_mask_txt & should_mask_img
+                should_mask_txt[both_mask] = False
+                should_mask_img[both_mask] = False
+                should_mask_img[batch["txt_sl"].all(dim=-1)] = False
+                move_indices[:, self.static_txt_sl] = torch.where(should_mask_txt, True, move_indices[:, self.static_txt_sl])
+                move_indices[:, self.static_img_sl] = torch.where(should_mask_img, True, move_indices[:, self.static_img_sl])
+                ignore_batch_mask_for_metrics = should_mask_img | should_mask_txt
+        for flag in ("joint_ar_nar_prob", "first_token_dropout"):
+            if cfg_get(tr, flag, None) is not None:
+                raise NotImplementedError(f"unidisc_amd: trainer.{flag} is not on the denoising hot path")
+        if cfg_get(tr, "add_label", False):
+            move_indices[:, 0] = False
+        if allow_move_mask is not None:
+            move_indices = move_indices & allow_move_mask
+        if cfg_get(tr, "discrete_diffusion_mode", "absorbing") != "absorbing":
+            raise NotImplementedError("unidisc_amd: only absorbing-state diffusion is implemented")
+        xt = torch.where(move_indices, self.mask_index, x)
+        if return_ignore_batch_mask_for_metrics:
+            return xt, ignore_batch_mask_for_metrics, None, should_mask_txt, should_mask_img, move_indices
+        return xt
+
+    def _sample_t(self, n, device):  # model.py:589-619
+        tr = cfg_get(self.config, "trainer")
+        _eps_t = self._rand(n, device=device)
+        if cfg_get(tr, "joint_ar_nar_timestep_warmup_steps", None) is not None:
+            raise NotImplementedError("unidisc_amd: joint AR/NAR timestep warm-up is not on the denoising hot path")
+        if self.antithetic_sampling:
+            offset = torch.arange(n, device=device) / n
+            _eps_t = (_eps_t / n + offset) % 1
+        if cfg_get(tr, "force_timestep", None) is not None:
+            _eps_t[:] = cfg_get(tr, "force_timestep")
+        t = (1 - self.sampling_eps) * _eps_t + self.sampling_eps
+        return t.to(torch.float32)
+
+    def _restrict(self):
+        return bool(cfg_get(cfg_get(self.config, "model"), "force_argmax_valid_indices", False))
+
+    def _subs_parameterization(self, logits, xt, batch=None, modality=None, **kwargs):
+        """model.py:621-658 on the HIP path: bf16 logits [B,L,V] -> SUBS log-probs [B,L,V] (same dtype)."""
+        B, L, V = logits.shape
+        flat = logits.reshape(B * L, V)
+        if flat.stride(0) % 8 != 0 or flat.stride(1) != 1 or flat.data_ptr() % 16 != 0 or flat.dtype != torch.bfloat16:
+            buf = torch.zeros((B * L, (V + 7) // 8 * 8), dtype=torch.bfloat16, device=logits.device)
+            buf[:, :V] = flat
+            flat = buf
+        mod = modality
+        if self._restrict() and mod is None and batch is not None and cfg_get(cfg_get(self.config, "trainer"), "multimodal_batches", False):
+            mod = batch["modality"]
+        if self._restrict() and mod is None:  # static slices (model.py:634-635)
+            mod = torch.zeros((B, L), dtype=torch.int64, device=logits.device)
+            mod[:, self.static_img_sl] = 1
+        out = K.subs_logprobs(flat, xt.reshape(-1).contiguous() if xt is not None else None, mod.reshape(-1).contiguous() if mod is not None else None, V,
+                              self.text_vocab_size, self.mask_index, self._restrict(), out_dtype=logits.dtype if logits.dtype == torch.float32 else torch.bfloat16)
+        return out.view(B, L, V)
+
+    def _process_sigma(self, sigma):  # model.py:660-672
+        if sigma is None:
+            assert cfg_get(cfg_get(self.config, "trainer"), "allow_null_sigma", False)
+            return sigma
+        if sigma.ndim > 1:
+            sigma = sigma.squeeze(-1)
+            assert sigma.ndim == 1, sigma.shape
+        if not self.time_conditioning and cfg_get(cfg_get(self.config, "model"), "force_time_conditioning", False):
+            sigma = torch.zeros_like(sigma)
+        return sigma
+
+    def forward(self, x, sigma, batch=None, forward_attention_mask=None, return_additional_loss=False, x_img_emb=None, disable_ar_shift=False,
+                continuous_mode=False, joint_ar_nar_mask=None, return_logits=False, block_mask=None, update_cache_slice=None, **kwargs):
+        """Returns log score (model.py:674-795): SUBS log-probs [B,L,V] (bf16), or raw logits when ``return_logits``."""
+        sigma = self._process_sigma(sigma)
+        logits = self.backbone(x, sigma, continuous_mode=continuous_mode, x_img_emb=x_img_emb, block_mask=block_mask,
+                               update_cache_slice=update_cache_slice, **kwargs)
+        if return_logits:
+            return logits
+        if logits.requires_grad:
+            raise RuntimeError("unidisc_amd.Diffusion.forward: full SUBS log-probs are an inference product (no autograd); "
+                               "training uses compute_loss (fused path) — wrap sampler calls in torch.no_grad()")
+        return self._subs_parameterization(logits, xt=x, batch=batch, **kwargs)
+
+    # ---- model.py:797-1173, SUBS / continuous-time branch
+    def compute_loss(self, batch, prefix, batch_idx=-1):
+        cfg, tr = self.config, cfg_get(self.config, "trainer")
+        kwargs = self.get_cond_dict(batch)
+        modality_mask = batch.get("modality_mask", None)
+        x0, attention_mask = batch["input_ids"], batch.get("attention_mask", None)
+        if x0.shape[1] > cfg_get(cfg_get(cfg, "model"), "length"):
+            raise NotImplementedError("unidisc_amd: sequence sub-sampling (text8-crop) is not on the denoising hot path")
+        t = self._sample_t(x0.shape[0], x0.device)
+        sigma, dsigma = self.noise(t)
+        unet_conditioning = sigma[:, None]
+        move_chance = 1 - torch.exp(-sigma[:, None])
+        xt, ignore_batch_mask_for_metrics, joint_ar_nar_mask, should_mask_txt, should_mask_img, move_indices = self.q_xt(
+            x0, move_chance, return_ignore_batch_mask_for_metrics=True, batch=batch)
+        m = cfg_get(cfg, "model")
+        if (cfg_get(m, "flex_attention_img_masking_prob", None) is not None or cfg_get(m, "flex_attention_txt_masking_prob", None) is not None) and self.backbone.training:
+            raise NotImplementedError("unidisc_amd: modality attention dropout (flex_attention_*_masking_prob) is not implemented")
+        if cfg_get(tr, "interleaved_training_flex_attention", False):
+            kwargs["sample_ids"] = batch["sample_ids"]  # the document mask is derived from sample_ids inside the attention kernel
+
+        # fused backbone + SUBS + gather: log p_theta(x0 | xt) per token, fp32 (model.py:908-925, :967)
+        log_p_theta = self.backbone.forward_logp(xt, x0, self._process_sigma(unet_conditioning), modality=kwargs.get("modality"),
+                                                 sample_ids=kwargs.get("sample_ids"), restrict_modality=self._restrict())
+        self._last = dict(t=t, sigma=sigma, dsigma=dsigma, xt=xt, move_indices=move_indices, log_p_theta=log_p_theta)
+
+        if cfg_get(tr, "no_ce_weighting", False):
+            std_weighting = 1
+        else:
+            std_weighting = (dsigma / torch.expm1(sigma))[:, None]
+        loss = -log_p_theta * std_weighting
+        if not cfg_get(tr, "no_ce_weighting", False):
+            gamma = cfg_get(tr, "softmin_snr", None)
+            if gamma is not None:
+                softmin_weighting = (dsigma / (torch.expm1(sigma) + (1 / gamma)))[:, None]
+                loss = -log_p_theta * softmin_weighting
+        std_loss = -log_p_theta * std_weighting
+        loss_dict = dict(std_loss=std_loss.detach(), extra_losses=dict())
+        if cfg_get(tr, "log_seperate_modal_losses", False):
+            loss_dict.update(dict(std_txt_loss=(std_loss.detach() * modality_mask[..., 0] * attention_mask),
+                                  std_img_loss=(std_loss.detach() * modality_mask[..., 1] * attention_mask)))
+        if cfg_get(tr, "mask_entire_modality", None) is not None and self.backbone.training:
+            loss_dict["batch_ignore_loss"] = ignore_batch_mask_for_metrics.squeeze(-1)
+        weighted = cfg_get(tr, "text_loss_weight", None) is not None and cfg_get(tr, "img_loss_weight", None) is not None
+        if cfg_get(tr, "multimodal_batches", False) or weighted:
+            txt_mask = modality_mask[..., 0] & attention_mask
+            img_mask = modality_mask[..., 1] & attention_mask
+            txt_count, img_count = txt_mask.sum(), img_mask.sum()
+            total_count = txt_count + img_count
+            txt_frac, img_frac = txt_count / total_count, img_count / total_count
+            loss_dict["extra_losses"]["trainer/img_frac"] = img_frac
+            loss_dict["extra_losses"]["trainer/txt_frac"] = txt_frac
+            loss_dict["extra_losses"]["trainer/attention_mask_valid_frac"] = attention_mask.sum() / attention_mask.numel()
+            if "batch_ignore_loss" in loss_dict:
+                loss_dict["extra_losses"]["trainer/ignore_batch_metrics_frac"] = loss_dict["batch_ignore_loss"].sum() / loss_dict["batch_ignore_loss"].numel()
+        if weighted:
+            loss = loss * attention_mask
+            # masked sums instead of boolean indexing: same value, no host sync for the dynamic shape
+            txt_loss = ((loss * txt_mask).sum() / txt_count) * txt_frac * cfg_get(tr, "text_loss_weight")
+            img_loss = ((loss * img_mask).sum() / img_count) * img_frac * cfg_get(tr, "img_loss_weight")
+            ratio = cfg_get(tr, "set_max_txt_loss_ratio", None)
+            if ratio is not None:
+                max_txt_loss = float(ratio) * img_loss.detach()
+                scale = torch.minimum(torch.tensor(1.0, device=txt_loss.device), max_txt_loss / (txt_loss.detach() + 1e-8))
+                ok = ~(torch.isnan(img_loss.detach()) | torch.isnan(txt_loss.detach()))
+                txt_loss = txt_loss * torch.where(ok, scale, torch.ones_like(scale))
+            txt_loss = torch.nan_to_num(txt_loss, nan=0.0)
+            img_loss = torch.nan_to_num(img_loss, nan=0.0)
+            loss = txt_loss + img_loss
+            loss_dict.update(dict(txt_loss=txt_loss.clone().detach(), img_loss=img_loss.clone().detach()))
+        else:
+            _attention_mask = torch.ones_like(attention_mask) if cfg_get(tr, "force_full_attention_mask_loss_only", False) else attention_mask
+            loss = (loss * _attention_mask).sum() / _attention_mask.sum()
+            loss = torch.nan_to_num(loss, nan=0.0)
+        loss_dict = dict(loss=loss, **loss_dict)
+        std_nlls = loss_dict.get("std_loss", 0) * attention_mask
+        if "batch_ignore_loss" in loss_dict:
+            attention_mask = torch.where(loss_dict["batch_ignore_loss"][:, None].repeat(1, attention_mask.shape[-1]),
+                                         torch.full_like(attention_mask, False), attention_mask)
+        losses = Loss(loss=loss_dict["loss"], img_loss=loss_dict.get("img_loss", 0), txt_loss=loss_dict.get("txt_loss", 0), nlls=std_nlls,
+                      txt_nlls=loss_dict.get("std_txt_loss", 0), img_nlls=loss_dict.get("std_img_loss", 0), token_mask=attention_mask,
+                      modality_mask=modality_mask, extra_losses=loss_dict.get("extra_losses", None))
+        if prefix == "train":
+            return losses
+        raise NotImplementedError(f"unidisc_amd.compute_loss: prefix={prefix!r} drives torchmetrics bookkeeping, which is outside the hot path; "
+                                  "call with prefix='train' and feed Loss.nlls / Loss.token_mask to your metrics")

@@ -1,0 +1,603 @@
+"""MI355X-native drop-in for the reference's ``models/dit.py::DIT``.
+
+Same constructor signature, ``forward`` signature and ``state_dict`` schema as the reference
+(models/dit.py:1095-1500), so ``config.backbone == "dit"`` can select this class in
+``model_setup.init`` (model_setup.py:134-161) and HF checkpoints load unchanged.  The sub-modules below
+exist to own parameters under the reference's names; compute does not go through ``nn.Module.forward``
+of the children.  Instead ``DIT`` runs a hand-scheduled engine: every op of the block is a HIP kernel
+from ``libunidisc_hip.so`` enqueued on the current stream, activations needed by the backward are
+kept in HBM (288 GB: no recompute needed at the BASELINE shapes), and the backward is an explicit
+reverse schedule that hands finished gradient ranges to an optional callback (used by
+``unidisc_amd.ddp`` to overlap the bf16 gradient all-reduce with the rest of the backward).
+
+Numerics follow the reference's bf16-autocast flow: fp32 residual stream and master
+weights, bf16 GEMM operands with fp32 accumulation, bf16 activations between GEMMs, fp32 statistics.
+Only bf16 compute is implemented (``trainer.precision=bf16``, the reference's training precision).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn as nn
+
+from . import kernels as K
+from .rope import lumina_rope_2d, rotary_table_1d
+
+try:  # optional, for from_pretrained / push_to_hub parity with the reference class
+    from huggingface_hub import PyTorchModelHubMixin as _HubMixin
+except Exception:  # pragma: no cover
+    class _HubMixin:  # type: ignore
+        pass
+
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+def cfg_get(node, key, default=None):
+    """getattr/getitem with default over OmegaConf nodes, attribute bags and dicts (the reference leans on getattr(cfg, k, default))."""
+    if node is None:
+        return default
+    if isinstance(node, dict):
+        return node.get(key, default)
+    try:
+        v = getattr(node, key)
+    except (AttributeError, KeyError):
+        return default
+    return v
+
+
+def _ceil(x, m):
+    return (x + m - 1) // m * m
+
+
+# ------------------------------------------------------------------------------------------------
+# parameter containers (names == reference state_dict keys)
+# ------------------------------------------------------------------------------------------------
+class EmbeddingLayer(nn.Module):  # models/dit.py:1036-1043
+    def __init__(self, dim, vocab_dim):
+        super().__init__()
+        self.embedding = nn.Parameter(torch.empty((vocab_dim, dim)))
+        torch.nn.init.kaiming_uniform_(self.embedding, a=math.sqrt(5))
+
+
+class RMSNorm(nn.Module):  # models/dit.py:77-100
+    def __init__(self, dim, eps=1e-6):
+        super().__init__()
+        self.eps = eps
+        self.weight = nn.Parameter(torch.ones(dim))
+
+
+class LayerNorm(nn.Module):  # models/dit.py:383-403 (weight only)
+    def __init__(self, dim):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones([dim]))
+        self.dim = dim
+
+
+def get_norm(dim, norm_type="layernorm"):
+    if norm_type == "layernorm":
+        return LayerNorm(dim)
+    if norm_type == "rms":
+        return RMSNorm(dim)
+    raise ValueError(f"Unknown norm type: {norm_type}")
+
+
+class TimestepEmbedder(nn.Module):  # models/dit.py:415-449
+    def __init__(self, hidden_size, frequency_embedding_size=256):
+        super().__init__()
+        self.mlp = nn.Sequential(nn.Linear(frequency_embedding_size, hidden_size, bias=True), nn.SiLU(), nn.Linear(hidden_size, hidden_size, bias=True))
+        self.frequency_embedding_size = frequency_embedding_size
+
+
+class Attention(nn.Module):  # models/dit.py:515-575
+    def __init__(self, dim, n_heads, qk_norm=False):
+        super().__init__()
+        self.n_heads, self.head_dim, self.qk_norm = n_heads, dim // n_heads, qk_norm
+        self.attn_qkv = nn.Linear(dim, 3 * dim, bias=False)
+        self.attn_out = nn.Linear(dim, dim, bias=False)
+        if qk_norm:
+            self.q_norm = nn.LayerNorm(dim)
+            self.k_norm = nn.LayerNorm(dim)
+
+
+class DDiTBlock(nn.Module):  # models/dit.py:890-934
+    def __init__(self, dim, n_heads, cond_dim, mlp_ratio=4, dropout=0.1, time_conditioning=True, norm_type="layernorm", sandwich_normalization=False,
+                 qk_norm=False):
+        super().__init__()
+        self.time_conditioning, self.dropout, self.sandwich_normalization = time_conditioning, dropout, sandwich_normalization
+        self.attention = Attention(dim, n_heads, qk_norm=qk_norm)
+        self.norm1 = get_norm(dim, norm_type)
+        self.norm2 = get_norm(dim, norm_type)
+        self.mlp = nn.Sequential(nn.Linear(dim, mlp_ratio * dim, bias=True), nn.GELU(approximate="tanh"), nn.Linear(mlp_ratio * dim, dim, bias=True))
+        if time_conditioning:
+            self.adaLN_modulation = nn.Linear(cond_dim, 6 * dim, bias=True)
+            self.adaLN_modulation.weight.data.zero_()
+            self.adaLN_modulation.bias.data.zero_()
+        if sandwich_normalization:
+            self.post_ff_norm = get_norm(dim, norm_type)
+            self.pre_residual_norm = get_norm(dim, norm_type)
+
+
+class DDitFinalLayer(nn.Module):  # models/dit.py:1063-1092
+    def __init__(self, hidden_size, out_channels, cond_dim, time_conditioning=True, norm_type="layernorm", zero_linear_init=True):
+        super().__init__()
+        self.time_conditioning = time_conditioning
+        self.norm_final = get_norm(hidden_size, norm_type)
+        self.linear = nn.Linear(hidden_size, out_channels)
+        if zero_linear_init:
+            self.linear.weight.data.zero_()
+        self.linear.bias.data.zero_()
+        if time_conditioning:
+            self.adaLN_modulation = nn.Linear(cond_dim, 2 * hidden_size, bias=True)
+            self.adaLN_modulation.weight.data.zero_()
+            self.adaLN_modulation.bias.data.zero_()
+
+
+class _Lin:
+    """bf16 shadows of one nn.Linear weight: w16 [out(p), in] for forward, w16t [in, out(p)] for dgrad."""
+
+    def __init__(self, weight: nn.Parameter, bias: Optional[nn.Parameter], out_pad: int = 8):
+        self.weight, self.bias = weight, bias
+        self.out, self.inp = weight.shape
+        self.outp = _ceil(self.out, out_pad)
+        self.w16 = self.w16t = None
+
+    def refresh(self):
+        dev = self.weight.device
+        if self.w16 is None or self.w16.device != dev:
+            self.w16 = torch.zeros((self.outp, self.inp), dtype=BF16, device=dev)
+            self.w16t = torch.zeros((self.inp, self.outp), dtype=BF16, device=dev)
+        K.cast_transpose(self.weight.detach(), self.w16, self.w16t)
+
+
+# ------------------------------------------------------------------------------------------------
+# the module
+# ------------------------------------------------------------------------------------------------
+class DIT(nn.Module, _HubMixin):
+    def __init__(self, config, vocab_size: int, text_vocab_size: int, mask_index: int, dtype=None, device=None, static_img_sl=None, static_txt_sl=None,
+                 **kwargs):
+        super().__init__()
+        self.config = config
+        m, tr, data = cfg_get(config, "model"), cfg_get(config, "trainer"), cfg_get(config, "data")
+        self.autocast_dtype = dtype
+        self.vocab_size, self.text_vocab_size, self.mask_index = vocab_size, text_vocab_size, mask_index
+        self.time_conditioning = bool(cfg_get(config, "time_conditioning", False) or cfg_get(m, "force_time_conditioning", False))
+        self.use_gradient_checkpointing = cfg_get(tr, "use_gradient_checkpointing", False)
+        self.sandwich_normalization = cfg_get(m, "sandwich_normalization", False)
+        self.static_img_sl, self.static_txt_sl = static_img_sl, static_txt_sl
+        for flag, why in (("img_cond", "cross-attention image conditioning"), ("cond_label", "class-label conditioning"),
+                          ("use_pretrained_img_emb", "pretrained VQ embedding table"), ("use_kv_cache", "inference KV cache"),
+                          ("use_flex_attention_cache", "inference modality KV cache")):
+            if cfg_get(m, flag, False):
+                raise NotImplementedError(f"unidisc_amd.DIT: model.{flag} ({why}) is outside the denoising hot path (SURVEY.md §8)")
+        if not cfg_get(m, "full_attention", True):
+            raise NotImplementedError("unidisc_amd.DIT: causal attention (model.full_attention=false) is not on the denoising hot path")
+        if cfg_get(tr, "image_mode", "discrete") == "continuous":
+            raise NotImplementedError("unidisc_amd.DIT: continuous image mode is not on the denoising hot path")
+        if cfg_get(m, "attn_dropout", None):
+            raise NotImplementedError("unidisc_amd.DIT: attention dropout is not implemented (no shipped config enables it)")
+
+        d, H = cfg_get(m, "hidden_size"), cfg_get(m, "n_heads")
+        self.hidden_size, self.n_heads, self.head_dim = d, H, d // H
+        self.cond_dim, self.n_blocks = cfg_get(m, "cond_dim"), cfg_get(m, "n_blocks")
+        self.norm_type, self.qk_norm = cfg_get(m, "norm_type", "layernorm"), cfg_get(m, "qk_norm", False)
+        self.dropout = float(cfg_get(m, "dropout", 0.0) or 0.0)
+        if self.head_dim not in (32, 64, 128):
+            raise NotImplementedError(f"unidisc_amd.DIT: head_dim {self.head_dim} unsupported (32/64/128)")
+
+        self.vocab_embed = EmbeddingLayer(d, vocab_size)
+        self.sigma_map = TimestepEmbedder(self.cond_dim) if self.time_conditioning else None
+        self.modality_embed = EmbeddingLayer(d, 2) if cfg_get(m, "modality_embed", False) else None
+
+        self.txt_length, self.img_length, self.total_length = cfg_get(m, "txt_length"), cfg_get(m, "img_length"), cfg_get(m, "length")
+        self.multimodal_batches = bool(cfg_get(tr, "multimodal_batches", False))
+        self.rope_2d = bool(cfg_get(m, "rope_2d", False))
+        self.require_sample_ids = bool(cfg_get(data, "require_sample_ids", False))
+        assert (self.txt_length + self.img_length == self.total_length) or self.multimodal_batches
+        D = self.head_dim
+        if self.rope_2d:  # models/dit.py:1203-1232
+            if self.require_sample_ids:
+                raise NotImplementedError("unidisc_amd.DIT: per-image-block 2-D RoPE for interleaved batches (SURVEY §8 row a19) is not built yet")
+            if not (self.multimodal_batches and self.modality_embed is not None):
+                raise NotImplementedError("unidisc_amd.DIT: rope_2d needs multimodal_batches and modality_embed (as in every shipped config)")
+            side = int(math.sqrt(self.img_length))
+            assert side * side == self.img_length, f"seq_len_2d must be a square number, got {self.img_length}"
+            emb = self._lumina(D, side, side, cfg_get(m, "linear_factor", 1.0))
+            self.register_buffer("rotary_cos_emb_img", emb.flatten(0, 1).real.contiguous(), persistent=False)
+            self.register_buffer("rotary_sin_emb_img", emb.flatten(0, 1).imag.contiguous(), persistent=False)
+            c, s = rotary_table_1d(self.total_length, D)
+            self.register_buffer("rotary_cos_emb_txt", c, persistent=False)
+            self.register_buffer("rotary_sin_emb_txt", s, persistent=False)
+        else:  # :1234-1239
+            c, s = rotary_table_1d(self.total_length, D)
+            self.register_buffer("rotary_cos_emb", c, persistent=False)
+            self.register_buffer("rotary_sin_emb", s, persistent=False)
+
+        self.blocks = nn.ModuleList([
+            DDiTBlock(d, H, self.cond_dim, dropout=self.dropout, time_conditioning=self.time_conditioning, norm_type=self.norm_type,
+                      sandwich_normalization=self.sandwich_normalization, qk_norm=self.qk_norm) for _ in range(self.n_blocks)
+        ])
+        self.output_layer = DDitFinalLayer(d, vocab_size, self.cond_dim, time_conditioning=self.time_conditioning, norm_type=self.norm_type,
+                                           zero_linear_init=cfg_get(m, "zero_linear_init", True))
+        self.allow_compiled_embed = False
+        if device is not None:
+            self.to(device)
+        # engine state
+        self._lins: Optional[Dict[str, _Lin]] = None
+        self._fwd_count = 0
+        self.grad_ready_callback = None   # fn(list[nn.Parameter]) called inside backward when those grads are final
+        self.recast_every_forward = True  # mirror autocast: fp32 master -> bf16 shadow on every training forward
+        self._shadow_versions = None
+
+    @staticmethod
+    def _lumina(D, h, w, linear_factor):
+        try:
+            from diffusers.models.embeddings import get_2d_rotary_pos_embed_lumina as fn  # the reference's source, when installed
+            return fn(D, h, w, linear_factor=linear_factor, ntk_factor=1.0)
+        except Exception:
+            return lumina_rope_2d(D, h, w, linear_factor=linear_factor, ntk_factor=1.0)
+
+    # reference API surface that callers touch; inference caches are out of scope
+    def reset_kv_cache(self, *a, **k):
+        raise NotImplementedError("unidisc_amd.DIT: KV cache is an inference feature outside the denoising hot path")
+
+    def set_flex_attention_cache(self, *a, **k):
+        raise NotImplementedError("unidisc_amd.DIT: modality KV cache is an inference feature outside the denoising hot path")
+
+    # -------------------------------------------------------------------------------------------- parameters / shadows
+    def _ordered_params(self) -> List[nn.Parameter]:
+        """Parameters in the order their gradients become final during backward (head first, embeddings last)."""
+        out = list(self.output_layer.parameters())
+        for blk in reversed(self.blocks):
+            out += list(blk.parameters())
+        out += list(self.vocab_embed.parameters())
+        if self.modality_embed is not None:
+            out += list(self.modality_embed.parameters())
+        if self.sigma_map is not None:
+            out += list(self.sigma_map.parameters())
+        seen = {id(p) for p in out}
+        assert len(seen) == len(out) == sum(1 for _ in self.parameters())
+        return out
+
+    def _build_lins(self):
+        L: Dict[str, _Lin] = {}
+        for i, blk in enumerate(self.blocks):
+            L[f"{i}.qkv"] = _Lin(blk.attention.attn_qkv.weight, None)
+            L[f"{i}.out"] = _Lin(blk.attention.attn_out.weight, None)
+            L[f"{i}.fc1"] = _Lin(blk.mlp[0].weight, blk.mlp[0].bias)
+            L[f"{i}.fc2"] = _Lin(blk.mlp[2].weight, blk.mlp[2].bias)
+            if self.time_conditioning:
+                L[f"{i}.ada"] = _Lin(blk.adaLN_modulation.weight, blk.adaLN_modulation.bias)
+        L["head"] = _Lin(self.output_layer.linear.weight, self.output_layer.linear.bias, out_pad=128)
+        if self.time_conditioning:
+            L["head.ada"] = _Lin(self.output_layer.adaLN_modulation.weight, self.output_layer.adaLN_modulation.bias)
+            L["sig0"] = _Lin(self.sigma_map.mlp[0].weight, self.sigma_map.mlp[0].bias)
+            L["sig2"] = _Lin(self.sigma_map.mlp[2].weight, self.sigma_map.mlp[2].bias)
+        self._lins = L
+
+    def refresh_weight_shadows(self, force=False):
+        if self._lins is None or next(iter(self._lins.values())).weight.device != self.vocab_embed.embedding.device:
+            self._build_lins()
+            force = True
+        versions = [l.weight._version for l in self._lins.values()]
+        if force or self.recast_every_forward and self.training or versions != self._shadow_versions:
+            for lin in self._lins.values():
+                lin.refresh()
+            self._shadow_versions = versions
+
+    # -------------------------------------------------------------------------------------------- public forward
+    def forward(self, indices, sigma=None, label=None, x_cond=None, attention_mask=None, continuous_mode=False, x_img_emb=None, modality=None,
+                start_pos=None, block_mask=None, update_cache_slice=None, sample_ids=None):
+        """→ logits [B, L, V] (bf16).  Signature of the reference's DIT.forward (models/dit.py:1324-1338)."""
+        self._check_unsupported(label, x_cond, attention_mask, continuous_mode, x_img_emb, start_pos, block_mask, update_cache_slice, sample_ids)
+        params = self._ordered_params()
+        inputs = dict(indices=indices, sigma=sigma, modality=modality, sample_ids=sample_ids, x0=None, save=self._needs_grad(params))
+        return _DitFn.apply(self, "logits", inputs, *params)
+
+    def forward_logp(self, xt, x0, sigma=None, modality=None, sample_ids=None, restrict_modality=False):
+        """Fused training path: log p_theta(x0 | xt) per token [B, L] fp32 under the SUBS parameterisation
+        (== gather(_subs_parameterization(logits, xt), x0), model.py:621-658 + :967) without materialising log-probs."""
+        params = self._ordered_params()
+        inputs = dict(indices=xt, sigma=sigma, modality=modality, sample_ids=sample_ids, x0=x0, restrict=restrict_modality, save=self._needs_grad(params))
+        return _DitFn.apply(self, "logp", inputs, *params)
+
+    @staticmethod
+    def _needs_grad(params):
+        return torch.is_grad_enabled() and any(p.requires_grad for p in params)
+
+    def _check_unsupported(self, label, x_cond, attention_mask, continuous_mode, x_img_emb, start_pos, block_mask, update_cache_slice, sample_ids):
+        for name, v in (("label", label), ("x_cond", x_cond), ("attention_mask", attention_mask), ("x_img_emb", x_img_emb), ("start_pos", start_pos),
+                        ("update_cache_slice", update_cache_slice)):
+            if v is not None:
+                raise NotImplementedError(f"unidisc_amd.DIT.forward: argument `{name}` is outside the denoising hot path")
+        if continuous_mode:
+            raise NotImplementedError("unidisc_amd.DIT.forward: continuous_mode is outside the denoising hot path")
+        if block_mask is not None and sample_ids is None:
+            raise NotImplementedError("unidisc_amd.DIT.forward: FlexAttention block_mask without sample_ids (modality attention dropout) is not implemented; "
+                                      "document masks are derived from sample_ids")
+
+    # -------------------------------------------------------------------------------------------- engine: forward
+    def _rotary(self, modality, L):
+        """models/dit.py:1413-1460 (non-interleaved branches) → fp32 [L, D/2] or per-sample [B, L, D/2]."""
+        if self.modality_embed is not None and self.rope_2d and self.multimodal_batches:
+            ci, si = self.rotary_cos_emb_img, self.rotary_sin_emb_img
+            if modality.shape[-1] != self.img_length:
+                pad = max(modality.shape[-1] - self.img_length, 0)
+                nanpad = torch.full((pad, ci.shape[-1]), float("nan"), device=ci.device, dtype=ci.dtype)
+                ci, si = torch.cat([nanpad, ci], 0), torch.cat([nanpad, si], 0)
+            sel = modality[:, :, None] == 0
+            cos = torch.where(sel, self.rotary_cos_emb_txt[None, :L], ci[None, :L]).contiguous()
+            sin = torch.where(sel, self.rotary_sin_emb_txt[None, :L], si[None, :L]).contiguous()
+            return cos, sin
+        return self.rotary_cos_emb[:L].contiguous(), self.rotary_sin_emb[:L].contiguous()
+
+    def _engine_forward(self, inp, mode, save):
+        ids = inp["indices"]
+        K.require_gpu(ids)
+        dev = ids.device
+        B, L = ids.shape
+        M, d, H, D = B * L, self.hidden_size, self.n_heads, self.head_dim
+        if M % 8 != 0:
+            raise ValueError(f"unidisc_amd.DIT: batch*length = {M} must be a multiple of 8")
+        nt = K.norm_id(self.norm_type)
+        tc, sw = self.time_conditioning, self.sandwich_normalization
+        train = self.training
+        self.refresh_weight_shadows()
+        lin = self._lins
+        self._fwd_count += 1
+        seed0 = (torch.initial_seed() * 1000003 + self._fwd_count * 4096) & ((1 << 62) - 1)
+        p_drop = self.dropout if train else 0.0
+
+        ids = ids.contiguous().view(-1).to(torch.int64)
+        modality = inp["modality"]
+        mod_flat = modality.contiguous().view(-1).to(torch.int64) if modality is not None else None
+        sample_ids = inp["sample_ids"]
+        sid = sample_ids.contiguous().to(torch.int64) if sample_ids is not None else None
+        if self.modality_embed is not None and mod_flat is None:
+            if self.multimodal_batches:
+                raise ValueError("unidisc_amd.DIT: modality_embed with multimodal_batches needs the `modality` argument")
+            pos = torch.arange(L, device=dev)  # static slices (models/dit.py:1409-1411)
+            is_img = torch.zeros(L, dtype=torch.bool, device=dev)
+            is_img[self.static_img_sl] = True
+            emb_mod = is_img.to(torch.int64)[None].expand(B, L).contiguous().view(-1)
+            del pos
+        else:
+            emb_mod = mod_flat
+        S = dict(B=B, L=L, ids=ids, modality=mod_flat, emb_mod=emb_mod, sid=sid, p_drop=p_drop, seed0=seed0, blocks=[])
+
+        x = K.embedding_fwd(ids, self.vocab_embed.embedding.detach(), emb_mod if self.modality_embed is not None else None,
+                            self.modality_embed.embedding.detach() if self.modality_embed is not None else None)
+        cos, sin = self._rotary(modality, L)
+        S["cos"], S["sin"] = cos, sin
+
+        any_img = None
+        if tc:
+            sigma = inp["sigma"]
+            if sigma is None:
+                raise ValueError("unidisc_amd.DIT: time_conditioning needs sigma")
+            sigma = sigma.reshape(-1).to(F32).contiguous()
+            Bp = _ceil(B, 8)
+            te = torch.zeros((Bp, 256), dtype=BF16, device=dev)
+            K.timestep_embedding(sigma, te, B, 256)
+            l1 = K.gemm_nt(te, lin["sig0"].w16, N=lin["sig0"].out, epilogue=K.EPI_BIAS, bias=lin["sig0"].bias.detach())
+            s1 = K.silu_fwd(l1)
+            l2 = K.gemm_nt(s1, lin["sig2"].w16, N=lin["sig2"].out, epilogue=K.EPI_BIAS, bias=lin["sig2"].bias.detach())
+            c = K.silu_fwd(l2)
+            if mod_flat is not None:
+                any_img = (mod_flat != 0).any().to(torch.int32).reshape(1)
+            S.update(Bp=Bp, te=te, l1=l1, s1=s1, l2=l2, c=c, any_img=any_img)
+
+        for i, blk in enumerate(self.blocks):
+            R = {}
+            mod = None
+            if tc:
+                a = lin[f"{i}.ada"]
+                mod = K.gemm_nt(S["c"], a.w16, N=a.out, epilogue=K.EPI_BIAS, bias=a.bias.detach())  # [Bp, 6d] bf16
+                R["mod"] = mod
+            h1, rstd1, mean1 = K.norm_fwd(x, blk.norm1.weight.detach(), nt, L, mod=mod, mod_idx=(0, 1), modality=mod_flat, any_img=any_img)
+            qkv = K.gemm_nt(h1, lin[f"{i}.qkv"].w16, N=3 * d)
+            at = blk.attention
+            qkr, qstats = K.qknorm_rope_fwd(qkv, cos, sin, L, D, gq=at.q_norm.weight.detach() if self.qk_norm else None,
+                                            bq=at.q_norm.bias.detach() if self.qk_norm else None, gk=at.k_norm.weight.detach() if self.qk_norm else None,
+                                            bk=at.k_norm.bias.detach() if self.qk_norm else None)
+            o, lse = K.attention_fwd(qkr, qkv, B, L, H, D, sid)
+            a_out = K.gemm_nt(o, lin[f"{i}.out"].w16, N=d)
+            if sw:  # x = x_skip + pre_residual_norm(attn)   (dit.py:993-994; no gate, no dropout)
+                x_mid, rstd_a, mean_a = K.residual_fwd(x, a_out, L, w_b=blk.pre_residual_norm.weight.detach(), norm_type=nt)
+            else:   # bias_dropout_add_scale with gate_msa on every token (Attention.time_conditioning is never set: dit.py:533,884)
+                x_mid, rstd_a, mean_a = K.residual_fwd(x, a_out, L, mod=mod, gate_idx=2 if tc else None, p_drop=p_drop, seed=seed0 + 4 * i + 1)
+            h2, rstd2, mean2 = K.norm_fwd(x_mid, blk.norm2.weight.detach(), nt, L, mod=mod, mod_idx=(3, 4), modality=mod_flat, any_img=any_img)
+            f1, f2 = lin[f"{i}.fc1"], lin[f"{i}.fc2"]
+            u1 = torch.empty((M, 4 * d), dtype=BF16, device=dev)
+            g = K.gemm_nt(h2, f1.w16, N=4 * d, epilogue=K.EPI_BIAS_GELU, bias=f1.bias.detach(), aux=u1)
+            u2 = K.gemm_nt(g, f2.w16, N=d, epilogue=K.EPI_BIAS, bias=f2.bias.detach())
+            x_out, rstd_m, mean_m = K.residual_fwd(x_mid, u2, L, w_b=blk.post_ff_norm.weight.detach() if sw else None, norm_type=nt, mod=mod,
+                                                   gate_idx=5 if tc else None, modality=mod_flat if tc else None, p_drop=p_drop, seed=seed0 + 4 * i + 2)
+            if save:
+                R.update(x_in=x, h1=h1, rstd1=rstd1, mean1=mean1, qkv=qkv, qkr=qkr, qstats=qstats, o=o, lse=lse, a_out=a_out, rstd_a=rstd_a, mean_a=mean_a,
+                         x_mid=x_mid, h2=h2, rstd2=rstd2, mean2=mean2, u1=u1, g=g, u2=u2, rstd_m=rstd_m, mean_m=mean_m)
+                S["blocks"].append(R)
+            x = x_out
+
+        fl = self.output_layer
+        fmod = None
+        if tc:
+            a = lin["head.ada"]
+            fmod = K.gemm_nt(S["c"], a.w16, N=a.out, epilogue=K.EPI_BIAS, bias=a.bias.detach())  # [Bp, 2d]
+        hf, rstdf, meanf = K.norm_fwd(x, fl.norm_final.weight.detach(), nt, L, mod=fmod, mod_idx=(0, 1), modality=mod_flat, any_img=any_img)
+        head = lin["head"]
+        V, Vp = self.vocab_size, head.outp
+        logits = torch.empty((M, Vp), dtype=BF16, device=dev)
+        K.gemm_nt(hf, head.w16, out=logits, N=V, epilogue=K.EPI_BIAS, bias=head.bias.detach())
+        if save:
+            S.update(x_final=x, hf=hf, rstdf=rstdf, meanf=meanf, fmod=fmod, logits=logits)
+        if mode == "logits":
+            return logits[:, :V].view(B, L, V), S
+        x0 = inp["x0"].contiguous().view(-1).to(torch.int64)
+        restrict = bool(inp.get("restrict", False))
+        if restrict and mod_flat is None:  # static slices (model.py:634-635)
+            cm = torch.zeros(L, dtype=torch.int64, device=dev)
+            cm[self.static_img_sl] = 1
+            ce_mod = cm[None].expand(B, L).contiguous().view(-1)
+        else:
+            ce_mod = mod_flat
+        log_p, lse_ce = K.subs_ce_fwd(logits, x0, ids, ce_mod, V, self.text_vocab_size, self.mask_index, restrict)
+        if save:
+            S.update(x0=x0, ce_mod=ce_mod, restrict=restrict, lse_ce=lse_ce)
+        return log_p.view(B, L), S
+
+    # -------------------------------------------------------------------------------------------- engine: backward
+    def _alloc_grads(self, params, dev):
+        offs, total = [], 0
+        for p in params:
+            offs.append(total)
+            total += _ceil(p.numel(), 64)
+        flat = torch.zeros(total, dtype=F32, device=dev)
+        return flat, {id(p): flat[o:o + p.numel()].view(p.shape) for p, o in zip(params, offs)}
+
+    def _wgrad(self, dY, X, lin: _Lin, G, n_rows=None):
+        """dW[out,in] = dY[M,out]^T X[M,in] (fp32), db = colsum(dY).  dY/X bf16 [M, *]."""
+        Mrows = dY.shape[0]
+        outp = dY.shape[1]
+        db = None
+        if lin.bias is not None:
+            db = G[id(lin.bias)] if outp == lin.out else torch.zeros(outp, dtype=F32, device=dY.device)
+        dYt = K.transpose(dY, colsum=db)
+        if db is not None and outp != lin.out:
+            G[id(lin.bias)].copy_(db[: lin.out])
+        Xt = K.transpose(X)
+        K.gemm_nt(dYt, Xt, out=G[id(lin.weight)], M=lin.out, N=lin.inp, K=Mrows)
+
+    def _engine_backward(self, S, grad_out, mode):
+        params = self._ordered_params()
+        B, L = S["B"], S["L"]
+        M, d, H, D = B * L, self.hidden_size, self.n_heads, self.head_dim
+        dev = S["ids"].device
+        nt = K.norm_id(self.norm_type)
+        tc, sw = self.time_conditioning, self.sandwich_normalization
+        lin = self._lins
+        flat, G = self._alloc_grads(params, dev)
+        S["grad_flat"] = flat
+        mod_flat, any_img, p_drop, seed0 = S["modality"], S.get("any_img"), S["p_drop"], S["seed0"]
+        cb = self.grad_ready_callback
+        V = self.vocab_size
+        head = lin["head"]
+        logits = S["logits"]
+
+        # ---- head: d logits -> dhf, dW_head, db_head
+        if mode == "logp":
+            g = grad_out.contiguous().view(-1).to(F32)
+            K.subs_ce_bwd(logits, S["x0"], S["ids"], S["ce_mod"], S["lse_ce"], g, V, self.text_vocab_size, self.mask_index, S["restrict"])
+            dlogits = logits
+        else:
+            dlogits = torch.zeros_like(logits)
+            dlogits[:, :V].copy_(grad_out.reshape(M, V))
+        dhf = K.gemm_nt(dlogits, head.w16t, N=d)
+        self._wgrad(dlogits, S["hf"], head, G)
+        del dlogits
+        S["logits"] = None
+
+        dc = dmodf = None
+        Bp = S.get("Bp")
+        if tc:
+            dc = torch.zeros((Bp, self.cond_dim), dtype=F32, device=dev)
+            dmodf = torch.zeros((Bp, 2 * d), dtype=F32, device=dev)
+        fl = self.output_layer
+        fmod = S["fmod"]
+        dx = torch.empty((M, d), dtype=F32, device=dev)
+        K.norm_bwd(dhf, S["x_final"], S["rstdf"], S["meanf"], fl.norm_final.weight.detach(), nt, L, dx, G[id(fl.norm_final.weight)], accumulate=False,
+                   mod=fmod, dmod=dmodf, mod_idx=(0, 1), modality=mod_flat, any_img=any_img)
+        if tc:
+            self._ada_backward(dmodf, lin["head.ada"], S["c"], dc, G)
+        if cb:
+            cb(list(fl.parameters()))
+
+        for i in reversed(range(self.n_blocks)):
+            blk, R = self.blocks[i], S["blocks"][i]
+            at = blk.attention
+            mod = R.get("mod")
+            dmod = torch.zeros((Bp, 6 * d), dtype=F32, device=dev) if tc else None
+            f1, f2 = lin[f"{i}.fc1"], lin[f"{i}.fc2"]
+            # MLP branch
+            du2 = K.residual_bwd(dx, R["u2"], L, w_b=blk.post_ff_norm.weight.detach() if sw else None, rstd=R["rstd_m"], mean=R["mean_m"], norm_type=nt,
+                                 mod=mod, dmod=dmod, gate_idx=5 if tc else None, modality=mod_flat if tc else None,
+                                 dw_b=G[id(blk.post_ff_norm.weight)] if sw else None, p_drop=p_drop, seed=seed0 + 4 * i + 2)
+            du1 = K.gemm_nt(du2, f2.w16t, N=4 * d, epilogue=K.EPI_DGELU, aux=R["u1"])
+            self._wgrad(du2, R["g"], f2, G)
+            dh2 = K.gemm_nt(du1, f1.w16t, N=d)
+            self._wgrad(du1, R["h2"], f1, G)
+            del du1, du2
+            K.norm_bwd(dh2, R["x_mid"], R["rstd2"], R["mean2"], blk.norm2.weight.detach(), nt, L, dx, G[id(blk.norm2.weight)], accumulate=True,
+                       mod=mod, dmod=dmod, mod_idx=(3, 4), modality=mod_flat, any_img=any_img)
+            # attention branch
+            if sw:
+                da = K.residual_bwd(dx, R["a_out"], L, w_b=blk.pre_residual_norm.weight.detach(), rstd=R["rstd_a"], mean=R["mean_a"], norm_type=nt,
+                                    dw_b=G[id(blk.pre_residual_norm.weight)])
+            else:
+                da = K.residual_bwd(dx, R["a_out"], L, mod=mod, dmod=dmod, gate_idx=2 if tc else None, p_drop=p_drop, seed=seed0 + 4 * i + 1)
+            lo, lq = lin[f"{i}.out"], lin[f"{i}.qkv"]
+            do = K.gemm_nt(da, lo.w16t, N=d)
+            self._wgrad(da, R["o"], lo, G)
+            dqkr = torch.empty((M, 2 * d), dtype=BF16, device=dev)
+            dqkv = torch.empty((M, 3 * d), dtype=BF16, device=dev)
+            K.attention_bwd(R["qkr"], R["qkv"], R["o"], do, R["lse"], dqkr, dqkv, B, L, H, D, S["sid"])
+            qn = self.qk_norm
+            K.qknorm_rope_bwd(dqkr, R["qkv"], dqkv, S["cos"], S["sin"], L, D, gq=at.q_norm.weight.detach() if qn else None,
+                              gk=at.k_norm.weight.detach() if qn else None, stats=R["qstats"], dgq=G[id(at.q_norm.weight)] if qn else None,
+                              dbq=G[id(at.q_norm.bias)] if qn else None, dgk=G[id(at.k_norm.weight)] if qn else None,
+                              dbk=G[id(at.k_norm.bias)] if qn else None)
+            dh1 = K.gemm_nt(dqkv, lq.w16t, N=d)
+            self._wgrad(dqkv, R["h1"], lq, G)
+            K.norm_bwd(dh1, R["x_in"], R["rstd1"], R["mean1"], blk.norm1.weight.detach(), nt, L, dx, G[id(blk.norm1.weight)], accumulate=True,
+                       mod=mod, dmod=dmod, mod_idx=(0, 1), modality=mod_flat, any_img=any_img)
+            if tc:
+                self._ada_backward(dmod, lin[f"{i}.ada"], S["c"], dc, G)
+            S["blocks"][i] = None  # free this block's activations
+            if cb:
+                cb(list(blk.parameters()))
+
+        # ---- embeddings
+        K.embedding_bwd(S["ids"], dx, G[id(self.vocab_embed.embedding)], self.mask_index,
+                        modality=S["emb_mod"] if self.modality_embed is not None else None,
+                        dEm=G[id(self.modality_embed.embedding)] if self.modality_embed is not None else None)
+        tail = list(self.vocab_embed.parameters()) + (list(self.modality_embed.parameters()) if self.modality_embed is not None else [])
+        if tc:  # c = silu(W2 silu(W0 te + b0) + b2)
+            dc16 = torch.empty((Bp, self.cond_dim), dtype=BF16, device=dev)
+            K.cast_f32_bf16(dc, dc16)
+            dl2 = K.silu_bwd(S["l2"], dc16)
+            ds1 = K.gemm_nt(dl2, lin["sig2"].w16t, N=lin["sig2"].inp)
+            self._wgrad(dl2, S["s1"], lin["sig2"], G)
+            dl1 = K.silu_bwd(S["l1"], ds1)
+            self._wgrad(dl1, S["te"], lin["sig0"], G)
+            tail += list(self.sigma_map.parameters())
+        if cb:
+            cb(tail)
+        return [G[id(p)] for p in params]
+
+    def _ada_backward(self, dmod, lin: _Lin, c, dc, G):
+        """adaLN_modulation backward: dmod fp32 [Bp, n*d] (atomically accumulated) -> dW, db, dc += dmod W."""
+        dmod16 = torch.empty(dmod.shape, dtype=BF16, device=dmod.device)
+        K.cast_f32_bf16(dmod, dmod16)
+        self._wgrad(dmod16, c, lin, G)
+        K.gemm_nt(dmod16, lin.w16t, out=dc, N=lin.inp, beta=1.0)
+
+
+class _DitFn(torch.autograd.Function):
+    """One autograd node for the whole backbone (+ fused SUBS cross-entropy in "logp" mode)."""
+
+    @staticmethod
+    def forward(ctx, module: DIT, mode: str, inputs: dict, *params):
+        need = bool(inputs.get("save", False))  # grad mode is off inside Function.forward, so the caller decides
+        out, S = module._engine_forward(inputs, mode, save=need)
+        ctx.module, ctx.mode, ctx.S = module, mode, S if need else None
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        if ctx.S is None:
+            raise RuntimeError("unidisc_amd.DIT: backward called but activations were not saved")
+        grads = ctx.module._engine_backward(ctx.S, grad_out, ctx.mode)
+        ctx.S = None
+        req = [p.requires_grad for p in ctx.module._ordered_params()]
+        return (None, None, None, *[g if r else None for g, r in zip(grads, req)])

@@ -1,0 +1,264 @@
+"""Typed Python wrappers over the C ABI (``include/unidisc_hip.h``).
+
+PyTorch supplies device memory and the stream only; every function here enqueues hand-written HIP
+kernels on ``torch.cuda.current_stream()``.  Tensors must live on a GPU — there is no CPU path.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import _lib
+
+EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_DGELU = 0, 1, 2, 3
+NORM_RMS, NORM_LN = 0, 1
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+def _p(t: Optional[torch.Tensor]):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("unidisc_amd kernels need GPU tensors (no CPU fallback); got a tensor on " + str(t.device))
+    return t.data_ptr()
+
+
+def require_gpu(t: torch.Tensor):
+    if not t.is_cuda:
+        raise RuntimeError("unidisc_amd.DIT runs on MI355X only: inputs must be GPU tensors (there is no CPU fallback)")
+    _lib.load()  # fail loudly here if the HIP extension is missing
+
+
+def _s():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(t, dtype, name):
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+
+
+def norm_id(norm_type: str) -> int:
+    return NORM_RMS if norm_type == "rms" else NORM_LN
+
+
+def norm_eps(norm_type: str) -> float:
+    return 1e-6 if norm_type == "rms" else 1e-5
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+def gemm_nt(a, b, out=None, *, out_dtype=BF16, M=None, N=None, K=None, lda=None, ldb=None, ldc=None, epilogue=EPI_NONE, bias=None, aux=None,
+            ldaux=None, beta=0.0):
+    """out[M,N] (+)= a[M,K] @ b[N,K]^T.  a, b bf16 2-D (row stride = stride(0)); out bf16 or fp32."""
+    _chk(a, BF16, "gemm_nt a"), _chk(b, BF16, "gemm_nt b")
+    M = a.shape[0] if M is None else M
+    K = a.shape[1] if K is None else K
+    N = b.shape[0] if N is None else N
+    lda = a.stride(0) if lda is None else lda
+    ldb = b.stride(0) if ldb is None else ldb
+    if out is None:
+        out = torch.empty((M, N), dtype=out_dtype, device=a.device)
+    ldc = out.stride(0) if ldc is None else ldc
+    if aux is not None and ldaux is None:
+        ldaux = aux.stride(0)
+    _lib.call("udm_gemm_nt_bf16", _p(a), _p(b), _p(out), M, N, K, lda, ldb, ldc, 1 if out.dtype == F32 else 0, epilogue, _p(bias), _p(aux),
+              ldaux or 0, float(beta), _s())
+    return out
+
+
+def transpose(x, out=None, colsum=None, R=None, C=None):
+    """out[C,R] = x[R,C]^T (bf16); colsum[c] += sum_r x[r,c] when given."""
+    _chk(x, BF16, "transpose")
+    R = x.shape[0] if R is None else R
+    C = x.shape[1] if C is None else C
+    if out is None:
+        out = torch.empty((C, R), dtype=BF16, device=x.device)
+    _lib.call("udm_transpose_bf16", _p(x), _p(out), R, C, x.stride(0), out.stride(0), _p(colsum), _s())
+    return out
+
+
+def cast_transpose(w, out, out_t):
+    """fp32 [R,C] -> bf16 [R,C] (out) and bf16 [C,R] (out_t); either may be None."""
+    _chk(w, F32, "cast_transpose")
+    R, C = w.shape
+    _lib.call("udm_cast_transpose_f32_bf16", _p(w), _p(out), _p(out_t), R, C, w.stride(0), out.stride(0) if out is not None else 0,
+              out_t.stride(0) if out_t is not None else 0, _s())
+
+
+def cast_f32_bf16(x, y, scale=1.0):
+    _lib.call("udm_cast_f32_bf16", _p(x), _p(y), x.numel(), float(scale), _s())
+    return y
+
+
+def cast_bf16_f32(x, y, scale=1.0):
+    _lib.call("udm_cast_bf16_f32", _p(x), _p(y), x.numel(), float(scale), _s())
+    return y
+
+
+# ------------------------------------------------------------------------------------------------ norms
+def _mod_ptrs(mod, idx, d):
+    """adaLN slices: `mod` is the bf16 (or fp32 gradient) [Bp, n*d] adaLN tensor, idx picks d-wide column chunks."""
+    if mod is None:
+        return [None] * len(idx), 0
+    es = mod.element_size()
+    return [mod.data_ptr() + es * k * d for k in idx], mod.stride(0)
+
+
+def norm_fwd(x, w, norm_type, L, *, mod=None, mod_idx=(0, 1), modality=None, any_img=None):
+    """y = modulate(norm(x) * w) -> bf16.  mod_idx = (shift chunk, scale chunk) of the adaLN output."""
+    M, d = x.shape
+    y = torch.empty((M, d), dtype=BF16, device=x.device)
+    rstd = torch.empty(M, dtype=F32, device=x.device)
+    mean = torch.empty(M, dtype=F32, device=x.device) if norm_type == NORM_LN else None
+    (shift, scale), ms = _mod_ptrs(mod, mod_idx, d)
+    _lib.call("udm_norm_fwd", _p(x), _p(y), _p(rstd), _p(mean), _p(w), shift, scale, ms, _p(modality) if mod is not None else None,
+              _p(any_img) if mod is not None else None, M, d, L, norm_type, 1e-6 if norm_type == NORM_RMS else 1e-5, _s())
+    return y, rstd, mean
+
+
+def norm_bwd(dy, x, rstd, mean, w, norm_type, L, dx, dw, *, accumulate=True, mod=None, dmod=None, mod_idx=(0, 1), modality=None, any_img=None):
+    """dx (+)= d norm / dx, dw += ..., dmod[:, shift/scale chunks] += ... (fp32 atomics)."""
+    M, d = x.shape
+    (shift, scale), ms = _mod_ptrs(mod, mod_idx, d)
+    (dshift, dscale), _ = _mod_ptrs(dmod, mod_idx, d)
+    _lib.call("udm_norm_bwd", _p(dy), _p(x), _p(rstd), _p(mean), _p(w), shift, scale, ms, _p(modality) if mod is not None else None,
+              _p(any_img) if mod is not None else None, _p(dx), _p(dw), dshift, dscale, M, d, L, norm_type, 1 if accumulate else 0, _s())
+
+
+def residual_fwd(x_in, branch, L, *, w_b=None, norm_type=NORM_RMS, mod=None, gate_idx=None, modality=None, p_drop=0.0, seed=0):
+    """x_out = x_in + gate * dropout(sandwich_norm(branch)).  gate = chunk gate_idx of `mod` (None: no gate)."""
+    M, d = x_in.shape
+    x_out = torch.empty_like(x_in)
+    rstd = torch.empty(M, dtype=F32, device=x_in.device) if w_b is not None else None
+    mean = torch.empty(M, dtype=F32, device=x_in.device) if (w_b is not None and norm_type == NORM_LN) else None
+    (gate,), ms = _mod_ptrs(mod if gate_idx is not None else None, (gate_idx,), d)
+    _lib.call("udm_residual_fwd", _p(x_in), _p(branch), _p(x_out), _p(w_b), _p(rstd), _p(mean), gate, ms, _p(modality), M, d, L, norm_type,
+              1e-6 if norm_type == NORM_RMS else 1e-5, float(p_drop), int(seed), _s())
+    return x_out, rstd, mean
+
+
+def residual_bwd(dx, branch, L, *, w_b=None, rstd=None, mean=None, norm_type=NORM_RMS, mod=None, dmod=None, gate_idx=None, modality=None, dw_b=None,
+                 p_drop=0.0, seed=0):
+    M, d = dx.shape
+    dbranch = torch.empty((M, d), dtype=BF16, device=dx.device)
+    use = gate_idx is not None and mod is not None
+    (gate,), ms = _mod_ptrs(mod if use else None, (gate_idx,), d)
+    (dgate,), _ = _mod_ptrs(dmod if use else None, (gate_idx,), d)
+    _lib.call("udm_residual_bwd", _p(dx), _p(branch), _p(dbranch), _p(w_b), _p(rstd), _p(mean), gate, ms, _p(modality), _p(dw_b), dgate, M, d, L,
+              norm_type, float(p_drop), int(seed), _s())
+    return dbranch
+
+
+# ------------------------------------------------------------------------------------------------ attention
+def qknorm_rope_fwd(qkv, cos, sin, L, D, *, gq=None, bq=None, gk=None, bk=None):
+    M, d3 = qkv.shape
+    d = d3 // 3
+    qkr = torch.empty((M, 2 * d), dtype=BF16, device=qkv.device)
+    stats = torch.empty((M, 4), dtype=F32, device=qkv.device) if gq is not None else None
+    per_sample = 1 if cos.dim() == 3 else 0
+    _lib.call("udm_qknorm_rope_fwd", _p(qkv), _p(qkr), _p(gq), _p(bq), _p(gk), _p(bk), _p(stats), _p(cos), _p(sin), per_sample, M, d, L, D, 1e-5, _s())
+    return qkr, stats
+
+
+def qknorm_rope_bwd(dqkr, qkv, dqkv, cos, sin, L, D, *, gq=None, gk=None, stats=None, dgq=None, dbq=None, dgk=None, dbk=None):
+    M, d3 = qkv.shape
+    d = d3 // 3
+    per_sample = 1 if cos.dim() == 3 else 0
+    _lib.call("udm_qknorm_rope_bwd", _p(dqkr), _p(qkv), _p(dqkv), _p(gq), _p(gk), _p(stats), _p(cos), _p(sin), per_sample, _p(dgq), _p(dbq), _p(dgk),
+              _p(dbk), M, d, L, D, _s())
+
+
+def attention_fwd(qkr, qkv, B, L, H, D, sample_ids=None):
+    """q, k from qkr [M,2d] (normalised+rotated), v from qkv [M,3d] columns [2d,3d)."""
+    d = H * D
+    M = B * L
+    o = torch.empty((M, d), dtype=BF16, device=qkr.device)
+    lse = torch.empty((B, H, L), dtype=F32, device=qkr.device)
+    q_ptr, k_ptr, v_ptr = qkr.data_ptr(), qkr.data_ptr() + 2 * d, qkv.data_ptr() + 4 * d
+    _lib.call("udm_attention_fwd", q_ptr, k_ptr, v_ptr, _p(o), _p(lse), _p(sample_ids), B, H, L, D, 2 * d, 2 * d, 3 * d, d, _s())
+    return o, lse
+
+
+def attention_bwd(qkr, qkv, o, do, lse, dqkr, dqkv, B, L, H, D, sample_ids=None):
+    """Writes dq|dk (wrt rotated q,k) into dqkr [M,2d] and dv into dqkv[:, 2d:3d]."""
+    d = H * D
+    delta = torch.empty((B, H, L), dtype=F32, device=qkr.device)
+    q_ptr, k_ptr, v_ptr = qkr.data_ptr(), qkr.data_ptr() + 2 * d, qkv.data_ptr() + 4 * d
+    dq_ptr, dk_ptr, dv_ptr = dqkr.data_ptr(), dqkr.data_ptr() + 2 * d, dqkv.data_ptr() + 4 * d
+    _lib.call("udm_attention_bwd", q_ptr, k_ptr, v_ptr, _p(o), _p(do), _p(lse), _p(delta), dq_ptr, dk_ptr, dv_ptr, _p(sample_ids), B, H, L, D, 2 * d,
+              2 * d, 3 * d, d, do.stride(0), 2 * d, 2 * d, 3 * d, _s())
+
+
+def attention_fwd_generic(q, k, v, B, L, H, D, sample_ids=None):
+    """q, k, v: separate contiguous bf16 [B*L, H*D] (unit tests)."""
+    d = H * D
+    o = torch.empty((B * L, d), dtype=BF16, device=q.device)
+    lse = torch.empty((B, H, L), dtype=F32, device=q.device)
+    _lib.call("udm_attention_fwd", _p(q), _p(k), _p(v), _p(o), _p(lse), _p(sample_ids), B, H, L, D, d, d, d, d, _s())
+    return o, lse
+
+
+def attention_bwd_generic(q, k, v, o, do, lse, B, L, H, D, sample_ids=None):
+    d = H * D
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    delta = torch.empty((B, H, L), dtype=F32, device=q.device)
+    _lib.call("udm_attention_bwd", _p(q), _p(k), _p(v), _p(o), _p(do), _p(lse), _p(delta), _p(dq), _p(dk), _p(dv), _p(sample_ids), B, H, L, D, d, d, d, d,
+              d, d, d, d, _s())
+    return dq, dk, dv
+
+
+def set_tr_read(enable: bool):
+    _lib.load().udm_attention_set_tr_read(1 if enable else 0)
+
+
+# ------------------------------------------------------------------------------------------------ embedding / CE / adaLN helpers
+def embedding_fwd(ids, E, modality=None, Em=None):
+    M = ids.numel()
+    V, d = E.shape
+    x = torch.empty((M, d), dtype=F32, device=E.device)
+    _lib.call("udm_embedding_fwd", _p(ids), _p(E), _p(modality), _p(Em), _p(x), M, d, V, _s())
+    return x
+
+
+def embedding_bwd(ids, dx, dE, hot_id, modality=None, dEm=None):
+    M = ids.numel()
+    V, d = dE.shape
+    _lib.call("udm_embedding_bwd", _p(ids), _p(modality), _p(dx), _p(dE), _p(dEm), M, d, V, hot_id, _s())
+
+
+def subs_ce_fwd(logits, x0, xt, modality, V, Vt, mask_id, restrict):
+    M, ld = logits.shape[0], logits.stride(0)
+    log_p = torch.empty(M, dtype=F32, device=logits.device)
+    lse = torch.empty(M, dtype=F32, device=logits.device)
+    _lib.call("udm_subs_ce_fwd", _p(logits), ld, _p(x0), _p(xt), _p(modality), _p(log_p), _p(lse), M, V, Vt, mask_id, 1 if restrict else 0, _s())
+    return log_p, lse
+
+
+def subs_ce_bwd(logits, x0, xt, modality, lse, g, V, Vt, mask_id, restrict):
+    M, ld = logits.shape[0], logits.stride(0)
+    _lib.call("udm_subs_ce_bwd", _p(logits), ld, _p(x0), _p(xt), _p(modality), _p(lse), _p(g), M, V, Vt, mask_id, 1 if restrict else 0, _s())
+
+
+def subs_logprobs(logits, xt, modality, V, Vt, mask_id, restrict, out_dtype=BF16):
+    M, ld = logits.shape[0], logits.stride(0)
+    out = torch.empty((M, V), dtype=out_dtype, device=logits.device)
+    _lib.call("udm_subs_logprobs", _p(logits), ld, _p(xt), _p(modality), _p(out), V, 1 if out_dtype == F32 else 0, M, V, Vt, mask_id, 1 if restrict else 0,
+              _s())
+    return out
+
+
+def timestep_embedding(sigma, out, B, dim=256):
+    _lib.call("udm_timestep_embedding", _p(sigma), _p(out), B, dim, _s())
+
+
+def silu_fwd(x, n=None):
+    y = torch.empty_like(x)
+    _lib.call("udm_silu_fwd", _p(x), _p(y), x.numel() if n is None else n, _s())
+    return y
+
+
+def silu_bwd(x, dy):
+    dx = torch.empty_like(x)
+    _lib.call("udm_silu_bwd", _p(x), _p(dy), _p(dx), x.numel(), _s())
+    return dx
