@@ -1,0 +1,93 @@
+"""world_size-2 gloo test of the bucketed bf16 gradient all-reduce (CPU; kernels replaced by test doubles)."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _grads(diff, golden, seed):
+    torch.manual_seed(seed)
+    batch = golden.batch()
+    g = torch.Generator().manual_seed(1000 + seed)
+    batch["txt_input_ids"] = torch.randint(0, golden.case["text_vocab_size"] - 1, batch["txt_input_ids"].shape, generator=g, dtype=torch.int32)
+    diff.backbone.zero_grad(set_to_none=True)
+    out = diff.training_step(batch, 1)
+    out.loss.backward()
+    return {k: p.grad.clone() for k, p in diff.backbone.named_parameters()}
+
+
+def _worker(rank, world, port, min_bucket, q):
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import fake_kernels
+        import unidisc_amd.dit as dit_mod
+        import unidisc_amd.diffusion as diff_mod
+        import unidisc_amd.ddp as ddp_mod
+        from golden_utils import Golden
+        from product_utils import build_product
+
+        dit_mod.K = diff_mod.K = ddp_mod.K = fake_kernels
+        golden = Golden("c_large")
+        diff = build_product(golden, "cpu")
+        ddp_mod.broadcast_parameters(diff.backbone)
+        local = _grads(diff, golden, seed=rank)            # unsynchronised local gradients
+        sync = ddp_mod.wrap(diff.backbone, min_bucket_elems=min_bucket)
+        synced = _grads(diff, golden, seed=rank)            # same step with the all-reduce hooked into backward
+        # expected: every rank's local grads, bf16-compressed, divided by world, summed (reference BF16 hook)
+        gathered = [None] * world
+        dist.all_gather_object(gathered, local)
+        ok, worst = True, 0.0
+        for k in local:
+            exp = sum((g[k].to(torch.bfloat16).float() / world).to(torch.bfloat16).float() for g in gathered)
+            exp = exp.to(torch.bfloat16).float()
+            err = (synced[k] - exp).abs().max().item()
+            tol = 2e-2 * exp.abs().max().item() + 1e-6   # gloo sums in bf16: one rounding per add
+            worst = max(worst, err / (exp.abs().max().item() + 1e-12))
+            ok = ok and err <= tol
+        # all ranks hold identical synchronised gradients
+        flat = torch.cat([synced[k].flatten() for k in sorted(synced)])
+        ref = flat.clone()
+        dist.broadcast(ref, src=0)
+        same = torch.equal(flat, ref)
+        sync.enabled = False                                   # no_sync micro-step: gradients stay local
+        unsynced = _grads(diff, golden, seed=rank)
+        local_ok = all(torch.equal(unsynced[k], local[k]) for k in local)
+        q.put((rank, ok, same, local_ok, worst, sync.bytes_on_wire))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("min_bucket", [1, 1 << 30])
+def test_bucketed_allreduce_world2(min_bucket):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, min_bucket, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, ok, same, local_ok, worst, nbytes in res:
+        assert ok, (rank, worst)
+        assert same, rank
+        assert local_ok, rank
+        assert nbytes > 0

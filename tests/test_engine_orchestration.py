@@ -27,7 +27,7 @@ def test_compute_loss_and_grads_match_golden(name, fake_k):
     diff = build_product(g, device="cpu")
     diff.rng_device = "cpu"
     ready = []
-    diff.backbone.grad_ready_callback = lambda ps: ready.append(len(ps))
+    diff.backbone.grad_ready_callback = lambda flat, lo, hi: ready.append((lo, hi))
     torch.manual_seed(g.case["step_seed"])
     out = diff.training_step(g.batch(), 1)
     assert torch.equal(diff._last["xt"], g.t("fp32/xt"))
@@ -37,7 +37,8 @@ def test_compute_loss_and_grads_match_golden(name, fake_k):
     assert abs(float(out.loss) - l32) <= 3 * abs(l16 - l32) + 5e-3 * abs(l32), (float(out.loss), l32, l16)
     assert torch.allclose(out.nlls, g.t("fp32/nlls"), atol=0.15, rtol=0.05)
     out.loss.backward()
-    assert sum(ready) == sum(1 for _ in diff.backbone.parameters())
+    assert ready[0][0] == 0 and all(a[1] == b[0] for a, b in zip(ready, ready[1:]))  # contiguous, in completion order
+    assert ready[-1][1] >= sum(p.numel() for p in diff.backbone.parameters())
     gref = g.grads("fp32")
     gb16 = g.grads("bf16")
     named = dict(diff.backbone.named_parameters())

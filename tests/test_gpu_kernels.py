@@ -43,6 +43,40 @@ def test_gemm_nt_plain(K, M, N, K_, out_f32):
     assert torch.allclose(out.float().cpu()[:4, 0], ref[:4, 0], atol=0.05 * ref.abs().max().item())
 
 
+@pytest.mark.parametrize("tile", [192, 256, 320, 0])
+@pytest.mark.parametrize("M,N,K_", [(640, 512, 256), (700, 1001, 192), (1280, 2048, 2048), (333, 260, 128)])
+def test_gemm_large_tile_kernels(K, tile, M, N, K_):
+    """The LDS-DMA / staggered-phase kernels (forced per tile family) incl. ragged M/N edges and every epilogue."""
+    a, b, bias = bf(rnd(M, K_, seed=80, scale=0.5)), bf(rnd(N, K_, seed=81, scale=0.3)), rnd(N, seed=82)
+    acc = a.float() @ b.float().t()
+    ga, gb, gbias = a.to(DEV), b.to(DEV), bias.to(DEV)
+    K.gemm_set_tile(tile)
+    try:
+        ldc = (N + 7) // 8 * 8
+        out = torch.zeros((M, ldc), dtype=torch.bfloat16, device=DEV)
+        K.gemm_nt(ga, gb, out=out, N=N)
+        assert rel_err(out.float().cpu()[:, :N], acc) < 4e-3
+        assert torch.all(out.cpu()[:, N:] == 0)
+        o32 = K.gemm_nt(ga, gb, out_dtype=torch.float32, epilogue=K.EPI_BIAS, bias=gbias)
+        assert rel_err(o32.cpu(), acc + bias) < 1e-5
+        aux = torch.zeros((M, ldc), dtype=torch.bfloat16, device=DEV)
+        g = torch.zeros((M, ldc), dtype=torch.bfloat16, device=DEV)
+        K.gemm_nt(ga, gb, out=g, N=N, epilogue=K.EPI_BIAS_GELU, bias=gbias, aux=aux)
+        assert rel_err(aux.float().cpu()[:, :N], (acc + bias).bfloat16().float()) < 4e-3
+        assert rel_err(g.float().cpu()[:, :N], torch.nn.functional.gelu(aux.float().cpu()[:, :N], approximate="tanh")) < 4e-3
+        u = aux.float().cpu()[:, :N].requires_grad_()
+        (gp,) = torch.autograd.grad(torch.nn.functional.gelu(u, approximate="tanh").sum(), u)
+        dg = torch.zeros((M, ldc), dtype=torch.bfloat16, device=DEV)
+        K.gemm_nt(ga, gb, out=dg, N=N, epilogue=K.EPI_DGELU, aux=aux)
+        assert rel_err(dg.float().cpu()[:, :N], acc * gp) < 5e-3
+        c0 = rnd(M, N, seed=83)
+        c = c0.clone().to(DEV)
+        K.gemm_nt(ga, gb, out=c, beta=1.0)
+        assert rel_err(c.cpu(), acc + c0) < 1e-5
+    finally:
+        K.gemm_set_tile(-1)
+
+
 def test_gemm_identity_asymmetric(K):
     # A = I (padded), B asymmetric: catches swapped row/col fragment maps
     n = 128

@@ -300,6 +300,249 @@ __global__ __launch_bounds__(256) void cast_transpose_kernel(const float* __rest
   }
 }
 
+
+// =================================================================================================
+// Large-shape path: BM x 256 x 64 tiles (BM = 192 / 256 / 320, chosen per shape so the tile count fills whole
+// rounds of the 256 CUs), 8 waves as 2 x 4, operands staged by LDS-DMA (global_load_lds_dwordx4; the XOR swizzle is
+// applied on the per-lane SOURCE address so the LDS image stays lane-linear), two 64-deep stages.
+// Schedule: each K tile is four phases { 16-deep fragment ds_reads (+ a slice of the next tile's LDS-DMA) ;
+// s_barrier ; MFMAs ; s_barrier } and waves 4-7 run ONE barrier behind waves 0-3.  A SIMD hosts wave w and
+// wave w+4, so while one of them owns the matrix pipe its partner is in its read section: the pipe alternates
+// between the two instead of idling while both sit at the same barrier.  Hazards:
+//   RAW: a wave waits vmcnt(0) for its own LDS-DMA in the LAST phase of a tile before that phase's first barrier;
+//        the first read of the new tile is at least one barrier later for both groups.
+//   WAR: fragment reads are retired (lgkmcnt(0)) before each phase's first barrier, and a stage is re-staged
+//        only from phase 0 of the following tile.
+// Epilogue: per wave, each 32x32 accumulator fragment is transposed through a wave-private 4 KiB LDS patch so a
+// lane owns 4 consecutive columns of a row (8/16-byte global accesses); bias / GELU / GELU' / beta are applied there.
+// =================================================================================================
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ void glds16(const void* gptr, char* lds_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gptr, (UDM_LDS void*)lds_base, 16, 0, 0);
+}
+
+template <int BMX, int EPI, bool OUT_F32>
+__global__ __launch_bounds__(512) void gemm_nt_stagger_kernel(GemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int BNX = 256, WGM = 2, WGN = 4, NWAVES = 8;
+  constexpr int WM = BMX / WGM, WN = BNX / WGN, FM = WM / 32, FN = WN / 32;
+  constexpr int A_BYTES = BMX * BK * 2, B_BYTES = BNX * BK * 2, STAGE_BYTES = A_BYTES + B_BYTES;
+  constexpr int A_PW = A_BYTES / 1024 / NWAVES, B_PW = B_BYTES / 1024 / NWAVES, LOADS = A_PW + B_PW;
+  constexpr int NPH = 4, ISSUE_PH = 2, PER = (LOADS + ISSUE_PH - 1) / ISSUE_PH;
+  static_assert(WM % 32 == 0 && (A_BYTES / 1024) % NWAVES == 0, "bad tile");
+
+  const int nwg = p.tiles_m * p.tiles_n;
+  int pid = xcd_remap(blockIdx.x, nwg);
+  const int per_group = GROUP_M * p.tiles_n;
+  const int grp = pid / per_group, first_m = grp * GROUP_M;
+  const int gsz = min(p.tiles_m - first_m, GROUP_M);
+  const int tm = first_m + (pid % per_group) % gsz, tn = (pid % per_group) / gsz;
+  const int row0 = tm * BMX, col0 = tn * BNX;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int late = __builtin_amdgcn_readfirstlane(wave >= NWAVES / 2 ? 1 : 0);
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int lrow = lane >> 3, lslot = lane & 7;
+  const bf16_t* src[LOADS];
+  int dst[LOADS];
+#pragma unroll
+  for (int j = 0; j < A_PW; ++j) {
+    const int r = (wave * A_PW + j) * 8 + lrow;
+    src[j] = p.A + (long)min(row0 + r, p.M - 1) * p.lda + ((lslot ^ ((r >> 1) & 7)) << 3);
+    dst[j] = (wave * A_PW + j) * 1024;
+  }
+#pragma unroll
+  for (int j = 0; j < B_PW; ++j) {
+    const int r = (wave * B_PW + j) * 8 + lrow;
+    src[A_PW + j] = p.B + (long)min(col0 + r, p.N - 1) * p.ldb + ((lslot ^ ((r >> 1) & 7)) << 3);
+    dst[A_PW + j] = A_BYTES + (wave * B_PW + j) * 1024;
+  }
+  const int sw = (l31 >> 1) & 7;
+  f32x16_t acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk = p.K / BK;
+#pragma unroll
+  for (int j = 0; j < LOADS; ++j) glds16(src[j], smem + dst[j]);
+  wait_vmcnt<0>();
+  __builtin_amdgcn_s_barrier();
+  if (late) __builtin_amdgcn_s_barrier();
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const char* As = smem + (kt & 1) * STAGE_BYTES;
+    const char* Bs = As + A_BYTES;
+    char* nxt = smem + ((kt + 1) & 1) * STAGE_BYTES;
+    const bool more = kt + 1 < nk;
+    const int knext = (kt + 1) * BK;
+#pragma unroll
+    for (int ph = 0; ph < NPH; ++ph) {
+      bf16x8_t a[FM], b[FN];
+      const int so = ((ph * 2 + hi) ^ sw) << 4;
+#pragma unroll
+      for (int i = 0; i < FM; ++i) a[i] = *reinterpret_cast<const bf16x8_t*>(As + (wm * WM + i * 32 + l31) * 128 + so);
+#pragma unroll
+      for (int j = 0; j < FN; ++j) b[j] = *reinterpret_cast<const bf16x8_t*>(Bs + (wn * WN + j * 32 + l31) * 128 + so);
+      if (ph < ISSUE_PH && more) {
+#pragma unroll
+        for (int j = ph * PER; j < (ph + 1) * PER && j < LOADS; ++j) glds16(src[j] + knext, nxt + dst[j]);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (ph == NPH - 1) wait_vmcnt<0>();
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  if (!late) __builtin_amdgcn_s_barrier();
+  __syncthreads();  // all LDS tile reads are done: the wave-private epilogue patches may overwrite stage memory
+
+  // ---- epilogue ----
+  float* patch0 = reinterpret_cast<float*>(smem) + wave * 2048;  // two 32 x 32 fp32 patches per wave (ping-pong)
+  const int er = lane >> 3, ec = (lane & 7) * 4;               // read side: this lane's row (within 8) and 4-column chunk
+  const bool interior = (row0 + BMX <= p.M) && (col0 + BNX <= p.N) && (p.ldc % 4 == 0) && (EPI < UDM_EPI_BIAS_GELU || p.ldaux % 4 == 0);
+  float bias4[FN][4];
+#pragma unroll
+  for (int j = 0; j < FN; ++j)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int gn = col0 + wn * WN + j * 32 + ec + e;
+      bias4[j][e] = ((EPI == UDM_EPI_BIAS || EPI == UDM_EPI_BIAS_GELU) && gn < p.N) ? p.bias[gn] : 0.f;
+    }
+#pragma clang loop unroll(full)
+  for (int i = 0; i < FM; ++i)
+#pragma clang loop unroll(full)
+    for (int j = 0; j < FN; ++j) {
+      float* patch = patch0 + ((i * FN + j) & 1) * 1024;
+#pragma clang loop unroll(full)
+      for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * hi) * 32 + l31] = acc[i][j][r];
+      const int gn = col0 + wn * WN + j * 32 + ec;
+      const int gm0 = row0 + wm * WM + i * 32 + er;
+      float4 v[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const float4*>(patch + (q * 8 + er) * 32 + ec);
+      if (interior) {
+        uint2 au[4];
+        float4 cold[4];
+        if (EPI == UDM_EPI_DGELU) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) au[q] = *reinterpret_cast<const uint2*>(p.aux + (long)(gm0 + q * 8) * p.ldaux + gn);
+        }
+        if (OUT_F32 && p.beta != 0.f) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) cold[q] = *reinterpret_cast<const float4*>(reinterpret_cast<float*>(p.C) + (long)(gm0 + q * 8) * p.ldc + gn);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float x[4] = {v[q].x + bias4[j][0], v[q].y + bias4[j][1], v[q].z + bias4[j][2], v[q].w + bias4[j][3]};
+          const long gm = gm0 + q * 8;
+          if (EPI == UDM_EPI_BIAS_GELU) {
+            bf16_t pre[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { pre[e] = f2bf(x[e]); x[e] = gelu_tanh(bf2f(pre[e])); }
+            *reinterpret_cast<uint2*>(p.aux + gm * p.ldaux + gn) = make_uint2((uint32_t)pre[0] | ((uint32_t)pre[1] << 16), (uint32_t)pre[2] | ((uint32_t)pre[3] << 16));
+          }
+          if (EPI == UDM_EPI_DGELU) {
+            x[0] *= gelu_tanh_grad(__uint_as_float(au[q].x << 16)); x[1] *= gelu_tanh_grad(__uint_as_float(au[q].x & 0xffff0000u));
+            x[2] *= gelu_tanh_grad(__uint_as_float(au[q].y << 16)); x[3] *= gelu_tanh_grad(__uint_as_float(au[q].y & 0xffff0000u));
+          }
+          if (OUT_F32) {
+            if (p.beta != 0.f) { x[0] += p.beta * cold[q].x; x[1] += p.beta * cold[q].y; x[2] += p.beta * cold[q].z; x[3] += p.beta * cold[q].w; }
+            *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + gm * p.ldc + gn) = make_float4(x[0], x[1], x[2], x[3]);
+          } else {
+            *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.C) + gm * p.ldc + gn) = make_uint2(pack2bf(x[0], x[1]), pack2bf(x[2], x[3]));
+          }
+        }
+      } else {  // edge tiles: element-wise predication
+        for (int q = 0; q < 4; ++q) {
+          const long gm = gm0 + q * 8;
+          if (gm >= p.M || gn >= p.N) continue;
+          float x[4] = {v[q].x + bias4[j][0], v[q].y + bias4[j][1], v[q].z + bias4[j][2], v[q].w + bias4[j][3]};
+          const int nvalid = min(4, p.N - gn);
+          for (int e = 0; e < nvalid; ++e) {
+            if (EPI == UDM_EPI_BIAS_GELU) {
+              const bf16_t pre = f2bf(x[e]);
+              p.aux[gm * p.ldaux + gn + e] = pre;
+              x[e] = gelu_tanh(bf2f(pre));
+            }
+            if (EPI == UDM_EPI_DGELU) x[e] *= gelu_tanh_grad(bf2f(p.aux[gm * p.ldaux + gn + e]));
+            if (OUT_F32) {
+              float* cp = reinterpret_cast<float*>(p.C) + gm * p.ldc + gn + e;
+              *cp = x[e] + (p.beta != 0.f ? p.beta * *cp : 0.f);
+            } else {
+              reinterpret_cast<bf16_t*>(p.C)[gm * p.ldc + gn + e] = f2bf(x[e]);
+            }
+          }
+        }
+      }
+    }
+}
+
+template <int BMX, int EPI, bool OUT_F32>
+int launch_big_t(const GemmArgs& a0, hipStream_t stream) {
+  GemmArgs a = a0;
+  a.tiles_m = (a.M + BMX - 1) / BMX;
+  a.tiles_n = (a.N + 255) / 256;
+  const size_t lds = (size_t)2 * (BMX + 256) * BK * 2;
+  auto kern = gemm_nt_stagger_kernel<BMX, EPI, OUT_F32>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n), dim3(512), lds, stream, a);
+  UDM_CHECK_LAUNCH("udm_gemm_nt_bf16(big)");
+  return 0;
+}
+template <int BMX>
+int launch_big(const GemmArgs& a, int epi, int out_f32, hipStream_t stream) {
+  switch (epi) {
+    case UDM_EPI_NONE: return out_f32 ? launch_big_t<BMX, UDM_EPI_NONE, true>(a, stream) : launch_big_t<BMX, UDM_EPI_NONE, false>(a, stream);
+    case UDM_EPI_BIAS: return out_f32 ? launch_big_t<BMX, UDM_EPI_BIAS, true>(a, stream) : launch_big_t<BMX, UDM_EPI_BIAS, false>(a, stream);
+    case UDM_EPI_BIAS_GELU: return launch_big_t<BMX, UDM_EPI_BIAS_GELU, false>(a, stream);
+    default: return out_f32 ? launch_big_t<BMX, UDM_EPI_DGELU, true>(a, stream) : launch_big_t<BMX, UDM_EPI_DGELU, false>(a, stream);
+  }
+}
+
+// Pick the tile whose tile count wastes the least of the 256-CU rounds.  Returns 0 for the 128x128 kernel.
+int g_force_tile = -1;  // diagnostics (udm_gemm_set_tile): -1 auto, 0 small kernel, 192/256/320
+int choose_tile(long M, long N, long K, long lda, long ldb) {
+  if (K % 64 != 0 || K < 128) return 0;  // the LDS-DMA path has no K-tail handling: such shapes take the register-staged kernel
+  if (g_force_tile >= 0) return g_force_tile;
+  if (M < 192 || N < 192) return 0;
+  const double eff[4] = {0.74, 0.93, 1.0, 1.0};  // measured relative throughput of {128x128, 192, 256, 320} x 256 tiles at full occupancy
+  const int bms[4] = {128, 192, 256, 320};
+  double best = 1e30;
+  int pick = 0;
+  for (int c = 0; c < 4; ++c) {
+    const long tm = (M + bms[c] - 1) / bms[c];
+    const long tn = c == 0 ? (N + 127) / 128 : (N + 255) / 256;
+    const long slots = c == 0 ? 512 : 256;  // co-resident blocks on the chip
+    const long rounds = (tm * tn + slots - 1) / slots;
+    const double t = rounds * (double)bms[c] * (c == 0 ? 128 : 256) * (c == 0 ? 2.0 : 1.0) / eff[c];  // time ~ rounds x tile area (2 blocks/CU share a CU)
+    if (t < best) { best = t; pick = c == 0 ? 0 : bms[c]; }
+  }
+  return pick;
+}
+
 template <int EPI>
 int launch_gemm(const GemmArgs& a, int out_f32, hipStream_t stream) {
   dim3 grid(a.tiles_m * a.tiles_n), block(NTHREADS);
@@ -328,6 +571,16 @@ extern "C" int udm_gemm_nt_bf16(const void* A, const void* B, void* C, int64_t M
   a.M = (int)M; a.N = (int)N; a.K = (int)K;
   a.tiles_m = (int)((M + BM - 1) / BM); a.tiles_n = (int)((N + BN - 1) / BN);
   a.beta = beta;
+  if (epilogue == UDM_EPI_BIAS || epilogue == UDM_EPI_BIAS_GELU) UDM_CHECK_ARG(bias, "udm_gemm_nt_bf16: bias epilogue without bias");
+  if (epilogue == UDM_EPI_BIAS_GELU) UDM_CHECK_ARG(aux && !out_f32, "udm_gemm_nt_bf16: EPI_BIAS_GELU needs aux and bf16 output");
+  if (epilogue == UDM_EPI_DGELU) UDM_CHECK_ARG(aux, "udm_gemm_nt_bf16: EPI_DGELU needs aux (saved pre-activation)");
+  UDM_CHECK_ARG(epilogue >= 0 && epilogue <= 3, "udm_gemm_nt_bf16: unknown epilogue %d", epilogue);
+  switch (choose_tile(M, N, K, lda, ldb)) {
+    case 192: return launch_big<192>(a, epilogue, out_f32, stream);
+    case 256: return launch_big<256>(a, epilogue, out_f32, stream);
+    case 320: return launch_big<320>(a, epilogue, out_f32, stream);
+    default: break;
+  }
   switch (epilogue) {
     case UDM_EPI_NONE: return launch_gemm<UDM_EPI_NONE>(a, out_f32, stream);
     case UDM_EPI_BIAS:
@@ -341,6 +594,12 @@ extern "C" int udm_gemm_nt_bf16(const void* A, const void* B, void* C, int64_t M
       return launch_gemm<UDM_EPI_DGELU>(a, out_f32, stream);
     default: udm_set_error("udm_gemm_nt_bf16: unknown epilogue %d", epilogue); return 2;
   }
+}
+
+extern "C" int udm_gemm_set_tile(int tile) {
+  UDM_CHECK_ARG(tile == -1 || tile == 0 || tile == 192 || tile == 256 || tile == 320, "udm_gemm_set_tile: tile must be -1 (auto), 0, 192, 256 or 320");
+  g_force_tile = tile;
+  return 0;
 }
 
 extern "C" int udm_transpose_bf16(const void* in, void* out, int64_t R, int64_t C, int64_t ld_in, int64_t ld_out, float* colsum, hipStream_t stream) {

@@ -1,0 +1,341 @@
+// EXPERIMENTAL tile/pipeline variants of the NT bf16 GEMM, selectable at run time for A/B measurement
+// (scripts/bench_gemm_variants.py).  The production entry point stays udm_gemm_nt_bf16 (gemm.hip); the
+// winning structure is folded in there.
+//
+// Variant = <BM, BN, WGM, WGN, STAGES>: block tile BM x BN x 64, WGM x WGN waves, each wave
+// (BM/WGM) x (BN/WGN) as 32x32x16 MFMA fragments; operands are staged with global_load_lds_dwordx4
+// (LDS-DMA, no VGPR round trip) into a STAGES-deep ring of XOR-swizzled tiles; waits are counted
+// s_waitcnt vmcnt(N) + raw s_barrier so the next tiles' loads stay in flight across barriers.
+#include "common.h"
+#include "../../include/unidisc_hip.h"
+
+namespace {
+using namespace udm;
+constexpr int BK = 64;
+
+struct XArgs {
+  const bf16_t* A;
+  const bf16_t* B;
+  bf16_t* C;
+  long lda, ldb, ldc;
+  int M, N, K, tiles_m, tiles_n;
+};
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// one 16-byte-per-lane LDS-DMA: lane i lands at lds_base + 16*i
+__device__ __forceinline__ void glds16(const void* gptr, char* lds_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gptr, (UDM_LDS void*)lds_base, 16, 0, 0);
+}
+
+template <int BM, int BN, int WGM, int WGN, int STAGES>
+__global__ __launch_bounds__(64 * WGM * WGN) void gemm_nt_glds_kernel(XArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NT = 64 * WGM * WGN;
+  constexpr int WM = BM / WGM, WN = BN / WGN, FM = WM / 32, FN = WN / 32;
+  constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE_BYTES = A_BYTES + B_BYTES;
+  constexpr int A_INSTR = A_BYTES / 1024, B_INSTR = B_BYTES / 1024;  // 1 KiB (8 rows) per wave-instruction
+  constexpr int NWAVES = WGM * WGN;
+  constexpr int A_PW = A_INSTR / NWAVES, B_PW = B_INSTR / NWAVES;    // instructions per wave per stage
+  constexpr int LOADS = A_PW + B_PW;
+  static_assert(A_INSTR % NWAVES == 0 && B_INSTR % NWAVES == 0, "tile rows must split evenly over waves");
+
+  const int nwg = p.tiles_m * p.tiles_n;
+  int pid = xcd_remap(blockIdx.x, nwg);
+  constexpr int GROUP_M = 8;
+  const int per_group = GROUP_M * p.tiles_n;
+  const int group = pid / per_group, first_m = group * GROUP_M;
+  const int gsz = min(p.tiles_m - first_m, GROUP_M);
+  const int tm = first_m + (pid % per_group) % gsz, tn = (pid % per_group) / gsz;
+  const int row0 = tm * BM, col0 = tn * BN;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int l31 = lane & 31, hi = lane >> 5;
+
+  // staging: wave w issues instruction j -> tile rows (w*PW + j)*8 .. +7; lane i -> row +i/8, LDS slot i%8,
+  // global k-slot (i%8) ^ ((row>>1)&7)   (swizzle applied on the SOURCE address, LDS image stays lane-linear)
+  const int lrow = lane >> 3, lslot = lane & 7;
+  const bf16_t* a_src[A_PW];
+  const bf16_t* b_src[B_PW];
+#pragma unroll
+  for (int j = 0; j < A_PW; ++j) {
+    const int r = (wave * A_PW + j) * 8 + lrow;
+    const int gr = min(row0 + r, p.M - 1);
+    a_src[j] = p.A + (long)gr * p.lda + ((lslot ^ ((r >> 1) & 7)) << 3);
+  }
+#pragma unroll
+  for (int j = 0; j < B_PW; ++j) {
+    const int r = (wave * B_PW + j) * 8 + lrow;
+    const int gr = min(col0 + r, p.N - 1);
+    b_src[j] = p.B + (long)gr * p.ldb + ((lslot ^ ((r >> 1) & 7)) << 3);
+  }
+  auto issue = [&](int kt, int stage) {
+    char* As = smem + stage * STAGE_BYTES;
+    char* Bs = As + A_BYTES;
+    const int k = kt * BK;
+#pragma unroll
+    for (int j = 0; j < A_PW; ++j) glds16(a_src[j] + k, As + (wave * A_PW + j) * 1024);
+#pragma unroll
+    for (int j = 0; j < B_PW; ++j) glds16(b_src[j] + k, Bs + (wave * B_PW + j) * 1024);
+  };
+
+  const int sw = (l31 >> 1) & 7;
+  f32x16_t acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  auto compute = [&](int stage) {
+    const char* As = smem + stage * STAGE_BYTES;
+    const char* Bs = As + A_BYTES;
+    // software-pipelined fragment reads: kk+1's ds_read_b128 are issued before kk's MFMAs (two fragment sets live)
+    bf16x8_t a[2][FM], b[2][FN];
+    auto ld = [&](int kk, int s) {
+      const int so = ((kk * 2 + hi) ^ sw) << 4;
+#pragma unroll
+      for (int i = 0; i < FM; ++i) a[s][i] = *reinterpret_cast<const bf16x8_t*>(As + (wm * WM + i * 32 + l31) * 128 + so);
+#pragma unroll
+      for (int j = 0; j < FN; ++j) b[s][j] = *reinterpret_cast<const bf16x8_t*>(Bs + (wn * WN + j * 32 + l31) * 128 + so);
+    };
+    ld(0, 0);
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      __builtin_amdgcn_sched_barrier(0);  // keep the k-steps apart: the scheduler otherwise chains dependent MFMAs and sinks the reads
+      if (kk < 3) ld(kk + 1, (kk + 1) & 1);
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[kk & 1][i], b[kk & 1][j], acc[i][j], 0, 0, 0);
+      if (kk < 3) __builtin_amdgcn_sched_group_barrier(0x100, FM + FN, 0);  // next k-step's fragment reads first ...
+      __builtin_amdgcn_sched_group_barrier(0x008, FM * FN, 0);              // ... then this k-step's MFMAs cover their latency
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  const int nk = p.K / BK;  // experimental kernels: K % 64 == 0
+  if (STAGES == 2) {
+    issue(0, 0);
+    if (nk > 1) issue(1, 1);
+    for (int kt = 0; kt < nk; ++kt) {
+      if (kt + 1 < nk) wait_vmcnt<LOADS>(); else wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+      compute(kt & 1);
+      __builtin_amdgcn_s_barrier();
+      if (kt + 2 < nk) issue(kt + 2, kt & 1);
+    }
+  } else {
+    issue(0, 0);
+    if (nk > 1) issue(1, 1);
+    int st = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+      if (kt + 1 < nk) wait_vmcnt<LOADS>(); else wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();  // tile kt visible to all waves; every wave has finished compute(kt-1)
+      int nxt = st + 2; if (nxt >= STAGES) nxt -= STAGES;
+      if (kt + 2 < nk) issue(kt + 2, nxt);
+      compute(st);
+      st = (st + 1 == STAGES) ? 0 : st + 1;
+    }
+  }
+  __syncthreads();
+
+  // epilogue: bf16 store straight from accumulators (row-strided 2-byte stores; fine for an A/B of the main loop)
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = row0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        const int n = col0 + wn * WN + j * 32 + l31;
+        if (m < p.M && n < p.N) p.C[(long)m * p.ldc + n] = f2bf(acc[i][j][r]);
+      }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Staggered two-group schedule (2 waves per SIMD): every K tile is cut into phases
+//     { fragment ds_reads (+ a slice of the next tile's LDS-DMA) ; s_barrier ; MFMAs ; s_barrier }
+// and the second half of the waves runs ONE barrier behind the first half, so while one wave of a SIMD
+// owns the matrix pipe its partner is in its read section.  KKPP = k-steps (of 16) per phase.
+// ------------------------------------------------------------------------------------------------
+template <int BM, int BN, int WGM, int WGN, int KKPP>
+__global__ __launch_bounds__(64 * WGM * WGN) void gemm_nt_stagger_kernel(XArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int WM = BM / WGM, WN = BN / WGN, FM = WM / 32, FN = WN / 32;
+  constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE_BYTES = A_BYTES + B_BYTES;
+  constexpr int NWAVES = WGM * WGN;
+  constexpr int A_PW = A_BYTES / 1024 / NWAVES, B_PW = B_BYTES / 1024 / NWAVES;
+  constexpr int NPH = 4 / KKPP;                 // phases per K tile
+  constexpr int LOADS = A_PW + B_PW;
+  constexpr int ISSUE_PH = NPH > 2 ? NPH - 2 : 1;  // phases of a tile that carry the next tile's loads (the last ones stay free = slack)
+  static_assert((BM * BK * 2 / 1024) % NWAVES == 0 && (BN * BK * 2 / 1024) % NWAVES == 0, "tile rows must split evenly over waves");
+
+  const int nwg = p.tiles_m * p.tiles_n;
+  int pid = xcd_remap(blockIdx.x, nwg);
+  constexpr int GROUP_M = 8;
+  const int per_group = GROUP_M * p.tiles_n;
+  const int grp = pid / per_group, first_m = grp * GROUP_M;
+  const int gsz = min(p.tiles_m - first_m, GROUP_M);
+  const int tm = first_m + (pid % per_group) % gsz, tn = (pid % per_group) / gsz;
+  const int row0 = tm * BM, col0 = tn * BN;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int late = __builtin_amdgcn_readfirstlane(wave >= NWAVES / 2 ? 1 : 0);  // second half runs one barrier behind
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int lrow = lane >> 3, lslot = lane & 7;
+  const bf16_t* src[LOADS];
+  int dst[LOADS];
+#pragma unroll
+  for (int j = 0; j < A_PW; ++j) {
+    const int r = (wave * A_PW + j) * 8 + lrow;
+    src[j] = p.A + (long)min(row0 + r, p.M - 1) * p.lda + ((lslot ^ ((r >> 1) & 7)) << 3);
+    dst[j] = (wave * A_PW + j) * 1024;
+  }
+#pragma unroll
+  for (int j = 0; j < B_PW; ++j) {
+    const int r = (wave * B_PW + j) * 8 + lrow;
+    src[A_PW + j] = p.B + (long)min(col0 + r, p.N - 1) * p.ldb + ((lslot ^ ((r >> 1) & 7)) << 3);
+    dst[A_PW + j] = A_BYTES + (wave * B_PW + j) * 1024;
+  }
+  const int sw = (l31 >> 1) & 7;
+  f32x16_t acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk = p.K / BK;
+#pragma unroll
+  for (int j = 0; j < LOADS; ++j) glds16(src[j], smem + dst[j]);
+  wait_vmcnt<0>();
+  __builtin_amdgcn_s_barrier();
+  if (late) __builtin_amdgcn_s_barrier();
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const char* As = smem + (kt & 1) * STAGE_BYTES;
+    const char* Bs = As + A_BYTES;
+    char* nxt = smem + ((kt + 1) & 1) * STAGE_BYTES;
+    const bool more = kt + 1 < nk;
+    const int knext = (kt + 1) * BK;
+#pragma unroll
+    for (int ph = 0; ph < NPH; ++ph) {
+      bf16x8_t a[KKPP][FM], b[KKPP][FN];
+#pragma unroll
+      for (int q = 0; q < KKPP; ++q) {
+        const int so = (((ph * KKPP + q) * 2 + hi) ^ sw) << 4;
+#pragma unroll
+        for (int i = 0; i < FM; ++i) a[q][i] = *reinterpret_cast<const bf16x8_t*>(As + (wm * WM + i * 32 + l31) * 128 + so);
+#pragma unroll
+        for (int j = 0; j < FN; ++j) b[q][j] = *reinterpret_cast<const bf16x8_t*>(Bs + (wn * WN + j * 32 + l31) * 128 + so);
+      }
+      if (ph < ISSUE_PH && more) {
+        constexpr int PER = (LOADS + ISSUE_PH - 1) / ISSUE_PH;
+#pragma unroll
+        for (int j = ph * PER; j < (ph + 1) * PER && j < LOADS; ++j) glds16(src[j] + knext, nxt + dst[j]);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (ph == NPH - 1) wait_vmcnt<0>();
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int q = 0; q < KKPP; ++q)
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+          for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[q][i], b[q][j], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  if (!late) __builtin_amdgcn_s_barrier();
+
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = row0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        const int n = col0 + wn * WN + j * 32 + l31;
+        if (m < p.M && n < p.N) p.C[(long)m * p.ldc + n] = f2bf(acc[i][j][r]);
+      }
+}
+
+template <int BM, int BN, int WGM, int WGN, int KKPP>
+int launch_stagger(const XArgs& a0, hipStream_t stream) {
+  XArgs a = a0;
+  a.tiles_m = (a.M + BM - 1) / BM;
+  a.tiles_n = (a.N + BN - 1) / BN;
+  const size_t lds = (size_t)2 * (BM + BN) * BK * 2;
+  auto kern = gemm_nt_stagger_kernel<BM, BN, WGM, WGN, KKPP>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n), dim3(64 * WGM * WGN), lds, stream, a);
+  UDM_CHECK_LAUNCH("udm_gemm_nt_bf16_variant(stagger)");
+  return 0;
+}
+
+template <int BM, int BN, int WGM, int WGN, int STAGES>
+int launch(const XArgs& a0, hipStream_t stream) {
+  XArgs a = a0;
+  a.tiles_m = (a.M + BM - 1) / BM;
+  a.tiles_n = (a.N + BN - 1) / BN;
+  const size_t lds = (size_t)STAGES * (BM + BN) * BK * 2;
+  auto kern = gemm_nt_glds_kernel<BM, BN, WGM, WGN, STAGES>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n), dim3(64 * WGM * WGN), lds, stream, a);
+  UDM_CHECK_LAUNCH("udm_gemm_nt_bf16_variant");
+  return 0;
+}
+}  // namespace
+
+// variant ids: see scripts/bench_gemm_variants.py
+extern "C" int udm_gemm_nt_bf16_variant(int variant, const void* A, const void* B, void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb,
+                                        int64_t ldc, hipStream_t stream) {
+  UDM_CHECK_ARG(A && B && C && M > 0 && N > 0 && K > 0 && K % 64 == 0, "udm_gemm_nt_bf16_variant: bad arguments (K %% 64 == 0 required)");
+  XArgs a{(const bf16_t*)A, (const bf16_t*)B, (bf16_t*)C, (long)lda, (long)ldb, (long)ldc, (int)M, (int)N, (int)K, 0, 0};
+  switch (variant) {
+    case 0: return launch<128, 128, 2, 2, 2>(a, stream);
+    case 1: return launch<128, 128, 2, 2, 3>(a, stream);
+    case 2: return launch<128, 128, 2, 2, 4>(a, stream);
+    case 3: return launch<256, 128, 4, 2, 2>(a, stream);
+    case 4: return launch<256, 128, 4, 2, 3>(a, stream);
+    case 5: return launch<256, 128, 2, 2, 3>(a, stream);
+    case 6: return launch<256, 256, 2, 4, 2>(a, stream);
+    case 7: return launch<256, 256, 4, 4, 2>(a, stream);
+    case 8: return launch<256, 256, 4, 2, 2>(a, stream);
+    case 9: return launch<128, 256, 2, 4, 3>(a, stream);
+    case 10: return launch_stagger<256, 256, 2, 4, 1>(a, stream);
+    case 11: return launch_stagger<256, 256, 2, 4, 2>(a, stream);
+    case 12: return launch_stagger<256, 128, 4, 2, 2>(a, stream);
+    case 13: return launch_stagger<128, 256, 2, 4, 2>(a, stream);
+    case 14: return launch_stagger<256, 256, 4, 2, 1>(a, stream);
+    case 15: return launch_stagger<128, 128, 2, 4, 2>(a, stream);
+    case 16: return launch_stagger<320, 256, 2, 4, 1>(a, stream);
+    case 17: return launch_stagger<256, 320, 2, 4, 1>(a, stream);
+    default: udm_set_error("udm_gemm_nt_bf16_variant: unknown variant %d", variant); return 2;
+  }
+}

@@ -226,7 +226,8 @@ class DIT(nn.Module, _HubMixin):
         # engine state
         self._lins: Optional[Dict[str, _Lin]] = None
         self._fwd_count = 0
-        self.grad_ready_callback = None   # fn(list[nn.Parameter]) called inside backward when those grads are final
+        self.grad_ready_callback = None   # fn(flat_grads, lo, hi): elements [lo, hi) of this backward's flat fp32 gradient buffer are final
+        self.grad_sync_finish = None      # fn(): called at the end of backward (e.g. make the compute stream wait for the all-reduces)
         self.recast_every_forward = True  # mirror autocast: fp32 master -> bf16 shadow on every training forward
         self._shadow_versions = None
 
@@ -454,7 +455,17 @@ class DIT(nn.Module, _HubMixin):
             offs.append(total)
             total += _ceil(p.numel(), 64)
         flat = torch.zeros(total, dtype=F32, device=dev)
+        self._grad_ranges = {id(p): (o, o + _ceil(p.numel(), 64)) for p, o in zip(params, offs)}
         return flat, {id(p): flat[o:o + p.numel()].view(p.shape) for p, o in zip(params, offs)}
+
+    def _notify(self, flat, group):
+        """Tell the gradient-sync hook that the flat range covering `group` (contiguous by construction) is final."""
+        cb = self.grad_ready_callback
+        if cb is None or not group:
+            return
+        lo = min(self._grad_ranges[id(p)][0] for p in group)
+        hi = max(self._grad_ranges[id(p)][1] for p in group)
+        cb(flat, lo, hi)
 
     def _wgrad(self, dY, X, lin: _Lin, G, n_rows=None):
         """dW[out,in] = dY[M,out]^T X[M,in] (fp32), db = colsum(dY).  dY/X bf16 [M, *]."""
@@ -480,7 +491,6 @@ class DIT(nn.Module, _HubMixin):
         flat, G = self._alloc_grads(params, dev)
         S["grad_flat"] = flat
         mod_flat, any_img, p_drop, seed0 = S["modality"], S.get("any_img"), S["p_drop"], S["seed0"]
-        cb = self.grad_ready_callback
         V = self.vocab_size
         head = lin["head"]
         logits = S["logits"]
@@ -510,8 +520,7 @@ class DIT(nn.Module, _HubMixin):
                    mod=fmod, dmod=dmodf, mod_idx=(0, 1), modality=mod_flat, any_img=any_img)
         if tc:
             self._ada_backward(dmodf, lin["head.ada"], S["c"], dc, G)
-        if cb:
-            cb(list(fl.parameters()))
+        self._notify(flat, list(fl.parameters()))
 
         for i in reversed(range(self.n_blocks)):
             blk, R = self.blocks[i], S["blocks"][i]
@@ -554,8 +563,7 @@ class DIT(nn.Module, _HubMixin):
             if tc:
                 self._ada_backward(dmod, lin[f"{i}.ada"], S["c"], dc, G)
             S["blocks"][i] = None  # free this block's activations
-            if cb:
-                cb(list(blk.parameters()))
+            self._notify(flat, list(blk.parameters()))
 
         # ---- embeddings
         K.embedding_bwd(S["ids"], dx, G[id(self.vocab_embed.embedding)], self.mask_index,
@@ -571,8 +579,9 @@ class DIT(nn.Module, _HubMixin):
             dl1 = K.silu_bwd(S["l1"], ds1)
             self._wgrad(dl1, S["te"], lin["sig0"], G)
             tail += list(self.sigma_map.parameters())
-        if cb:
-            cb(tail)
+        self._notify(flat, tail)
+        if self.grad_sync_finish is not None:
+            self.grad_sync_finish()
         return [G[id(p)] for p in params]
 
     def _ada_backward(self, dmod, lin: _Lin, c, dc, G):

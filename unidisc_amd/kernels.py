@@ -67,6 +67,11 @@ def gemm_nt(a, b, out=None, *, out_dtype=BF16, M=None, N=None, K=None, lda=None,
     return out
 
 
+def gemm_set_tile(tile: int):
+    """Diagnostics: force the GEMM tile family (-1 auto, 0 small kernel, 192/256/320)."""
+    _lib.call("udm_gemm_set_tile", tile)
+
+
 def transpose(x, out=None, colsum=None, R=None, C=None):
     """out[C,R] = x[R,C]^T (bf16); colsum[c] += sum_r x[r,c] when given."""
     _chk(x, BF16, "transpose")
