@@ -45,6 +45,9 @@ int udm_abi_version(void);
  * C[M,N] = A[M,K] · B[N,K]ᵀ, A/B bf16 K-contiguous; C bf16 or fp32; beta accumulates into an fp32 C.   */
 int udm_gemm_nt_bf16(const void* A, const void* B, void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int out_f32,
                      int epilogue, const float* bias, void* aux, int64_t ldaux, float beta, hipStream_t stream);
+/* wgrad form read straight from row-major activations: C[M,N] (fp32) = beta*C + A[K,M]ᵀ · B[K,N]  (K % 64 == 0). */
+int udm_gemm_tn_bf16(const void* A, const void* B, void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, float beta,
+                     hipStream_t stream);
 int udm_gemm_set_tile(int tile); /* diagnostics: force the tile family (-1 auto, 0 = 128x128 kernel, 192/256/320 = BMx256 kernel) */
 /* out[C,R] = in[R,C]ᵀ (bf16); optional colsum[c] += Σ_r in[r,c] (bias gradient).  Feeds the wgrad GEMMs. */
 int udm_transpose_bf16(const void* in, void* out, int64_t R, int64_t C, int64_t ld_in, int64_t ld_out, float* colsum, hipStream_t stream);

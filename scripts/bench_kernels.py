@@ -42,6 +42,12 @@ def main():
         ms_t = timeit(lambda: torch.matmul(a, b.t()))
         res[f"gemm/{name}"] = dict(ms=round(ms, 4), tflops=round(2 * m * n * k / ms / 1e9, 1), torch_matmul_tflops=round(2 * m * n * k / ms_t / 1e9, 1))
         del a, b, out
+    for name, (kc, m, n) in {"fc1_wgrad_tn": (M, 8192, 2048), "fc2_wgrad_tn": (M, 2048, 8192), "qkv_wgrad_tn": (M, 6144, 2048), "out_wgrad_tn": (M, 2048, 2048)}.items():
+        a, b = rn(kc, m), rn(kc, n)
+        out = torch.empty((m, n), dtype=torch.float32, device=DEV)
+        ms = timeit(lambda: K.gemm_tn(a, b, out))
+        res[f"gemm/{name}"] = dict(ms=round(ms, 4), tflops=round(2 * m * n * kc / ms / 1e9, 1))
+        del a, b, out
     # epilogue variants
     a, b, bias = rn(M, 2048), rn(8192, 2048), torch.randn(8192, device=DEV)
     aux = torch.empty((M, 8192), dtype=BF16, device=DEV)

@@ -318,3 +318,16 @@ def subs_logprobs(logits, xt, modality, V, Vt, mask_id, restrict, out_dtype=BF16
         onehot = F.one_hot(xt.clamp(0, V - 1), V).bool()
         out = torch.where(un, torch.where(onehot, torch.zeros_like(out), torch.full_like(out, -1e6)), out)
     return out.to(out_dtype)
+
+
+def gemm_tn(a, b, out, *, M=None, N=None, beta=0.0):
+    M = a.shape[1] if M is None else M
+    N = b.shape[1] if N is None else N
+    acc = a[:, :M].float().t() @ b[:, :N].float()
+    out[:M, :N] = acc + (beta * out[:M, :N] if beta != 0.0 else 0)
+    return out
+
+
+def colsum(x, out):
+    out += x.float().sum(0)
+    return out

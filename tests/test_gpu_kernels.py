@@ -77,6 +77,24 @@ def test_gemm_large_tile_kernels(K, tile, M, N, K_):
         K.gemm_set_tile(-1)
 
 
+@pytest.mark.parametrize("Kc,M,N", [(256, 192, 256), (1280, 2048, 2048), (128, 64, 200), (640, 1001, 328), (2560, 6144, 2048), (192, 320, 8192)])
+def test_gemm_tn_kmajor(K, Kc, M, N):
+    """wgrad form C = A^T B with both operands K-major (transposing LDS reads), incl. ragged M/N and padded strides."""
+    lda, ldb = (M + 7) // 8 * 8, (N + 7) // 8 * 8
+    a, b = torch.zeros(Kc, lda, dtype=torch.bfloat16), torch.zeros(Kc, ldb, dtype=torch.bfloat16)
+    a[:, :M], b[:, :N] = bf(rnd(Kc, M, seed=90, scale=0.5)), bf(rnd(Kc, N, seed=91, scale=0.5))
+    ref = a[:, :M].float().t() @ b[:, :N].float()
+    c0 = rnd(M, N, seed=92)
+    out = c0.clone().to(DEV)
+    K.gemm_tn(a.to(DEV), b.to(DEV), out, M=M, N=N, beta=0.0)
+    assert rel_err(out.cpu(), ref) < 1e-5
+    K.gemm_tn(a.to(DEV), b.to(DEV), out, M=M, N=N, beta=1.0)
+    assert rel_err(out.cpu(), 2 * ref) < 1e-5
+    cs = torch.zeros(lda, device=DEV)
+    K.colsum(a.to(DEV), cs)
+    assert torch.allclose(cs.cpu()[:M], a[:, :M].float().sum(0), atol=2e-3, rtol=1e-4)
+
+
 def test_gemm_identity_asymmetric(K):
     # A = I (padded), B asymmetric: catches swapped row/col fragment maps
     n = 128

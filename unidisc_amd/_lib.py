@@ -21,6 +21,7 @@ _P, _I64, _I, _F, _U64 = c_void_p, c_int64, c_int, c_float, c_uint64
 # name -> argument ctypes (the trailing hipStream_t is a pointer); must mirror include/unidisc_hip.h exactly
 PROTOTYPES = {
     "udm_gemm_nt_bf16": [_P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _I, _I, _P, _P, _I64, _F, _P],
+    "udm_gemm_tn_bf16": [_P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _F, _P],
     "udm_gemm_set_tile": [_I],
     "udm_transpose_bf16": [_P, _P, _I64, _I64, _I64, _I64, _P, _P],
     "udm_cast_transpose_f32_bf16": [_P, _P, _P, _I64, _I64, _I64, _I64, _I64, _P],

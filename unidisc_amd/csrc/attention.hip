@@ -83,28 +83,29 @@ struct AttnArgs {
   float scale;          // 1 / sqrt(D)
 };
 
-// stage a [ROWS][D] tile: registers <- global (predicated on row < L), then registers -> swizzled LDS
+// stage a [ROWS][D] bf16 tile with LDS-DMA (global_load_lds_dwordx4: no VGPR round trip, no ds_write).  One wave
+// instruction moves 1 KiB = 1024/(2D) rows; lane i lands at +16*i, so the XOR swizzle is applied on the per-lane SOURCE
+// slot (the swizzle is an involution).  Rows past L are clamped to row L-1: finite data that every consumer masks out.
 template <int D, int ROWS>
-struct TileStager {
-  static constexpr int CPR = D / 8;                   // 16-byte chunks per row
-  static constexpr int CPT = ROWS * CPR / 256;        // chunks per thread
-  static_assert(CPT >= 1, "tile too small for 256 threads");
-  uint4 r[CPT];
-  __device__ __forceinline__ void load(const bf16_t* base, long stride, int row0, int L, int tid) {
+struct DmaStager {
+  static constexpr int LPR = D / 8;               // lanes (16-byte slots) per row
+  static constexpr int RPI = 64 / LPR;            // rows per wave instruction
+  static constexpr int NINSTR = ROWS / RPI;       // instructions per tile
+  static constexpr int PW = NINSTR / 4;           // per wave (4 waves per block)
+  static_assert(NINSTR % 4 == 0 && PW >= 1, "tile must split evenly over 4 waves");
+  static __device__ __forceinline__ void issue(const bf16_t* base, long stride, int row0, int L, char* tile, int wave, int lane) {
 #pragma unroll
-    for (int i = 0; i < CPT; ++i) {
-      const int c = tid + i * 256, row = c / CPR, s = c % CPR;
-      r[i] = (row0 + row < L) ? *reinterpret_cast<const uint4*>(base + (long)(row0 + row) * stride + s * 8) : make_uint4(0, 0, 0, 0);
-    }
-  }
-  __device__ __forceinline__ void store(char* tile, int tid) const {
-#pragma unroll
-    for (int i = 0; i < CPT; ++i) {
-      const int c = tid + i * 256, row = c / CPR, s = c % CPR;
-      *reinterpret_cast<uint4*>(tile + tile_off<D>(row, s)) = r[i];
+    for (int j = 0; j < PW; ++j) {
+      const int idx = wave * PW + j;
+      const int row = idx * RPI + lane / LPR;
+      const int slot = (lane % LPR) ^ swz<D>(row);
+      const int grow = min(row0 + row, L - 1);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + (long)grow * stride + slot * 8),
+                                       (UDM_LDS void*)(tile + idx * 1024), 16, 0, 0);
     }
   }
 };
+__device__ __forceinline__ void wait_all_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 constexpr int BQ = 128;   // query rows per block (4 waves x 32)
 constexpr int BKV = 64;   // keys per tile
@@ -113,12 +114,13 @@ constexpr int BKV = 64;   // keys per tile
 // forward
 // ------------------------------------------------------------------------------------------------
 template <int D, bool HAS_SID, bool USE_TR>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
-  __shared__ __attribute__((aligned(16))) char Ks[BKV * D * 2];
-  __shared__ __attribute__((aligned(16))) char Vs[BKV * D * 2];
-  __shared__ long sidk[BKV];
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // K0 | K1 | V0 | V1 | sidk[2][64]   (one array: keeps LDS-DMA waits exact)
+  constexpr int TB = BKV * D * 2;
+  long* sid_s = reinterpret_cast<long*>(smem + 4 * TB);
   constexpr int KS = D / 16, DB = D / 32;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b = blockIdx.z, h = blockIdx.y;
   const int qi = blockIdx.x * BQ + wave * 32 + l31;
   const bool q_ok = qi < a.L;
@@ -140,20 +142,21 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
 
   const bf16_t* kbase = a.k + rowbase * a.k_stride + h * D;
   const bf16_t* vbase = a.v + rowbase * a.v_stride + h * D;
-  TileStager<D, BKV> sk, sv;
+  using Stg = DmaStager<D, BKV>;
   const int nkv = (a.L + BKV - 1) / BKV;
-  sk.load(kbase, a.k_stride, 0, a.L, tid);
-  sv.load(vbase, a.v_stride, 0, a.L, tid);
+  Stg::issue(kbase, a.k_stride, 0, a.L, smem, wave, lane);
+  Stg::issue(vbase, a.v_stride, 0, a.L, smem + 2 * TB, wave, lane);
   for (int t = 0; t < nkv; ++t) {
-    const int kv0 = t * BKV;
-    __syncthreads();
-    sk.store(Ks, tid);
-    sv.store(Vs, tid);
-    if (HAS_SID && tid < BKV) sidk[tid] = (kv0 + tid < a.L) ? a.sample_ids[rowbase + kv0 + tid] : -2;
-    __syncthreads();
+    const int kv0 = t * BKV, st = t & 1;
+    const char* Ks = smem + st * TB;
+    const char* Vs = smem + (2 + st) * TB;
+    const long* sidk = sid_s + st * BKV;
+    if (HAS_SID && tid < BKV) sid_s[st * BKV + tid] = (kv0 + tid < a.L) ? a.sample_ids[rowbase + kv0 + tid] : -2;
+    wait_all_vmem();   // this wave's share of tile t has landed
+    __syncthreads();   // ... and everybody's; all waves are also done with tile t-1, so its stage may be refilled
     if (t + 1 < nkv) {
-      sk.load(kbase, a.k_stride, kv0 + BKV, a.L, tid);
-      sv.load(vbase, a.v_stride, kv0 + BKV, a.L, tid);
+      Stg::issue(kbase, a.k_stride, kv0 + BKV, a.L, smem + (st ^ 1) * TB, wave, lane);
+      Stg::issue(vbase, a.v_stride, kv0 + BKV, a.L, smem + (2 + (st ^ 1)) * TB, wave, lane);
     }
     // S^T = K Q^T : [64 keys] x [32 queries per wave]
     f32x16_t sT[2];
@@ -259,12 +262,13 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restric
 // backward, dQ: block owns 128 queries, walks key tiles.  dQ^T = K^T dS^T (lane owns a query column).
 // ------------------------------------------------------------------------------------------------
 template <int D, bool HAS_SID, bool USE_TR>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
-  __shared__ __attribute__((aligned(16))) char Ks[BKV * D * 2];
-  __shared__ __attribute__((aligned(16))) char Vs[BKV * D * 2];
-  __shared__ long sidk[BKV];
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // K0 | K1 | V0 | V1 | sidk[2][64]
+  constexpr int TB = BKV * D * 2;
+  long* sid_s = reinterpret_cast<long*>(smem + 4 * TB);
   constexpr int KS = D / 16, DB = D / 32;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b = blockIdx.z, h = blockIdx.y;
   const int qi = blockIdx.x * BQ + wave * 32 + l31;
   const bool q_ok = qi < a.L;
@@ -291,20 +295,21 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
 
   const bf16_t* kbase = a.k + rowbase * a.k_stride + h * D;
   const bf16_t* vbase = a.v + rowbase * a.v_stride + h * D;
-  TileStager<D, BKV> sk, sv;
+  using Stg = DmaStager<D, BKV>;
   const int nkv = (a.L + BKV - 1) / BKV;
-  sk.load(kbase, a.k_stride, 0, a.L, tid);
-  sv.load(vbase, a.v_stride, 0, a.L, tid);
+  Stg::issue(kbase, a.k_stride, 0, a.L, smem, wave, lane);
+  Stg::issue(vbase, a.v_stride, 0, a.L, smem + 2 * TB, wave, lane);
   for (int t = 0; t < nkv; ++t) {
-    const int kv0 = t * BKV;
-    __syncthreads();
-    sk.store(Ks, tid);
-    sv.store(Vs, tid);
-    if (HAS_SID && tid < BKV) sidk[tid] = (kv0 + tid < a.L) ? a.sample_ids[rowbase + kv0 + tid] : -2;
-    __syncthreads();
+    const int kv0 = t * BKV, st = t & 1;
+    const char* Ks = smem + st * TB;
+    const char* Vs = smem + (2 + st) * TB;
+    const long* sidk = sid_s + st * BKV;
+    if (HAS_SID && tid < BKV) sid_s[st * BKV + tid] = (kv0 + tid < a.L) ? a.sample_ids[rowbase + kv0 + tid] : -2;
+    wait_all_vmem();   // this wave's share of tile t has landed
+    __syncthreads();   // ... and everybody's; all waves are also done with tile t-1, so its stage may be refilled
     if (t + 1 < nkv) {
-      sk.load(kbase, a.k_stride, kv0 + BKV, a.L, tid);
-      sv.load(vbase, a.v_stride, kv0 + BKV, a.L, tid);
+      Stg::issue(kbase, a.k_stride, kv0 + BKV, a.L, smem + (st ^ 1) * TB, wave, lane);
+      Stg::issue(vbase, a.v_stride, kv0 + BKV, a.L, smem + (2 + (st ^ 1)) * TB, wave, lane);
     }
     float ds[2][16];
 #pragma unroll
@@ -355,15 +360,16 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
 //   S = Q K^T (regs walk queries), dP = dO V^T, dV^T += dO^T P, dK^T += Q^T dS
 // ------------------------------------------------------------------------------------------------
 constexpr int BQT = 64;
-template <int D, bool HAS_SID, bool USE_TR>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
-  __shared__ __attribute__((aligned(16))) char Qs[BQT * D * 2];
-  __shared__ __attribute__((aligned(16))) char Os[BQT * D * 2];
-  __shared__ __attribute__((aligned(16))) float lse_s[BQT];
-  __shared__ __attribute__((aligned(16))) float delta_s[BQT];
-  __shared__ long sidq[BQT];
+template <int D, bool HAS_SID, bool USE_TR, int DKV_WAVES>
+__global__ __launch_bounds__(256, DKV_WAVES) void attn_bwd_dkv_kernel(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // Q0 | Q1 | dO0 | dO1 | lse[2][64] | delta[2][64] | sidq[2][64]
+  constexpr int TB = BQT * D * 2;
+  float* lse_all = reinterpret_cast<float*>(smem + 4 * TB);
+  float* delta_all = lse_all + 2 * BQT;
+  long* sid_all = reinterpret_cast<long*>(delta_all + 2 * BQT);
   constexpr int KS = D / 16, DB = D / 32;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b = blockIdx.z, h = blockIdx.y;
   const int ki = blockIdx.x * 128 + wave * 32 + l31;
   const bool k_ok = ki < a.L;
@@ -388,25 +394,28 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
   const bf16_t* qbase = a.q + rowbase * a.q_stride + h * D;
   const bf16_t* dobase = a.dout + rowbase * a.do_stride + h * D;
   const long sbase = ((long)b * a.H + h) * a.L;
-  TileStager<D, BQT> sq, so;
+  using Stg = DmaStager<D, BQT>;
   const int nq = (a.L + BQT - 1) / BQT;
-  sq.load(qbase, a.q_stride, 0, a.L, tid);
-  so.load(dobase, a.do_stride, 0, a.L, tid);
+  Stg::issue(qbase, a.q_stride, 0, a.L, smem, wave, lane);
+  Stg::issue(dobase, a.do_stride, 0, a.L, smem + 2 * TB, wave, lane);
   for (int t = 0; t < nq; ++t) {
-    const int q0 = t * BQT;
-    __syncthreads();
-    sq.store(Qs, tid);
-    so.store(Os, tid);
+    const int q0 = t * BQT, st = t & 1;
+    const char* Qs = smem + st * TB;
+    const char* Os = smem + (2 + st) * TB;
+    const float* lse_s = lse_all + st * BQT;
+    const float* delta_s = delta_all + st * BQT;
+    const long* sidq = sid_all + st * BQT;
     if (tid < BQT) {
       const bool ok = q0 + tid < a.L;
-      lse_s[tid] = ok ? a.lse[sbase + q0 + tid] : INFINITY;
-      delta_s[tid] = ok ? a.delta[sbase + q0 + tid] : 0.f;
-      if (HAS_SID) sidq[tid] = ok ? a.sample_ids[rowbase + q0 + tid] : -1;
+      lse_all[st * BQT + tid] = ok ? a.lse[sbase + q0 + tid] : INFINITY;
+      delta_all[st * BQT + tid] = ok ? a.delta[sbase + q0 + tid] : 0.f;
+      if (HAS_SID) sid_all[st * BQT + tid] = ok ? a.sample_ids[rowbase + q0 + tid] : -1;
     }
+    wait_all_vmem();
     __syncthreads();
     if (t + 1 < nq) {
-      sq.load(qbase, a.q_stride, q0 + BQT, a.L, tid);
-      so.load(dobase, a.do_stride, q0 + BQT, a.L, tid);
+      Stg::issue(qbase, a.q_stride, q0 + BQT, a.L, smem + (st ^ 1) * TB, wave, lane);
+      Stg::issue(dobase, a.do_stride, q0 + BQT, a.L, smem + (2 + (st ^ 1)) * TB, wave, lane);
     }
 #pragma unroll
     for (int qs = 0; qs < 2; ++qs) {
@@ -464,16 +473,31 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
   }
 }
 
+template <typename KernT>
+void set_lds(KernT kern, size_t bytes) {
+  (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
 template <int D, bool SID, bool TR>
 void launch_fwd(const AttnArgs& a, hipStream_t s) {
   dim3 grid((a.L + BQ - 1) / BQ, a.H, a.B);
-  hipLaunchKernelGGL((attn_fwd_kernel<D, SID, TR>), grid, dim3(256), 0, s, a);
+  const size_t lds = 4 * BKV * D * 2 + 2 * BKV * sizeof(long);
+  auto kern = attn_fwd_kernel<D, SID, TR>;
+  static bool once = false;
+  if (!once) { set_lds(kern, lds); once = true; }
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
 }
 template <int D, bool SID, bool TR>
 void launch_bwd(const AttnArgs& a, hipStream_t s) {
   dim3 gq((a.L + BQ - 1) / BQ, a.H, a.B), gk((a.L + 127) / 128, a.H, a.B);
-  hipLaunchKernelGGL((attn_bwd_dq_kernel<D, SID, TR>), gq, dim3(256), 0, s, a);
-  hipLaunchKernelGGL((attn_bwd_dkv_kernel<D, SID, TR>), gk, dim3(256), 0, s, a);
+  const size_t lds_q = 4 * BKV * D * 2 + 2 * BKV * sizeof(long);
+  const size_t lds_k = 4 * BQT * D * 2 + 4 * BQT * sizeof(float) + 2 * BQT * sizeof(long);
+  auto kq = attn_bwd_dq_kernel<D, SID, TR>;
+  constexpr int W = (D == 128) ? 1 : 2;  // dK/dV at D=128 keeps 192 accumulator/operand registers live: one wave per SIMD
+  auto kk = attn_bwd_dkv_kernel<D, SID, TR, W>;
+  static bool once = false;
+  if (!once) { set_lds(kq, lds_q); set_lds(kk, lds_k); once = true; }
+  hipLaunchKernelGGL(kq, gq, dim3(256), lds_q, s, a);
+  hipLaunchKernelGGL(kk, gk, dim3(256), lds_k, s, a);
 }
 
 #define ATTN_DISPATCH(FN, a, D, sid, tr, s)                                    \

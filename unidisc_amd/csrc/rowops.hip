@@ -474,23 +474,37 @@ __device__ __forceinline__ void load4_f32(const float* p, float (&v)[4]) {
   v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
 }
 
+// Lane item t -> (part, head, j): 8 columns at c_lo = part*d + head*D + 8j and 8 at c_hi = c_lo + D/2 (16-byte accesses; the
+// rotation partners live in the same lane).  The LayerNorm affine vectors are staged once per block in LDS.
 template <int NIT>
 __global__ __launch_bounds__(256) void qknorm_rope_fwd_kernel(QkArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float aff[];  // gq | bq | gk | bk, d floats each (only with qk-norm)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int half = a.D / 2, per_head = a.D / 8, per_part = a.d / 8;
+  const int half = a.D / 2, per_head = a.D / 16, per_part = a.d / 16;
   const bool do_norm = a.gq != nullptr;
+  if (do_norm) {
+    for (int c = threadIdx.x * 4; c < a.d; c += 1024) {
+      *reinterpret_cast<float4*>(aff + c) = *reinterpret_cast<const float4*>(a.gq + c);
+      *reinterpret_cast<float4*>(aff + a.d + c) = *reinterpret_cast<const float4*>(a.bq + c);
+      *reinterpret_cast<float4*>(aff + 2 * a.d + c) = *reinterpret_cast<const float4*>(a.gk + c);
+      *reinterpret_cast<float4*>(aff + 3 * a.d + c) = *reinterpret_cast<const float4*>(a.bk + c);
+    }
+    __syncthreads();
+  }
   for (long row = (long)blockIdx.x * ROWS_PER_BLOCK + wave; row < a.M; row += (long)gridDim.x * ROWS_PER_BLOCK) {
-    float lo[NIT][4], hi[NIT][4];
+    float lo[NIT][8], hi[NIT][8];
     float sq = 0.f, sk = 0.f;
 #pragma unroll
     for (int i = 0; i < NIT; ++i) {
       const int t = i * 64 + lane;
       if (t < 2 * per_part) {
         const int part = t / per_part, r = t % per_part;
-        const int c = part * a.d + (r / per_head) * a.D + (r % per_head) * 4;
-        load4_bf16(a.qkv + row * 3 * a.d + c, lo[i]);
-        load4_bf16(a.qkv + row * 3 * a.d + c + half, hi[i]);
-        float s = lo[i][0] + lo[i][1] + lo[i][2] + lo[i][3] + hi[i][0] + hi[i][1] + hi[i][2] + hi[i][3];
+        const int c = part * a.d + (r / per_head) * a.D + (r % per_head) * 8;
+        load8_bf16(a.qkv + row * 3 * a.d + c, lo[i]);
+        load8_bf16(a.qkv + row * 3 * a.d + c + half, hi[i]);
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s += lo[i][k] + hi[i][k];
         if (part == 0) sq += s; else sk += s;
       }
     }
@@ -507,15 +521,13 @@ __global__ __launch_bounds__(256) void qknorm_rope_fwd_kernel(QkArgs a) {
           const float m = part ? mk : mq;
           float s = 0.f;
 #pragma unroll
-          for (int k = 0; k < 4; ++k) { float u = lo[i][k] - m, w = hi[i][k] - m; s += u * u + w * w; }
+          for (int k = 0; k < 8; ++k) { float u = lo[i][k] - m, w = hi[i][k] - m; s += u * u + w * w; }
           if (part == 0) vq += s; else vk += s;
         }
       }
       rq = rsqrtf(wave_sum(vq) / a.d + a.eps);
       rk = rsqrtf(wave_sum(vk) / a.d + a.eps);
-      if (lane == 0) {
-        a.stats[row * 4 + 0] = mq; a.stats[row * 4 + 1] = rq; a.stats[row * 4 + 2] = mk; a.stats[row * 4 + 3] = rk;
-      }
+      if (lane == 0) *reinterpret_cast<float4*>(a.stats + row * 4) = make_float4(mq, rq, mk, rk);
     }
     const long trow = a.rope_per_sample ? row : (row % a.L);
 #pragma unroll
@@ -523,34 +535,34 @@ __global__ __launch_bounds__(256) void qknorm_rope_fwd_kernel(QkArgs a) {
       const int t = i * 64 + lane;
       if (t >= 2 * per_part) continue;
       const int part = t / per_part, r = t % per_part;
-      const int hc = (r / per_head) * a.D + (r % per_head) * 4;  // column within the part
-      float xl[4], xh[4];
+      const int hc = (r / per_head) * a.D + (r % per_head) * 8;  // column within the part
+      float xl[8], xh[8];
       if (do_norm) {
-        const float* g = part ? a.gk : a.gq;
-        const float* bb = part ? a.bk : a.bq;
+        const float* g = aff + part * 2 * a.d;
+        const float* bb = g + a.d;
         const float m = part ? mk : mq, rs = part ? rk : rq;
-        float g0[4], g1[4], b0[4], b1[4];
-        load4_f32(g + hc, g0); load4_f32(g + hc + half, g1); load4_f32(bb + hc, b0); load4_f32(bb + hc + half, b1);
+        float g0[8], g1[8], b0[8], b1[8];
+        load8_f32(g + hc, g0); load8_f32(g + hc + half, g1); load8_f32(bb + hc, b0); load8_f32(bb + hc + half, b1);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < 8; ++k) {
           xl[k] = rbf((lo[i][k] - m) * rs * g0[k] + b0[k]);  // LayerNorm result is written back in bf16 (dit.py:681-682)
           xh[k] = rbf((hi[i][k] - m) * rs * g1[k] + b1[k]);
         }
       } else {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { xl[k] = lo[i][k]; xh[k] = hi[i][k]; }
+        for (int k = 0; k < 8; ++k) { xl[k] = lo[i][k]; xh[k] = hi[i][k]; }
       }
-      float cs[4], sn[4], ol[4], oh[4];
-      const int pc = (r % per_head) * 4;
-      load4_f32(a.cos_t + trow * half + pc, cs);
-      load4_f32(a.sin_t + trow * half + pc, sn);
+      float cs[8], sn[8], ol[8], oh[8];
+      const int pc = (r % per_head) * 8;
+      load8_f32(a.cos_t + trow * half + pc, cs);
+      load8_f32(a.sin_t + trow * half + pc, sn);
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
+      for (int k = 0; k < 8; ++k) {
         ol[k] = xl[k] * cs[k] - xh[k] * sn[k];
         oh[k] = xh[k] * cs[k] + xl[k] * sn[k];
       }
-      store4_bf16(a.qkr + row * 2 * a.d + part * a.d + hc, ol);
-      store4_bf16(a.qkr + row * 2 * a.d + part * a.d + hc + half, oh);
+      store8_bf16(a.qkr + row * 2 * a.d + part * a.d + hc, ol);
+      store8_bf16(a.qkr + row * 2 * a.d + part * a.d + hc + half, oh);
     }
   }
 }
@@ -568,55 +580,64 @@ struct QkBwdArgs {
 
 template <int NIT>
 __global__ __launch_bounds__(256) void qknorm_rope_bwd_kernel(QkBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float aff[];  // gq | gk (d floats each), then the reduction scratch
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int half = a.D / 2, per_head = a.D / 8, per_part = a.d / 8;
+  const int half = a.D / 2, per_head = a.D / 16, per_part = a.d / 16;
   const bool do_norm = a.gq != nullptr;
-  float dg_acc[NIT][8], db_acc[NIT][8];
+  if (do_norm) {
+    for (int c = threadIdx.x * 4; c < a.d; c += 1024) {
+      *reinterpret_cast<float4*>(aff + c) = *reinterpret_cast<const float4*>(a.gq + c);
+      *reinterpret_cast<float4*>(aff + a.d + c) = *reinterpret_cast<const float4*>(a.gk + c);
+    }
+    __syncthreads();
+  }
+  float dg_acc[NIT][16], db_acc[NIT][16];
 #pragma unroll
   for (int i = 0; i < NIT; ++i)
 #pragma unroll
-    for (int k = 0; k < 8; ++k) { dg_acc[i][k] = 0.f; db_acc[i][k] = 0.f; }
+    for (int k = 0; k < 16; ++k) { dg_acc[i][k] = 0.f; db_acc[i][k] = 0.f; }
   for (long row = (long)blockIdx.x * ROWS_PER_BLOCK + wave; row < a.M; row += (long)gridDim.x * ROWS_PER_BLOCK) {
     const long trow = a.rope_per_sample ? row : (row % a.L);
     float mq = 0.f, rq = 1.f, mk = 0.f, rk = 1.f;
     if (do_norm) {
-      mq = a.stats[row * 4 + 0]; rq = a.stats[row * 4 + 1]; mk = a.stats[row * 4 + 2]; rk = a.stats[row * 4 + 3];
+      const float4 st = *reinterpret_cast<const float4*>(a.stats + row * 4);
+      mq = st.x; rq = st.y; mk = st.z; rk = st.w;
     }
-    float gl[NIT][4], gh[NIT][4], xl[NIT][4], xh[NIT][4];
+    float gl[NIT][8], gh[NIT][8], xl[NIT][8], xh[NIT][8];
     float sgq = 0.f, sgxq = 0.f, sgk = 0.f, sgxk = 0.f;
 #pragma unroll
     for (int i = 0; i < NIT; ++i) {
       const int t = i * 64 + lane;
       if (t < 2 * per_part) {
         const int part = t / per_part, r = t % per_part;
-        const int hc = (r / per_head) * a.D + (r % per_head) * 4;
-        const int pc = (r % per_head) * 4;
-        float dl[4], dh[4], cs[4], sn[4];
-        load4_bf16(a.dqkr + row * 2 * a.d + part * a.d + hc, dl);
-        load4_bf16(a.dqkr + row * 2 * a.d + part * a.d + hc + half, dh);
-        load4_f32(a.cos_t + trow * half + pc, cs);
-        load4_f32(a.sin_t + trow * half + pc, sn);
+        const int hc = (r / per_head) * a.D + (r % per_head) * 8;
+        const int pc = (r % per_head) * 8;
+        float dl[8], dh[8], cs[8], sn[8];
+        load8_bf16(a.dqkr + row * 2 * a.d + part * a.d + hc, dl);
+        load8_bf16(a.dqkr + row * 2 * a.d + part * a.d + hc + half, dh);
+        load8_f32(a.cos_t + trow * half + pc, cs);
+        load8_f32(a.sin_t + trow * half + pc, sn);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {  // transpose of the rotation
+        for (int k = 0; k < 8; ++k) {  // transpose of the rotation
           gl[i][k] = dl[k] * cs[k] + dh[k] * sn[k];
           gh[i][k] = dh[k] * cs[k] - dl[k] * sn[k];
         }
         if (do_norm) {
-          const float* g = part ? a.gk : a.gq;
+          const float* g = aff + part * a.d;
           const float m = part ? mk : mq, rs = part ? rk : rq;
-          float g0[4], g1[4], r0[4], r1[4];
-          load4_f32(g + hc, g0); load4_f32(g + hc + half, g1);
-          load4_bf16(a.qkv + row * 3 * a.d + part * a.d + hc, r0);
-          load4_bf16(a.qkv + row * 3 * a.d + part * a.d + hc + half, r1);
+          float g0[8], g1[8], r0[8], r1[8];
+          load8_f32(g + hc, g0); load8_f32(g + hc + half, g1);
+          load8_bf16(a.qkv + row * 3 * a.d + part * a.d + hc, r0);
+          load8_bf16(a.qkv + row * 3 * a.d + part * a.d + hc + half, r1);
           float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-          for (int k = 0; k < 4; ++k) {
+          for (int k = 0; k < 8; ++k) {
             xl[i][k] = (r0[k] - m) * rs;
             xh[i][k] = (r1[k] - m) * rs;
             dg_acc[i][k] += gl[i][k] * xl[i][k];
-            dg_acc[i][k + 4] += gh[i][k] * xh[i][k];
+            dg_acc[i][k + 8] += gh[i][k] * xh[i][k];
             db_acc[i][k] += gl[i][k];
-            db_acc[i][k + 4] += gh[i][k];
+            db_acc[i][k + 8] += gh[i][k];
             gl[i][k] *= g0[k];
             gh[i][k] *= g1[k];
             s1 += gl[i][k] + gh[i][k];
@@ -635,40 +656,40 @@ __global__ __launch_bounds__(256) void qknorm_rope_bwd_kernel(QkBwdArgs a) {
       const int t = i * 64 + lane;
       if (t >= 2 * per_part) continue;
       const int part = t / per_part, r = t % per_part;
-      const int hc = (r / per_head) * a.D + (r % per_head) * 4;
-      float ol[4], oh[4];
+      const int hc = (r / per_head) * a.D + (r % per_head) * 8;
+      float ol[8], oh[8];
       if (do_norm) {
         const float rs = part ? rk : rq, sg = part ? sgk : sgq, sgx = part ? sgxk : sgxq;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < 8; ++k) {
           ol[k] = rs * (gl[i][k] - sg - xl[i][k] * sgx);
           oh[k] = rs * (gh[i][k] - sg - xh[i][k] * sgx);
         }
       } else {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { ol[k] = gl[i][k]; oh[k] = gh[i][k]; }
+        for (int k = 0; k < 8; ++k) { ol[k] = gl[i][k]; oh[k] = gh[i][k]; }
       }
-      store4_bf16(a.dqkv + row * 3 * a.d + part * a.d + hc, ol);
-      store4_bf16(a.dqkv + row * 3 * a.d + part * a.d + hc + half, oh);
+      store8_bf16(a.dqkv + row * 3 * a.d + part * a.d + hc, ol);
+      store8_bf16(a.dqkv + row * 3 * a.d + part * a.d + hc + half, oh);
     }
   }
   if (!do_norm) return;
-  // reduce dgamma/dbeta over the block's 4 waves via LDS, then atomics
-  __shared__ float red[ROWS_PER_BLOCK][64 * 8 + 8];
+  // reduce dgamma/dbeta over the block's 4 waves via LDS (after the affine copy), then one atomic per column per block
+  float* red = aff + 2 * a.d;  // [4 waves][64 lanes * 16]
   for (int pass = 0; pass < 2; ++pass) {
 #pragma unroll
     for (int i = 0; i < NIT; ++i) {
       __syncthreads();
 #pragma unroll
-      for (int k = 0; k < 8; ++k) red[wave][lane * 8 + k] = pass ? db_acc[i][k] : dg_acc[i][k];
+      for (int k = 0; k < 16; ++k) red[wave * 1024 + lane * 16 + k] = pass ? db_acc[i][k] : dg_acc[i][k];
       __syncthreads();
-      for (int u = threadIdx.x; u < 512; u += 256) {
-        const int ln = u >> 3, k = u & 7;
+      for (int u = threadIdx.x; u < 1024; u += 256) {
+        const int ln = u >> 4, k = u & 15;
         const int t = i * 64 + ln;
         if (t < 2 * per_part) {
           const int part = t / per_part, r = t % per_part;
-          const int hc = (r / per_head) * a.D + (r % per_head) * 4 + (k & 3) + (k >> 2) * half;
-          float s = red[0][u] + red[1][u] + red[2][u] + red[3][u];
+          const int hc = (r / per_head) * a.D + (r % per_head) * 8 + (k & 7) + (k >> 3) * half;
+          const float s = red[u] + red[1024 + u] + red[2048 + u] + red[3072 + u];
           float* dst = pass ? (part ? a.dbk : a.dbq) : (part ? a.dgk : a.dgq);
           atomicAdd(dst + hc, s);
         }
@@ -866,13 +887,22 @@ extern "C" int udm_qknorm_rope_fwd(const void* qkv, void* qkr, const float* gq, 
                                    const float* cos_t, const float* sin_t, int rope_per_sample, int64_t M, int64_t d, int64_t L, int64_t D, float eps,
                                    hipStream_t stream) {
   UDM_CHECK_ARG(qkv && qkr && cos_t && sin_t, "udm_qknorm_rope_fwd: null pointer");
-  UDM_CHECK_ARG(M > 0 && d > 0 && D > 0 && d % D == 0 && D % 8 == 0, "udm_qknorm_rope_fwd: bad shape d=%ld D=%ld", (long)d, (long)D);
+  UDM_CHECK_ARG(M > 0 && d > 0 && D > 0 && d % D == 0 && D % 16 == 0, "udm_qknorm_rope_fwd: bad shape d=%ld D=%ld", (long)d, (long)D);
   UDM_CHECK_ARG(!gq || (bq && gk && bk && stats), "udm_qknorm_rope_fwd: qk-norm needs all four affine vectors and stats");
   QkArgs a{(const bf16_t*)qkv, (bf16_t*)qkr, gq, bq, gk, bk, stats, cos_t, sin_t, (int)M, (int)d, (int)L, (int)D, rope_per_sample, eps};
-  int nit = (int)((2 * (d / 8) + 63) / 64);
-  int nch = nit <= 4 ? (nit == 3 ? 3 : (nit <= 1 ? 1 : (nit == 2 ? 2 : 4))) : 8;
+  UDM_CHECK_ARG(D % 16 == 0 && d % 16 == 0, "udm_qknorm_rope_fwd: head_dim and hidden size must be multiples of 16");
+  const int nit = (int)((2 * (d / 16) + 63) / 64);
   UDM_CHECK_ARG(nit <= 8, "udm_qknorm_rope_fwd: hidden size too large");
-  DISPATCH_NCH(nch, qknorm_rope_fwd_kernel, grid_rows(M), stream, a);
+  const int nch = nit <= 1 ? 1 : (nit == 2 ? 2 : (nit == 3 ? 3 : (nit == 4 ? 4 : 8)));
+  const size_t lds = gq ? (size_t)4 * d * sizeof(float) : 0;
+  const int grid = min(grid_rows(M), 1024);
+  switch (nch) {
+    case 1: hipLaunchKernelGGL((qknorm_rope_fwd_kernel<1>), dim3(grid), dim3(256), lds, stream, a); break;
+    case 2: hipLaunchKernelGGL((qknorm_rope_fwd_kernel<2>), dim3(grid), dim3(256), lds, stream, a); break;
+    case 3: hipLaunchKernelGGL((qknorm_rope_fwd_kernel<3>), dim3(grid), dim3(256), lds, stream, a); break;
+    case 4: hipLaunchKernelGGL((qknorm_rope_fwd_kernel<4>), dim3(grid), dim3(256), lds, stream, a); break;
+    default: hipLaunchKernelGGL((qknorm_rope_fwd_kernel<8>), dim3(grid), dim3(256), lds, stream, a); break;
+  }
   UDM_CHECK_LAUNCH("udm_qknorm_rope_fwd");
   return 0;
 }
@@ -885,11 +915,19 @@ extern "C" int udm_qknorm_rope_bwd(const void* dqkr, const void* qkv, void* dqkv
   UDM_CHECK_ARG(!gq || (gk && stats && dgq && dbq && dgk && dbk), "udm_qknorm_rope_bwd: qk-norm needs gk, stats and the four gradient vectors");
   QkBwdArgs a{(const bf16_t*)dqkr, (const bf16_t*)qkv, (bf16_t*)dqkv, gq, gk, stats, cos_t, sin_t, dgq, dbq, dgk, dbk, (int)M, (int)d, (int)L, (int)D,
               rope_per_sample};
-  int nit = (int)((2 * (d / 8) + 63) / 64);
+  UDM_CHECK_ARG(D % 16 == 0 && d % 16 == 0, "udm_qknorm_rope_bwd: head_dim and hidden size must be multiples of 16");
+  const int nit = (int)((2 * (d / 16) + 63) / 64);
   UDM_CHECK_ARG(nit <= 8, "udm_qknorm_rope_bwd: hidden size too large");
-  int nch = nit <= 4 ? (nit == 3 ? 3 : (nit <= 1 ? 1 : (nit == 2 ? 2 : 4))) : 8;
-  const int grid = min(grid_rows(M), 512);
-  DISPATCH_NCH(nch, qknorm_rope_bwd_kernel, grid, stream, a);
+  const int nch = nit <= 1 ? 1 : (nit == 2 ? 2 : (nit == 3 ? 3 : (nit == 4 ? 4 : 8)));
+  const size_t lds = gq ? ((size_t)2 * d + 4096) * sizeof(float) : 0;
+  const int grid = min(grid_rows(M), 256);
+  switch (nch) {
+    case 1: hipLaunchKernelGGL((qknorm_rope_bwd_kernel<1>), dim3(grid), dim3(256), lds, stream, a); break;
+    case 2: hipLaunchKernelGGL((qknorm_rope_bwd_kernel<2>), dim3(grid), dim3(256), lds, stream, a); break;
+    case 3: hipLaunchKernelGGL((qknorm_rope_bwd_kernel<3>), dim3(grid), dim3(256), lds, stream, a); break;
+    case 4: hipLaunchKernelGGL((qknorm_rope_bwd_kernel<4>), dim3(grid), dim3(256), lds, stream, a); break;
+    default: hipLaunchKernelGGL((qknorm_rope_bwd_kernel<8>), dim3(grid), dim3(256), lds, stream, a); break;
+  }
   UDM_CHECK_LAUNCH("udm_qknorm_rope_bwd");
   return 0;
 }

@@ -474,11 +474,16 @@ class DIT(nn.Module, _HubMixin):
         db = None
         if lin.bias is not None:
             db = G[id(lin.bias)] if outp == lin.out else torch.zeros(outp, dtype=F32, device=dY.device)
-        dYt = K.transpose(dY, colsum=db)
+        if Mrows % 64 == 0:  # K-major GEMM reads dY and X in place (transposing LDS reads); bias grad = column sums
+            if db is not None:
+                K.colsum(dY, db)
+            K.gemm_tn(dY, X, G[id(lin.weight)], M=lin.out, N=lin.inp)
+        else:  # short contraction (e.g. adaLN over the padded batch): explicit transposes + NT kernel
+            dYt = K.transpose(dY, colsum=db)
+            Xt = K.transpose(X)
+            K.gemm_nt(dYt, Xt, out=G[id(lin.weight)], M=lin.out, N=lin.inp, K=Mrows)
         if db is not None and outp != lin.out:
             G[id(lin.bias)].copy_(db[: lin.out])
-        Xt = K.transpose(X)
-        K.gemm_nt(dYt, Xt, out=G[id(lin.weight)], M=lin.out, N=lin.inp, K=Mrows)
 
     def _engine_backward(self, S, grad_out, mode):
         params = self._ordered_params()

@@ -67,6 +67,23 @@ def gemm_nt(a, b, out=None, *, out_dtype=BF16, M=None, N=None, K=None, lda=None,
     return out
 
 
+def gemm_tn(a, b, out, *, M=None, N=None, beta=0.0):
+    """out[M,N] (fp32) = beta*out + a[K,M]^T @ b[K,N]; a, b bf16 row-major with K (rows) a multiple of 64."""
+    _chk(a, BF16, "gemm_tn a"), _chk(b, BF16, "gemm_tn b"), _chk(out, F32, "gemm_tn out")
+    K = a.shape[0]
+    M = a.shape[1] if M is None else M
+    N = b.shape[1] if N is None else N
+    _lib.call("udm_gemm_tn_bf16", _p(a), _p(b), _p(out), M, N, K, a.stride(0), b.stride(0), out.stride(0), float(beta), _s())
+    return out
+
+
+def colsum(x, out):
+    """out[c] += sum_r x[r, c] (bias gradient) without writing a transpose."""
+    _chk(x, BF16, "colsum")
+    _lib.call("udm_transpose_bf16", _p(x), None, x.shape[0], x.shape[1], x.stride(0), 0, _p(out), _s())
+    return out
+
+
 def gemm_set_tile(tile: int):
     """Diagnostics: force the GEMM tile family (-1 auto, 0 small kernel, 192/256/320)."""
     _lib.call("udm_gemm_set_tile", tile)
