@@ -45,7 +45,7 @@ def main():
     for name, (kc, m, n) in {"fc1_wgrad_tn": (M, 8192, 2048), "fc2_wgrad_tn": (M, 2048, 8192), "qkv_wgrad_tn": (M, 6144, 2048), "out_wgrad_tn": (M, 2048, 2048)}.items():
         a, b = rn(kc, m), rn(kc, n)
         out = torch.empty((m, n), dtype=torch.float32, device=DEV)
-        ms = timeit(lambda: K.gemm_tn(a, b, out))
+        ms = timeit(lambda: K.gemm_tn(a, b, out, beta=1.0))
         res[f"gemm/{name}"] = dict(ms=round(ms, 4), tflops=round(2 * m * n * kc / ms / 1e9, 1))
         del a, b, out
     # epilogue variants

@@ -77,7 +77,7 @@ def test_gemm_large_tile_kernels(K, tile, M, N, K_):
         K.gemm_set_tile(-1)
 
 
-@pytest.mark.parametrize("Kc,M,N", [(256, 192, 256), (1280, 2048, 2048), (128, 64, 200), (640, 1001, 328), (2560, 6144, 2048), (192, 320, 8192)])
+@pytest.mark.parametrize("Kc,M,N", [(256, 192, 256), (1280, 2048, 2048), (128, 64, 200), (640, 1001, 328), (2560, 6144, 2048), (192, 320, 8192), (10240, 512, 512), (4096, 300, 260)])
 def test_gemm_tn_kmajor(K, Kc, M, N):
     """wgrad form C = A^T B with both operands K-major (transposing LDS reads), incl. ragged M/N and padded strides."""
     lda, ldb = (M + 7) // 8 * 8, (N + 7) // 8 * 8
@@ -89,7 +89,7 @@ def test_gemm_tn_kmajor(K, Kc, M, N):
     K.gemm_tn(a.to(DEV), b.to(DEV), out, M=M, N=N, beta=0.0)
     assert rel_err(out.cpu(), ref) < 1e-5
     K.gemm_tn(a.to(DEV), b.to(DEV), out, M=M, N=N, beta=1.0)
-    assert rel_err(out.cpu(), 2 * ref) < 1e-5
+    assert rel_err(out.cpu(), 2 * ref) < 2e-5  # beta=1 may split K and accumulate atomically
     cs = torch.zeros(lda, device=DEV)
     K.colsum(a.to(DEV), cs)
     assert torch.allclose(cs.cpu()[:M], a[:, :M].float().sum(0), atol=2e-3, rtol=1e-4)

@@ -366,8 +366,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
 //   S = Q K^T (regs walk queries), dP = dO V^T, dV^T += dO^T P, dK^T += Q^T dS
 // ------------------------------------------------------------------------------------------------
 constexpr int BQT = 64;
-template <int D, bool HAS_SID, bool USE_TR, int DKV_WAVES>
-__global__ __launch_bounds__(256, DKV_WAVES) void attn_bwd_dkv_kernel(AttnArgs a) {
+// MODE: 1 = dK only, 2 = dV only, 3 = both.  At D = 128 both accumulators (128 registers) plus K/V operands (64) do not fit two
+// waves per SIMD, so the backward launches the dK and dV halves separately (each recomputes S; 40 instead of 32 MFMAs per
+// 32-query step, but twice the occupancy).
+template <int D, bool HAS_SID, bool USE_TR, int MODE, int WAVES>
+__global__ __launch_bounds__(256, WAVES) void attn_bwd_dkv_kernel(AttnArgs a) {
+  constexpr bool DO_DK = (MODE & 1) != 0, DO_DV = (MODE & 2) != 0;
   extern __shared__ __attribute__((aligned(16))) char smem[];  // Q0 | Q1 | dO0 | dO1 | lse[2][64] | delta[2][64] | sidq[2][64]
   constexpr int TB = BQT * D * 2;
   float* lse_all = reinterpret_cast<float*>(smem + 4 * TB);
@@ -388,7 +392,7 @@ __global__ __launch_bounds__(256, DKV_WAVES) void attn_bwd_dkv_kernel(AttnArgs a
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) {
     kf[ks] = load_frag_global(a.k + (rowbase + ki) * a.k_stride + h * D + ks * 16 + hi * 8, k_ok);
-    vf[ks] = load_frag_global(a.v + (rowbase + ki) * a.v_stride + h * D + ks * 16 + hi * 8, k_ok);
+    if (DO_DK) vf[ks] = load_frag_global(a.v + (rowbase + ki) * a.v_stride + h * D + ks * 16 + hi * 8, k_ok);
   }
   long sid_k = 0;
   if (HAS_SID) sid_k = k_ok ? a.sample_ids[rowbase + ki] : -2;
@@ -431,12 +435,18 @@ __global__ __launch_bounds__(256, DKV_WAVES) void attn_bwd_dkv_kernel(AttnArgs a
       f32x16_t s, dp;
 #pragma unroll
       for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         const int off = tile_off<D>(qs * 32 + l31, ks * 2 + hi);
         s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag(Qs, off), kf[ks], s, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag(Os, off), vf[ks], dp, 0, 0, 0);
+        if (DO_DK) dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag(Os, off), vf[ks], dp, 0, 0, 0);
       }
+      if (WAVES == 1) {  // one wave per SIMD: nothing else hides LDS latency, so issue all fragment reads up front (registers are free)
+        __builtin_amdgcn_sched_group_barrier(0x100, DO_DK ? 2 * KS : KS, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, DO_DK ? 2 * KS : KS, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
       float p[16], ds[16];
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg) {
@@ -453,16 +463,20 @@ __global__ __launch_bounds__(256, DKV_WAVES) void attn_bwd_dkv_kernel(AttnArgs a
           ds[r] = p[r] * (dp[r] - dv[e]);
         }
       }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int c2 = 0; c2 < 2; ++c2) {
         bf16x8_t pb = pack8(&p[8 * c2]);
         bf16x8_t dsb = pack8(&ds[8 * c2]);
 #pragma unroll
         for (int i = 0; i < DB; ++i) {
-          bf16x8_t dot = lds_frag_T<D, USE_TR>(Os, qs * 32 + c2 * 16, i * 32, lane);
-          dvT[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dot, pb, dvT[i], 0, 0, 0);
-          bf16x8_t qt = lds_frag_T<D, USE_TR>(Qs, qs * 32 + c2 * 16, i * 32, lane);
-          dkT[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qt, dsb, dkT[i], 0, 0, 0);
+          bf16x8_t dot;
+          if (DO_DV) dot = lds_frag_T<D, USE_TR>(Os, qs * 32 + c2 * 16, i * 32, lane);
+          if (DO_DV) dvT[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dot, pb, dvT[i], 0, 0, 0);
+          if (DO_DK) {
+            bf16x8_t qt = lds_frag_T<D, USE_TR>(Qs, qs * 32 + c2 * 16, i * 32, lane);
+            dkT[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qt, dsb, dkT[i], 0, 0, 0);
+          }
         }
       }
     }
@@ -475,9 +489,9 @@ __global__ __launch_bounds__(256, DKV_WAVES) void attn_bwd_dkv_kernel(AttnArgs a
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg) {
         const int d0 = i * 32 + 8 * rg + 4 * hi;
-        *reinterpret_cast<uint2*>(kp + d0) = make_uint2(pack2bf(dkT[i][rg * 4] * a.scale, dkT[i][rg * 4 + 1] * a.scale),
-                                                        pack2bf(dkT[i][rg * 4 + 2] * a.scale, dkT[i][rg * 4 + 3] * a.scale));
-        *reinterpret_cast<uint2*>(vp + d0) = make_uint2(pack2bf(dvT[i][rg * 4], dvT[i][rg * 4 + 1]), pack2bf(dvT[i][rg * 4 + 2], dvT[i][rg * 4 + 3]));
+        if (DO_DK) *reinterpret_cast<uint2*>(kp + d0) = make_uint2(pack2bf(dkT[i][rg * 4] * a.scale, dkT[i][rg * 4 + 1] * a.scale),
+                                                                   pack2bf(dkT[i][rg * 4 + 2] * a.scale, dkT[i][rg * 4 + 3] * a.scale));
+        if (DO_DV) *reinterpret_cast<uint2*>(vp + d0) = make_uint2(pack2bf(dvT[i][rg * 4], dvT[i][rg * 4 + 1]), pack2bf(dvT[i][rg * 4 + 2], dvT[i][rg * 4 + 3]));
       }
   }
 }
@@ -501,8 +515,10 @@ void launch_bwd(const AttnArgs& a, hipStream_t s) {
   const size_t lds_q = 4 * BKV * D * 2 + 2 * BKV * sizeof(long);
   const size_t lds_k = 4 * BQT * D * 2 + 4 * BQT * sizeof(float) + 2 * BQT * sizeof(long);
   auto kq = attn_bwd_dq_kernel<D, SID, TR>;
-  constexpr int W = (D == 128) ? 1 : 2;  // dK/dV at D=128 keeps ~190 accumulator/operand registers live: one wave per SIMD (2 waves spill and run 1.7x slower)
-  auto kk = attn_bwd_dkv_kernel<D, SID, TR, W>;
+  // Measured at D = 128 (B8 H16 L1280): one launch with both accumulators at one wave per SIMD (0.75 ms for dQ+dK+dV) beats both
+  // separate dK / dV launches at two waves per SIMD (0.85 ms) and the spilling two-wave build (1.28 ms).
+  constexpr int W = (D == 128) ? 1 : 2;
+  auto kk = attn_bwd_dkv_kernel<D, SID, TR, 3, W>;
   static bool once = false;
   if (!once) { set_lds(kq, lds_q); set_lds(kk, lds_k); once = true; }
   hipLaunchKernelGGL(kq, gq, dim3(256), lds_q, s, a);

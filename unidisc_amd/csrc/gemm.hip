@@ -30,6 +30,7 @@ struct GemmArgs {
   int M, N, K;
   int tiles_m, tiles_n;
   float beta;
+  int splitk;  // > 1: the K range is cut into `splitk` slices per tile and partial tiles are atomically added into an fp32 C
 };
 
 template <int EPI, bool OUT_F32>
@@ -338,8 +339,11 @@ __global__ __launch_bounds__(512) void gemm_nt_stagger_kernel(GemmArgs p) {
   constexpr int NPH = 4, ISSUE_PH = 2, PER = (LOADS + ISSUE_PH - 1) / ISSUE_PH;
   static_assert(WM % 32 == 0 && (A_BYTES / 1024) % NWAVES == 0, "bad tile");
 
+  const int S = p.splitk > 1 ? p.splitk : 1;
   const int nwg = p.tiles_m * p.tiles_n;
-  int pid = xcd_remap(blockIdx.x, nwg);
+  int pid = xcd_remap(blockIdx.x, nwg * S);
+  const int slice = pid % S;  // slices of one tile are neighbours in the remapped order: same XCD, shared operand panels
+  pid /= S;
   const int per_group = GROUP_M * p.tiles_n;
   const int grp = pid / per_group, first_m = grp * GROUP_M;
   const int gsz = min(p.tiles_m - first_m, GROUP_M);
@@ -405,14 +409,15 @@ __global__ __launch_bounds__(512) void gemm_nt_stagger_kernel(GemmArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int nk = p.K / BK;
+  const int nk_all = p.K / BK;
+  const int kt0 = (int)((long)nk_all * slice / S), nk = (int)((long)nk_all * (slice + 1) / S);
 #pragma unroll
-  for (int j = 0; j < LOADS; ++j) glds16(src[j], smem + dst[j]);
+  for (int j = 0; j < LOADS; ++j) glds16(src[j] + kt0 * (j < A_PW ? kstep_a : kstep_b), smem + dst[j] + (kt0 & 1) * STAGE_BYTES);
   wait_vmcnt<0>();
   __builtin_amdgcn_s_barrier();
   if (late) __builtin_amdgcn_s_barrier();
 
-  for (int kt = 0; kt < nk; ++kt) {
+  for (int kt = kt0; kt < nk; ++kt) {
     const char* As = smem + (kt & 1) * STAGE_BYTES;
     const char* Bs = As + A_BYTES;
     char* nxt = smem + ((kt + 1) & 1) * STAGE_BYTES;
@@ -441,21 +446,28 @@ __global__ __launch_bounds__(512) void gemm_nt_stagger_kernel(GemmArgs p) {
           b[j] = __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7));
         }
       }
-      if (ph < ISSUE_PH && more) {
-#pragma unroll
-        for (int j = ph * PER; j < (ph + 1) * PER && j < LOADS; ++j) glds16(src[j] + (kt + 1) * (j < A_PW ? kstep_a : kstep_b), nxt + dst[j]);
-      }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       if (ph == NPH - 1) wait_vmcnt<0>();
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_setprio(1);
+      // The next tile's LDS-DMA is issued from INSIDE the MFMA section (an MFMA occupies the pipe for 32 cycles while the wave
+      // itself is idle), so the read section stays short and the partner wave gets the matrix pipe back sooner.
+      if (ph < ISSUE_PH && more) {
+#pragma unroll
+        for (int j = ph * PER; j < (ph + 1) * PER && j < LOADS; ++j) glds16(src[j] + (kt + 1) * (j < A_PW ? kstep_a : kstep_b), nxt + dst[j]);
+      }
 #pragma unroll
       for (int i = 0; i < FM; ++i)
 #pragma unroll
         for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
-      __builtin_amdgcn_s_setprio(0);
+      if (ph < ISSUE_PH) {
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        }
+      }
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
@@ -495,7 +507,7 @@ __global__ __launch_bounds__(512) void gemm_nt_stagger_kernel(GemmArgs p) {
 #pragma unroll
           for (int q = 0; q < 4; ++q) au[q] = *reinterpret_cast<const uint2*>(p.aux + (long)(gm0 + q * 8) * p.ldaux + gn);
         }
-        if (OUT_F32 && p.beta != 0.f) {
+        if (OUT_F32 && p.beta != 0.f && S == 1) {
 #pragma unroll
           for (int q = 0; q < 4; ++q) cold[q] = *reinterpret_cast<const float4*>(reinterpret_cast<float*>(p.C) + (long)(gm0 + q * 8) * p.ldc + gn);
         }
@@ -513,7 +525,11 @@ __global__ __launch_bounds__(512) void gemm_nt_stagger_kernel(GemmArgs p) {
             x[0] *= gelu_tanh_grad(__uint_as_float(au[q].x << 16)); x[1] *= gelu_tanh_grad(__uint_as_float(au[q].x & 0xffff0000u));
             x[2] *= gelu_tanh_grad(__uint_as_float(au[q].y << 16)); x[3] *= gelu_tanh_grad(__uint_as_float(au[q].y & 0xffff0000u));
           }
-          if (OUT_F32) {
+          if (OUT_F32 && S > 1) {
+            float* cp = reinterpret_cast<float*>(p.C) + gm * p.ldc + gn;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) atomicAdd(cp + e, x[e]);
+          } else if (OUT_F32) {
             if (p.beta != 0.f) { x[0] += p.beta * cold[q].x; x[1] += p.beta * cold[q].y; x[2] += p.beta * cold[q].z; x[3] += p.beta * cold[q].w; }
             *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + gm * p.ldc + gn) = make_float4(x[0], x[1], x[2], x[3]);
           } else {
@@ -533,7 +549,9 @@ __global__ __launch_bounds__(512) void gemm_nt_stagger_kernel(GemmArgs p) {
               x[e] = gelu_tanh(bf2f(pre));
             }
             if (EPI == UDM_EPI_DGELU) x[e] *= gelu_tanh_grad(bf2f(p.aux[gm * p.ldaux + gn + e]));
-            if (OUT_F32) {
+            if (OUT_F32 && S > 1) {
+              atomicAdd(reinterpret_cast<float*>(p.C) + gm * p.ldc + gn + e, x[e]);
+            } else if (OUT_F32) {
               float* cp = reinterpret_cast<float*>(p.C) + gm * p.ldc + gn + e;
               *cp = x[e] + (p.beta != 0.f ? p.beta * *cp : 0.f);
             } else {
@@ -557,7 +575,7 @@ int launch_big_t(const GemmArgs& a0, hipStream_t stream) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n), dim3(512), lds, stream, a);
+  hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n * (a.splitk > 1 ? a.splitk : 1)), dim3(512), lds, stream, a);
   UDM_CHECK_LAUNCH("udm_gemm_nt_bf16(big)");
   return 0;
 }
@@ -620,6 +638,7 @@ extern "C" int udm_gemm_nt_bf16(const void* A, const void* B, void* C, int64_t M
   a.M = (int)M; a.N = (int)N; a.K = (int)K;
   a.tiles_m = (int)((M + BM - 1) / BM); a.tiles_n = (int)((N + BN - 1) / BN);
   a.beta = beta;
+  a.splitk = 1;
   if (epilogue == UDM_EPI_BIAS || epilogue == UDM_EPI_BIAS_GELU) UDM_CHECK_ARG(bias, "udm_gemm_nt_bf16: bias epilogue without bias");
   if (epilogue == UDM_EPI_BIAS_GELU) UDM_CHECK_ARG(aux && !out_f32, "udm_gemm_nt_bf16: EPI_BIAS_GELU needs aux and bf16 output");
   if (epilogue == UDM_EPI_DGELU) UDM_CHECK_ARG(aux, "udm_gemm_nt_bf16: EPI_DGELU needs aux (saved pre-activation)");
@@ -658,6 +677,16 @@ extern "C" int udm_gemm_tn_bf16(const void* A, const void* B, void* C, int64_t M
   a.M = (int)M; a.N = (int)N; a.K = (int)K; a.beta = beta;
   int tile = choose_tile(M, N, K, lda, ldb);
   if (tile == 0) tile = M <= 192 ? 192 : 256;  // the K-major path has no small-tile kernel; the large one handles any M, N by clamping
+  a.splitk = 1;
+  if (beta == 1.0f) {  // accumulate form: few output tiles over a long K (e.g. the 2048x2048 out-proj wgrad, K = B*L) -> split K, atomically add
+    const long tiles = ((M + tile - 1) / tile) * ((N + 255) / 256);
+    const long nkt = K / 64;
+    int sk = 1;
+    // Measured on MI355X (2048x2048 output, K = 10240): 4-way split + fp32 atomics is SLOWER (0.31 ms) than one slice per tile on a
+    // quarter of the CUs (0.24 ms) — 16.8 M L2 atomics cost more than the idle CUs.  Only split when the output is tiny.
+    while (tiles * sk * 2 <= 32 && nkt / (sk * 2) >= 16 && sk < 8) sk *= 2;
+    a.splitk = sk;
+  }
   switch (tile) {
     case 192: return launch_big_t<192, UDM_EPI_NONE, true, true>(a, stream);
     case 320: return launch_big_t<320, UDM_EPI_NONE, true, true>(a, stream);

@@ -454,7 +454,23 @@ class DIT(nn.Module, _HubMixin):
         for p in params:
             offs.append(total)
             total += _ceil(p.numel(), 64)
-        flat = torch.zeros(total, dtype=F32, device=dev)
+        # GEMM weights (92 % of the buffer) are fully overwritten by their wgrad kernel; only atomically accumulated gradients
+        # (norm / bias / qk-norm vectors, embeddings) and the alignment gaps need zeroing.
+        flat = torch.empty(total, dtype=F32, device=dev)
+        gemm_w = {id(l.weight) for l in self._lins.values()}
+        lo = None
+        for p, o in zip(params, offs):
+            end = o + _ceil(p.numel(), 64)
+            if id(p) in gemm_w:
+                if lo is not None:
+                    flat[lo:o].zero_()
+                    lo = None
+                if end > o + p.numel():
+                    flat[o + p.numel():end].zero_()
+            elif lo is None:
+                lo = o
+        if lo is not None:
+            flat[lo:total].zero_()
         self._grad_ranges = {id(p): (o, o + _ceil(p.numel(), 64)) for p, o in zip(params, offs)}
         return flat, {id(p): flat[o:o + p.numel()].view(p.shape) for p, o in zip(params, offs)}
 
@@ -474,7 +490,8 @@ class DIT(nn.Module, _HubMixin):
         db = None
         if lin.bias is not None:
             db = G[id(lin.bias)] if outp == lin.out else torch.zeros(outp, dtype=F32, device=dY.device)
-        if Mrows % 64 == 0:  # K-major GEMM reads dY and X in place (transposing LDS reads); bias grad = column sums
+        few_tiles = ((lin.out + 255) // 256) * ((lin.inp + 255) // 256) < 128 and lin.out * lin.inp >= 1 << 20
+        if Mrows % 64 == 0 and not few_tiles:  # K-major GEMM reads dY and X in place (transposing LDS reads); bias grad = column sums
             if db is not None:
                 K.colsum(dY, db)
             K.gemm_tn(dY, X, G[id(lin.weight)], M=lin.out, N=lin.inp)
