@@ -74,7 +74,7 @@ int udm_residual_fwd(const float* x_in, const void* branch, float* x_out, const 
                      hipStream_t stream);
 int udm_residual_bwd(const float* dx, const void* branch, void* dbranch, const float* w_b, const float* rstd_b, const float* mean_b, const void* gate,
                      int64_t mod_stride, const int64_t* modality, float* dw_b, float* dgate, int64_t M, int64_t d, int64_t L, int norm_type, float p_drop,
-                     uint64_t seed, hipStream_t stream);
+                     uint64_t seed, float* ws, int64_t ws_elems, hipStream_t stream); /* ws: optional fp32 scratch (>= 1024*d) for a two-phase dw_b reduction */
 
 /* ---- QK LayerNorm (models/dit.py:569-572, 680-682) + rotary (models/standalone_rotary.py:14-31, call dit.py:723-726)
  * qkv bf16 [M,3d] -> qkr bf16 [M,2d] (normalised, rotated q | k).  cos/sin fp32 [L,D/2] or per-sample [M,D/2]. */
@@ -82,7 +82,7 @@ int udm_qknorm_rope_fwd(const void* qkv, void* qkr, const float* gq, const float
                         const float* sin_t, int rope_per_sample, int64_t M, int64_t d, int64_t L, int64_t D, float eps, hipStream_t stream);
 int udm_qknorm_rope_bwd(const void* dqkr, const void* qkv, void* dqkv, const float* gq, const float* gk, const float* stats, const float* cos_t,
                         const float* sin_t, int rope_per_sample, float* dgq, float* dbq, float* dgk, float* dbk, int64_t M, int64_t d, int64_t L, int64_t D,
-                        hipStream_t stream);
+                        float* ws, int64_t ws_elems, hipStream_t stream); /* ws: optional fp32 scratch (>= 4096*d); then dgq|dbq|dgk|dbk must be contiguous */
 
 /* ---- attention core: flash_attn_qkvpacked_func models/dit.py:843 / SDPA :826-829 / FlexAttention doc mask :784-812
  * bidirectional softmax(QKᵀ/√D)V; element (b,l,h,:) of a tensor lives at base + (b*L+l)*stride + h*D.

@@ -166,7 +166,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_nt_glds_kernel(XArgs p) {
 // and the second half of the waves runs ONE barrier behind the first half, so while one wave of a SIMD
 // owns the matrix pipe its partner is in its read section.  KKPP = k-steps (of 16) per phase.
 // ------------------------------------------------------------------------------------------------
-template <int BM, int BN, int WGM, int WGN, int KKPP>
+template <int BM, int BN, int WGM, int WGN, int KKPP, int OPT = 2>  // OPT bit0: LDS-DMA issued inside the MFMA section; bit1: s_setprio around MFMAs
 __global__ __launch_bounds__(64 * WGM * WGN) void gemm_nt_stagger_kernel(XArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int WM = BM / WGM, WN = BN / WGN, FM = WM / 32, FN = WN / 32;
@@ -240,8 +240,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_nt_stagger_kernel(XArgs p
 #pragma unroll
         for (int j = 0; j < FN; ++j) b[q][j] = *reinterpret_cast<const bf16x8_t*>(Bs + (wn * WN + j * 32 + l31) * 128 + so);
       }
-      if (ph < ISSUE_PH && more) {
-        constexpr int PER = (LOADS + ISSUE_PH - 1) / ISSUE_PH;
+      constexpr int PER = (LOADS + ISSUE_PH - 1) / ISSUE_PH;
+      if (!(OPT & 1) && ph < ISSUE_PH && more) {
 #pragma unroll
         for (int j = ph * PER; j < (ph + 1) * PER && j < LOADS; ++j) glds16(src[j] + knext, nxt + dst[j]);
       }
@@ -250,14 +250,25 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_nt_stagger_kernel(XArgs p
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_setprio(1);
+      if (OPT & 2) __builtin_amdgcn_s_setprio(1);
+      if ((OPT & 1) && ph < ISSUE_PH && more) {
+#pragma unroll
+        for (int j = ph * PER; j < (ph + 1) * PER && j < LOADS; ++j) glds16(src[j] + knext, nxt + dst[j]);
+      }
 #pragma unroll
       for (int q = 0; q < KKPP; ++q)
 #pragma unroll
         for (int i = 0; i < FM; ++i)
 #pragma unroll
           for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[q][i], b[q][j], acc[i][j], 0, 0, 0);
-      __builtin_amdgcn_s_setprio(0);
+      if ((OPT & 1) && ph < ISSUE_PH) {
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        }
+      }
+      if (OPT & 2) __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
@@ -277,13 +288,13 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_nt_stagger_kernel(XArgs p
       }
 }
 
-template <int BM, int BN, int WGM, int WGN, int KKPP>
+template <int BM, int BN, int WGM, int WGN, int KKPP, int OPT = 2>
 int launch_stagger(const XArgs& a0, hipStream_t stream) {
   XArgs a = a0;
   a.tiles_m = (a.M + BM - 1) / BM;
   a.tiles_n = (a.N + BN - 1) / BN;
   const size_t lds = (size_t)2 * (BM + BN) * BK * 2;
-  auto kern = gemm_nt_stagger_kernel<BM, BN, WGM, WGN, KKPP>;
+  auto kern = gemm_nt_stagger_kernel<BM, BN, WGM, WGN, KKPP, OPT>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -336,6 +347,11 @@ extern "C" int udm_gemm_nt_bf16_variant(int variant, const void* A, const void* 
     case 15: return launch_stagger<128, 128, 2, 4, 2>(a, stream);
     case 16: return launch_stagger<320, 256, 2, 4, 1>(a, stream);
     case 17: return launch_stagger<256, 320, 2, 4, 1>(a, stream);
+    case 20: return launch_stagger<320, 256, 2, 4, 1, 1>(a, stream);
+    case 21: return launch_stagger<320, 256, 2, 4, 1, 3>(a, stream);
+    case 22: return launch_stagger<320, 256, 2, 4, 2, 1>(a, stream);
+    case 23: return launch_stagger<320, 256, 2, 4, 2, 3>(a, stream);
+    case 24: return launch_stagger<320, 256, 2, 4, 1, 0>(a, stream);
     default: udm_set_error("udm_gemm_nt_bf16_variant: unknown variant %d", variant); return 2;
   }
 }

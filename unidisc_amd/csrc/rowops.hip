@@ -345,6 +345,7 @@ struct ResidBwdArgs {
   const bf16_t* gate;
   const int64_t* modality;
   float* dw_b;            // [d] atomics
+  float* ws;              // optional [gridDim.x, d] partial-sum workspace (block-per-row form): no same-address atomic chains
   float* dgate;           // [B, mod_stride] atomics
   long mod_stride;
   int M, d, L, norm_type;
@@ -575,6 +576,7 @@ struct QkBwdArgs {
   const float* stats;
   const float* cos_t; const float* sin_t;
   float* dgq; float* dbq; float* dgk; float* dbk;  // [d] atomics
+  float* ws;           // optional [gridDim.x, 4, d] partial-sum workspace (block-per-row form)
   int M, d, L, D, rope_per_sample;
 };
 
@@ -805,6 +807,352 @@ __global__ void scale_cast_f32_bf16_kernel(const float* __restrict__ x, bf16_t* 
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Block-per-row variants for wide rows (d >= 1024): the 4 waves of a block share ONE row, so a thread holds 8*NCB
+// elements instead of 32+ and 6-8 waves fit per SIMD (the wave-per-row forms of these three kernels sit at 1-2
+// waves per SIMD and reach only 30-50 % of HBM bandwidth).  Row statistics are combined across the 4 waves in LDS.
+// ---------------------------------------------------------------------------------------------
+template <int N>
+__device__ __forceinline__ void block_sum4(float (&v)[N], float* sm) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < N; ++k) v[k] = wave_sum(v[k]);
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < N; ++k) sm[wave * N + k] = v[k];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < N; ++k) v[k] = sm[k] + sm[N + k] + sm[2 * N + k] + sm[3 * N + k];
+  __syncthreads();
+}
+
+template <int NCB>  // chunks of 8 columns per thread: column = (i * 256 + tid) * 8
+__global__ __launch_bounds__(256) void residual_bwd_brow_kernel(ResidBwdArgs a) {
+  __shared__ float sm[8];
+  const int tid = threadIdx.x;
+  float dw_acc[NCB][8];
+#pragma unroll
+  for (int i = 0; i < NCB; ++i)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) dw_acc[i][k] = 0.f;
+  const float keep_scale = 1.f / (1.f - a.p_drop);
+  for (long row = blockIdx.x; row < a.M; row += gridDim.x) {
+    const int b = (int)(row / a.L);
+    const bool special = !a.modality || a.modality[row] == 1;
+    const float rs = a.w_b ? a.rstd_b[row] : 1.f;
+    const float mu = (a.w_b && a.norm_type) ? a.mean_b[row] : 0.f;
+    float nh[NCB][8], g[NCB][8];
+    float red[2] = {0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < NCB; ++i) {
+      const int c = (i * 256 + tid) * 8;
+      if (c < a.d) {
+        float br[8], dn[8], w8[8];
+        load8_bf16(a.branch + row * a.d + c, br);
+        load8_f32(a.dx + row * a.d + c, dn);
+        if (a.w_b) load8_f32(a.w_b + c, w8);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) nh[i][k] = (br[k] - mu) * rs;
+        if (special) {
+          float g8[8];
+          if (a.gate) load8_bf16(a.gate + (long)b * a.mod_stride + c, g8);
+          bool keep[8];
+          if (a.p_drop > 0.f) dropout_keep8(a.seed, (uint64_t)row * a.d + c, a.p_drop, keep);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const float dm = (a.p_drop > 0.f) ? (keep[k] ? keep_scale : 0.f) : 1.f;
+            if (a.gate) {
+              float nn = a.w_b ? ((a.norm_type == 0 ? rbf(nh[i][k]) : nh[i][k]) * w8[k]) : br[k];
+              atomicAdd(a.dgate + (long)b * a.mod_stride + c + k, dn[k] * nn * dm);
+              dn[k] *= g8[k];
+            }
+            dn[k] *= dm;
+          }
+        }
+        if (a.w_b) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const float nr = (a.norm_type == 0) ? rbf(nh[i][k]) : nh[i][k];
+            dw_acc[i][k] += dn[k] * nr;
+            g[i][k] = dn[k] * w8[k];
+            red[0] += g[i][k];
+            red[1] += g[i][k] * nh[i][k];
+          }
+        } else {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) g[i][k] = dn[k];
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { nh[i][k] = 0.f; g[i][k] = 0.f; }
+      }
+    }
+    float s_g = 0.f, s_gx = 0.f;
+    if (a.w_b) {
+      block_sum4<2>(red, sm);
+      s_gx = red[1] / a.d;
+      s_g = a.norm_type ? red[0] / a.d : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < NCB; ++i) {
+      const int c = (i * 256 + tid) * 8;
+      if (c >= a.d) continue;
+      float o[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) o[k] = a.w_b ? rs * (g[i][k] - s_g - nh[i][k] * s_gx) : g[i][k];
+      store8_bf16(a.dbranch + row * a.d + c, o);
+    }
+  }
+  if (!a.w_b) return;
+#pragma unroll
+  for (int i = 0; i < NCB; ++i) {
+    const int c = (i * 256 + tid) * 8;
+    if (c < a.d) {
+      if (a.ws) {
+        store8_f32(a.ws + (long)blockIdx.x * a.d + c, dw_acc[i]);
+      } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) atomicAdd(a.dw_b + c + k, dw_acc[i][k]);
+      }
+    }
+  }
+}
+
+// out[c] += sum_r ws[r, c]: finishes the two-phase column reductions of the block-per-row backward kernels.  A 1024-deep chain of
+// fp32 atomics on one address costs ~190 us on MI355X (cross-XCD atomics serialise at the memory side); here the depth is gridDim.y.
+__global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict__ ws, float* __restrict__ out, int nrows, int ncols) {
+  __shared__ float red[4][64];
+  const int col = blockIdx.x * 64 + (threadIdx.x & 63), sub = threadIdx.x >> 6;
+  const int per = (nrows + gridDim.y - 1) / gridDim.y;
+  const int r0 = blockIdx.y * per, r1 = min(nrows, r0 + per);
+  float s = 0.f;
+  if (col < ncols)
+    for (int r = r0 + sub; r < r1; r += 4) s += ws[(long)r * ncols + col];
+  red[sub][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (sub == 0 && col < ncols) atomicAdd(out + col, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// item t = i * 256 + tid -> (part, head, j): 8 columns at c_lo and 8 at c_lo + D/2 (see the wave-per-row kernels above)
+template <int NIB>
+__global__ __launch_bounds__(256) void qknorm_rope_fwd_brow_kernel(QkArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float aff[];  // gq | bq | gk | bk
+  __shared__ float sm[8];
+  const int tid = threadIdx.x;
+  const int half = a.D / 2, per_head = a.D / 16, per_part = a.d / 16;
+  const bool do_norm = a.gq != nullptr;
+  if (do_norm) {
+    for (int c = tid * 4; c < a.d; c += 1024) {
+      *reinterpret_cast<float4*>(aff + c) = *reinterpret_cast<const float4*>(a.gq + c);
+      *reinterpret_cast<float4*>(aff + a.d + c) = *reinterpret_cast<const float4*>(a.bq + c);
+      *reinterpret_cast<float4*>(aff + 2 * a.d + c) = *reinterpret_cast<const float4*>(a.gk + c);
+      *reinterpret_cast<float4*>(aff + 3 * a.d + c) = *reinterpret_cast<const float4*>(a.bk + c);
+    }
+    __syncthreads();
+  }
+  for (long row = blockIdx.x; row < a.M; row += gridDim.x) {
+    float lo[NIB][8], hi[NIB][8];
+    float s[2] = {0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < NIB; ++i) {
+      const int t = i * 256 + tid;
+      if (t < 2 * per_part) {
+        const int part = t / per_part, r = t % per_part;
+        const int c = part * a.d + (r / per_head) * a.D + (r % per_head) * 8;
+        load8_bf16(a.qkv + row * 3 * a.d + c, lo[i]);
+        load8_bf16(a.qkv + row * 3 * a.d + c + half, hi[i]);
+        float u = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) u += lo[i][k] + hi[i][k];
+        s[part] += u;
+      }
+    }
+    float mq = 0.f, mk = 0.f, rq = 1.f, rk = 1.f;
+    if (do_norm) {
+      block_sum4<2>(s, sm);
+      mq = s[0] / a.d;
+      mk = s[1] / a.d;
+      float v[2] = {0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < NIB; ++i) {
+        const int t = i * 256 + tid;
+        if (t < 2 * per_part) {
+          const int part = t / per_part;
+          const float m = part ? mk : mq;
+          float u = 0.f;
+#pragma unroll
+          for (int k = 0; k < 8; ++k) { float x = lo[i][k] - m, y = hi[i][k] - m; u += x * x + y * y; }
+          v[part] += u;
+        }
+      }
+      block_sum4<2>(v, sm);
+      rq = rsqrtf(v[0] / a.d + a.eps);
+      rk = rsqrtf(v[1] / a.d + a.eps);
+      if (tid == 0) *reinterpret_cast<float4*>(a.stats + row * 4) = make_float4(mq, rq, mk, rk);
+    }
+    const long trow = a.rope_per_sample ? row : (row % a.L);
+#pragma unroll
+    for (int i = 0; i < NIB; ++i) {
+      const int t = i * 256 + tid;
+      if (t >= 2 * per_part) continue;
+      const int part = t / per_part, r = t % per_part;
+      const int hc = (r / per_head) * a.D + (r % per_head) * 8;
+      float xl[8], xh[8];
+      if (do_norm) {
+        const float* g = aff + part * 2 * a.d;
+        const float* bb = g + a.d;
+        const float m = part ? mk : mq, rs = part ? rk : rq;
+        float g0[8], g1[8], b0[8], b1[8];
+        load8_f32(g + hc, g0); load8_f32(g + hc + half, g1); load8_f32(bb + hc, b0); load8_f32(bb + hc + half, b1);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          xl[k] = rbf((lo[i][k] - m) * rs * g0[k] + b0[k]);
+          xh[k] = rbf((hi[i][k] - m) * rs * g1[k] + b1[k]);
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { xl[k] = lo[i][k]; xh[k] = hi[i][k]; }
+      }
+      float cs[8], sn[8], ol[8], oh[8];
+      const int pc = (r % per_head) * 8;
+      load8_f32(a.cos_t + trow * half + pc, cs);
+      load8_f32(a.sin_t + trow * half + pc, sn);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        ol[k] = xl[k] * cs[k] - xh[k] * sn[k];
+        oh[k] = xh[k] * cs[k] + xl[k] * sn[k];
+      }
+      store8_bf16(a.qkr + row * 2 * a.d + part * a.d + hc, ol);
+      store8_bf16(a.qkr + row * 2 * a.d + part * a.d + hc + half, oh);
+    }
+  }
+}
+
+template <int NIB>
+__global__ __launch_bounds__(256) void qknorm_rope_bwd_brow_kernel(QkBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float aff[];  // gq | gk
+  __shared__ float sm[16];
+  const int tid = threadIdx.x;
+  const int half = a.D / 2, per_head = a.D / 16, per_part = a.d / 16;
+  const bool do_norm = a.gq != nullptr;
+  if (do_norm) {
+    for (int c = tid * 4; c < a.d; c += 1024) {
+      *reinterpret_cast<float4*>(aff + c) = *reinterpret_cast<const float4*>(a.gq + c);
+      *reinterpret_cast<float4*>(aff + a.d + c) = *reinterpret_cast<const float4*>(a.gk + c);
+    }
+    __syncthreads();
+  }
+  float dg_acc[NIB][16], db_acc[NIB][16];
+#pragma unroll
+  for (int i = 0; i < NIB; ++i)
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { dg_acc[i][k] = 0.f; db_acc[i][k] = 0.f; }
+  for (long row = blockIdx.x; row < a.M; row += gridDim.x) {
+    const long trow = a.rope_per_sample ? row : (row % a.L);
+    float mq = 0.f, rq = 1.f, mk = 0.f, rk = 1.f;
+    if (do_norm) {
+      const float4 st = *reinterpret_cast<const float4*>(a.stats + row * 4);
+      mq = st.x; rq = st.y; mk = st.z; rk = st.w;
+    }
+    float gl[NIB][8], gh[NIB][8], xl[NIB][8], xh[NIB][8];
+    float red[4] = {0.f, 0.f, 0.f, 0.f};  // sum g (q), sum g*xhat (q), sum g (k), sum g*xhat (k)
+#pragma unroll
+    for (int i = 0; i < NIB; ++i) {
+      const int t = i * 256 + tid;
+      if (t < 2 * per_part) {
+        const int part = t / per_part, r = t % per_part;
+        const int hc = (r / per_head) * a.D + (r % per_head) * 8;
+        const int pc = (r % per_head) * 8;
+        float dl[8], dh[8], cs[8], sn[8];
+        load8_bf16(a.dqkr + row * 2 * a.d + part * a.d + hc, dl);
+        load8_bf16(a.dqkr + row * 2 * a.d + part * a.d + hc + half, dh);
+        load8_f32(a.cos_t + trow * half + pc, cs);
+        load8_f32(a.sin_t + trow * half + pc, sn);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          gl[i][k] = dl[k] * cs[k] + dh[k] * sn[k];
+          gh[i][k] = dh[k] * cs[k] - dl[k] * sn[k];
+        }
+        if (do_norm) {
+          const float* g = aff + part * a.d;
+          const float m = part ? mk : mq, rs = part ? rk : rq;
+          float g0[8], g1[8], r0[8], r1[8];
+          load8_f32(g + hc, g0); load8_f32(g + hc + half, g1);
+          load8_bf16(a.qkv + row * 3 * a.d + part * a.d + hc, r0);
+          load8_bf16(a.qkv + row * 3 * a.d + part * a.d + hc + half, r1);
+          float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            xl[i][k] = (r0[k] - m) * rs;
+            xh[i][k] = (r1[k] - m) * rs;
+            dg_acc[i][k] += gl[i][k] * xl[i][k];
+            dg_acc[i][k + 8] += gh[i][k] * xh[i][k];
+            db_acc[i][k] += gl[i][k];
+            db_acc[i][k + 8] += gh[i][k];
+            gl[i][k] *= g0[k];
+            gh[i][k] *= g1[k];
+            s1 += gl[i][k] + gh[i][k];
+            s2 += gl[i][k] * xl[i][k] + gh[i][k] * xh[i][k];
+          }
+          red[2 * part] += s1;
+          red[2 * part + 1] += s2;
+        }
+      }
+    }
+    if (do_norm) {
+      block_sum4<4>(red, sm);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) red[k] /= a.d;
+    }
+#pragma unroll
+    for (int i = 0; i < NIB; ++i) {
+      const int t = i * 256 + tid;
+      if (t >= 2 * per_part) continue;
+      const int part = t / per_part, r = t % per_part;
+      const int hc = (r / per_head) * a.D + (r % per_head) * 8;
+      float ol[8], oh[8];
+      if (do_norm) {
+        const float rs = part ? rk : rq, sg = red[2 * part], sgx = red[2 * part + 1];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          ol[k] = rs * (gl[i][k] - sg - xl[i][k] * sgx);
+          oh[k] = rs * (gh[i][k] - sg - xh[i][k] * sgx);
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { ol[k] = gl[i][k]; oh[k] = gh[i][k]; }
+      }
+      store8_bf16(a.dqkv + row * 3 * a.d + part * a.d + hc, ol);
+      store8_bf16(a.dqkv + row * 3 * a.d + part * a.d + hc + half, oh);
+    }
+  }
+  if (!do_norm) return;
+#pragma unroll
+  for (int i = 0; i < NIB; ++i) {
+    const int t = i * 256 + tid;
+    if (t < 2 * per_part) {
+      const int part = t / per_part, r = t % per_part;
+      const int hc = (r / per_head) * a.D + (r % per_head) * 8;
+      if (a.ws) {  // workspace row layout: [dgq | dbq | dgk | dbk], d floats each
+        float* wr = a.ws + (long)blockIdx.x * 4 * a.d + part * 2 * a.d;
+        float t0[8], t1[8], t2[8], t3[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { t0[k] = dg_acc[i][k]; t1[k] = dg_acc[i][k + 8]; t2[k] = db_acc[i][k]; t3[k] = db_acc[i][k + 8]; }
+        store8_f32(wr + hc, t0); store8_f32(wr + hc + half, t1);
+        store8_f32(wr + a.d + hc, t2); store8_f32(wr + a.d + hc + half, t3);
+      } else {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+          const int col = hc + (k & 7) + (k >> 3) * half;
+          atomicAdd((part ? a.dgk : a.dgq) + col, dg_acc[i][k]);
+          atomicAdd((part ? a.dbk : a.dbq) + col, db_acc[i][k]);
+        }
+      }
+    }
+  }
+}
+
 inline int grid_rows(long M) {
   long g = (M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
   return (int)(g < 2048 ? (g < 1 ? 1 : g) : 2048);
@@ -869,13 +1217,26 @@ extern "C" int udm_residual_fwd(const float* x_in, const void* branch, float* x_
 
 extern "C" int udm_residual_bwd(const float* dx, const void* branch, void* dbranch, const float* w_b, const float* rstd_b, const float* mean_b,
                                 const void* gate, int64_t mod_stride, const int64_t* modality, float* dw_b, float* dgate, int64_t M, int64_t d, int64_t L,
-                                int norm_type, float p_drop, uint64_t seed, hipStream_t stream) {
+                                int norm_type, float p_drop, uint64_t seed, float* ws, int64_t ws_elems, hipStream_t stream) {
   UDM_CHECK_ARG(dx && branch && dbranch, "udm_residual_bwd: null pointer");
   UDM_CHECK_ARG(M > 0 && d > 0 && d % 8 == 0 && L > 0, "udm_residual_bwd: bad shape");
   UDM_CHECK_ARG(!w_b || (rstd_b && dw_b), "udm_residual_bwd: sandwich norm needs rstd and dw");
   UDM_CHECK_ARG(!gate || dgate, "udm_residual_bwd: gate needs dgate");
-  ResidBwdArgs a{dx, (const bf16_t*)branch, (bf16_t*)dbranch, w_b, rstd_b, mean_b, (const bf16_t*)gate, modality, dw_b, dgate, (long)mod_stride,
+  ResidBwdArgs a{dx, (const bf16_t*)branch, (bf16_t*)dbranch, w_b, rstd_b, mean_b, (const bf16_t*)gate, modality, dw_b, nullptr, dgate, (long)mod_stride,
                  (int)M, (int)d, (int)L, norm_type, p_drop, seed};
+  if (d >= 2048 && d <= 4096) {  // wide rows: block-per-row form (8 elements per thread, high occupancy)
+    int g = (int)(M < 1024 ? M : 1024);
+    if (w_b && ws && ws_elems >= (int64_t)g * d) a.ws = ws;
+    else if (w_b) g = g < 256 ? g : 256;  // no workspace: keep the same-address atomic chains short
+    if (d <= 2048) hipLaunchKernelGGL((residual_bwd_brow_kernel<1>), dim3(g), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((residual_bwd_brow_kernel<2>), dim3(g), dim3(256), 0, stream, a);
+    UDM_CHECK_LAUNCH("udm_residual_bwd");
+    if (a.ws) {
+      hipLaunchKernelGGL(colreduce_kernel, dim3((unsigned)((d + 63) / 64), 8), dim3(256), 0, stream, (const float*)ws, dw_b, g, (int)d);
+      UDM_CHECK_LAUNCH("udm_residual_bwd(colreduce)");
+    }
+    return 0;
+  }
   int nch = nch_for(d); if (nch > 4) nch = 8;
   const int grid = min(grid_rows(M), 512);
   DISPATCH_NCH(nch, residual_bwd_kernel, grid, stream, a);
@@ -895,6 +1256,13 @@ extern "C" int udm_qknorm_rope_fwd(const void* qkv, void* qkr, const float* gq, 
   UDM_CHECK_ARG(nit <= 8, "udm_qknorm_rope_fwd: hidden size too large");
   const int nch = nit <= 1 ? 1 : (nit == 2 ? 2 : (nit == 3 ? 3 : (nit == 4 ? 4 : 8)));
   const size_t lds = gq ? (size_t)4 * d * sizeof(float) : 0;
+  if (d >= 2048 && d <= 4096) {
+    const int g = (int)(M < 2048 ? M : 2048);
+    if (d <= 2048) hipLaunchKernelGGL((qknorm_rope_fwd_brow_kernel<1>), dim3(g), dim3(256), lds, stream, a);
+    else hipLaunchKernelGGL((qknorm_rope_fwd_brow_kernel<2>), dim3(g), dim3(256), lds, stream, a);
+    UDM_CHECK_LAUNCH("udm_qknorm_rope_fwd");
+    return 0;
+  }
   const int grid = min(grid_rows(M), 1024);
   switch (nch) {
     case 1: hipLaunchKernelGGL((qknorm_rope_fwd_kernel<1>), dim3(grid), dim3(256), lds, stream, a); break;
@@ -909,17 +1277,32 @@ extern "C" int udm_qknorm_rope_fwd(const void* qkv, void* qkr, const float* gq, 
 
 extern "C" int udm_qknorm_rope_bwd(const void* dqkr, const void* qkv, void* dqkv, const float* gq, const float* gk, const float* stats, const float* cos_t,
                                    const float* sin_t, int rope_per_sample, float* dgq, float* dbq, float* dgk, float* dbk, int64_t M, int64_t d, int64_t L,
-                                   int64_t D, hipStream_t stream) {
+                                   int64_t D, float* ws, int64_t ws_elems, hipStream_t stream) {
   UDM_CHECK_ARG(dqkr && qkv && dqkv && cos_t && sin_t, "udm_qknorm_rope_bwd: null pointer");
   UDM_CHECK_ARG(M > 0 && d > 0 && D > 0 && d % D == 0 && D % 8 == 0, "udm_qknorm_rope_bwd: bad shape");
   UDM_CHECK_ARG(!gq || (gk && stats && dgq && dbq && dgk && dbk), "udm_qknorm_rope_bwd: qk-norm needs gk, stats and the four gradient vectors");
-  QkBwdArgs a{(const bf16_t*)dqkr, (const bf16_t*)qkv, (bf16_t*)dqkv, gq, gk, stats, cos_t, sin_t, dgq, dbq, dgk, dbk, (int)M, (int)d, (int)L, (int)D,
+  QkBwdArgs a{(const bf16_t*)dqkr, (const bf16_t*)qkv, (bf16_t*)dqkv, gq, gk, stats, cos_t, sin_t, dgq, dbq, dgk, dbk, nullptr, (int)M, (int)d, (int)L, (int)D,
               rope_per_sample};
   UDM_CHECK_ARG(D % 16 == 0 && d % 16 == 0, "udm_qknorm_rope_bwd: head_dim and hidden size must be multiples of 16");
   const int nit = (int)((2 * (d / 16) + 63) / 64);
   UDM_CHECK_ARG(nit <= 8, "udm_qknorm_rope_bwd: hidden size too large");
   const int nch = nit <= 1 ? 1 : (nit == 2 ? 2 : (nit == 3 ? 3 : (nit == 4 ? 4 : 8)));
   const size_t lds = gq ? ((size_t)2 * d + 4096) * sizeof(float) : 0;
+  if (d >= 2048 && d <= 4096) {
+    int g = (int)(M < 1024 ? M : 1024);
+    UDM_CHECK_ARG(!gq || (dbq == dgq + d && dgk == dgq + 2 * d && dbk == dgq + 3 * d) || !ws, "udm_qknorm_rope_bwd: the workspace form needs dgq|dbq|dgk|dbk contiguous");
+    if (gq && ws && ws_elems >= (int64_t)g * 4 * d) a.ws = ws;
+    else if (gq) g = g < 256 ? g : 256;
+    const size_t l2 = gq ? (size_t)2 * d * sizeof(float) : 0;
+    if (d <= 2048) hipLaunchKernelGGL((qknorm_rope_bwd_brow_kernel<1>), dim3(g), dim3(256), l2, stream, a);
+    else hipLaunchKernelGGL((qknorm_rope_bwd_brow_kernel<2>), dim3(g), dim3(256), l2, stream, a);
+    UDM_CHECK_LAUNCH("udm_qknorm_rope_bwd");
+    if (a.ws) {
+      hipLaunchKernelGGL(colreduce_kernel, dim3((unsigned)((4 * d + 63) / 64), 8), dim3(256), 0, stream, (const float*)ws, dgq, g, (int)(4 * d));
+      UDM_CHECK_LAUNCH("udm_qknorm_rope_bwd(colreduce)");
+    }
+    return 0;
+  }
   const int grid = min(grid_rows(M), 256);
   switch (nch) {
     case 1: hipLaunchKernelGGL((qknorm_rope_bwd_kernel<1>), dim3(grid), dim3(256), lds, stream, a); break;

@@ -39,6 +39,19 @@ def _chk(t, dtype, name):
         raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
 
 
+_SCRATCH = {}
+
+
+def _scratch(n: int, device) -> torch.Tensor:
+    """Per-device fp32 scratch for two-phase column reductions (stream-ordered reuse: every user runs on the current stream)."""
+    key = (device.type, device.index)
+    buf = _SCRATCH.get(key)
+    if buf is None or buf.numel() < n:
+        buf = torch.empty(n, dtype=F32, device=device)
+        _SCRATCH[key] = buf
+    return buf
+
+
 def norm_id(norm_type: str) -> int:
     return NORM_RMS if norm_type == "rms" else NORM_LN
 
@@ -167,8 +180,9 @@ def residual_bwd(dx, branch, L, *, w_b=None, rstd=None, mean=None, norm_type=NOR
     use = gate_idx is not None and mod is not None
     (gate,), ms = _mod_ptrs(mod if use else None, (gate_idx,), d)
     (dgate,), _ = _mod_ptrs(dmod if use else None, (gate_idx,), d)
+    ws = _scratch(1024 * d, dx.device) if (w_b is not None and d >= 2048) else None
     _lib.call("udm_residual_bwd", _p(dx), _p(branch), _p(dbranch), _p(w_b), _p(rstd), _p(mean), gate, ms, _p(modality), _p(dw_b), dgate, M, d, L,
-              norm_type, float(p_drop), int(seed), _s())
+              norm_type, float(p_drop), int(seed), _p(ws), ws.numel() if ws is not None else 0, _s())
     return dbranch
 
 
@@ -187,8 +201,10 @@ def qknorm_rope_bwd(dqkr, qkv, dqkv, cos, sin, L, D, *, gq=None, gk=None, stats=
     M, d3 = qkv.shape
     d = d3 // 3
     per_sample = 1 if cos.dim() == 3 else 0
+    contig = gq is not None and dbq.data_ptr() == dgq.data_ptr() + 4 * d and dgk.data_ptr() == dgq.data_ptr() + 8 * d and dbk.data_ptr() == dgq.data_ptr() + 12 * d
+    ws = _scratch(4096 * d, qkv.device) if (contig and d >= 2048) else None
     _lib.call("udm_qknorm_rope_bwd", _p(dqkr), _p(qkv), _p(dqkv), _p(gq), _p(gk), _p(stats), _p(cos), _p(sin), per_sample, _p(dgq), _p(dbq), _p(dgk),
-              _p(dbk), M, d, L, D, _s())
+              _p(dbk), M, d, L, D, _p(ws), ws.numel() if ws is not None else 0, _s())
 
 
 def attention_fwd(qkr, qkv, B, L, H, D, sample_ids=None):
