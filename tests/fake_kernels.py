@@ -39,6 +39,8 @@ def gemm_nt(a, b, out=None, *, out_dtype=BF16, M=None, N=None, K=None, lda=None,
         u = aux[:M, :N].float().requires_grad_()
         (gr,) = torch.autograd.grad(F.gelu(u, approximate="tanh").sum(), u)
         acc = acc * gr
+        if bias is not None:  # EPI_DGELU: `bias` is the bias-gradient OUTPUT (column sums of the result)
+            bias[:N] += acc.detach().bfloat16().float().sum(0)
     if out is None:
         out = torch.empty((M, N), dtype=out_dtype)
     if beta != 0.0:

@@ -67,8 +67,10 @@ def test_gemm_large_tile_kernels(K, tile, M, N, K_):
         u = aux.float().cpu()[:, :N].requires_grad_()
         (gp,) = torch.autograd.grad(torch.nn.functional.gelu(u, approximate="tanh").sum(), u)
         dg = torch.zeros((M, ldc), dtype=torch.bfloat16, device=DEV)
-        K.gemm_nt(ga, gb, out=dg, N=N, epilogue=K.EPI_DGELU, aux=aux)
+        dbias = torch.zeros(N, dtype=torch.float32, device=DEV)
+        K.gemm_nt(ga, gb, out=dg, N=N, epilogue=K.EPI_DGELU, aux=aux, bias=dbias)
         assert rel_err(dg.float().cpu()[:, :N], acc * gp) < 5e-3
+        assert torch.allclose(dbias.cpu(), dg.float().cpu()[:, :N].sum(0), atol=2e-2, rtol=2e-3)  # fused bias gradient = column sums
         c0 = rnd(M, N, seed=83)
         c = c0.clone().to(DEV)
         K.gemm_nt(ga, gb, out=c, beta=1.0)

@@ -17,14 +17,17 @@ namespace udm {
 
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 
-__device__ __forceinline__ bf16_t f2bf(float f) {  // round-to-nearest-even, NaN preserved
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40u);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (bf16_t)(u >> 16);
+// fp32 -> bf16 (round-to-nearest-even) with the gfx950 hardware converter: the compiler lowers a float->__bf16 vector
+// conversion to one v_cvt_pk_bf16_f32 per PAIR of values (vs ~8 integer VALU ops per value in software).  Deliberately NOT
+// inline asm: the hazard recogniser does not look inside asm blocks, and a cvt issued right behind the v_exp_f32 that
+// produced its input (transcendental-result hazard) read stale data in the attention softmax.
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
+  f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
 }
-
-__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

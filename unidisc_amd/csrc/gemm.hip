@@ -180,7 +180,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(GemmArgs p) {
       const bf16_t* ap = p.aux + (long)gm * p.ldaux + gn;
 #pragma unroll
       for (int e = 0; e < 4; ++e)
-        if (e < nvalid) x[e] *= gelu_tanh_grad(bf2f(ap[e]));
+        if (e < nvalid) {
+          x[e] *= gelu_tanh_grad(bf2f(ap[e]));
+          if (p.bias) atomicAdd(const_cast<float*>(p.bias) + gn + e, OUT_F32 ? x[e] : bf2f(f2bf(x[e])));  // bias-gradient output (see header)
+        }
     }
     if (OUT_F32) {
       float* cp = reinterpret_cast<float*>(p.C) + (long)gm * p.ldc + gn;
@@ -329,14 +332,16 @@ __device__ __forceinline__ void glds16(const void* gptr, char* lds_base) {
 // form dW = dY^T X read straight from the row-major activations.  Tiles are staged as [64 k-rows][columns] and the
 // MFMA operands are gathered with ds_read_b64_tr_b16 transposing reads; rows are rotated by (k & 3) 64-byte
 // granules (applied on the LDS-DMA source address) so the four k-rows of one transposing read hit different banks.
-template <int BMX, int EPI, bool OUT_F32, bool TN>
+template <int BMX, int EPI, bool OUT_F32, bool TN, int KKPP = (TN ? 2 : 1)>  // KKPP = 16-deep k-steps per phase
 __global__ __launch_bounds__(512) void gemm_nt_stagger_kernel(GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int BNX = 256, WGM = 2, WGN = 4, NWAVES = 8;
   constexpr int WM = BMX / WGM, WN = BNX / WGN, FM = WM / 32, FN = WN / 32;
   constexpr int A_BYTES = BMX * BK * 2, B_BYTES = BNX * BK * 2, STAGE_BYTES = A_BYTES + B_BYTES;
   constexpr int A_PW = A_BYTES / 1024 / NWAVES, B_PW = B_BYTES / 1024 / NWAVES, LOADS = A_PW + B_PW;
-  constexpr int NPH = 4, ISSUE_PH = 2, PER = (LOADS + ISSUE_PH - 1) / ISSUE_PH;
+  // The transposing-read (TN) form issues twice as many LDS instructions per k-step, so its read section outlasts an 8-10 MFMA
+  // section (measured: 40-50 % pipe utilisation vs 57 %); two k-steps per phase amortise the LDS latency there.
+  constexpr int NPH = 4 / KKPP, ISSUE_PH = NPH > 2 ? 2 : 1, PER = (LOADS + ISSUE_PH - 1) / ISSUE_PH;
   static_assert(WM % 32 == 0 && (A_BYTES / 1024) % NWAVES == 0, "bad tile");
 
   const int S = p.splitk > 1 ? p.splitk : 1;
@@ -424,26 +429,30 @@ __global__ __launch_bounds__(512) void gemm_nt_stagger_kernel(GemmArgs p) {
     const bool more = kt + 1 < nk;
 #pragma unroll
     for (int ph = 0; ph < NPH; ++ph) {
-      bf16x8_t a[FM], b[FN];
-      if (!TN) {
-        const int so = ((ph * 2 + hi) ^ sw) << 4;
+      bf16x8_t a[KKPP][FM], b[KKPP][FN];
 #pragma unroll
-        for (int i = 0; i < FM; ++i) a[i] = *reinterpret_cast<const bf16x8_t*>(As + (wm * WM + i * 32 + l31) * 128 + so);
+      for (int q = 0; q < KKPP; ++q) {
+        const int kk = ph * KKPP + q;
+        if (!TN) {
+          const int so = ((kk * 2 + hi) ^ sw) << 4;
 #pragma unroll
-        for (int j = 0; j < FN; ++j) b[j] = *reinterpret_cast<const bf16x8_t*>(Bs + (wn * WN + j * 32 + l31) * 128 + so);
-      } else {
-        const int kr = ph * 16 + hi * 8 + rot;
+          for (int i = 0; i < FM; ++i) a[q][i] = *reinterpret_cast<const bf16x8_t*>(As + (wm * WM + i * 32 + l31) * 128 + so);
 #pragma unroll
-        for (int i = 0; i < FM; ++i) {
-          s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((UDM_LDS s16x4_t*)(As + kr * RB_A + a_fo[i]));
-          s16x4_t hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((UDM_LDS s16x4_t*)(As + (kr + 4) * RB_A + a_fo[i]));
-          a[i] = __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7));
-        }
+          for (int j = 0; j < FN; ++j) b[q][j] = *reinterpret_cast<const bf16x8_t*>(Bs + (wn * WN + j * 32 + l31) * 128 + so);
+        } else {
+          const int kr = kk * 16 + hi * 8 + rot;
 #pragma unroll
-        for (int j = 0; j < FN; ++j) {
-          s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((UDM_LDS s16x4_t*)(Bs + kr * RB_B + b_fo[j]));
-          s16x4_t hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((UDM_LDS s16x4_t*)(Bs + (kr + 4) * RB_B + b_fo[j]));
-          b[j] = __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7));
+          for (int i = 0; i < FM; ++i) {
+            s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((UDM_LDS s16x4_t*)(As + kr * RB_A + a_fo[i]));
+            s16x4_t hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((UDM_LDS s16x4_t*)(As + (kr + 4) * RB_A + a_fo[i]));
+            a[q][i] = __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7));
+          }
+#pragma unroll
+          for (int j = 0; j < FN; ++j) {
+            s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((UDM_LDS s16x4_t*)(Bs + kr * RB_B + b_fo[j]));
+            s16x4_t hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((UDM_LDS s16x4_t*)(Bs + (kr + 4) * RB_B + b_fo[j]));
+            b[q][j] = __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7));
+          }
         }
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -458,9 +467,11 @@ __global__ __launch_bounds__(512) void gemm_nt_stagger_kernel(GemmArgs p) {
         for (int j = ph * PER; j < (ph + 1) * PER && j < LOADS; ++j) glds16(src[j] + (kt + 1) * (j < A_PW ? kstep_a : kstep_b), nxt + dst[j]);
       }
 #pragma unroll
-      for (int i = 0; i < FM; ++i)
+      for (int q = 0; q < KKPP; ++q)
 #pragma unroll
-        for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+          for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[q][i], b[q][j], acc[i][j], 0, 0, 0);
       if (ph < ISSUE_PH) {
 #pragma unroll
         for (int q = 0; q < PER; ++q) {
@@ -488,6 +499,14 @@ __global__ __launch_bounds__(512) void gemm_nt_stagger_kernel(GemmArgs p) {
       const int gn = col0 + wn * WN + j * 32 + ec + e;
       bias4[j][e] = ((EPI == UDM_EPI_BIAS || EPI == UDM_EPI_BIAS_GELU) && gn < p.N) ? p.bias[gn] : 0.f;
     }
+  // EPI_DGELU + non-null `bias`: the pointer is an fp32 [N] OUTPUT that receives the column sums of the (bf16-rounded) result,
+  // i.e. the bias gradient of the Linear whose dgrad this is — saves a separate pass over the [M, 4d] gradient.
+  float* colsum = (EPI == UDM_EPI_DGELU) ? const_cast<float*>(p.bias) : nullptr;
+  float csum[FN][4];
+#pragma unroll
+  for (int j = 0; j < FN; ++j)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) csum[j][e] = 0.f;
 #pragma clang loop unroll(full)
   for (int i = 0; i < FM; ++i)
 #pragma clang loop unroll(full)
@@ -525,6 +544,10 @@ __global__ __launch_bounds__(512) void gemm_nt_stagger_kernel(GemmArgs p) {
             x[0] *= gelu_tanh_grad(__uint_as_float(au[q].x << 16)); x[1] *= gelu_tanh_grad(__uint_as_float(au[q].x & 0xffff0000u));
             x[2] *= gelu_tanh_grad(__uint_as_float(au[q].y << 16)); x[3] *= gelu_tanh_grad(__uint_as_float(au[q].y & 0xffff0000u));
           }
+          if (EPI == UDM_EPI_DGELU && colsum) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) csum[j][e] += OUT_F32 ? x[e] : bf2f(f2bf(x[e]));
+          }
           if (OUT_F32 && S > 1) {
             float* cp = reinterpret_cast<float*>(p.C) + gm * p.ldc + gn;
 #pragma unroll
@@ -548,7 +571,10 @@ __global__ __launch_bounds__(512) void gemm_nt_stagger_kernel(GemmArgs p) {
               p.aux[gm * p.ldaux + gn + e] = pre;
               x[e] = gelu_tanh(bf2f(pre));
             }
-            if (EPI == UDM_EPI_DGELU) x[e] *= gelu_tanh_grad(bf2f(p.aux[gm * p.ldaux + gn + e]));
+            if (EPI == UDM_EPI_DGELU) {
+              x[e] *= gelu_tanh_grad(bf2f(p.aux[gm * p.ldaux + gn + e]));
+              if (colsum) atomicAdd(colsum + gn + e, OUT_F32 ? x[e] : bf2f(f2bf(x[e])));
+            }
             if (OUT_F32 && S > 1) {
               atomicAdd(reinterpret_cast<float*>(p.C) + gm * p.ldc + gn + e, x[e]);
             } else if (OUT_F32) {
@@ -561,6 +587,18 @@ __global__ __launch_bounds__(512) void gemm_nt_stagger_kernel(GemmArgs p) {
         }
       }
     }
+  if (EPI == UDM_EPI_DGELU && colsum && interior) {
+#pragma unroll
+    for (int j = 0; j < FN; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float v = csum[j][e];
+        v += __shfl_xor(v, 8, 64);
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        if (er == 0) atomicAdd(colsum + col0 + wn * WN + j * 32 + ec + e, v);
+      }
+  }
 }
 
 template <int BMX, int EPI, bool OUT_F32, bool TN = false>

@@ -483,12 +483,12 @@ class DIT(nn.Module, _HubMixin):
         hi = max(self._grad_ranges[id(p)][1] for p in group)
         cb(flat, lo, hi)
 
-    def _wgrad(self, dY, X, lin: _Lin, G, n_rows=None):
+    def _wgrad(self, dY, X, lin: _Lin, G, n_rows=None, bias_done=False):
         """dW[out,in] = dY[M,out]^T X[M,in] (fp32), db = colsum(dY).  dY/X bf16 [M, *]."""
         Mrows = dY.shape[0]
         outp = dY.shape[1]
         db = None
-        if lin.bias is not None:
+        if lin.bias is not None and not bias_done:
             db = G[id(lin.bias)] if outp == lin.out else torch.zeros(outp, dtype=F32, device=dY.device)
         few_tiles = ((lin.out + 255) // 256) * ((lin.inp + 255) // 256) < 128 and lin.out * lin.inp >= 1 << 20
         if Mrows % 64 == 0 and not few_tiles:  # K-major GEMM reads dY and X in place (transposing LDS reads); bias grad = column sums
@@ -554,10 +554,11 @@ class DIT(nn.Module, _HubMixin):
             du2 = K.residual_bwd(dx, R["u2"], L, w_b=blk.post_ff_norm.weight.detach() if sw else None, rstd=R["rstd_m"], mean=R["mean_m"], norm_type=nt,
                                  mod=mod, dmod=dmod, gate_idx=5 if tc else None, modality=mod_flat if tc else None,
                                  dw_b=G[id(blk.post_ff_norm.weight)] if sw else None, p_drop=p_drop, seed=seed0 + 4 * i + 2)
-            du1 = K.gemm_nt(du2, f2.w16t, N=4 * d, epilogue=K.EPI_DGELU, aux=R["u1"])
+            # dgrad through mlp.2 with the GELU' multiply and the mlp.0 bias gradient (column sums of du1) fused into the epilogue
+            du1 = K.gemm_nt(du2, f2.w16t, N=4 * d, epilogue=K.EPI_DGELU, aux=R["u1"], bias=G[id(f1.bias)])
             self._wgrad(du2, R["g"], f2, G)
             dh2 = K.gemm_nt(du1, f1.w16t, N=d)
-            self._wgrad(du1, R["h2"], f1, G)
+            self._wgrad(du1, R["h2"], f1, G, bias_done=True)
             del du1, du2
             K.norm_bwd(dh2, R["x_mid"], R["rstd2"], R["mean2"], blk.norm2.weight.detach(), nt, L, dx, G[id(blk.norm2.weight)], accumulate=True,
                        mod=mod, dmod=dmod, mod_idx=(3, 4), modality=mod_flat, any_img=any_img)
