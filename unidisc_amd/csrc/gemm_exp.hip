@@ -9,6 +9,9 @@
 #include "common.h"
 #include "../../include/unidisc_hip.h"
 
+#include <stdio.h>
+#include <type_traits>
+
 namespace {
 using namespace udm;
 constexpr int BK = 64;
@@ -19,6 +22,7 @@ struct XArgs {
   bf16_t* C;
   long lda, ldb, ldc;
   int M, N, K, tiles_m, tiles_n;
+  unsigned long long* tl;   // quad timeline (OPT bit 4): cycle stamps of block 0, [wave][K tile 8..15][tag]
 };
 
 template <int N>
@@ -305,6 +309,220 @@ int launch_stagger(const XArgs& a0, hipStream_t stream) {
   return 0;
 }
 
+// ---- "quad": 256 x 256 x 64 tile, FOUR waves (2 x 2), 128 x 128 per wave (16 accumulators = 256 AGPRs), ONE wave per SIMD ----
+// A 128 x 128 wave tile needs (128 + 128) fragment rows per 16 MFMAs = 512 B of LDS reads per MFMA, against 717-768 B for the
+// 160 x 64 / 128 x 64 wave tiles of the 8-wave kernels.  With one wave per SIMD nothing but the wave's own stream hides latency, so
+// the loop is software-pipelined by hand: fragments of k-step s+1 are read (into the other register buffer) under the MFMAs of
+// k-step s; the single barrier of a K tile sits BEFORE the last k-step's MFMAs (its fragments are already in registers), so the
+// barrier wait, the first reads of the next tile and the LDS-DMA refill of the stage just retired all run under those 16 MFMAs.
+// Requires M, N multiples of 256 (the production dispatcher keeps the 8-wave kernels for ragged shapes).
+// OPT bit 0: interleave hints (sched_group_barrier) inside a k-step.  Ablations (wrong results, timing only): bit 1 drops the
+// fragment reads of the loop, bit 2 drops the LDS-DMA refills, bit 3 drops the barrier.
+template <int OPT>
+__global__ __launch_bounds__(256, 1) void gemm_nt_quad_kernel(XArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int BM = 256, BN = 256, A_BYTES = BM * BK * 2, STAGE_BYTES = 2 * A_BYTES, PW = 8;  // PW: 1 KiB pieces per wave per operand
+  const int nwg = p.tiles_m * p.tiles_n;
+  int pid = xcd_remap(blockIdx.x, nwg);
+  constexpr int GROUP_M = 8;
+  const int per_group = GROUP_M * p.tiles_n;
+  const int grp = pid / per_group, first_m = grp * GROUP_M;
+  const int gsz = min(p.tiles_m - first_m, GROUP_M);
+  const int tm = first_m + (pid % per_group) % gsz, tn = (pid % per_group) / gsz;
+  const int row0 = tm * BM, col0 = tn * BN;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, hi = lane >> 5, lrow = lane >> 3, lslot = lane & 7;
+
+  // LDS-DMA sources: wave w stages tile rows [64 w, 64 w + 64) of A and of B, 8 rows per piece.  Piece j = 2 q + e covers rows
+  // 64 w + 16 q + 8 e + lrow; the swizzle term ((row >> 1) & 7) only depends on e, so two 32-bit lane offsets per operand suffice and
+  // everything else is a wave-uniform base (SALU).
+  uint32_t offa[2], offb[2];
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const int r = wave * 64 + 8 * e + lrow;
+    offa[e] = (uint32_t)((r * p.lda + ((lslot ^ ((r >> 1) & 7)) << 3)) * 2);
+    offb[e] = (uint32_t)((r * p.ldb + ((lslot ^ ((r >> 1) & 7)) << 3)) * 2);
+  }
+  const char* abase = reinterpret_cast<const char*>(p.A + (long)row0 * p.lda);
+  const char* bbase = reinterpret_cast<const char*>(p.B + (long)col0 * p.ldb);
+  const long qa = 16 * p.lda * 2, qb = 16 * p.ldb * 2;
+  auto ubase = [&](const char* ptr) {   // pin a wave-uniform pointer into SGPRs so the DMA takes the (SGPR base + 32-bit VGPR offset) form
+    const uint64_t u = reinterpret_cast<uint64_t>(ptr);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u), hi32 = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
+    return reinterpret_cast<const char*>(((uint64_t)hi32 << 32) | lo);
+  };
+  auto dma_piece = [&](int kt, int stage, int j) {   // j in 0..15: 0..7 A pieces, 8..15 B pieces
+    const int jj = j & 7, q = jj >> 1, e = jj & 1;
+    char* dst = smem + stage * STAGE_BYTES + (j >> 3) * A_BYTES + (wave * PW + jj) * 1024;
+    if (j < 8) glds16(ubase(abase + (long)kt * (BK * 2) + q * qa) + (size_t)offa[e], dst);
+    else glds16(ubase(bbase + (long)kt * (BK * 2) + q * qb) + (size_t)offb[e], dst);
+  };
+
+  // fragment addresses: row (wm 128 + 32 i + l31), 16-byte granule ((2 kk + hi) ^ sw); i, the B region and the stage are immediates
+  const int sw = (l31 >> 1) & 7;
+  const uint32_t lds0 = (uint32_t)(size_t)(UDM_LDS char*)smem;
+  uint32_t fa_addr[4], fb_addr[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) {
+    const uint32_t so = ((kk * 2 + hi) ^ sw) << 4;
+    fa_addr[kk] = lds0 + (wm * 128 + l31) * 128 + so;
+    fb_addr[kk] = lds0 + (wn * 128 + l31) * 128 + so;
+  }
+  bf16x8_t fa[2][4], fb[2][4];
+  auto read_frags = [&](int stage, int kk, int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      fa[buf][i] = *reinterpret_cast<UDM_LDS const bf16x8_t*>((size_t)(fa_addr[kk] + stage * STAGE_BYTES + i * 4096));
+      fb[buf][i] = *reinterpret_cast<UDM_LDS const bf16x8_t*>((size_t)(fb_addr[kk] + stage * STAGE_BYTES + A_BYTES + i * 4096));
+    }
+  };
+  // Accumulators are zeroed BY the matrix pipe (MFMA of an opaque zero fragment onto the constant 0): 256 v_mov + copies into the
+  // AGPR file would put 256 live VGPRs at this point and make the allocator spill the loop's addresses and fragments.
+  f32x16_t acc[4][4];
+  {
+    bf16x8_t zf = {};
+    asm volatile("" : "+v"(zf));
+    const f32x16_t zc = {};
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zf, zf, zc, 0, 0, 0);
+  }
+  auto read_one = [&](int stage, int kk, int buf, int n) {   // n in 0..7: A fragment n (n < 4) or B fragment n - 4
+    if (n < 4) fa[buf][n] = *reinterpret_cast<UDM_LDS const bf16x8_t*>((size_t)(fa_addr[kk] + stage * STAGE_BYTES + n * 4096));
+    else fb[buf][n - 4] = *reinterpret_cast<UDM_LDS const bf16x8_t*>((size_t)(fb_addr[kk] + stage * STAGE_BYTES + A_BYTES + (n - 4) * 4096));
+  };
+
+  const int nk = p.K / BK;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) dma_piece(0, 0, j);
+  if (nk > 1) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) dma_piece(1, 1, j);
+    wait_vmcnt<16>();
+  } else {
+    wait_vmcnt<0>();
+  }
+  __builtin_amdgcn_s_barrier();
+  read_frags(0, 0, 0);
+
+  // One K tile.  The issue order is written out and pinned (sched_barrier after every MFMA pair): per pair one fragment read of the
+  // next k-step and, in the last k-step, two LDS-DMA pieces of the tile after next -- an in-order wave can only hide those issue
+  // slots in the shadow of an MFMA that is already executing, never in a block of their own.
+  auto tile_body = [&](int kt, auto stage_c) {
+    // stage_c: 0 / 1 = steady-state tile (stage is a compile-time constant, a next tile and a refill always exist: no branches);
+    // -1 = one of the last three tiles (everything derived from kt at run time)
+    constexpr int STC = decltype(stage_c)::value;
+    const int ST = STC >= 0 ? STC : (kt & 1);
+    const bool HAS_NEXT = STC >= 0 || kt + 1 < nk, HAS_DMA = STC >= 0 || kt + 2 < nk;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const int buf = kk & 1;
+      if (kk == 3) {
+        // boundary: k-step 3's fragments are in registers; everything of this stage has been read
+        __builtin_amdgcn_sched_barrier(0);
+        if ((OPT & 16) && p.tl && blockIdx.x == 0 && kt >= 8 && kt < 16) {
+          const unsigned long long t = __builtin_amdgcn_s_memtime();
+          if (lane == 0) p.tl[(wave * 8 + kt - 8) * 4 + 0] = t;
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (OPT & 8) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if ((OPT & 16) && p.tl && blockIdx.x == 0 && kt >= 8 && kt < 16) {
+          __builtin_amdgcn_sched_barrier(0);
+          const unsigned long long t = __builtin_amdgcn_s_memtime();
+          if (lane == 0) p.tl[(wave * 8 + kt - 8) * 4 + 1] = t;
+        }
+      }
+#pragma unroll
+      for (int n = 0; n < 8; ++n) {   // MFMA pair n: accumulators (i, j) = (n >> 1, 2 (n & 1)) and (n >> 1, 2 (n & 1) + 1)
+        __builtin_amdgcn_sched_barrier(0);
+        const int i = n >> 1, j0 = 2 * (n & 1);
+        acc[i][j0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[buf][i], fb[buf][j0], acc[i][j0], 0, 0, 0);
+        if (kk == 3 && HAS_DMA && !(OPT & 4)) dma_piece(kt + 2, ST, 2 * n);
+        acc[i][j0 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[buf][i], fb[buf][j0 + 1], acc[i][j0 + 1], 0, 0, 0);
+        if (kk == 3 && HAS_DMA && !(OPT & 4)) dma_piece(kt + 2, ST, 2 * n + 1);
+        if (!(OPT & 2)) {   // (after the MFMAs: the waitcnt the compiler places before the first MFMA behind the barrier asm must not cover a new read)
+          if (kk < 3) read_one(ST, kk + 1, buf ^ 1, n);
+          else if (HAS_NEXT) read_one(ST ^ 1, 0, 0, n);
+        }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if ((OPT & 16) && p.tl && blockIdx.x == 0 && kt >= 8 && kt < 16) {
+      const unsigned long long t = __builtin_amdgcn_s_memtime();
+      if (lane == 0) p.tl[(wave * 8 + kt - 8) * 4 + 2] = t;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  int kt = 0;
+  for (; kt + 3 < nk; kt += 2) {
+    tile_body(kt, std::integral_constant<int, 0>{});
+    tile_body(kt + 1, std::integral_constant<int, 1>{});
+  }
+  for (; kt < nk; ++kt) tile_body(kt, std::integral_constant<int, -1>{});
+  __syncthreads();  // all LDS tile reads are done: the wave-private epilogue patches may overwrite stage memory
+
+  // epilogue: each 32 x 32 accumulator block goes through a wave-private 4 KiB LDS patch so a lane owns 4 consecutive columns of a row
+  float* patch0 = reinterpret_cast<float*>(smem) + wave * 2048;
+  const int er = lane >> 3, ec = (lane & 7) * 4;
+#pragma clang loop unroll(full)
+  for (int i = 0; i < 4; ++i)
+#pragma clang loop unroll(full)
+    for (int j = 0; j < 4; ++j) {
+      float* patch = patch0 + ((i * 4 + j) & 1) * 1024;
+#pragma clang loop unroll(full)
+      for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * hi) * 32 + l31] = acc[i][j][r];
+      const int gn = col0 + wn * 128 + j * 32 + ec;
+      const int gm0 = row0 + wm * 128 + i * 32 + er;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 v = *reinterpret_cast<const float4*>(patch + (q * 8 + er) * 32 + ec);
+        *reinterpret_cast<uint2*>(p.C + (long)(gm0 + q * 8) * p.ldc + gn) = make_uint2(pack2bf(v.x, v.y), pack2bf(v.z, v.w));
+      }
+    }
+}
+
+template <int OPT>
+int launch_quad(const XArgs& a0, hipStream_t stream) {
+  XArgs a = a0;
+  UDM_CHECK_ARG(a.M % 256 == 0 && a.N % 256 == 0, "udm_gemm_nt_bf16_variant(quad): M, N must be multiples of 256");
+  a.tiles_m = a.M / 256;
+  a.tiles_n = a.N / 256;
+  const size_t lds = 2 * 2 * 256 * BK * 2;
+  auto kern = gemm_nt_quad_kernel<OPT>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  if (OPT & 16) {
+    static int calls = 0;
+    if (++calls == 3) {
+      unsigned long long* buf = nullptr;
+      (void)hipMalloc(&buf, 4 * 8 * 4 * 8);
+      (void)hipMemset(buf, 0, 4 * 8 * 4 * 8);
+      a.tl = buf;
+      hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n), dim3(256), lds, stream, a);
+      (void)hipStreamSynchronize(stream);
+      static unsigned long long h[4 * 8 * 4];
+      (void)hipMemcpy(h, buf, sizeof(h), hipMemcpyDeviceToHost);
+      for (int w = 0; w < 4; ++w)
+        for (int t = 0; t < 8; ++t)
+          fprintf(stderr, "QTL wave %d kt %d: wait@%lld released@%lld end@%lld\n", w, t + 8, (long long)(h[(w * 8 + t) * 4] - h[0]), (long long)(h[(w * 8 + t) * 4 + 1] - h[0]),
+                  (long long)(h[(w * 8 + t) * 4 + 2] - h[0]));
+      (void)hipFree(buf);
+      return 0;
+    }
+  }
+  hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n), dim3(256), lds, stream, a);
+  UDM_CHECK_LAUNCH("udm_gemm_nt_bf16_variant(quad)");
+  return 0;
+}
+
 template <int BM, int BN, int WGM, int WGN, int STAGES>
 int launch(const XArgs& a0, hipStream_t stream) {
   XArgs a = a0;
@@ -327,7 +545,7 @@ int launch(const XArgs& a0, hipStream_t stream) {
 extern "C" int udm_gemm_nt_bf16_variant(int variant, const void* A, const void* B, void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb,
                                         int64_t ldc, hipStream_t stream) {
   UDM_CHECK_ARG(A && B && C && M > 0 && N > 0 && K > 0 && K % 64 == 0, "udm_gemm_nt_bf16_variant: bad arguments (K %% 64 == 0 required)");
-  XArgs a{(const bf16_t*)A, (const bf16_t*)B, (bf16_t*)C, (long)lda, (long)ldb, (long)ldc, (int)M, (int)N, (int)K, 0, 0};
+  XArgs a{(const bf16_t*)A, (const bf16_t*)B, (bf16_t*)C, (long)lda, (long)ldb, (long)ldc, (int)M, (int)N, (int)K, 0, 0, nullptr};
   switch (variant) {
     case 0: return launch<128, 128, 2, 2, 2>(a, stream);
     case 1: return launch<128, 128, 2, 2, 3>(a, stream);
@@ -352,6 +570,14 @@ extern "C" int udm_gemm_nt_bf16_variant(int variant, const void* A, const void* 
     case 22: return launch_stagger<320, 256, 2, 4, 2, 1>(a, stream);
     case 23: return launch_stagger<320, 256, 2, 4, 2, 3>(a, stream);
     case 24: return launch_stagger<320, 256, 2, 4, 1, 0>(a, stream);
+    case 30: return launch_quad<0>(a, stream);
+    case 31: return launch_quad<1>(a, stream);
+    case 32: return launch_quad<3>(a, stream);    // no fragment reads
+    case 33: return launch_quad<5>(a, stream);    // no refills
+    case 34: return launch_quad<7>(a, stream);    // neither
+    case 35: return launch_quad<15>(a, stream);   // neither, no barrier: bare MFMA stream
+    case 36: return launch_quad<9>(a, stream);    // no barrier only
+    case 37: return launch_quad<17>(a, stream);   // timeline
     default: udm_set_error("udm_gemm_nt_bf16_variant: unknown variant %d", variant); return 2;
   }
 }
