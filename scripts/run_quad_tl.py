@@ -6,8 +6,10 @@ from unidisc_amd import _lib
 lib = _lib.load()
 fn = lib.udm_gemm_nt_bf16_variant
 fn.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 3 + [ctypes.c_int64] * 6 + [ctypes.c_void_p]
-m, n, k = 8192, 2048, 10240
+m, n, k = 10240, 2048, 8192
 a = torch.randn(m, k, device="cuda").to(torch.bfloat16); b = torch.randn(n, k, device="cuda").to(torch.bfloat16)
 out = torch.empty(m, n, dtype=torch.bfloat16, device="cuda")
-for _ in range(4): fn(37, a.data_ptr(), b.data_ptr(), out.data_ptr(), m, n, k, k, k, n, torch.cuda.current_stream().cuda_stream)
+import sys as _s
+V = int(_s.argv[1]) if len(_s.argv) > 1 else 37
+for _ in range(4): fn(V, a.data_ptr(), b.data_ptr(), out.data_ptr(), m, n, k, k, k, n, torch.cuda.current_stream().cuda_stream)
 torch.cuda.synchronize()

@@ -226,6 +226,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_nt_stagger_kernel(XArgs p
   wait_vmcnt<0>();
   __builtin_amdgcn_s_barrier();
   if (late) __builtin_amdgcn_s_barrier();
+  unsigned long long tl[24];   // OPT bit 2: cycle stamps (kept in SGPRs, stored after the loop): K tiles 8, 9 x 4 phases x {reads done, barrier released, MFMAs done}
+#pragma unroll
+  for (int q = 0; q < 24; ++q) tl[q] = 0;
 
   for (int kt = 0; kt < nk; ++kt) {
     const char* As = smem + (kt & 1) * STAGE_BYTES;
@@ -252,7 +255,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_nt_stagger_kernel(XArgs p
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       if (ph == NPH - 1) wait_vmcnt<0>();
       __builtin_amdgcn_sched_barrier(0);
+      if ((OPT & 4) && NPH == 4) { if (kt == 8) tl[ph * 3] = __builtin_amdgcn_s_memtime(); if (kt == 9) tl[12 + ph * 3] = __builtin_amdgcn_s_memtime(); }
       __builtin_amdgcn_s_barrier();
+      if ((OPT & 4) && NPH == 4) { if (kt == 8) tl[ph * 3 + 1] = __builtin_amdgcn_s_memtime(); if (kt == 9) tl[12 + ph * 3 + 1] = __builtin_amdgcn_s_memtime(); }
       __builtin_amdgcn_sched_barrier(0);
       if (OPT & 2) __builtin_amdgcn_s_setprio(1);
       if ((OPT & 1) && ph < ISSUE_PH && more) {
@@ -274,11 +279,16 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_nt_stagger_kernel(XArgs p
       }
       if (OPT & 2) __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
+      if ((OPT & 4) && NPH == 4) { if (kt == 8) tl[ph * 3 + 2] = __builtin_amdgcn_s_memtime(); if (kt == 9) tl[12 + ph * 3 + 2] = __builtin_amdgcn_s_memtime(); }
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
     }
   }
   if (!late) __builtin_amdgcn_s_barrier();
+  if ((OPT & 4) && p.tl && blockIdx.x == 0 && lane == 0) {
+#pragma unroll
+    for (int q = 0; q < 24; ++q) p.tl[wave * 24 + q] = tl[q];
+  }
 
 #pragma unroll
   for (int i = 0; i < FM; ++i)
@@ -298,6 +308,28 @@ int launch_stagger(const XArgs& a0, hipStream_t stream) {
   a.tiles_m = (a.M + BM - 1) / BM;
   a.tiles_n = (a.N + BN - 1) / BN;
   const size_t lds = (size_t)2 * (BM + BN) * BK * 2;
+  if (OPT & 4) {
+    static int calls = 0;
+    if (++calls == 3) {
+      auto kern2 = gemm_nt_stagger_kernel<BM, BN, WGM, WGN, KKPP, OPT>;
+      (void)hipFuncSetAttribute((const void*)kern2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      unsigned long long* buf = nullptr;
+      (void)hipMalloc(&buf, 8 * 24 * 8);
+      (void)hipMemset(buf, 0, 8 * 24 * 8);
+      a.tl = buf;
+      hipLaunchKernelGGL(kern2, dim3(a.tiles_m * a.tiles_n), dim3(64 * WGM * WGN), lds, stream, a);
+      (void)hipStreamSynchronize(stream);
+      static unsigned long long h[8 * 24];
+      (void)hipMemcpy(h, buf, sizeof(h), hipMemcpyDeviceToHost);
+      for (int w = 0; w < 8; ++w) {
+        fprintf(stderr, "STL wave %d:", w);
+        for (int q = 0; q < 24; ++q) fprintf(stderr, " %lld", (long long)(h[w * 24 + q] - h[0]));
+        fprintf(stderr, "\n");
+      }
+      (void)hipFree(buf);
+      return 0;
+    }
+  }
   auto kern = gemm_nt_stagger_kernel<BM, BN, WGM, WGN, KKPP, OPT>;
   static bool attr_set = false;
   if (!attr_set) {
@@ -578,6 +610,7 @@ extern "C" int udm_gemm_nt_bf16_variant(int variant, const void* A, const void* 
     case 35: return launch_quad<15>(a, stream);   // neither, no barrier: bare MFMA stream
     case 36: return launch_quad<9>(a, stream);    // no barrier only
     case 37: return launch_quad<17>(a, stream);   // timeline
+    case 38: return launch_stagger<320, 256, 2, 4, 1, 5>(a, stream);   // production-like schedule with cycle stamps
     default: udm_set_error("udm_gemm_nt_bf16_variant: unknown variant %d", variant); return 2;
   }
 }
