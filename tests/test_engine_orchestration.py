@@ -64,3 +64,23 @@ def test_logits_path_and_state_dict(fake_k):
     finite = ref > -1e5
     assert torch.equal(lp.float() > -1e5, finite)
     assert torch.allclose(lp.float()[finite], ref[finite], atol=0.1, rtol=0.05)
+
+
+@pytest.mark.parametrize("name", ["b_small", "d_adaln_mm"])
+def test_masked_row_head_compaction_is_exact(name, fake_k):
+    """The vocabulary head restricted to the [MASK] rows must give the same loss and the same gradients as the full-row head."""
+    g = Golden(name)
+    res = []
+    for compact in (False, True):
+        diff = build_product(g, device="cpu")
+        diff.rng_device = "cpu"
+        diff.backbone.compact_head = compact
+        torch.manual_seed(g.case["step_seed"])
+        out = diff.training_step(g.batch(), 1)
+        out.loss.backward()
+        res.append((out.loss.detach().clone(), out.nlls.detach().clone(), {k: p.grad.clone() for k, p in diff.backbone.named_parameters() if p.grad is not None}))
+    (l0, n0, g0), (l1, n1, g1) = res
+    assert torch.allclose(l0, l1, rtol=1e-6, atol=1e-7) and torch.allclose(n0, n1, rtol=1e-6, atol=1e-7)
+    assert set(g0) == set(g1)
+    for k in g0:
+        assert torch.allclose(g0[k], g1[k], rtol=1e-5, atol=1e-7), k

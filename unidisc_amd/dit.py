@@ -226,6 +226,7 @@ class DIT(nn.Module, _HubMixin):
         # engine state
         self._lins: Optional[Dict[str, _Lin]] = None
         self._fwd_count = 0
+        self.compact_head = True          # "logp" mode: run the vocabulary head on the [MASK] rows only (exact: other rows have log p = 0)
         self.grad_ready_callback = None   # fn(flat_grads, lo, hi): elements [lo, hi) of this backward's flat fp32 gradient buffer are final
         self.grad_sync_finish = None      # fn(): called at the end of backward (e.g. make the compute stream wait for the all-reduces)
         self.recast_every_forward = True  # mirror autocast: fp32 master -> bf16 shadow on every training forward
@@ -366,6 +367,11 @@ class DIT(nn.Module, _HubMixin):
         else:
             emb_mod = mod_flat
         S = dict(B=B, L=L, ids=ids, modality=mod_flat, emb_mod=emb_mod, sid=sid, p_drop=p_drop, seed0=seed0, blocks=[])
+        # SUBS: only [MASK] rows have a non-zero log-probability (model.py:621-658), so in "logp" mode the vocabulary head (GEMM fwd,
+        # dgrad, wgrad and the cross-entropy) runs on the masked rows only.  Their number is data dependent: it is counted on a side
+        # stream NOW and only read back right before the head, when the host has already queued every block of this forward -- the
+        # device never waits for the host.
+        head_plan = self._plan_masked_rows(ids) if (mode == "logp" and self.compact_head) else None
 
         x = K.embedding_fwd(ids, self.vocab_embed.embedding.detach(), emb_mod if self.modality_embed is not None else None,
                             self.modality_embed.embedding.detach() if self.modality_embed is not None else None)
@@ -429,11 +435,11 @@ class DIT(nn.Module, _HubMixin):
         hf, rstdf, meanf = K.norm_fwd(x, fl.norm_final.weight.detach(), nt, L, mod=fmod, mod_idx=(0, 1), modality=mod_flat, any_img=any_img)
         head = lin["head"]
         V, Vp = self.vocab_size, head.outp
-        logits = torch.empty((M, Vp), dtype=BF16, device=dev)
-        K.gemm_nt(hf, head.w16, out=logits, N=V, epilogue=K.EPI_BIAS, bias=head.bias.detach())
-        if save:
-            S.update(x_final=x, hf=hf, rstdf=rstdf, meanf=meanf, fmod=fmod, logits=logits)
         if mode == "logits":
+            logits = torch.empty((M, Vp), dtype=BF16, device=dev)
+            K.gemm_nt(hf, head.w16, out=logits, N=V, epilogue=K.EPI_BIAS, bias=head.bias.detach())
+            if save:
+                S.update(x_final=x, hf=hf, rstdf=rstdf, meanf=meanf, fmod=fmod, logits=logits, head_rows=None)
             return logits[:, :V].view(B, L, V), S
         x0 = inp["x0"].contiguous().view(-1).to(torch.int64)
         restrict = bool(inp.get("restrict", False))
@@ -443,10 +449,60 @@ class DIT(nn.Module, _HubMixin):
             ce_mod = cm[None].expand(B, L).contiguous().view(-1)
         else:
             ce_mod = mod_flat
-        log_p, lse_ce = K.subs_ce_fwd(logits, x0, ids, ce_mod, V, self.text_vocab_size, self.mask_index, restrict)
+        ids_h = ids
+        head_rows = self._masked_rows(head_plan, M) if head_plan is not None else None
+        if head_rows is not None:  # compact operands: masked rows first, padded (with an unmasked row: zero loss, zero gradient) to a multiple of 64
+            rows_p, n_masked = head_rows
+            hf_h = hf.index_select(0, rows_p)
+            x0, ids_h = x0.index_select(0, rows_p), ids.index_select(0, rows_p)
+            ce_mod = ce_mod.index_select(0, rows_p) if ce_mod is not None else None
+        else:
+            hf_h = hf
+        logits = torch.empty((hf_h.shape[0], Vp), dtype=BF16, device=dev)
+        K.gemm_nt(hf_h, head.w16, out=logits, N=V, epilogue=K.EPI_BIAS, bias=head.bias.detach())
+        log_p, lse_ce = K.subs_ce_fwd(logits, x0, ids_h, ce_mod, V, self.text_vocab_size, self.mask_index, restrict)
+        if head_rows is not None:
+            full = torch.zeros(M, dtype=log_p.dtype, device=dev)
+            full.index_copy_(0, rows_p[:n_masked], log_p[:n_masked])
+            log_p = full
         if save:
-            S.update(x0=x0, ce_mod=ce_mod, restrict=restrict, lse_ce=lse_ce)
+            S.update(x_final=x, hf=hf_h, rstdf=rstdf, meanf=meanf, fmod=fmod, logits=logits, head_rows=head_rows, ids_h=ids_h,
+                     x0=x0, ce_mod=ce_mod, restrict=restrict, lse_ce=lse_ce)
         return log_p.view(B, L), S
+
+    def _plan_masked_rows(self, ids):
+        """Queue (without synchronising) a stable partition of the row indices with the [MASK] rows first and their count."""
+        is_mask = ids == self.mask_index
+        if not ids.is_cuda:  # CPU orchestration tests
+            return dict(order=torch.argsort((~is_mask).to(torch.int8), stable=True), count=int(is_mask.sum()), event=None)
+        main = torch.cuda.current_stream()
+        if getattr(self, "_side_stream", None) is None:
+            self._side_stream = torch.cuda.Stream()
+            self._count_host = torch.zeros(1, dtype=torch.int64).pin_memory()
+        side = self._side_stream
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            order = torch.argsort((~is_mask).to(torch.int8), stable=True)
+            self._count_host.copy_(is_mask.sum().view(1), non_blocking=True)
+            event = torch.cuda.Event()
+            event.record(side)
+        is_mask.record_stream(side)
+        order.record_stream(main)
+        return dict(order=order, count=None, event=event)
+
+    def _masked_rows(self, plan, M):
+        """(row indices: the [MASK] rows, then as many unmasked rows as pad the list to a multiple of 64; number of masked rows), or
+        None when compaction would not shrink the head.  Unmasked rows have zero loss and zero gradient, so padding with them is exact."""
+        if plan["event"] is not None:
+            plan["event"].synchronize()
+            n = int(self._count_host[0])
+            torch.cuda.current_stream().wait_stream(self._side_stream)
+        else:
+            n = plan["count"]
+        n_pad = _ceil(max(n, 1), 64)
+        if n_pad >= M:
+            return None
+        return plan["order"][:n_pad], n
 
     # -------------------------------------------------------------------------------------------- engine: backward
     def _alloc_grads(self, params, dev):
@@ -518,15 +574,23 @@ class DIT(nn.Module, _HubMixin):
         logits = S["logits"]
 
         # ---- head: d logits -> dhf, dW_head, db_head
+        head_rows = S.get("head_rows")
         if mode == "logp":
             g = grad_out.contiguous().view(-1).to(F32)
-            K.subs_ce_bwd(logits, S["x0"], S["ids"], S["ce_mod"], S["lse_ce"], g, V, self.text_vocab_size, self.mask_index, S["restrict"])
+            if head_rows is not None:
+                g = g.index_select(0, head_rows[0])
+            K.subs_ce_bwd(logits, S["x0"], S["ids_h"], S["ce_mod"], S["lse_ce"], g, V, self.text_vocab_size, self.mask_index, S["restrict"])
             dlogits = logits
         else:
             dlogits = torch.zeros_like(logits)
             dlogits[:, :V].copy_(grad_out.reshape(M, V))
         dhf = K.gemm_nt(dlogits, head.w16t, N=d)
         self._wgrad(dlogits, S["hf"], head, G)
+        if head_rows is not None:  # scatter the masked rows' gradient back; every other row of d(final norm output) is exactly zero
+            rows_p, n_masked = head_rows
+            full = torch.zeros((M, d), dtype=dhf.dtype, device=dev)
+            full.index_copy_(0, rows_p[:n_masked], dhf[:n_masked])
+            dhf = full
         del dlogits
         S["logits"] = None
 
