@@ -35,6 +35,23 @@ WORKLOADS = {
 }
 
 
+def pmc_traffic(kernel_prefix):
+    """HBM bytes per launch of the dominant kernel (launch-weighted mean over its template instances) from the committed PMC pass
+    (scripts/gpu_pmc_bench.sh: separate FETCH_SIZE / WRITE_SIZE runs of this same command, unit and gfx950 corrections of the guide).
+    PMC counters cannot be collected from inside the timed run, so the figure is read from profiles/; None if the file is absent."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_hbm_traffic_per_kernel*.json")))
+    if not files:
+        return None, None
+    try:
+        data = json.load(open(files[-1]))
+        rows = [v for k, v in data.items() if k.startswith(kernel_prefix)]
+        n = sum(v["launches"] for v in rows)
+        return (sum(v["launches"] * v["hbm_bytes_per_launch"] for v in rows) / n if n else None), os.path.relpath(files[-1], ROOT)
+    except Exception:
+        return None, None
+
+
 def flops_per_token(n_blocks, d, V, L_att):
     """F_tok = 6·P_mm + 12·n·L_att·d with P_mm = n·12d² + d·V (matmul weights only; no recompute credit)."""
     p_mm = n_blocks * 12 * d * d + d * V
@@ -236,8 +253,9 @@ def main():
     gs = timer.summary()
     if gs:
         ach = gs["flops"] / (gs["total_ms"] * 1e-3) / 1e12
+        traffic, traffic_src = pmc_traffic("gemm_nt_stagger_kernel") if args.workload == "unidisc-1.4b-l1280" else (None, None)
         result["roofline"] = {"bound": "mfma", "kernel": "gemm_nt_stagger_kernel (udm_gemm_nt_bf16 / udm_gemm_tn_bf16)", "achieved": ach, "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s",
-                              "frac": ach / PEAK_BF16_DENSE_TFLOPS, "traffic": None, "launches": gs["launches"],
+                              "frac": ach / PEAK_BF16_DENSE_TFLOPS, "traffic": traffic, "traffic_source": traffic_src, "launches": gs["launches"],
                               "avg_launch_ms": gs["total_ms"] / gs["launches"], "share_of_step_time": gs["total_ms"] * 1e-3 / dt}
     if sync is not None:
         result["allreduce_bytes_per_step"] = sync.bytes_on_wire // (args.steps + args.warmup)

@@ -643,7 +643,7 @@ int choose_tile(long M, long N, long K, long lda, long ldb) {
     const long slots = c == 0 ? 512 : 256;  // co-resident blocks on the chip
     const long rounds = (tm * tn + slots - 1) / slots;
     const double t = rounds * (double)bms[c] * (c == 0 ? 128 : 256) * (c == 0 ? 2.0 : 1.0) / eff[c];  // time ~ rounds x tile area (2 blocks/CU share a CU)
-    if (t < best) { best = t; pick = c == 0 ? 0 : bms[c]; }
+    if (t < best || (t == best && c > 0)) { best = t; pick = c == 0 ? 0 : bms[c]; }  // ties go to the larger tile (fewer operand re-reads)
   }
   return pick;
 }

@@ -180,7 +180,7 @@ def residual_bwd(dx, branch, L, *, w_b=None, rstd=None, mean=None, norm_type=NOR
     use = gate_idx is not None and mod is not None
     (gate,), ms = _mod_ptrs(mod if use else None, (gate_idx,), d)
     (dgate,), _ = _mod_ptrs(dmod if use else None, (gate_idx,), d)
-    ws = _scratch(1024 * d, dx.device) if (w_b is not None and d >= 2048) else None
+    ws = _scratch(1536 * d, dx.device) if (w_b is not None and d >= 2048) else None
     _lib.call("udm_residual_bwd", _p(dx), _p(branch), _p(dbranch), _p(w_b), _p(rstd), _p(mean), gate, ms, _p(modality), _p(dw_b), dgate, M, d, L,
               norm_type, float(p_drop), int(seed), _p(ws), ws.numel() if ws is not None else 0, _s())
     return dbranch
