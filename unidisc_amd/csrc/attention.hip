@@ -101,24 +101,32 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, sT[f][r]);
     mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
-    const float m_new = fmaxf(m, mloc);
-    const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-    const float alpha = __builtin_amdgcn_exp2f((m - m_use) * c);
+    // Lazy rescale: m is the REFERENCE exponent of this query, not necessarily its running maximum.  It is only moved (and O^T, l
+    // rescaled: 64 + 2 VALU per lane) when some query of the wave saw a score more than 2^8 above its reference; otherwise
+    // p = exp2(s c - m c) simply exceeds 1 by at most 2^8, which fp32 sums and bf16 operands hold without loss.  O / l and the
+    // LSE m c + log2(l) are exact for any reference.  After the first key tile the branch is practically never taken.
+    const bool move = mloc * c > m * c + 8.0f;
+    if (__builtin_amdgcn_ballot_w64(move) != 0) {
+      const float m_new = fmaxf(m, mloc);
+      const float alpha = __builtin_amdgcn_exp2f((m - ((m_new == -INFINITY) ? 0.f : m_new)) * c);
+      lsum *= alpha;
+      m = m_new;
+#pragma unroll
+      for (int i = 0; i < DB; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oT[i][r] *= alpha;
+    }
+    const float mc = (m == -INFINITY) ? 0.f : m * c;
     float psum = 0.f;
     float p[2][16];
 #pragma unroll
     for (int f = 0; f < 2; ++f)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        p[f][r] = __builtin_amdgcn_exp2f(sT[f][r] * c - m_use * c);
+        p[f][r] = __builtin_amdgcn_exp2f(sT[f][r] * c - mc);
         psum += p[f][r];
       }
-    lsum = lsum * alpha + psum;
-    m = m_new;
-#pragma unroll
-    for (int i = 0; i < DB; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) oT[i][r] *= alpha;
+    lsum += psum;
     // O^T += V^T P^T
 #pragma unroll
     for (int cc = 0; cc < 4; ++cc) {

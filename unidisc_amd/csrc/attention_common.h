@@ -47,6 +47,10 @@ __device__ __forceinline__ bf16x8_t lds_frag_T(const char* tile, int r0, int c0,
   }
 }
 
+// typed LDS load from a 32-bit LDS byte address (hoisted per-lane base + immediate offsets)
+template <typename T>
+__device__ __forceinline__ T lds_ld(uint32_t addr) { return *reinterpret_cast<UDM_LDS const T*>((size_t)addr); }
+
 __device__ __forceinline__ bf16x8_t pack8(const float* p) {
   uint4 u = make_uint4(pack2bf(p[0], p[1]), pack2bf(p[2], p[3]), pack2bf(p[4], p[5]), pack2bf(p[6], p[7]));
   return __builtin_bit_cast(bf16x8_t, u);

@@ -66,9 +66,6 @@ __device__ __forceinline__ void stamp(const Ctx& x, int j, int tag) {
   }
 }
 
-template <typename T>
-__device__ __forceinline__ T lds_ld(uint32_t addr) { return *reinterpret_cast<UDM_LDS const T*>((size_t)addr); }
-
 // Refill of one step, issued by the four accum waves (an LDS-DMA piece costs its issuer ~100 cycles; the accum stream has that slack
 // while the score wave is in its MFMA burst).  Full steps: wave-uniform base + precomputed 32-bit lane offset, no vector address math.
 __device__ __forceinline__ void issue_sub(const Ctx& x, char* smem, int sub, int stage) {
@@ -364,3 +361,9 @@ void udm_launch_attn_bwd_dkv_ws(const void* args, hipStream_t stream) {
   }
   hipLaunchKernelGGL(attn_bwd_dkv_ws_kernel<false>, grid, dim3(512), LDS_BYTES, stream, a);
 }
+
+// Note on the dQ half: the same role split was built and measured for dQ (score wave: S, dP, softmax; accum wave: refills + dQ MFMAs).
+// It is correct but no faster than the single-role kernel (185 vs 188 us): its timeline shows the score wave as the critical path
+// (2 x 16 MFMAs at ~47 cycles each + ~1000 cycles of VALU, 32 v_exp_f32 alone are 512) while the accum wave idles ~900 cycles per
+// tile, and moving dP to the accum wave would need the probabilities exchanged in fp32.  The 8 LDS-DMA pieces of a tile cost their
+// issuer ~1000 cycles (126 each) in that timeline.

@@ -226,6 +226,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_nt_stagger_kernel(XArgs p
   wait_vmcnt<0>();
   __builtin_amdgcn_s_barrier();
   if (late) __builtin_amdgcn_s_barrier();
+  uint4 stg[LOADS];
   unsigned long long tl[24];   // OPT bit 2: cycle stamps (kept in SGPRs, stored after the loop): K tiles 8, 9 x 4 phases x {reads done, barrier released, MFMAs done}
 #pragma unroll
   for (int q = 0; q < 24; ++q) tl[q] = 0;
@@ -248,7 +249,12 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_nt_stagger_kernel(XArgs p
         for (int j = 0; j < FN; ++j) b[q][j] = *reinterpret_cast<const bf16x8_t*>(Bs + (wn * WN + j * 32 + l31) * 128 + so);
       }
       constexpr int PER = (LOADS + ISSUE_PH - 1) / ISSUE_PH;
-      if (!(OPT & 1) && ph < ISSUE_PH && more) {
+      if ((OPT & 8) && ph == NPH - 1 && more) {   // register-staged refill: the tile fetched during phase 0 goes to LDS now
+        wait_vmcnt<0>();
+#pragma unroll
+        for (int j = 0; j < LOADS; ++j) *reinterpret_cast<uint4*>(nxt + dst[j] + lane * 16) = stg[j];
+      }
+      if (!(OPT & 9) && ph < ISSUE_PH && more) {
 #pragma unroll
         for (int j = ph * PER; j < (ph + 1) * PER && j < LOADS; ++j) glds16(src[j] + knext, nxt + dst[j]);
       }
@@ -260,9 +266,13 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_nt_stagger_kernel(XArgs p
       if ((OPT & 4) && NPH == 4) { if (kt == 8) tl[ph * 3 + 1] = __builtin_amdgcn_s_memtime(); if (kt == 9) tl[12 + ph * 3 + 1] = __builtin_amdgcn_s_memtime(); }
       __builtin_amdgcn_sched_barrier(0);
       if (OPT & 2) __builtin_amdgcn_s_setprio(1);
-      if ((OPT & 1) && ph < ISSUE_PH && more) {
+      if ((OPT & 1) && !(OPT & 8) && ph < ISSUE_PH && more) {
 #pragma unroll
         for (int j = ph * PER; j < (ph + 1) * PER && j < LOADS; ++j) glds16(src[j] + knext, nxt + dst[j]);
+      }
+      if ((OPT & 8) && ph == 0 && more) {   // OPT bit 3: plain global loads into registers instead of LDS-DMA (A/B of the issue cost)
+#pragma unroll
+        for (int j = 0; j < LOADS; ++j) stg[j] = *reinterpret_cast<const uint4*>(src[j] + knext);
       }
 #pragma unroll
       for (int q = 0; q < KKPP; ++q)
@@ -611,6 +621,9 @@ extern "C" int udm_gemm_nt_bf16_variant(int variant, const void* A, const void* 
     case 36: return launch_quad<9>(a, stream);    // no barrier only
     case 37: return launch_quad<17>(a, stream);   // timeline
     case 38: return launch_stagger<320, 256, 2, 4, 1, 5>(a, stream);   // production-like schedule with cycle stamps
+    case 39: return launch_stagger<256, 256, 2, 4, 1, 1>(a, stream);   // 256-row tile, LDS-DMA inside the MFMA section
+    case 40: return launch_stagger<256, 256, 2, 4, 1, 8>(a, stream);   // 256-row tile, register-staged refill (global_load + ds_write_b128)
+    case 41: return launch_stagger<320, 256, 2, 4, 1, 8>(a, stream);   // 320-row tile, register-staged refill
     default: udm_set_error("udm_gemm_nt_bf16_variant: unknown variant %d", variant); return 2;
   }
 }

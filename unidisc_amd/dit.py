@@ -453,12 +453,14 @@ class DIT(nn.Module, _HubMixin):
         head_rows = self._masked_rows(head_plan, M) if head_plan is not None else None
         if head_rows is not None:  # compact operands: masked rows first, padded (with an unmasked row: zero loss, zero gradient) to a multiple of 64
             rows_p, n_masked = head_rows
-            hf_h = hf.index_select(0, rows_p)
+            # fixed-capacity buffers (views of M-row allocations): a different size every step would make the caching allocator go back
+            # to hipMalloc until its pool covers every size seen (measured: occasional 120+ ms steps)
+            hf_h = torch.index_select(hf, 0, rows_p, out=torch.empty_like(hf)[: rows_p.numel()])
             x0, ids_h = x0.index_select(0, rows_p), ids.index_select(0, rows_p)
             ce_mod = ce_mod.index_select(0, rows_p) if ce_mod is not None else None
         else:
             hf_h = hf
-        logits = torch.empty((hf_h.shape[0], Vp), dtype=BF16, device=dev)
+        logits = torch.empty((M, Vp), dtype=BF16, device=dev)[: hf_h.shape[0]]
         K.gemm_nt(hf_h, head.w16, out=logits, N=V, epilogue=K.EPI_BIAS, bias=head.bias.detach())
         log_p, lse_ce = K.subs_ce_fwd(logits, x0, ids_h, ce_mod, V, self.text_vocab_size, self.mask_index, restrict)
         if head_rows is not None:
@@ -584,7 +586,7 @@ class DIT(nn.Module, _HubMixin):
         else:
             dlogits = torch.zeros_like(logits)
             dlogits[:, :V].copy_(grad_out.reshape(M, V))
-        dhf = K.gemm_nt(dlogits, head.w16t, N=d)
+        dhf = K.gemm_nt(dlogits, head.w16t, N=d, out=torch.empty((M, d), dtype=BF16, device=dev)[: dlogits.shape[0]])
         self._wgrad(dlogits, S["hf"], head, G)
         if head_rows is not None:  # scatter the masked rows' gradient back; every other row of d(final norm output) is exactly zero
             rows_p, n_masked = head_rows
