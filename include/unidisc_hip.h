@@ -73,6 +73,11 @@ int udm_norm_bwd(const void* dy, const float* x, const float* rstd, const float*
 int udm_residual_fwd(const float* x_in, const void* branch, float* x_out, const float* w_b, float* rstd_b, float* mean_b, const void* gate,
                      int64_t mod_stride, const int64_t* modality, int64_t M, int64_t d, int64_t L, int norm_type, float eps, float p_drop, uint64_t seed,
                      hipStream_t stream);
+/* the same add with the NEXT (unmodulated) pre-norm fused: h_out = norm(x_out; w_next) as bf16 (norm2 of the block `dit.py:1008`, norm1 of the next
+ * block `:985`, norm_final `:1091` when there is no adaLN) -- x_out is normalised while its row is still in registers */
+int udm_residual_norm_fwd(const float* x_in, const void* branch, float* x_out, const float* w_b, float* rstd_b, float* mean_b, const void* gate,
+                          int64_t mod_stride, const int64_t* modality, int64_t M, int64_t d, int64_t L, int norm_type, float eps, float p_drop,
+                          uint64_t seed, const float* w_next, void* h_out, float* rstd_next, float* mean_next, hipStream_t stream);
 int udm_residual_bwd(const float* dx, const void* branch, void* dbranch, const float* w_b, const float* rstd_b, const float* mean_b, const void* gate,
                      int64_t mod_stride, const int64_t* modality, float* dw_b, float* dgate, int64_t M, int64_t d, int64_t L, int norm_type, float p_drop,
                      uint64_t seed, float* ws, int64_t ws_elems, hipStream_t stream); /* ws: optional fp32 scratch (>= 1024*d) for a two-phase dw_b reduction */

@@ -141,10 +141,12 @@ def _branch(x_in, br, L, w_b, norm_type, mod, gate_idx, modality):
     return x_in + out, rstd, mean
 
 
-def residual_fwd(x_in, branch, L, *, w_b=None, norm_type=NORM_RMS, mod=None, gate_idx=None, modality=None, p_drop=0.0, seed=0):
+def residual_fwd(x_in, branch, L, *, w_b=None, norm_type=NORM_RMS, mod=None, gate_idx=None, modality=None, p_drop=0.0, seed=0, next_w=None):
     assert p_drop == 0.0, "fake kernels: dropout not emulated"
     out, rstd, mean = _branch(x_in, branch.float(), L, w_b, norm_type, mod.float() if mod is not None else None, gate_idx, modality)
-    return out, rstd, mean
+    if next_w is None:
+        return out, rstd, mean
+    return out, rstd, mean, norm_fwd(out, next_w, norm_type, L)
 
 
 @torch.enable_grad()

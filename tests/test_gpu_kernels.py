@@ -233,6 +233,27 @@ def test_residual_fwd_bwd(K, d, variant):
         assert rel_err(dmod.cpu(), dmod_r) < 5e-3
 
 
+@pytest.mark.parametrize("d", [64, 768, 2048])
+@pytest.mark.parametrize("variant", ["plain", "sandwich_rms", "sandwich_ln", "dropout"])
+def test_residual_with_fused_next_norm_equals_separate_kernels(K, d, variant):
+    """udm_residual_norm_fwd must be bit-identical to udm_residual_fwd followed by udm_norm_fwd (same arithmetic, row kept in registers)."""
+    B, L = 2, 24
+    M = B * L
+    x_in, br = rnd(M, d, seed=71).to(DEV), bf(rnd(M, d, seed=72, scale=1.5)).to(DEV)
+    w_b = (1 + 0.1 * rnd(d, seed=73)).to(DEV) if variant.startswith("sandwich") else None
+    nt = 1 if variant == "sandwich_ln" else 0
+    w_n = (1 + 0.1 * rnd(d, seed=74)).to(DEV)
+    kw = dict(w_b=w_b, norm_type=nt, p_drop=0.2 if variant == "dropout" else 0.0, seed=99)
+    x1, r1, m1 = K.residual_fwd(x_in, br, L, **kw)
+    h1, rn1, mn1 = K.norm_fwd(x1, w_n, nt, L)
+    x2, r2, m2, (h2, rn2, mn2) = K.residual_fwd(x_in, br, L, next_w=w_n, **kw)
+    assert torch.equal(x1, x2) and torch.equal(h1, h2) and torch.equal(rn1, rn2)
+    if w_b is not None:
+        assert torch.equal(r1, r2)
+    if nt == 1:
+        assert torch.equal(mn1, mn2) and torch.equal(m1, m2)
+
+
 def test_residual_dropout_mask_consistent(K):
     M, d, L, p = 64, 256, 32, 0.25
     x_in, br, dx = torch.zeros(M, d), bf(torch.ones(M, d)), torch.ones(M, d)

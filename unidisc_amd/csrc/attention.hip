@@ -248,13 +248,20 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
         sT = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag(Ks, off), qf[ks], sT, 0, 0, 0);
         dpT = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag(Vs, off), dof[ks], dpT, 0, 0, 0);
       }
+      // per-element masks only for document masks and the ragged last tile: full tiles have no out-of-range keys, and an out-of-range
+      // QUERY has lse = +inf (p = 0) and zero operands
+      if (HAS_SID || kv0 + BKV > a.L) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int kl = f * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        bool ok = (kv0 + kl < a.L) && q_ok;
-        if (HAS_SID) ok = ok && (sidk[kl] == sid_q) && (sid_q >= 0);
-        const float pv = ok ? __builtin_amdgcn_exp2f(sT[r] * c - lse_q) : 0.f;
-        ds[f][r] = pv * (dpT[r] - delta_q);
+        for (int r = 0; r < 16; ++r) {
+          const int kl = f * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          bool ok = (kv0 + kl < a.L) && q_ok;
+          if (HAS_SID) ok = ok && (sidk[kl] == sid_q) && (sid_q >= 0);
+          const float pv = ok ? __builtin_amdgcn_exp2f(sT[r] * c - lse_q) : 0.f;
+          ds[f][r] = pv * (dpT[r] - delta_q);
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ds[f][r] = __builtin_amdgcn_exp2f(sT[r] * c - lse_q) * (dpT[r] - delta_q);
       }
     }
 #pragma unroll

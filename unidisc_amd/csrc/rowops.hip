@@ -247,6 +247,11 @@ struct ResidArgs {
   int M, d, L, norm_type;
   float eps, p_drop;
   uint64_t seed;
+  // optional fused NEXT norm (unmodulated): h_out = norm(x_out; w_n) as bf16 -- saves the separate norm kernel's read of x_out
+  const float* w_n;
+  bf16_t* h_out;
+  float* rstd_n;
+  float* mean_n;
 };
 
 template <int NCH>
@@ -331,6 +336,50 @@ __global__ __launch_bounds__(256) void residual_fwd_kernel(ResidArgs a) {
 #pragma unroll
       for (int k = 0; k < 8; ++k) o[k] += xi[k];
       store8_f32(a.x_out + row * a.d + c, o);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[i][k] = o[k];   // the row of x_out stays in registers for the fused next norm
+    }
+    if (a.w_n) {  // same arithmetic as norm_fwd_kernel (unmodulated)
+      float t1 = 0.f;
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) {
+        const int c = (i * 64 + lane) * 8;
+        if (c < a.d) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) t1 += (a.norm_type == 0) ? v[i][k] * v[i][k] : v[i][k];
+        }
+      }
+      t1 = wave_sum(t1);
+      float mu2 = 0.f, rs2;
+      if (a.norm_type == 0) {
+        rs2 = rsqrtf(t1 / a.d + a.eps);
+      } else {
+        mu2 = t1 / a.d;
+        float t2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+          const int c = (i * 64 + lane) * 8;
+          if (c < a.d) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { float t = v[i][k] - mu2; t2 += t * t; }
+          }
+        }
+        rs2 = rsqrtf(wave_sum(t2) / a.d + a.eps);
+      }
+      if (lane == 0) {
+        a.rstd_n[row] = rs2;
+        if (a.mean_n) a.mean_n[row] = mu2;
+      }
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) {
+        const int c = (i * 64 + lane) * 8;
+        if (c >= a.d) continue;
+        float w8[8], o[8];
+        load8_f32(a.w_n + c, w8);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[k] = (v[i][k] - mu2) * rs2 * w8[k];
+        store8_bf16(a.h_out + row * a.d + c, o);
+      }
     }
   }
 }
@@ -1228,10 +1277,27 @@ extern "C" int udm_residual_fwd(const float* x_in, const void* branch, float* x_
   UDM_CHECK_ARG(!(w_b && norm_type) || mean_b, "udm_residual_fwd: sandwich LayerNorm needs mean buffer");
   UDM_CHECK_ARG(p_drop >= 0.f && p_drop < 1.f, "udm_residual_fwd: dropout p out of range");
   ResidArgs a{x_in, (const bf16_t*)branch, x_out, w_b, rstd_b, (w_b && norm_type) ? mean_b : nullptr, (const bf16_t*)gate, modality, (long)mod_stride,
-              (int)M, (int)d, (int)L, norm_type, eps, p_drop, seed};
+              (int)M, (int)d, (int)L, norm_type, eps, p_drop, seed, nullptr, nullptr, nullptr, nullptr};
   int nch = nch_for(d); if (nch > 4) nch = 8;
   DISPATCH_NCH(nch, residual_fwd_kernel, grid_rows(M), stream, a);
   UDM_CHECK_LAUNCH("udm_residual_fwd");
+  return 0;
+}
+
+extern "C" int udm_residual_norm_fwd(const float* x_in, const void* branch, float* x_out, const float* w_b, float* rstd_b, float* mean_b, const void* gate,
+                                     int64_t mod_stride, const int64_t* modality, int64_t M, int64_t d, int64_t L, int norm_type, float eps, float p_drop,
+                                     uint64_t seed, const float* w_next, void* h_out, float* rstd_next, float* mean_next, hipStream_t stream) {
+  UDM_CHECK_ARG(x_in && branch && x_out && w_next && h_out && rstd_next, "udm_residual_norm_fwd: null pointer");
+  UDM_CHECK_ARG(M > 0 && d > 0 && d % 8 == 0 && L > 0, "udm_residual_norm_fwd: bad shape");
+  UDM_CHECK_ARG(!w_b || rstd_b, "udm_residual_norm_fwd: sandwich norm needs rstd buffer");
+  UDM_CHECK_ARG(!(w_b && norm_type) || mean_b, "udm_residual_norm_fwd: sandwich LayerNorm needs mean buffer");
+  UDM_CHECK_ARG(!norm_type || mean_next, "udm_residual_norm_fwd: LayerNorm needs mean_next");
+  UDM_CHECK_ARG(p_drop >= 0.f && p_drop < 1.f, "udm_residual_norm_fwd: dropout p out of range");
+  ResidArgs a{x_in, (const bf16_t*)branch, x_out, w_b, rstd_b, (w_b && norm_type) ? mean_b : nullptr, (const bf16_t*)gate, modality, (long)mod_stride,
+              (int)M, (int)d, (int)L, norm_type, eps, p_drop, seed, w_next, (bf16_t*)h_out, rstd_next, norm_type ? mean_next : nullptr};
+  int nch = nch_for(d); if (nch > 4) nch = 8;
+  DISPATCH_NCH(nch, residual_fwd_kernel, grid_rows(M), stream, a);
+  UDM_CHECK_LAUNCH("udm_residual_norm_fwd");
   return 0;
 }
 

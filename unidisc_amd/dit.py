@@ -395,6 +395,7 @@ class DIT(nn.Module, _HubMixin):
                 any_img = (mod_flat != 0).any().to(torch.int32).reshape(1)
             S.update(Bp=Bp, te=te, l1=l1, s1=s1, l2=l2, c=c, any_img=any_img)
 
+        pre = None
         for i, blk in enumerate(self.blocks):
             R = {}
             mod = None
@@ -402,7 +403,10 @@ class DIT(nn.Module, _HubMixin):
                 a = lin[f"{i}.ada"]
                 mod = K.gemm_nt(S["c"], a.w16, N=a.out, epilogue=K.EPI_BIAS, bias=a.bias.detach())  # [Bp, 6d] bf16
                 R["mod"] = mod
-            h1, rstd1, mean1 = K.norm_fwd(x, blk.norm1.weight.detach(), nt, L, mod=mod, mod_idx=(0, 1), modality=mod_flat, any_img=any_img)
+            if pre is not None:  # norm1 came fused out of the previous block's MLP residual add
+                h1, rstd1, mean1 = pre
+            else:
+                h1, rstd1, mean1 = K.norm_fwd(x, blk.norm1.weight.detach(), nt, L, mod=mod, mod_idx=(0, 1), modality=mod_flat, any_img=any_img)
             qkv = K.gemm_nt(h1, lin[f"{i}.qkv"].w16, N=3 * d)
             at = blk.attention
             qkr, qstats = K.qknorm_rope_fwd(qkv, cos, sin, L, D, gq=at.q_norm.weight.detach() if self.qk_norm else None,
@@ -410,17 +414,28 @@ class DIT(nn.Module, _HubMixin):
                                             bk=at.k_norm.bias.detach() if self.qk_norm else None)
             o, lse = K.attention_fwd(qkr, qkv, B, L, H, D, sid)
             a_out = K.gemm_nt(o, lin[f"{i}.out"].w16, N=d)
+            # Without adaLN the next pre-norm is unmodulated and is fused into the residual add (x_out is normalised while in registers)
+            fuse_w2 = None if tc else blk.norm2.weight.detach()
             if sw:  # x = x_skip + pre_residual_norm(attn)   (dit.py:993-994; no gate, no dropout)
-                x_mid, rstd_a, mean_a = K.residual_fwd(x, a_out, L, w_b=blk.pre_residual_norm.weight.detach(), norm_type=nt)
+                res = K.residual_fwd(x, a_out, L, w_b=blk.pre_residual_norm.weight.detach(), norm_type=nt, next_w=fuse_w2)
             else:   # bias_dropout_add_scale with gate_msa on every token (Attention.time_conditioning is never set: dit.py:533,884)
-                x_mid, rstd_a, mean_a = K.residual_fwd(x, a_out, L, mod=mod, gate_idx=2 if tc else None, p_drop=p_drop, seed=seed0 + 4 * i + 1)
-            h2, rstd2, mean2 = K.norm_fwd(x_mid, blk.norm2.weight.detach(), nt, L, mod=mod, mod_idx=(3, 4), modality=mod_flat, any_img=any_img)
+                res = K.residual_fwd(x, a_out, L, mod=mod, gate_idx=2 if tc else None, p_drop=p_drop, seed=seed0 + 4 * i + 1, next_w=fuse_w2)
+            x_mid, rstd_a, mean_a = res[:3]
+            if fuse_w2 is not None:
+                h2, rstd2, mean2 = res[3]
+            else:
+                h2, rstd2, mean2 = K.norm_fwd(x_mid, blk.norm2.weight.detach(), nt, L, mod=mod, mod_idx=(3, 4), modality=mod_flat, any_img=any_img)
             f1, f2 = lin[f"{i}.fc1"], lin[f"{i}.fc2"]
             u1 = torch.empty((M, 4 * d), dtype=BF16, device=dev)
             g = K.gemm_nt(h2, f1.w16, N=4 * d, epilogue=K.EPI_BIAS_GELU, bias=f1.bias.detach(), aux=u1)
             u2 = K.gemm_nt(g, f2.w16, N=d, epilogue=K.EPI_BIAS, bias=f2.bias.detach())
-            x_out, rstd_m, mean_m = K.residual_fwd(x_mid, u2, L, w_b=blk.post_ff_norm.weight.detach() if sw else None, norm_type=nt, mod=mod,
-                                                   gate_idx=5 if tc else None, modality=mod_flat if tc else None, p_drop=p_drop, seed=seed0 + 4 * i + 2)
+            nxt_w = None
+            if not tc:  # the consumer of x_out: norm1 of the next block, or norm_final
+                nxt_w = (self.blocks[i + 1].norm1.weight if i + 1 < self.n_blocks else self.output_layer.norm_final.weight).detach()
+            res = K.residual_fwd(x_mid, u2, L, w_b=blk.post_ff_norm.weight.detach() if sw else None, norm_type=nt, mod=mod,
+                                 gate_idx=5 if tc else None, modality=mod_flat if tc else None, p_drop=p_drop, seed=seed0 + 4 * i + 2, next_w=nxt_w)
+            x_out, rstd_m, mean_m = res[:3]
+            pre = res[3] if nxt_w is not None else None
             if save:
                 R.update(x_in=x, h1=h1, rstd1=rstd1, mean1=mean1, qkv=qkv, qkr=qkr, qstats=qstats, o=o, lse=lse, a_out=a_out, rstd_a=rstd_a, mean_a=mean_a,
                          x_mid=x_mid, h2=h2, rstd2=rstd2, mean2=mean2, u1=u1, g=g, u2=u2, rstd_m=rstd_m, mean_m=mean_m)
@@ -432,7 +447,10 @@ class DIT(nn.Module, _HubMixin):
         if tc:
             a = lin["head.ada"]
             fmod = K.gemm_nt(S["c"], a.w16, N=a.out, epilogue=K.EPI_BIAS, bias=a.bias.detach())  # [Bp, 2d]
-        hf, rstdf, meanf = K.norm_fwd(x, fl.norm_final.weight.detach(), nt, L, mod=fmod, mod_idx=(0, 1), modality=mod_flat, any_img=any_img)
+        if pre is not None:
+            hf, rstdf, meanf = pre
+        else:
+            hf, rstdf, meanf = K.norm_fwd(x, fl.norm_final.weight.detach(), nt, L, mod=fmod, mod_idx=(0, 1), modality=mod_flat, any_img=any_img)
         head = lin["head"]
         V, Vp = self.vocab_size, head.outp
         if mode == "logits":

@@ -161,16 +161,25 @@ def norm_bwd(dy, x, rstd, mean, w, norm_type, L, dx, dw, *, accumulate=True, mod
               _p(any_img) if mod is not None else None, _p(dx), _p(dw), dshift, dscale, M, d, L, norm_type, 1 if accumulate else 0, _s())
 
 
-def residual_fwd(x_in, branch, L, *, w_b=None, norm_type=NORM_RMS, mod=None, gate_idx=None, modality=None, p_drop=0.0, seed=0):
-    """x_out = x_in + gate * dropout(sandwich_norm(branch)).  gate = chunk gate_idx of `mod` (None: no gate)."""
+def residual_fwd(x_in, branch, L, *, w_b=None, norm_type=NORM_RMS, mod=None, gate_idx=None, modality=None, p_drop=0.0, seed=0, next_w=None):
+    """x_out = x_in + gate * dropout(sandwich_norm(branch)).  gate = chunk gate_idx of `mod` (None: no gate).
+    next_w: weight of the (unmodulated) norm that consumes x_out next -- fused; returns (x_out, rstd, mean, (h, rstd_n, mean_n))."""
     M, d = x_in.shape
     x_out = torch.empty_like(x_in)
     rstd = torch.empty(M, dtype=F32, device=x_in.device) if w_b is not None else None
     mean = torch.empty(M, dtype=F32, device=x_in.device) if (w_b is not None and norm_type == NORM_LN) else None
     (gate,), ms = _mod_ptrs(mod if gate_idx is not None else None, (gate_idx,), d)
-    _lib.call("udm_residual_fwd", _p(x_in), _p(branch), _p(x_out), _p(w_b), _p(rstd), _p(mean), gate, ms, _p(modality), M, d, L, norm_type,
-              1e-6 if norm_type == NORM_RMS else 1e-5, float(p_drop), int(seed), _s())
-    return x_out, rstd, mean
+    eps = 1e-6 if norm_type == NORM_RMS else 1e-5
+    if next_w is None:
+        _lib.call("udm_residual_fwd", _p(x_in), _p(branch), _p(x_out), _p(w_b), _p(rstd), _p(mean), gate, ms, _p(modality), M, d, L, norm_type,
+                  eps, float(p_drop), int(seed), _s())
+        return x_out, rstd, mean
+    h = torch.empty((M, d), dtype=BF16, device=x_in.device)
+    rstd_n = torch.empty(M, dtype=F32, device=x_in.device)
+    mean_n = torch.empty(M, dtype=F32, device=x_in.device) if norm_type == NORM_LN else None
+    _lib.call("udm_residual_norm_fwd", _p(x_in), _p(branch), _p(x_out), _p(w_b), _p(rstd), _p(mean), gate, ms, _p(modality), M, d, L, norm_type,
+              eps, float(p_drop), int(seed), _p(next_w), _p(h), _p(rstd_n), _p(mean_n), _s())
+    return x_out, rstd, mean, (h, rstd_n, mean_n)
 
 
 def residual_bwd(dx, branch, L, *, w_b=None, rstd=None, mean=None, norm_type=NORM_RMS, mod=None, dmod=None, gate_idx=None, modality=None, dw_b=None,
