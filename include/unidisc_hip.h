@@ -49,6 +49,11 @@ int udm_gemm_nt_bf16(const void* A, const void* B, void* C, int64_t M, int64_t N
 /* wgrad form read straight from row-major activations: C[M,N] (fp32) = beta*C + A[K,M]ᵀ · B[K,N]  (K % 64 == 0). */
 int udm_gemm_tn_bf16(const void* A, const void* B, void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, float beta,
                      hipStream_t stream);
+/* the same wgrad for FEW output tiles over a LONG contraction (2048 x 2048 out-proj weight, K = B*L): K is split so that tiles x slices fill
+ * the CUs, partial tiles go to `ws` (fp32, >= slices*M*N elements; no atomics), a reduce pass sums them into C.  Falls back to
+ * udm_gemm_tn_bf16 when the workspace is too small.  C contiguous (ldc == N). */
+int udm_gemm_tn_splitk_bf16(const void* A, const void* B, void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, float beta,
+                            float* ws, int64_t ws_elems, hipStream_t stream);
 int udm_gemm_set_tile(int tile); /* diagnostics: force the tile family (-1 auto, 0 = 128x128 kernel, 192/256/320 = BMx256 kernel) */
 /* out[C,R] = in[R,C]ᵀ (bf16); optional colsum[c] += Σ_r in[r,c] (bias gradient).  Feeds the wgrad GEMMs. */
 int udm_transpose_bf16(const void* in, void* out, int64_t R, int64_t C, int64_t ld_in, int64_t ld_out, float* colsum, hipStream_t stream);

@@ -47,6 +47,9 @@ def main():
         out = torch.empty((m, n), dtype=torch.float32, device=DEV)
         ms = timeit(lambda: K.gemm_tn(a, b, out, beta=1.0))
         res[f"gemm/{name}"] = dict(ms=round(ms, 4), tflops=round(2 * m * n * kc / ms / 1e9, 1))
+        if name == "out_wgrad_tn":
+            ms = timeit(lambda: K.gemm_tn_splitk(a, b, out, beta=0.0))
+            res["gemm/out_wgrad_tn_splitk_ws"] = dict(ms=round(ms, 4), tflops=round(2 * m * n * kc / ms / 1e9, 1))
         del a, b, out
     # epilogue variants
     a, b, bias = rn(M, 2048), rn(8192, 2048), torch.randn(8192, device=DEV)

@@ -332,6 +332,9 @@ def gemm_tn(a, b, out, *, M=None, N=None, beta=0.0):
     return out
 
 
+gemm_tn_splitk = gemm_tn
+
+
 def colsum(x, out):
     out += x.float().sum(0)
     return out

@@ -97,6 +97,19 @@ def test_gemm_tn_kmajor(K, Kc, M, N):
     assert torch.allclose(cs.cpu()[:M], a[:, :M].float().sum(0), atol=2e-3, rtol=1e-4)
 
 
+@pytest.mark.parametrize("Kc,M,N", [(10240, 2048, 2048), (2048, 512, 768), (4096, 256, 256), (256, 2048, 2048), (1024, 304, 264)])
+def test_gemm_tn_splitk_workspace(K, Kc, M, N):
+    """few tiles x long K: K split across CUs through a workspace + reduce pass (falls back to the plain kernel when it cannot split)."""
+    a, b = bf(rnd(Kc, M, seed=93, scale=0.5)), bf(rnd(Kc, N, seed=94, scale=0.5))
+    ref = a.float().t() @ b.float()
+    c0 = rnd(M, N, seed=95)
+    out = c0.clone().to(DEV)
+    K.gemm_tn_splitk(a.to(DEV), b.to(DEV), out, beta=0.0)
+    assert rel_err(out.cpu(), ref) < 1e-5
+    K.gemm_tn_splitk(a.to(DEV), b.to(DEV), out, beta=1.0)
+    assert rel_err(out.cpu(), 2 * ref) < 2e-5
+
+
 def test_gemm_identity_asymmetric(K):
     # A = I (padded), B asymmetric: catches swapped row/col fragment maps
     n = 128

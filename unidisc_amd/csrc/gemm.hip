@@ -31,6 +31,7 @@ struct GemmArgs {
   int tiles_m, tiles_n;
   float beta;
   int splitk;  // > 1: the K range is cut into `splitk` slices per tile and partial tiles are atomically added into an fp32 C
+  long slice_stride;  // split-K with a workspace: slice s stores its partial tile (no atomics) at C + s * slice_stride; 0 = atomic form
 };
 
 template <int EPI, bool OUT_F32>
@@ -549,9 +550,13 @@ __global__ __launch_bounds__(512) void gemm_nt_stagger_kernel(GemmArgs p) {
             for (int e = 0; e < 4; ++e) csum[j][e] += OUT_F32 ? x[e] : bf2f(f2bf(x[e]));
           }
           if (OUT_F32 && S > 1) {
-            float* cp = reinterpret_cast<float*>(p.C) + gm * p.ldc + gn;
+            float* cp = reinterpret_cast<float*>(p.C) + slice * p.slice_stride + gm * p.ldc + gn;
+            if (p.slice_stride) {
+              *reinterpret_cast<float4*>(cp) = make_float4(x[0], x[1], x[2], x[3]);
+            } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) atomicAdd(cp + e, x[e]);
+              for (int e = 0; e < 4; ++e) atomicAdd(cp + e, x[e]);
+            }
           } else if (OUT_F32) {
             if (p.beta != 0.f) { x[0] += p.beta * cold[q].x; x[1] += p.beta * cold[q].y; x[2] += p.beta * cold[q].z; x[3] += p.beta * cold[q].w; }
             *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + gm * p.ldc + gn) = make_float4(x[0], x[1], x[2], x[3]);
@@ -576,7 +581,9 @@ __global__ __launch_bounds__(512) void gemm_nt_stagger_kernel(GemmArgs p) {
               if (colsum) atomicAdd(colsum + gn + e, OUT_F32 ? x[e] : bf2f(f2bf(x[e])));
             }
             if (OUT_F32 && S > 1) {
-              atomicAdd(reinterpret_cast<float*>(p.C) + gm * p.ldc + gn + e, x[e]);
+              float* cp = reinterpret_cast<float*>(p.C) + slice * p.slice_stride + gm * p.ldc + gn + e;
+              if (p.slice_stride) *cp = x[e];
+              else atomicAdd(cp, x[e]);
             } else if (OUT_F32) {
               float* cp = reinterpret_cast<float*>(p.C) + gm * p.ldc + gn + e;
               *cp = x[e] + (p.beta != 0.f ? p.beta * *cp : 0.f);
@@ -677,6 +684,7 @@ extern "C" int udm_gemm_nt_bf16(const void* A, const void* B, void* C, int64_t M
   a.tiles_m = (int)((M + BM - 1) / BM); a.tiles_n = (int)((N + BN - 1) / BN);
   a.beta = beta;
   a.splitk = 1;
+  a.slice_stride = 0;
   if (epilogue == UDM_EPI_BIAS || epilogue == UDM_EPI_BIAS_GELU) UDM_CHECK_ARG(bias, "udm_gemm_nt_bf16: bias epilogue without bias");
   if (epilogue == UDM_EPI_BIAS_GELU) UDM_CHECK_ARG(aux && !out_f32, "udm_gemm_nt_bf16: EPI_BIAS_GELU needs aux and bf16 output");
   if (epilogue == UDM_EPI_DGELU) UDM_CHECK_ARG(aux, "udm_gemm_nt_bf16: EPI_DGELU needs aux (saved pre-activation)");
@@ -716,6 +724,7 @@ extern "C" int udm_gemm_tn_bf16(const void* A, const void* B, void* C, int64_t M
   int tile = choose_tile(M, N, K, lda, ldb);
   if (tile == 0) tile = M <= 192 ? 192 : 256;  // the K-major path has no small-tile kernel; the large one handles any M, N by clamping
   a.splitk = 1;
+  a.slice_stride = 0;
   if (beta == 1.0f) {  // accumulate form: few output tiles over a long K (e.g. the 2048x2048 out-proj wgrad, K = B*L) -> split K, atomically add
     const long tiles = ((M + tile - 1) / tile) * ((N + 255) / 256);
     const long nkt = K / 64;
@@ -730,6 +739,54 @@ extern "C" int udm_gemm_tn_bf16(const void* A, const void* B, void* C, int64_t M
     case 320: return launch_big_t<320, UDM_EPI_NONE, true, true>(a, stream);
     default: return launch_big_t<256, UDM_EPI_NONE, true, true>(a, stream);
   }
+}
+
+namespace {
+// out = beta * out + sum_s ws[s]: finishes a workspace split-K GEMM (fp32, 16-byte accesses)
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out, long n4, int S, long stride, float beta) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    float4 acc = reinterpret_cast<const float4*>(ws)[i];
+    for (int s = 1; s < S; ++s) {
+      const float4 v = reinterpret_cast<const float4*>(ws + s * stride)[i];
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    if (beta != 0.f) {
+      const float4 o = reinterpret_cast<const float4*>(out)[i];
+      acc.x += beta * o.x; acc.y += beta * o.y; acc.z += beta * o.z; acc.w += beta * o.w;
+    }
+    reinterpret_cast<float4*>(out)[i] = acc;
+  }
+}
+}  // namespace
+
+// C[M,N] (fp32) = beta*C + A[K,M]^T B[K,N] for FEW output tiles over a LONG contraction (the 2048 x 2048 out-proj wgrad, K = B*L): the K
+// range is cut into slices so that tiles x slices fill the 256 CUs, every slice writes its partial tile into `ws` (no atomics: a 4-way
+// atomic split measured slower than leaving 3/4 of the CUs idle) and a reduce pass sums them.  Falls back to udm_gemm_tn_bf16 when the
+// workspace is too small or splitting does not pay.  C must be contiguous (ldc == N).
+extern "C" int udm_gemm_tn_splitk_bf16(const void* A, const void* B, void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc,
+                                       float beta, float* ws, int64_t ws_elems, hipStream_t stream) {
+  UDM_CHECK_ARG(A && B && C, "udm_gemm_tn_splitk_bf16: null operand");
+  UDM_CHECK_ARG(M > 0 && N > 0 && K > 0 && K % 64 == 0, "udm_gemm_tn_splitk_bf16: K must be a positive multiple of 64 (got M=%ld N=%ld K=%ld)", (long)M, (long)N, (long)K);
+  const long tiles = ((M + 255) / 256) * ((N + 255) / 256);
+  const long nkt = K / 64;
+  int sk = 1;
+  while (tiles * sk * 2 <= 256 && nkt / (sk * 2) >= 16 && sk < 16) sk *= 2;
+  if (sk == 1 || !ws || ws_elems < (int64_t)sk * M * N || ldc != N || (M * N) % 4 != 0)
+    return udm_gemm_tn_bf16(A, B, C, M, N, K, lda, ldb, ldc, beta, stream);
+  UDM_CHECK_ARG(lda % 8 == 0 && ldb % 8 == 0 && lda >= M && ldb >= N, "udm_gemm_tn_splitk_bf16: lda/ldb must be multiples of 8 and cover the rows");
+  UDM_CHECK_ARG(((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0) && ((uintptr_t)C % 16 == 0) && ((uintptr_t)ws % 16 == 0), "udm_gemm_tn_splitk_bf16: operands must be 16-byte aligned");
+  GemmArgs a;
+  a.A = (const bf16_t*)A; a.B = (const bf16_t*)B; a.C = ws; a.bias = nullptr; a.aux = nullptr;
+  a.lda = lda; a.ldb = ldb; a.ldc = N; a.ldaux = 0;
+  a.M = (int)M; a.N = (int)N; a.K = (int)K; a.beta = 0.f;
+  a.splitk = sk;
+  a.slice_stride = (long)M * N;
+  if (int rc = launch_big_t<256, UDM_EPI_NONE, true, true>(a, stream)) return rc;
+  const long n4 = (long)M * N / 4;
+  const int grid = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid), dim3(256), 0, stream, (const float*)ws, (float*)C, n4, sk, (long)M * N, beta);
+  UDM_CHECK_LAUNCH("udm_gemm_tn_splitk_bf16(reduce)");
+  return 0;
 }
 
 extern "C" int udm_gemm_set_tile(int tile) {

@@ -567,10 +567,13 @@ class DIT(nn.Module, _HubMixin):
         if lin.bias is not None and not bias_done:
             db = G[id(lin.bias)] if outp == lin.out else torch.zeros(outp, dtype=F32, device=dY.device)
         few_tiles = ((lin.out + 255) // 256) * ((lin.inp + 255) // 256) < 128 and lin.out * lin.inp >= 1 << 20
-        if Mrows % 64 == 0 and not few_tiles:  # K-major GEMM reads dY and X in place (transposing LDS reads); bias grad = column sums
+        if Mrows % 64 == 0:  # K-major GEMM reads dY and X in place (transposing LDS reads); bias grad = column sums
             if db is not None:
                 K.colsum(dY, db)
-            K.gemm_tn(dY, X, G[id(lin.weight)], M=lin.out, N=lin.inp)
+            if few_tiles:  # e.g. the 2048 x 2048 out-proj weight: 64 tiles over K = B*L -> split K through a workspace
+                K.gemm_tn_splitk(dY, X, G[id(lin.weight)], M=lin.out, N=lin.inp)
+            else:
+                K.gemm_tn(dY, X, G[id(lin.weight)], M=lin.out, N=lin.inp)
         else:  # short contraction (e.g. adaLN over the padded batch): explicit transposes + NT kernel
             dYt = K.transpose(dY, colsum=db)
             Xt = K.transpose(X)

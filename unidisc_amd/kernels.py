@@ -90,6 +90,22 @@ def gemm_tn(a, b, out, *, M=None, N=None, beta=0.0):
     return out
 
 
+def gemm_tn_splitk(a, b, out, *, M=None, N=None, beta=0.0):
+    """gemm_tn for few output tiles over a long contraction: K split across CUs through an fp32 workspace (no atomics)."""
+    _chk(a, BF16, "gemm_tn_splitk a"), _chk(b, BF16, "gemm_tn_splitk b"), _chk(out, F32, "gemm_tn_splitk out")
+    K = a.shape[0]
+    M = a.shape[1] if M is None else M
+    N = b.shape[1] if N is None else N
+    tiles = ((M + 255) // 256) * ((N + 255) // 256)
+    sk = 1
+    while tiles * sk * 2 <= 256 and (K // 64) // (sk * 2) >= 16 and sk < 16:
+        sk *= 2
+    ws = _scratch(sk * M * N, a.device) if sk > 1 else None
+    _lib.call("udm_gemm_tn_splitk_bf16", _p(a), _p(b), _p(out), M, N, K, a.stride(0), b.stride(0), out.stride(0), float(beta), _p(ws),
+              ws.numel() if ws is not None else 0, _s())
+    return out
+
+
 def colsum(x, out):
     """out[c] += sum_r x[r, c] (bias gradient) without writing a transpose."""
     _chk(x, BF16, "colsum")
