@@ -996,8 +996,18 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict_
   const int per = (nrows + gridDim.y - 1) / gridDim.y;
   const int r0 = blockIdx.y * per, r1 = min(nrows, r0 + per);
   float s = 0.f;
-  if (col < ncols)
-    for (int r = r0 + sub; r < r1; r += 4) s += ws[(long)r * ncols + col];
+  if (col < ncols) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;   // four loads in flight per thread (the loop is latency-bound otherwise)
+    int r = r0 + sub;
+    for (; r + 12 < r1; r += 16) {
+      s0 += ws[(long)r * ncols + col];
+      s1 += ws[(long)(r + 4) * ncols + col];
+      s2 += ws[(long)(r + 8) * ncols + col];
+      s3 += ws[(long)(r + 12) * ncols + col];
+    }
+    for (; r < r1; r += 4) s0 += ws[(long)r * ncols + col];
+    s = (s0 + s1) + (s2 + s3);
+  }
   red[sub][threadIdx.x & 63] = s;
   __syncthreads();
   if (sub == 0 && col < ncols) atomicAdd(out + col, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
@@ -1318,7 +1328,7 @@ extern "C" int udm_residual_bwd(const float* dx, const void* branch, void* dbran
     else hipLaunchKernelGGL((residual_bwd_brow_kernel<2>), dim3(g), dim3(256), 0, stream, a);
     UDM_CHECK_LAUNCH("udm_residual_bwd");
     if (a.ws) {
-      hipLaunchKernelGGL(colreduce_kernel, dim3((unsigned)((d + 63) / 64), 8), dim3(256), 0, stream, (const float*)ws, dw_b, g, (int)d);
+      hipLaunchKernelGGL(colreduce_kernel, dim3((unsigned)((d + 63) / 64), 16), dim3(256), 0, stream, (const float*)ws, dw_b, g, (int)d);
       UDM_CHECK_LAUNCH("udm_residual_bwd(colreduce)");
     }
     return 0;
@@ -1384,7 +1394,7 @@ extern "C" int udm_qknorm_rope_bwd(const void* dqkr, const void* qkv, void* dqkv
     else hipLaunchKernelGGL((qknorm_rope_bwd_brow_kernel<2>), dim3(g), dim3(256), l2, stream, a);
     UDM_CHECK_LAUNCH("udm_qknorm_rope_bwd");
     if (a.ws) {
-      hipLaunchKernelGGL(colreduce_kernel, dim3((unsigned)((4 * d + 63) / 64), 8), dim3(256), 0, stream, (const float*)ws, dgq, g, (int)(4 * d));
+      hipLaunchKernelGGL(colreduce_kernel, dim3((unsigned)((4 * d + 63) / 64), 16), dim3(256), 0, stream, (const float*)ws, dgq, g, (int)(4 * d));
       UDM_CHECK_LAUNCH("udm_qknorm_rope_bwd(colreduce)");
     }
     return 0;
