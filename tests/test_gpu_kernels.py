@@ -110,6 +110,25 @@ def test_gemm_tn_splitk_workspace(K, Kc, M, N):
     assert rel_err(out.cpu(), 2 * ref) < 2e-5
 
 
+@pytest.mark.parametrize("M,N", [(64, 128), (320, 512)])
+def test_gemm_gelu_epilogues_extreme_preactivations(K, M, N):
+    """GELU / GELU' in the epilogues are written through the logistic function (exp2 + rcp): no inf * 0 for |x| up to 100."""
+    K_ = 128
+    a, b = bf(torch.full((M, K_), 0.125)), bf(torch.full((N, K_), 0.0625))  # accumulator = 1.0 everywhere
+    vals = torch.tensor([-100.0, -40.0, -12.0, -9.0, -5.0, -1.0, -1e-3, 0.0, 1e-3, 1.0, 5.0, 9.0, 12.0, 40.0, 100.0, -0.75])
+    bias = vals.repeat(N // vals.numel() + 1)[:N].clone()
+    aux = torch.empty((M, N), dtype=torch.bfloat16, device=DEV)
+    g = K.gemm_nt(a.to(DEV), b.to(DEV), epilogue=K.EPI_BIAS_GELU, bias=(bias - 1.0).to(DEV), aux=aux).float().cpu()
+    pre = aux.float().cpu()
+    assert torch.equal(pre[0], bias.bfloat16().float())
+    ref = torch.nn.functional.gelu(pre.double(), approximate="tanh").float()
+    assert torch.isfinite(g).all() and torch.allclose(g, ref, atol=2e-3, rtol=8e-3)
+    u = pre.double().requires_grad_()
+    (gp,) = torch.autograd.grad(torch.nn.functional.gelu(u, approximate="tanh").sum(), u)
+    dg = K.gemm_nt(a.to(DEV), b.to(DEV), epilogue=K.EPI_DGELU, aux=aux).float().cpu()
+    assert torch.isfinite(dg).all() and torch.allclose(dg, gp.float(), atol=2e-3, rtol=8e-3)
+
+
 def test_gemm_identity_asymmetric(K):
     # A = I (padded), B asymmetric: catches swapped row/col fragment maps
     n = 128
