@@ -71,7 +71,8 @@ int udm_norm_fwd(const float* x, void* y, float* rstd, float* mean, const float*
                  const int64_t* modality, const int* any_img, int64_t M, int64_t d, int64_t L, int norm_type, float eps, hipStream_t stream);
 int udm_norm_bwd(const void* dy, const float* x, const float* rstd, const float* mean, const float* w, const void* shift, const void* scale,
                  int64_t mod_stride, const int64_t* modality, const int* any_img, float* dx, float* dw, float* dshift, float* dscale, int64_t M,
-                 int64_t d, int64_t L, int norm_type, int accumulate, hipStream_t stream);
+                 int64_t d, int64_t L, int norm_type, int accumulate, float* ws, int64_t ws_elems, hipStream_t stream);
+/* ws: optional fp32 scratch (>= 512*d): per-block dw partials + a reduce pass instead of 512-deep same-address atomic chains */
 
 /* ---- residual branch: bias_dropout_add_scale models/dit.py:229-253 and the sandwich adds :993-994, :1015-1031
  * x_out = x_in + gate ⊙ dropout_p(sandwich_norm(branch; w_b)); every stage optional (NULL / p = 0).       */

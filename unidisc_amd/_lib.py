@@ -29,7 +29,7 @@ PROTOTYPES = {
     "udm_cast_f32_bf16": [_P, _P, _I64, _F, _P],
     "udm_cast_bf16_f32": [_P, _P, _I64, _F, _P],
     "udm_norm_fwd": [_P, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _I64, _I64, _I64, _I, _F, _P],
-    "udm_norm_bwd": [_P, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I, _I, _P],
+    "udm_norm_bwd": [_P, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I, _I, _P, _I64, _P],
     "udm_residual_fwd": [_P, _P, _P, _P, _P, _P, _P, _I64, _P, _I64, _I64, _I64, _I, _F, _F, _U64, _P],
     "udm_residual_norm_fwd": [_P, _P, _P, _P, _P, _P, _P, _I64, _P, _I64, _I64, _I64, _I, _F, _F, _U64, _P, _P, _P, _P, _P],
     "udm_residual_bwd": [_P, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _P, _I64, _I64, _I64, _I, _F, _U64, _P, _I64, _P],

@@ -139,6 +139,7 @@ struct NormBwdArgs {
   float* dscale;
   long mod_stride;
   int M, d, L, norm_type, accumulate;
+  float* ws;          // optional [gridDim.x, d] fp32: per-block dw partials (two-phase column reduction instead of deep atomic chains)
 };
 
 template <int NCH>
@@ -224,7 +225,8 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(NormBwdArgs a) {
       const int c = i * 512 + t;
       if (c < a.d) {
         float s = red[0][t] + red[1][t] + red[2][t] + red[3][t];
-        atomicAdd(a.dw + c, s);
+        if (a.ws) a.ws[(long)blockIdx.x * a.d + c] = s;
+        else atomicAdd(a.dw + c, s);
       }
     }
   }
@@ -1270,16 +1272,21 @@ extern "C" int udm_norm_fwd(const float* x, void* y, float* rstd, float* mean, c
 
 extern "C" int udm_norm_bwd(const void* dy, const float* x, const float* rstd, const float* mean, const float* w, const void* shift, const void* scale,
                             int64_t mod_stride, const int64_t* modality, const int* any_img, float* dx, float* dw, float* dshift, float* dscale,
-                            int64_t M, int64_t d, int64_t L, int norm_type, int accumulate, hipStream_t stream) {
+                            int64_t M, int64_t d, int64_t L, int norm_type, int accumulate, float* ws, int64_t ws_elems, hipStream_t stream) {
   UDM_CHECK_ARG(dy && x && rstd && w && dx && dw, "udm_norm_bwd: null pointer");
   UDM_CHECK_ARG(M > 0 && d > 0 && d % 8 == 0 && L > 0, "udm_norm_bwd: bad shape");
   UDM_CHECK_ARG(!shift || (scale && dshift && dscale), "udm_norm_bwd: modulated norm needs scale, dshift, dscale");
   NormBwdArgs a{(const bf16_t*)dy, x, rstd, mean, w, (const bf16_t*)shift, (const bf16_t*)scale, modality, any_img, dx, dw, dshift, dscale,
-                (long)mod_stride, (int)M, (int)d, (int)L, norm_type, accumulate};
+                (long)mod_stride, (int)M, (int)d, (int)L, norm_type, accumulate, nullptr};
   int nch = nch_for(d); if (nch > 4) nch = 8;
   const int grid = min(grid_rows(M), 512);
+  if (ws && ws_elems >= (int64_t)grid * d && grid >= 64) a.ws = ws;   // short chains (few blocks) stay on atomics
   DISPATCH_NCH(nch, norm_bwd_kernel, grid, stream, a);
   UDM_CHECK_LAUNCH("udm_norm_bwd");
+  if (a.ws) {
+    hipLaunchKernelGGL(colreduce_kernel, dim3((unsigned)((d + 63) / 64), 16), dim3(256), 0, stream, (const float*)ws, dw, grid, (int)d);
+    UDM_CHECK_LAUNCH("udm_norm_bwd(colreduce)");
+  }
   return 0;
 }
 

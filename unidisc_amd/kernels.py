@@ -173,8 +173,10 @@ def norm_bwd(dy, x, rstd, mean, w, norm_type, L, dx, dw, *, accumulate=True, mod
     M, d = x.shape
     (shift, scale), ms = _mod_ptrs(mod, mod_idx, d)
     (dshift, dscale), _ = _mod_ptrs(dmod, mod_idx, d)
+    ws = _scratch(512 * d, x.device) if M >= 2048 else None
     _lib.call("udm_norm_bwd", _p(dy), _p(x), _p(rstd), _p(mean), _p(w), shift, scale, ms, _p(modality) if mod is not None else None,
-              _p(any_img) if mod is not None else None, _p(dx), _p(dw), dshift, dscale, M, d, L, norm_type, 1 if accumulate else 0, _s())
+              _p(any_img) if mod is not None else None, _p(dx), _p(dw), dshift, dscale, M, d, L, norm_type, 1 if accumulate else 0,
+              _p(ws), ws.numel() if ws is not None else 0, _s())
 
 
 def residual_fwd(x_in, branch, L, *, w_b=None, norm_type=NORM_RMS, mod=None, gate_idx=None, modality=None, p_drop=0.0, seed=0, next_w=None):
