@@ -373,6 +373,24 @@ def test_attention_fwd_bwd(K, tr, D, H, L, use_sid):
         K.set_tr_read(True)
 
 
+@pytest.mark.parametrize("L", [2, 31, 33, 64, 65, 127, 129, 191, 193, 257, 640, 1000])
+@pytest.mark.parametrize("B,H", [(1, 1), (3, 5)])
+def test_attention_d128_wave_specialised_backward_ragged_lengths(K, L, B, H):
+    """D = 128 without a document mask takes the wave-specialised dK/dV kernel (32-query steps through a 6-stage ring, head / tail
+    iterations, ragged last step, key blocks past L): every boundary length class, and B*H not a multiple of 8."""
+    D = 128
+    M, d = B * L, H * D
+    q, k, v, do = (bf(rnd(M, d, seed=s)) for s in (130, 131, 132, 133))
+    o_r, dq_r, dk_r, dv_r = _attn_ref(q, k, v, B, L, H, D, None, do)
+    g = lambda t: t.to(DEV)
+    o, lse = K.attention_fwd_generic(g(q), g(k), g(v), B, L, H, D, None)
+    assert rel_err(o.float().cpu(), o_r) < 1e-2
+    dq, dk, dv = K.attention_bwd_generic(g(q), g(k), g(v), o, g(do), lse, B, L, H, D, None)
+    assert rel_err(dv.float().cpu(), dv_r) < 1.5e-2
+    assert rel_err(dq.float().cpu(), dq_r) < 1.5e-2
+    assert rel_err(dk.float().cpu(), dk_r) < 1.5e-2
+
+
 def test_attention_online_softmax_rescale_branch(K):
     # a key far above the others late in the sequence forces the running max to jump (rule: test the rare branch)
     B, H, L, D = 1, 1, 256, 64
