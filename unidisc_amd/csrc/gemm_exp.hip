@@ -212,6 +212,14 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_nt_stagger_kernel(XArgs p
     dst[A_PW + j] = A_BYTES + (wave * B_PW + j) * 1024;
   }
   const int sw = (l31 >> 1) & 7;
+  // OPT bit 4: refills through buffer_load ... lds (buffer resource + 32-bit lane offset + SGPR k offset): no 64-bit vector address per piece
+#if defined(__HIP_DEVICE_COMPILE__)   // (the buffer builtins do not exist in the host pass)
+  __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)(((long)p.M * p.lda) * 2), 0x00020000);
+  __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, (int)(((long)p.N * p.ldb) * 2), 0x00020000);
+#endif
+  int voff[LOADS];
+#pragma unroll
+  for (int j = 0; j < LOADS; ++j) voff[j] = (int)((reinterpret_cast<const char*>(src[j]) - reinterpret_cast<const char*>(j < A_PW ? p.A : p.B)));
   f32x16_t acc[FM][FN];
 #pragma unroll
   for (int i = 0; i < FM; ++i)
@@ -268,7 +276,13 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_nt_stagger_kernel(XArgs p
       if (OPT & 2) __builtin_amdgcn_s_setprio(1);
       if ((OPT & 1) && !(OPT & 8) && ph < ISSUE_PH && more) {
 #pragma unroll
-        for (int j = ph * PER; j < (ph + 1) * PER && j < LOADS; ++j) glds16(src[j] + knext, nxt + dst[j]);
+        for (int j = ph * PER; j < (ph + 1) * PER && j < LOADS; ++j) {
+#if defined(__HIP_DEVICE_COMPILE__)
+          if (OPT & 16) __builtin_amdgcn_raw_ptr_buffer_load_lds(j < A_PW ? rsA : rsB, (UDM_LDS void*)(nxt + dst[j]), 16, voff[j], knext * 2, 0, 0);
+          else
+#endif
+            glds16(src[j] + knext, nxt + dst[j]);
+        }
       }
       if ((OPT & 8) && ph == 0 && more) {   // OPT bit 3: plain global loads into registers instead of LDS-DMA (A/B of the issue cost)
 #pragma unroll
@@ -624,6 +638,8 @@ extern "C" int udm_gemm_nt_bf16_variant(int variant, const void* A, const void* 
     case 39: return launch_stagger<256, 256, 2, 4, 1, 1>(a, stream);   // 256-row tile, LDS-DMA inside the MFMA section
     case 40: return launch_stagger<256, 256, 2, 4, 1, 8>(a, stream);   // 256-row tile, register-staged refill (global_load + ds_write_b128)
     case 41: return launch_stagger<320, 256, 2, 4, 1, 8>(a, stream);   // 320-row tile, register-staged refill
+    case 42: return launch_stagger<320, 256, 2, 4, 1, 1>(a, stream);   // 320-row tile, LDS-DMA by global_load_lds (production form)
+    case 43: return launch_stagger<320, 256, 2, 4, 1, 17>(a, stream);  // 320-row tile, LDS-DMA by buffer_load ... lds
     default: udm_set_error("udm_gemm_nt_bf16_variant: unknown variant %d", variant); return 2;
   }
 }
