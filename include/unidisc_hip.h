@@ -125,6 +125,18 @@ int udm_timestep_embedding(const float* sigma, void* out, int64_t B, int64_t dim
 int udm_silu_fwd(const void* x, void* y, int64_t n, hipStream_t stream);
 int udm_silu_bwd(const void* x, const void* dy, void* dx, int64_t n, hipStream_t stream);
 
+/* ---- optimizer step: torch.optim.AdamW(fused=True) `model_setup.py:385-424` + accelerator.clip_grad_norm_ `model.py:1516-1520`.
+ * fp32 masters and moments; `step` is the 1-based update count (bias corrections are computed from it); `grad_norm_sq` (nullable) is a DEVICE
+ * scalar holding the sum of squares of ALL gradients (udm_sumsq_f32 over the engine's flat gradient buffer): g is scaled by
+ * min(1, max_grad_norm / (sqrt(*grad_norm_sq) + 1e-6)) without a host round trip.  The _shadow form updates a row-major [R, C] GEMM weight and
+ * writes its bf16 copy [R, ld16] and transposed bf16 copy [C, ldt] in the same pass (replaces the per-forward autocast weight cast). */
+int udm_sumsq_f32(const float* x, int64_t n, float* out, float* ws, int64_t ws_elems, hipStream_t stream); /* ws: >= 1024 floats */
+int udm_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay,
+                   int64_t step, const float* grad_norm_sq, float max_grad_norm, hipStream_t stream);
+int udm_adamw_step_shadow(float* p, const float* g, float* m, float* v, int64_t R, int64_t C, float lr, float beta1, float beta2, float eps,
+                          float weight_decay, int64_t step, const float* grad_norm_sq, float max_grad_norm, void* w16, int64_t ld16, void* w16t,
+                          int64_t ldt, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

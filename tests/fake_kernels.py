@@ -338,3 +338,34 @@ gemm_tn_splitk = gemm_tn
 def colsum(x, out):
     out += x.float().sum(0)
     return out
+
+
+# ------------------------------------------------------------------------------------------------ optimizer (csrc/optim.hip)
+def sumsq(x, out):
+    out[0] = (x.float() ** 2).sum()
+    return out
+
+
+def _adam(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_norm_sq, max_grad_norm):
+    clip = 1.0
+    if grad_norm_sq is not None:
+        clip = torch.clamp(max_grad_norm / (grad_norm_sq.sqrt() + 1e-6), max=1.0)
+    g = g * clip
+    p.mul_(1 - lr * weight_decay)
+    m.add_((1 - beta1) * (g - m))
+    v.mul_(beta2).add_((1 - beta2) * g * g)
+    bc1, bc2 = 1 - beta1 ** step, 1 - beta2 ** step
+    p.sub_((lr / bc1) * (m / (v.sqrt() / (bc2 ** 0.5) + eps)))
+
+
+def adamw_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_norm_sq=None, max_grad_norm=None):
+    _adam(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_norm_sq, max_grad_norm)
+
+
+def adamw_step_shadow(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_norm_sq, max_grad_norm, w16, w16t):
+    _adam(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_norm_sq, max_grad_norm)
+    R, C = p.shape
+    if w16 is not None:
+        w16[:R, :C] = p.bfloat16()
+    if w16t is not None:
+        w16t[:C, :R] = p.t().bfloat16()

@@ -8,7 +8,8 @@ from .config import Cfg, make_config, MODEL_PRESETS  # noqa: F401
 from .dit import DIT  # noqa: F401
 from .diffusion import Diffusion, Loss  # noqa: F401
 from .noise_schedule import LogLinearNoise  # noqa: F401
+from .optim import FusedAdamW  # noqa: F401
 from .checkpoint import load_backbone_checkpoint, save_backbone_checkpoint, read_state_dict  # noqa: F401
 
 __all__ = ["DIT", "Diffusion", "Loss", "LogLinearNoise", "Cfg", "make_config", "MODEL_PRESETS", "load_backbone_checkpoint",
-           "save_backbone_checkpoint", "read_state_dict"]
+           "save_backbone_checkpoint", "read_state_dict", "FusedAdamW"]

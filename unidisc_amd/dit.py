@@ -19,6 +19,8 @@ from __future__ import annotations
 import math
 from typing import Dict, List, Optional
 
+import weakref
+
 import torch
 import torch.nn as nn
 
@@ -692,6 +694,8 @@ class DIT(nn.Module, _HubMixin):
         self._notify(flat, tail)
         if self.grad_sync_finish is not None:
             self.grad_sync_finish()
+        # for the fused optimizer's one-pass global norm; a weak reference: the buffer lives exactly as long as the p.grad views do
+        self._last_grad_flat_ref, self._last_grad_numel = weakref.ref(flat), sum(p.numel() for p in params)
         return [G[id(p)] for p in params]
 
     def _ada_backward(self, dmod, lin: _Lin, c, dc, G):

@@ -106,6 +106,32 @@ def gemm_tn_splitk(a, b, out, *, M=None, N=None, beta=0.0):
     return out
 
 
+def sumsq(x, out):
+    """out[0] = sum(x**2) (fp32, 1-D contiguous x); two-phase reduction through the scratch buffer."""
+    _chk(x, F32, "sumsq x"), _chk(out, F32, "sumsq out")
+    ws = _scratch(1024, x.device)
+    _lib.call("udm_sumsq_f32", _p(x), x.numel(), _p(out), _p(ws), ws.numel(), _s())
+    return out
+
+
+def adamw_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_norm_sq=None, max_grad_norm=None):
+    """In-place AdamW update of a flat fp32 tensor (torch.optim.AdamW arithmetic); optional device-side global-norm clipping."""
+    for t, n in ((p, "p"), (g, "g"), (m, "m"), (v, "v")):
+        _chk(t, F32, f"adamw_step {n}")
+    _lib.call("udm_adamw_step", _p(p), _p(g), _p(m), _p(v), p.numel(), float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), int(step),
+              _p(grad_norm_sq), float(max_grad_norm or 0.0), _s())
+
+
+def adamw_step_shadow(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_norm_sq, max_grad_norm, w16, w16t):
+    """AdamW update of a 2-D GEMM weight [R, C] that also writes its bf16 shadow w16 [>=R, C] and transposed shadow w16t [C, >=R]."""
+    for t, n in ((p, "p"), (g, "g"), (m, "m"), (v, "v")):
+        _chk(t, F32, f"adamw_step_shadow {n}")
+    R, C = p.shape
+    _lib.call("udm_adamw_step_shadow", _p(p), _p(g), _p(m), _p(v), R, C, float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), int(step),
+              _p(grad_norm_sq), float(max_grad_norm or 0.0), _p(w16), w16.stride(0) if w16 is not None else 0, _p(w16t),
+              w16t.stride(0) if w16t is not None else 0, _s())
+
+
 def colsum(x, out):
     """out[c] += sum_r x[r, c] (bias gradient) without writing a transpose."""
     _chk(x, BF16, "colsum")

@@ -1,0 +1,108 @@
+"""Fused AdamW + global-norm clipping for the engine's parameters.
+
+Mirrors what the reference's training loop does between backward and the next forward (model.py:1516-1545):
+``accelerator.clip_grad_norm_(backbone.parameters(), trainer.gradient_clip_val)`` then ``torch.optim.AdamW(fused=True).step()``
+(model_setup.py:385-424; config.optim: lr 3e-4, betas (0.9, 0.999), eps 1e-8, weight_decay 0) — in hand-written HIP kernels
+(csrc/optim.hip).  For the GEMM weights the update also refreshes the bf16 shadows W / Wᵀ the forward and dgrad GEMMs read, so the
+per-forward weight cast (autocast in the reference, ``cast_transpose`` here: ≈3 % of a 1.4 B step) leaves the training step.
+"""
+from __future__ import annotations
+
+from typing import Iterable, Optional
+
+import torch
+
+from . import kernels as K
+
+
+class FusedAdamW:
+    """``opt = FusedAdamW(backbone, lr=..., max_grad_norm=1.0); loss.backward(); opt.step(); opt.zero_grad()``.
+
+    ``lr`` may be changed between steps (``opt.lr = scheduler(...)``), like ``param_group["lr"]``.  ``grad_norm`` holds the pre-clip global
+    norm of the last step as a device tensor (no host synchronisation anywhere in ``step``)."""
+
+    def __init__(self, backbone: torch.nn.Module, lr: float = 3e-4, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0,
+                 max_grad_norm: Optional[float] = None, maintain_shadows: bool = True, params: Optional[Iterable[torch.nn.Parameter]] = None):
+        self.backbone = backbone
+        self.params = [p for p in (params if params is not None else backbone.parameters()) if p.requires_grad]
+        for p in self.params:
+            if p.dtype != torch.float32 or not p.is_contiguous():
+                raise ValueError("FusedAdamW: parameters must be contiguous fp32 masters")
+        self.lr, self.betas, self.eps, self.weight_decay = float(lr), (float(betas[0]), float(betas[1])), float(eps), float(weight_decay)
+        self.max_grad_norm = float(max_grad_norm) if max_grad_norm is not None else None
+        self.maintain_shadows = bool(maintain_shadows) and hasattr(backbone, "refresh_weight_shadows")
+        self.step_count = 0
+        self.state = {id(p): (torch.zeros_like(p), torch.zeros_like(p)) for p in self.params}
+        self._gsq = None
+        self.grad_norm = None
+
+    # ------------------------------------------------------------------------------------------------
+    def _grad_sumsq(self, grads):
+        """Device scalar Σ g² over all gradients: one pass over the engine's flat gradient buffer when every p.grad is a view of it."""
+        dev = grads[0].device
+        if self._gsq is None or self._gsq.device != dev:
+            self._gsq = torch.zeros(1, dtype=torch.float32, device=dev)
+        ref = getattr(self.backbone, "_last_grad_flat_ref", None)
+        flat = ref() if ref is not None else None
+        if flat is not None and flat.device == dev:
+            lo, hi = flat.data_ptr(), flat.data_ptr() + flat.numel() * 4
+            inside = sum(g.numel() for g in grads if lo <= g.data_ptr() < hi)
+            covered = getattr(self.backbone, "_last_grad_numel", -1)
+            if inside == covered == sum(g.numel() for g in grads):  # the buffer holds exactly these gradients (alignment gaps are zero)
+                K.sumsq(flat, self._gsq)
+                return self._gsq
+        self._gsq.zero_()
+        for g in grads:  # generic path (accumulated / foreign gradients): one pass per tensor
+            part = torch.zeros(1, dtype=torch.float32, device=dev)
+            K.sumsq(g.reshape(-1), part)
+            self._gsq += part
+        return self._gsq
+
+    @torch.no_grad()
+    def step(self):
+        todo = [p for p in self.params if p.grad is not None]
+        if not todo:
+            return
+        for p in todo:
+            if p.grad.dtype != torch.float32 or not p.grad.is_contiguous():
+                raise ValueError("FusedAdamW: gradients must be contiguous fp32")
+        self.step_count += 1
+        gsq = None
+        if self.max_grad_norm is not None:
+            gsq = self._grad_sumsq([p.grad for p in todo])
+            self.grad_norm = gsq.sqrt()
+        lins = {}
+        if self.maintain_shadows:
+            if getattr(self.backbone, "_lins", None) is None:
+                self.backbone.refresh_weight_shadows(force=True)
+            lins = {id(l.weight): l for l in self.backbone._lins.values()}
+        b1, b2 = self.betas
+        for p in todo:
+            m, v = self.state[id(p)]
+            lin = lins.get(id(p))
+            if lin is not None and lin.w16 is not None:
+                K.adamw_step_shadow(p, p.grad, m, v, self.lr, b1, b2, self.eps, self.weight_decay, self.step_count, gsq, self.max_grad_norm, lin.w16, lin.w16t)
+            else:
+                K.adamw_step(p, p.grad, m, v, self.lr, b1, b2, self.eps, self.weight_decay, self.step_count, gsq, self.max_grad_norm)
+        if self.maintain_shadows:
+            # the shadows are current: the next forward must not re-cast (kernel writes do not bump tensor versions, so record them)
+            self.backbone.recast_every_forward = False
+            self.backbone._shadow_versions = [l.weight._version for l in self.backbone._lins.values()]
+
+    def zero_grad(self, set_to_none: bool = True):
+        for p in self.params:
+            if p.grad is not None:
+                if set_to_none:
+                    p.grad = None
+                else:
+                    p.grad.zero_()
+
+    def state_dict(self):
+        return dict(step=self.step_count, lr=self.lr, betas=self.betas, eps=self.eps, weight_decay=self.weight_decay, max_grad_norm=self.max_grad_norm,
+                    exp_avg=[self.state[id(p)][0] for p in self.params], exp_avg_sq=[self.state[id(p)][1] for p in self.params])
+
+    def load_state_dict(self, sd):
+        self.step_count, self.lr = int(sd["step"]), float(sd["lr"])
+        for p, m, v in zip(self.params, sd["exp_avg"], sd["exp_avg_sq"]):
+            self.state[id(p)][0].copy_(m)
+            self.state[id(p)][1].copy_(v)
