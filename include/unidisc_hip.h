@@ -125,6 +125,15 @@ int udm_timestep_embedding(const float* sigma, void* out, int64_t B, int64_t dim
 int udm_silu_fwd(const void* x, void* y, int64_t n, hipStream_t stream);
 int udm_silu_bwd(const void* x, const void* dy, void* dx, int64_t n, hipStream_t stream);
 
+/* ---- sampler step: one reverse-diffusion update of [MASK] rows straight from bf16 logits, no [rows, V] probabilities.
+ * p = exp(SUBS log-probs) (`_ddpm_forward` model_eval.py:1761-1834 no-CFG branch); q_i = p_i (t - s), q_mask = s (`_ddpm_caching_update`
+ * :2073-2106); out = argmax_i q_i / (1e-10 - log(u_i + 1e-10)) (`_sample_categorical` model_utils.py:95-97; first index on ties).
+ * logits: [M, ld] rows of masked positions only; t / s: per-row move chance now / next; u: explicit uniforms [M, ldu] (parity runs replay the
+ * reference's rand stream) or NULL -> Philox(seed).  greedy != 0: argmax of the log-probs (`noise_removal` :2437-2444), t / s / u ignored. */
+int udm_ddpm_sample_rows(const void* logits, int64_t ld, const int64_t* modality, const float* t, const float* s, const float* u, int64_t ldu,
+                         uint64_t seed, int64_t* out, int64_t M, int64_t V, int64_t Vt, int64_t mask_id, int restrict_modality, int greedy,
+                         hipStream_t stream);
+
 /* ---- optimizer step: torch.optim.AdamW(fused=True) `model_setup.py:385-424` + accelerator.clip_grad_norm_ `model.py:1516-1520`.
  * fp32 masters and moments; `step` is the 1-based update count (bias corrections are computed from it); `grad_norm_sq` (nullable) is a DEVICE
  * scalar holding the sum of squares of ALL gradients (udm_sumsq_f32 over the engine's flat gradient buffer): g is scaled by

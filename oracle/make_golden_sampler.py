@@ -1,0 +1,124 @@
+"""Golden vectors for the sampler inner loop, made by running the IMPORTED reference (build container only).
+
+    python -m oracle.make_golden_sampler        # writes tests/golden/sampler_<case>.npz
+
+TEST INFRASTRUCTURE (same status as make_golden.py).  Reference entry points exercised (file:line in /root/reference):
+  model_eval.py:2073 _ddpm_caching_update, :1761 _ddpm_forward (no-CFG branch), model_utils.py:95 _sample_categorical,
+  model.py:674 forward (log-probs and return_logits=True), and the `ddpm_cache` branch of the loop in model_eval.py:2307-2444
+  (timesteps = linspace(1, eps, steps+1), dt = (1-eps)/steps, cache reuse when nothing changed, x0/x0_unmask conditioning,
+  noise_removal arg-max).  The loop around the reference's own update function is restated here because `_sample` itself needs a
+  tokenizer, decode and logging stack; every model/sampling call inside it is the reference's.
+
+Recorded per step: x before, t, the uniforms `torch.rand_like` drew (captured by wrapping torch.rand_like), the logits the backbone
+produced, x after.  Plus the final (noise-removed) tokens.
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+import torch
+
+from oracle import ref_shim
+from oracle.cases import CASES
+from oracle.make_golden import GOLDEN_DIR, build_reference, make_batch, _np
+
+SAMPLER_CASES = {"c_large": dict(steps=6, eps=1e-5, seed=1234, conditional=True), "b_small": dict(steps=5, eps=1e-5, seed=77, conditional=False)}
+
+
+def run(name, spec):
+    case = CASES[name]
+    d = build_reference(case, torch.float32)
+    d.backbone.eval()
+    C = ref_shim.Cfg
+    d.config.noise = C(type="loglinear")
+    d.config.eval = C(cfg=None, attention_caching=False)
+    d.config.trainer.force_null_sigma = False
+    d.config.sampling = C(predictor="ddpm_cache", steps=spec["steps"], noise_removal=True)
+    d.sampler = "ddpm_cache"
+    import model_utils as ref_utils
+    import model_eval as ref_eval
+
+    batch = d.update_batch({k: v.clone() for k, v in make_batch(case).items()})
+    x0_data = batch["input_ids"]
+    modality = batch.get("modality")
+    B, L = x0_data.shape
+    steps, eps = spec["steps"], spec["eps"]
+    x0 = x0_unmask = None
+    if spec["conditional"]:  # keep the text half as conditioning (x0 / x0_unmask branch of _sample)
+        x0 = x0_data.clone()
+        x0_unmask = torch.zeros(B, L, dtype=torch.bool)
+        x0_unmask[:, : case["txt_length"]] = True
+    x = d._sample_prior(B, L)
+    if x0 is not None:
+        x = torch.where(x0_unmask, x0, x)
+    timesteps = torch.linspace(1, eps, steps + 1)
+    dt = (1 - eps) / steps
+    rec = {"x_init": x.clone(), "timesteps": timesteps.clone(), "dt": torch.tensor(dt)}
+    if modality is not None:
+        rec["modality"] = modality.clone()
+    if x0 is not None:
+        rec.update(x0=x0.clone(), x0_unmask=x0_unmask.clone())
+    kwargs = dict(modality=modality) if modality is not None else {}
+    drawn = []
+    orig_rand_like = torch.rand_like
+
+    def rand_like(t, *a, **k):
+        u = orig_rand_like(t, *a, **k)
+        drawn.append(u.detach().clone())
+        return u
+
+    p_x0_cache = None
+    nfe = 0
+    torch.manual_seed(spec["seed"])
+    with torch.no_grad():
+        for i in range(steps):
+            t = timesteps[i] * torch.ones(B, 1)
+            rec[f"step{i}/x"] = x.clone()
+            rec[f"step{i}/reused_cache"] = torch.tensor(p_x0_cache is not None)
+            if p_x0_cache is None:  # the logits this step's forward sees (side call: deterministic, consumes no RNG)
+                sigma_t, _ = d.noise(t)
+                rec[f"step{i}/logits"] = d.forward(x=x, sigma=sigma_t, return_logits=True, **kwargs).float().clone()
+            torch.rand_like = rand_like
+            ref_utils.torch.rand_like = rand_like
+            try:
+                p_x0_cache, x_next, n = d._ddpm_caching_update(x, t, dt, p_x0=p_x0_cache, x0=x0, x0_unmask=x0_unmask, **kwargs)
+            finally:
+                torch.rand_like = orig_rand_like
+            nfe += n
+            rec[f"step{i}/u"] = drawn.pop()
+            assert not drawn
+            rec[f"step{i}/p_x0"] = p_x0_cache.float().clone()
+            if not torch.allclose(x_next, x) or d.time_conditioning:
+                p_x0_cache = None
+            x = x_next
+            if x0 is not None:
+                x = torch.where(x0_unmask, x0, x)
+            rec[f"step{i}/x_next"] = x.clone()
+        t = timesteps[-1] * torch.ones(B, 1)
+        x_final = d.forward(x=x, sigma=d.noise(t)[0], **kwargs).argmax(dim=-1)
+        if x0 is not None:
+            x_final = torch.where(x0_unmask, x0, x_final)
+    rec["x_before_noise_removal"] = x.clone()
+    rec["x_final"] = x_final.clone()
+    rec["nfe"] = torch.tensor(nfe)
+    return rec
+
+
+def main(names=None):
+    os.makedirs(GOLDEN_DIR, exist_ok=True)
+    for name, spec in SAMPLER_CASES.items():
+        if names and name not in names:
+            continue
+        rec = run(name, spec)
+        out = {k: _np(v) for k, v in rec.items()}
+        out["steps"], out["eps"], out["seed"] = np.array(spec["steps"]), np.array(spec["eps"]), np.array(spec["seed"])
+        path = os.path.join(GOLDEN_DIR, f"sampler_{name}.npz")
+        np.savez_compressed(path, **out)
+        left = int((rec["x_before_noise_removal"] == CASES[name]["text_vocab_size"] - 1).sum())
+        print(f"sampler_{name}: steps={spec['steps']} nfe={int(rec['nfe'])} masks left before noise removal={left} -> {path} ({os.path.getsize(path) / 1024:.0f} KiB)")
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:] or None)

@@ -474,3 +474,62 @@ def compute_loss(cfg: OracleConfig, P, buffers, batch, generator=None, bf16=Fals
     out.aux = dict(t=t, sigma=sigma, dsigma=dsigma, xt=xt, move_indices=move, logits=logits, log_probs=lp,
                    ignore_batch_mask=ignore, should_mask_txt=smt, should_mask_img=smi, log_p=log_p)
     return out
+
+
+# ------------------------------------------------------------------------------------------------
+# sampler inner loop: `ddpm_cache` predictor, no CFG, no attention caching
+# ------------------------------------------------------------------------------------------------
+def sample_categorical(q, u):
+    """model_utils.py:95-97 with the uniforms passed in: argmax(q / (1e-10 - log(u + 1e-10)))."""
+    gumbel_norm = 1e-10 - (u + 1e-10).log()
+    return (q / gumbel_norm).argmax(dim=-1)
+
+
+def ddpm_forward(cfg: OracleConfig, P, buffers, x, sigma_t, modality=None, batch=None, bf16=False):
+    """model_eval.py:1761-1834, branch without CFG: p_x0 = exp(forward(x, sigma)) = exp(SUBS log-probs)."""
+    logits = dit_forward(cfg, P, buffers, x, sigma_t, modality, None, bf16)
+    return subs_parameterization(cfg, logits, x, modality, batch, bf16).float().exp(), logits
+
+
+def ddpm_caching_update(cfg: OracleConfig, P, buffers, x, t, dt, u, p_x0=None, modality=None, batch=None, bf16=False):
+    """model_eval.py:2073-2106.  t: [B] or [B,1]; u: uniforms [B, L, V] (what torch.rand_like drew).  Returns (p_x0, x_next, nfe)."""
+    if t.ndim > 1:
+        t = t.squeeze(-1)
+    sigma_t, _ = loglinear_noise(t)
+    move_t, move_s = t[:, None, None], (t - dt)[:, None, None]
+    nfe = 0
+    if p_x0 is None:
+        p_x0, _ = ddpm_forward(cfg, P, buffers, x, sigma_t, modality, batch, bf16)
+        nfe = 1
+    q_xs = p_x0 * (move_t - move_s)
+    q_xs[:, :, cfg.mask_index] = move_s[:, :, 0]
+    _x = sample_categorical(q_xs, u)
+    copy_flag = (x != cfg.mask_index).to(x.dtype)
+    return p_x0, copy_flag * x + (1 - copy_flag) * _x, nfe
+
+
+def sample_ddpm_cache(cfg: OracleConfig, P, buffers, x_init, timesteps, dt, us, x0=None, x0_unmask=None, modality=None, batch=None,
+                      noise_removal=True, bf16=False):
+    """The `ddpm_cache` path of model_eval.py:2307-2444 (`_sample`): loop over timesteps[:-1], p_x0 reused while x does not change (and
+    there is no time conditioning), x0 / x0_unmask conditioning re-imposed after every step, final arg-max of the log-probs."""
+    x = x_init.clone()
+    B = x.shape[0]
+    p_cache, nfe, xs = None, 0, []
+    for i in range(len(timesteps) - 1):
+        t = timesteps[i] * torch.ones(B, 1)
+        p_cache, x_next, n = ddpm_caching_update(cfg, P, buffers, x, t, dt, us[i], p_x0=p_cache, modality=modality, batch=batch, bf16=bf16)
+        nfe += n
+        if not torch.allclose(x_next, x) or cfg.time_conditioning:
+            p_cache = None
+        x = x_next
+        if x0 is not None:
+            x = torch.where(x0_unmask, x0, x)
+        xs.append(x.clone())
+    x_last = x
+    if noise_removal:
+        t = timesteps[-1] * torch.ones(B)
+        logits = dit_forward(cfg, P, buffers, x, loglinear_noise(t)[0], modality, None, bf16)
+        x = subs_parameterization(cfg, logits, x, modality, batch, bf16).float().argmax(dim=-1)
+        if x0 is not None:
+            x = torch.where(x0_unmask, x0, x)
+    return x, xs, x_last, nfe

@@ -369,3 +369,18 @@ def adamw_step_shadow(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, gra
         w16[:R, :C] = p.bfloat16()
     if w16t is not None:
         w16t[:C, :R] = p.t().bfloat16()
+
+
+# ------------------------------------------------------------------------------------------------ sampler (csrc/ce.hip: udm_ddpm_sample_rows)
+def ddpm_sample_rows(logits, V, Vt, mask_id, *, t=None, s=None, modality=None, restrict=False, u=None, seed=0, greedy=False):
+    M = logits.shape[0]
+    valid = _valid(M, V, Vt, mask_id, modality, restrict)
+    z = logits[:, :V].float().masked_fill(~valid, float("-inf"))
+    logp = z - torch.logsumexp(z, -1, keepdim=True)
+    if greedy:
+        return torch.where(valid, logp, torch.full_like(logp, -1e6)).argmax(-1)
+    q = torch.where(valid, logp.exp() * (t - s)[:, None], torch.zeros_like(logp))
+    q[:, mask_id] = s
+    if u is None:
+        u = torch.rand(M, V, generator=torch.Generator().manual_seed(int(seed) & 0x7FFFFFFF))
+    return (q / (1e-10 - (u[:, :V] + 1e-10).log())).argmax(-1)

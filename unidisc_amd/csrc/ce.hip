@@ -200,6 +200,85 @@ extern "C" int udm_subs_ce_bwd(void* logits, int64_t ld, const int64_t* x0, cons
   return 0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// One reverse-diffusion step for [MASK] rows without materialising [rows, V] probabilities:
+//   p      = exp(SUBS log-probs)                      `_ddpm_forward` model_eval.py:1761-1834 (no-CFG branch), `_subs_parameterization`
+//   q_i    = p_i (t - s),  q_mask = s                 `_ddpm_caching_update` model_eval.py:2073-2106
+//   x_new  = argmax_i q_i / (1e-10 - log(u_i + 1e-10))   `_sample_categorical` model_utils.py:95-97  (first index on ties, like torch.argmax)
+// u comes from the caller (parity runs replay the reference's rand stream) or from Philox.  greedy != 0: argmax of the log-probs instead
+// (`noise_removal`, model_eval.py:2437-2444).
+// ------------------------------------------------------------------------------------------------
+struct SampleArgs {
+  const bf16_t* logits; long ld;
+  const int64_t* modality;   // per row, nullable
+  const float* t; const float* s;   // per row: move chance at this step / at the next one
+  const float* u; long ldu;  // explicit uniforms [rows, ldu >= V], nullable
+  uint64_t seed;
+  int64_t* out;
+  int V, Vt, mask_id, restrict_modality, greedy;
+};
+
+__global__ __launch_bounds__(256) void ddpm_sample_rows_kernel(SampleArgs a) {
+  __shared__ float sm[4], ss[4];
+  __shared__ float bs[4];
+  __shared__ int bi[4];
+  const long row = blockIdx.x;
+  const int tid = threadIdx.x;
+  int lo = 0, hi = a.V;
+  if (a.restrict_modality) {
+    const bool img = a.modality && a.modality[row] == 1;
+    if (img) lo = a.Vt; else hi = a.Vt;
+  }
+  const bf16_t* z = a.logits + row * a.ld;
+  float m = -INFINITY, s = 0.f;
+  for (int c = tid; c < a.V; c += 256) {
+    const bool ok = c >= lo && c < hi && c != a.mask_id;
+    if (!ok) continue;
+    const float v = bf2f(z[c]);
+    if (v > m) { s = (m == -INFINITY) ? 0.f : s * __expf(m - v); m = v; }
+    s += __expf(v - m);
+  }
+  block_reduce_ms(m, s, sm, ss);
+  const float lse = m + __logf(s);
+  const float dt = a.greedy ? 0.f : a.t[row] - a.s[row], sr = a.greedy ? 0.f : a.s[row];
+  float best = -INFINITY;
+  int besti = 0x7fffffff;
+  for (int c = tid; c < a.V; c += 256) {
+    const bool ok = c >= lo && c < hi && c != a.mask_id;
+    float score;
+    if (a.greedy) {
+      score = ok ? bf2f(z[c]) - lse : NEG;   // the reference's argmax runs over log-probs with invalid ids at -1e6
+      if (c == a.mask_id) score = NEG + bf2f(z[c]) - lse;
+    } else {
+      const float q = (c == a.mask_id) ? sr : (ok ? __expf(bf2f(z[c]) - lse) * dt : 0.f);
+      float uu;
+      if (a.u) {
+        uu = a.u[row * a.ldu + c];
+      } else {
+        const uint4 r = philox4x32(a.seed, (uint64_t)row * (uint64_t)((a.V + 3) / 4) + (uint64_t)(c >> 2));
+        const uint32_t w = (c & 3) == 0 ? r.x : (c & 3) == 1 ? r.y : (c & 3) == 2 ? r.z : r.w;
+        uu = (float)(w >> 8) * (1.0f / 16777216.0f);
+      }
+      score = q / (1e-10f - __logf(uu + 1e-10f));
+    }
+    if (score > best) { best = score; besti = c; }   // c increases per thread: the first maximum is kept
+  }
+  // block argmax, smallest index on ties
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    const float b2 = __shfl_xor(best, o, 64);
+    const int i2 = __shfl_xor(besti, o, 64);
+    if (b2 > best || (b2 == best && i2 < besti)) { best = b2; besti = i2; }
+  }
+  if ((tid & 63) == 0) { bs[tid >> 6] = best; bi[tid >> 6] = besti; }
+  __syncthreads();
+  if (tid == 0) {
+    for (int w = 1; w < 4; ++w)
+      if (bs[w] > best || (bs[w] == best && bi[w] < besti)) { best = bs[w]; besti = bi[w]; }
+    a.out[row] = besti;
+  }
+}
+
 extern "C" int udm_subs_logprobs(const void* logits, int64_t ld, const int64_t* xt, const int64_t* modality, void* out, int64_t ld_out, int out_f32, int64_t M,
                                  int64_t V, int64_t Vt, int64_t mask_id, int restrict_modality, hipStream_t stream) {
   if (int rc = check("udm_subs_logprobs", logits, M, V, ld, Vt, mask_id)) return rc;
@@ -211,5 +290,18 @@ extern "C" int udm_subs_logprobs(const void* logits, int64_t ld, const int64_t* 
   else
     hipLaunchKernelGGL(subs_logprobs_kernel<false>, dim3((unsigned)M), dim3(256), 0, stream, a, out, (long)ld_out);
   UDM_CHECK_LAUNCH("udm_subs_logprobs");
+  return 0;
+}
+
+extern "C" int udm_ddpm_sample_rows(const void* logits, int64_t ld, const int64_t* modality, const float* t, const float* s, const float* u, int64_t ldu,
+                                    uint64_t seed, int64_t* out, int64_t M, int64_t V, int64_t Vt, int64_t mask_id, int restrict_modality, int greedy,
+                                    hipStream_t stream) {
+  if (int rc = check("udm_ddpm_sample_rows", logits, M, V, ld, Vt, mask_id)) return rc;
+  UDM_CHECK_ARG(out && (greedy || (t && s)), "udm_ddpm_sample_rows: null pointer");
+  UDM_CHECK_ARG(!u || ldu >= V, "udm_ddpm_sample_rows: noise row stride too small");
+  UDM_CHECK_ARG(!restrict_modality || modality, "udm_ddpm_sample_rows: restrict_modality needs the per-row modality");
+  SampleArgs a{(const bf16_t*)logits, (long)ld, modality, t, s, u, (long)ldu, seed, out, (int)V, (int)Vt, (int)mask_id, restrict_modality, greedy};
+  hipLaunchKernelGGL(ddpm_sample_rows_kernel, dim3((unsigned)M), dim3(256), 0, stream, a);
+  UDM_CHECK_LAUNCH("udm_ddpm_sample_rows");
   return 0;
 }

@@ -313,6 +313,95 @@ class Diffusion:
                                "training uses compute_loss (fused path) — wrap sampler calls in torch.no_grad()")
         return self._subs_parameterization(logits, xt=x, batch=batch, **kwargs)
 
+    # ---- sampler inner loop: the `ddpm_cache` predictor (config.sampling.predictor default), no CFG, no attention caching
+    def _sample_prior(self, *batch_dims):  # model_eval.py:1734-1735
+        return self.mask_index * torch.ones(*batch_dims, dtype=torch.int64, device=self.device)
+
+    def _row_modality(self, rows, B, L, modality):
+        """Per-row modality for the SUBS vocabulary restriction (model.py:627-635), or None when it is off."""
+        if not self._restrict():
+            return None
+        if modality is None:  # static slices
+            modality = torch.zeros((B, L), dtype=torch.int64, device=rows.device)
+            modality[:, self.static_img_sl] = 1
+        return modality.reshape(-1).to(torch.int64).index_select(0, rows)
+
+    @torch.no_grad()
+    def _ddpm_caching_update(self, x, t, dt, p_x0=None, x0=None, x0_unmask=None, modality=None, sample_ids=None, u=None, seed=None, **kwargs):
+        """model_eval.py:2073-2106 for the [MASK] rows only, fused (`udm_ddpm_sample_rows`): no [B, L, V] probabilities are built.
+        `p_x0` is this implementation's cache: the masked rows' logits of the last forward (reused while x does not change, like the
+        reference's p_x0 cache).  `u`: explicit uniforms [B, L, V] (parity runs); otherwise Philox keyed by `seed`.
+        Returns (cache, x_next, nfe) like the reference."""
+        if t.ndim > 1:
+            t = t.squeeze(-1)
+        B, L = x.shape
+        nfe = 0
+        if p_x0 is None:
+            sigma_t, _ = self.noise(t)
+            p_x0 = self.backbone.forward_masked_logits(x, self._process_sigma(sigma_t), modality=modality, sample_ids=sample_ids)
+            nfe = 1
+        logits, rows, n = p_x0
+        x_next = x.clone()
+        if n > 0:
+            rows_n = rows[:n]
+            b_of = torch.div(rows_n, L, rounding_mode="floor")
+            t_rows = t.to(torch.float32).index_select(0, b_of).contiguous()
+            s_rows = (t.to(torch.float32) - dt).index_select(0, b_of).contiguous()
+            u_rows = u.reshape(B * L, -1).index_select(0, rows_n).contiguous() if u is not None else None
+            tok = K.ddpm_sample_rows(logits[:n], self.vocab_size, self.text_vocab_size, self.mask_index, t=t_rows, s=s_rows,
+                                     modality=self._row_modality(rows_n, B, L, modality), restrict=self._restrict(), u=u_rows,
+                                     seed=int(seed if seed is not None else torch.initial_seed()))
+            x_next.view(-1).index_copy_(0, rows_n, tok)
+        return p_x0, x_next, nfe
+
+    @torch.no_grad()
+    def sample(self, num_steps=None, eps=1e-5, x0=None, x0_unmask=None, batch_size=None, modality=None, sample_ids=None, seed=None, noise=None,
+               noise_removal=True, return_nfe=False):
+        """Token sampler: the `ddpm_cache` path of `_sample` (model_eval.py:2109-2455) without the decode / logging stack: prior = all [MASK]
+        (x0 / x0_unmask conditioning kept fixed), timesteps = linspace(1, eps, steps + 1), one fused update per step with the logits
+        cache reused while nothing changes, final arg-max of the log-probs (`noise_removal`).  Returns token ids [B, L]
+        (and the number of backbone evaluations).  `noise`: optional list of uniforms [B, L, V] per step (replay of a recorded run)."""
+        assert (x0 is None) == (x0_unmask is None)
+        sampling = cfg_get(self.config, "sampling", None)
+        if num_steps is None:
+            num_steps = int(cfg_get(sampling, "steps", 1000)) if sampling is not None else 1000
+        B = x0.shape[0] if x0 is not None else int(batch_size)
+        L = x0.shape[1] if x0 is not None else int(cfg_get(cfg_get(self.config, "model"), "length"))
+        x = self._sample_prior(B, L)
+        if x0 is not None:
+            x0 = x0.to(self.device).to(torch.int64)
+            x0_unmask = x0_unmask.to(self.device).bool()
+            x = torch.where(x0_unmask, x0, x)
+        if modality is not None:
+            modality = modality.to(self.device)
+        timesteps = torch.linspace(1, eps, num_steps + 1, device=self.device)
+        dt = (1 - eps) / num_steps
+        base_seed = int(seed if seed is not None else torch.initial_seed())
+        cache, nfe = None, 0
+        for i in range(num_steps):
+            t = timesteps[i] * torch.ones(B, 1, device=self.device)
+            cache, x_next, n = self._ddpm_caching_update(x, t, dt, p_x0=cache, x0=x0, x0_unmask=x0_unmask, modality=modality, sample_ids=sample_ids,
+                                                         u=noise[i] if noise is not None else None, seed=base_seed + 7919 * i)
+            nfe += n
+            if self.time_conditioning or not torch.equal(x_next, x):
+                cache = None  # the reference's `if not allclose(x_next, x) or time_conditioning: p_x0_cache = None`
+            x = x_next
+            if x0 is not None:
+                x = torch.where(x0_unmask, x0, x)
+        if noise_removal:  # x = forward(x, sigma(t_last)).argmax(-1): unmasked positions keep their token, masked ones take the best valid id
+            t = timesteps[-1] * torch.ones(B, device=self.device)
+            sigma_t, _ = self.noise(t)
+            logits, rows, n = self.backbone.forward_masked_logits(x, self._process_sigma(sigma_t), modality=modality, sample_ids=sample_ids)
+            nfe += 1
+            if n > 0:
+                tok = K.ddpm_sample_rows(logits[:n], self.vocab_size, self.text_vocab_size, self.mask_index,
+                                         modality=self._row_modality(rows[:n], B, L, modality), restrict=self._restrict(), greedy=True)
+                x = x.clone()
+                x.view(-1).index_copy_(0, rows[:n], tok)
+            if x0 is not None:
+                x = torch.where(x0_unmask, x0, x)
+        return (x, nfe) if return_nfe else x
+
     # ---- model.py:797-1173, SUBS / continuous-time branch
     def compute_loss(self, batch, prefix, batch_idx=-1):
         cfg, tr = self.config, cfg_get(self.config, "trainer")

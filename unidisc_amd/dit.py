@@ -306,6 +306,14 @@ class DIT(nn.Module, _HubMixin):
         inputs = dict(indices=xt, sigma=sigma, modality=modality, sample_ids=sample_ids, x0=x0, restrict=restrict_modality, save=self._needs_grad(params))
         return _DitFn.apply(self, "logp", inputs, *params)
 
+    @torch.no_grad()
+    def forward_masked_logits(self, xt, sigma=None, modality=None, sample_ids=None):
+        """Sampler path: (logits [R, Vp] bf16 of the [MASK] positions of `xt` first, then padding rows; their flat row indices [R];
+        the number of [MASK] rows).  Unmasked positions keep their token under SUBS (model.py:646-656), so they need no logits."""
+        inputs = dict(indices=xt, sigma=sigma, modality=modality, sample_ids=sample_ids, x0=None, save=False)
+        out, _ = self._engine_forward(inputs, "rows", save=False)
+        return out
+
     @staticmethod
     def _needs_grad(params):
         return torch.is_grad_enabled() and any(p.requires_grad for p in params)
@@ -373,7 +381,7 @@ class DIT(nn.Module, _HubMixin):
         # dgrad, wgrad and the cross-entropy) runs on the masked rows only.  Their number is data dependent: it is counted on a side
         # stream NOW and only read back right before the head, when the host has already queued every block of this forward -- the
         # device never waits for the host.
-        head_plan = self._plan_masked_rows(ids) if (mode == "logp" and self.compact_head) else None
+        head_plan = self._plan_masked_rows(ids) if ((mode == "logp" and self.compact_head) or mode == "rows") else None
 
         x = K.embedding_fwd(ids, self.vocab_embed.embedding.detach(), emb_mod if self.modality_embed is not None else None,
                             self.modality_embed.embedding.detach() if self.modality_embed is not None else None)
@@ -455,6 +463,12 @@ class DIT(nn.Module, _HubMixin):
             hf, rstdf, meanf = K.norm_fwd(x, fl.norm_final.weight.detach(), nt, L, mod=fmod, mod_idx=(0, 1), modality=mod_flat, any_img=any_img)
         head = lin["head"]
         V, Vp = self.vocab_size, head.outp
+        if mode == "rows":  # sampler: logits of the [MASK] rows only (no autograd); rows = their flat indices, padded to a multiple of 64
+            rows_p, n_masked = self._masked_rows(head_plan, M, always=True)
+            hf_h = hf.index_select(0, rows_p)
+            logits = torch.empty((hf_h.shape[0], Vp), dtype=BF16, device=dev)
+            K.gemm_nt(hf_h, head.w16, out=logits, N=V, epilogue=K.EPI_BIAS, bias=head.bias.detach())
+            return (logits, rows_p, n_masked), S
         if mode == "logits":
             logits = torch.empty((M, Vp), dtype=BF16, device=dev)
             K.gemm_nt(hf, head.w16, out=logits, N=V, epilogue=K.EPI_BIAS, bias=head.bias.detach())
@@ -512,7 +526,7 @@ class DIT(nn.Module, _HubMixin):
         order.record_stream(main)
         return dict(order=order, count=None, event=event)
 
-    def _masked_rows(self, plan, M):
+    def _masked_rows(self, plan, M, always=False):
         """(row indices: the [MASK] rows, then as many unmasked rows as pad the list to a multiple of 64; number of masked rows), or
         None when compaction would not shrink the head.  Unmasked rows have zero loss and zero gradient, so padding with them is exact."""
         if plan["event"] is not None:
@@ -523,7 +537,7 @@ class DIT(nn.Module, _HubMixin):
             n = plan["count"]
         n_pad = _ceil(max(n, 1), 64)
         if n_pad >= M:
-            return None
+            return (plan["order"], n) if always else None   # always: every row, [MASK] rows first
         return plan["order"][:n_pad], n
 
     # -------------------------------------------------------------------------------------------- engine: backward

@@ -106,6 +106,16 @@ def gemm_tn_splitk(a, b, out, *, M=None, N=None, beta=0.0):
     return out
 
 
+def ddpm_sample_rows(logits, V, Vt, mask_id, *, t=None, s=None, modality=None, restrict=False, u=None, seed=0, greedy=False):
+    """Sampled (or, greedy, arg-max) token per row of `logits` [rows, ld] bf16: one reverse-diffusion update of [MASK] rows."""
+    _chk(logits, BF16, "ddpm_sample_rows logits")
+    M = logits.shape[0]
+    out = torch.empty(M, dtype=torch.int64, device=logits.device)
+    _lib.call("udm_ddpm_sample_rows", _p(logits), logits.stride(0), _p(modality), _p(t), _p(s), _p(u), u.stride(0) if u is not None else 0, int(seed),
+              _p(out), M, V, Vt, mask_id, 1 if restrict else 0, 1 if greedy else 0, _s())
+    return out
+
+
 def sumsq(x, out):
     """out[0] = sum(x**2) (fp32, 1-D contiguous x); two-phase reduction through the scratch buffer."""
     _chk(x, F32, "sumsq x"), _chk(out, F32, "sumsq out")
