@@ -10,6 +10,7 @@
 #include "../../include/unidisc_hip.h"
 
 #include <stdio.h>
+#include <stdlib.h>
 #include <type_traits>
 
 namespace {
@@ -23,6 +24,7 @@ struct XArgs {
   long lda, ldb, ldc;
   int M, N, K, tiles_m, tiles_n;
   unsigned long long* tl;   // quad timeline (OPT bit 4): cycle stamps of block 0, [wave][K tile 8..15][tag]
+  int sg_mod, sg_mul;       // ring: block pid starts its K loop at tile ((pid % sg_mod) * sg_mul) % nk and wraps (0: no stagger)
 };
 
 template <int N>
@@ -579,6 +581,231 @@ int launch_quad(const XArgs& a0, hipStream_t stream) {
   return 0;
 }
 
+// ---- "ring": the quad tile (256 x 256, four waves, 128 x 128 per wave) over a FOUR-stage ring of 32-wide K tiles --------------
+// What the quad timeline showed (variant 37): the 16 LDS-DMA pieces of a K tile, issued back to back under 16 MFMAs, stretch that
+// section from 512 to ~1000 cycles (four waves x 1 KiB per 32 cycles = 128 B/clk against the CU's 64 B/clk vector-memory path), and
+// the vmcnt(0) + barrier before it waits ~420 cycles (prefetch distance of one 2048-cycle tile).  Here a stage is 32 KiB (256 rows x
+// 64 B per operand), so four stages fit: a stage is released by the ONE barrier of its tile (after the last fragment read of the
+// tile), the refill pieces go out one per four MFMAs (32 B/clk per CU) and land two to three tiles (2-3 k cycles) before they are read,
+// and the wait is a counted vmcnt(16) - the two younger tiles stay in flight.
+// LDS tile: row r at r * 64 B, 16-byte granule g stored at slot g ^ ((r >> 2) & 3) (16 consecutive lanes of a ds_read_b128 cover all
+// 64 banks).  A piece is 16 rows; the swizzle is applied on the global-source side of the DMA.
+template <int OPT>
+__global__ __launch_bounds__(256, 1) void gemm_nt_ring_kernel(XArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int BKR = 32, OP_BYTES = 256 * BKR * 2, STAGE_BYTES = 2 * OP_BYTES;
+  const int nwg = p.tiles_m * p.tiles_n;
+  int pid = xcd_remap(blockIdx.x, nwg);
+  constexpr int GROUP_M = 8;
+  const int per_group = GROUP_M * p.tiles_n;
+  const int grp = pid / per_group, first_m = grp * GROUP_M;
+  const int gsz = min(p.tiles_m - first_m, GROUP_M);
+  const int tm = first_m + (pid % per_group) % gsz, tn = (pid % per_group) / gsz;
+  const int row0 = tm * 256, col0 = tn * 256;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, hi = lane >> 5;
+
+  // LDS-DMA sources: wave w stages tile rows [64 w, 64 w + 64) of A and of B, 16 rows per piece; lane l lands at row l >> 2, slot l & 3
+  const int prow = lane >> 2, pslot = lane & 3;
+  const uint32_t offa = (uint32_t)((prow * p.lda + ((pslot ^ ((lane >> 4) & 3)) << 3)) * 2);
+  const uint32_t offb = (uint32_t)((prow * p.ldb + ((pslot ^ ((lane >> 4) & 3)) << 3)) * 2);
+  const char* abase = reinterpret_cast<const char*>(p.A + (long)(row0 + wave * 64) * p.lda);
+  const char* bbase = reinterpret_cast<const char*>(p.B + (long)(col0 + wave * 64) * p.ldb);
+  const long qa = 16 * p.lda * 2, qb = 16 * p.ldb * 2;
+  auto ubase = [&](const char* ptr) {
+    const uint64_t u = reinterpret_cast<uint64_t>(ptr);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u), hi32 = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
+    return reinterpret_cast<const char*>(((uint64_t)hi32 << 32) | lo);
+  };
+#if defined(__HIP_DEVICE_COMPILE__)
+  // OPT bit 5: buffer_load ... lds with a wave-uniform descriptor per operand: the per-piece / per-tile part of the address is an SGPR
+  // offset (SALU), the per-lane part one constant VGPR - no vector address arithmetic in the loop at all
+  __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)ubase(abase), 0, 0x7ffff000, 0x00020000);
+  __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)ubase(bbase), 0, 0x7ffff000, 0x00020000);
+#endif
+  const int qa32 = (int)qa, qb32 = (int)qb;
+  const int nk = p.K / BKR;
+  // K stagger: blocks that share an operand panel would otherwise request every line at the same moment (they run in lock step) and all
+  // of them wait out the one L2 miss; started at rotated K offsets, the first block pulls a line into L2 and the others hit it there.
+  const int koff = p.sg_mod > 0 ? ((pid % p.sg_mod) * p.sg_mul) % nk : 0;
+  auto dma_piece = [&](int tl_, int stage, int j) {   // j in 0..7: 0..3 A pieces, 4..7 B pieces
+    int t = tl_ + koff;
+    if (t >= nk) t -= nk;
+    const int jj = j & 3;
+    char* dst = smem + stage * STAGE_BYTES + (j >> 2) * OP_BYTES + (wave * 4 + jj) * 1024;
+    if ((OPT & 64) && wave != 0) return;   // ablation: only wave 0 refills (timing only)
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (OPT & 32) {
+      if (j < 4) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (UDM_LDS void*)dst, 16, offa, t * (BKR * 2) + jj * qa32, 0, 0);
+      else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (UDM_LDS void*)dst, 16, offb, t * (BKR * 2) + jj * qb32, 0, 0);
+      return;
+    }
+#endif
+    if (j < 4) glds16(ubase(abase + (long)t * (BKR * 2) + jj * qa) + (size_t)offa, dst);
+    else glds16(ubase(bbase + (long)t * (BKR * 2) + jj * qb) + (size_t)offb, dst);
+  };
+
+  const int sw = (l31 >> 2) & 3;
+  const uint32_t lds0 = (uint32_t)(size_t)(UDM_LDS char*)smem;
+  uint32_t fa_addr[2], fb_addr[2];
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) {
+    const uint32_t so = ((kk * 2 + hi) ^ sw) << 4;
+    fa_addr[kk] = lds0 + (wm * 128 + l31) * 64 + so;
+    fb_addr[kk] = lds0 + OP_BYTES + (wn * 128 + l31) * 64 + so;
+  }
+  bf16x8_t fa[2][4], fb[2][4];
+  auto read_one = [&](int stage, int kk, int buf, int n) {   // n in 0..7: A fragment n (n < 4) or B fragment n - 4
+    if (n < 4) fa[buf][n] = *reinterpret_cast<UDM_LDS const bf16x8_t*>((size_t)(fa_addr[kk] + stage * STAGE_BYTES + n * 2048));
+    else fb[buf][n - 4] = *reinterpret_cast<UDM_LDS const bf16x8_t*>((size_t)(fb_addr[kk] + stage * STAGE_BYTES + (n - 4) * 2048));
+  };
+  f32x16_t acc[4][4];
+  {
+    bf16x8_t zf = {};
+    asm volatile("" : "+v"(zf));
+    const f32x16_t zc = {};
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zf, zf, zc, 0, 0, 0);
+  }
+
+  // prologue: tiles 0..2 whole, pieces 0..3 of tile 3 (steady state: k-step 0 of tile t issues pieces 4..7 of tile t + 3, k-step 1 pieces 0..3 of t + 4)
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+    if (t < nk) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) dma_piece(t, t, j);
+    }
+  if (3 < nk) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dma_piece(3, 3, j);
+  }
+  if (nk >= 4) wait_vmcnt<20>();
+  else wait_vmcnt<0>();
+  __builtin_amdgcn_s_barrier();
+#pragma unroll
+  for (int n = 0; n < 8; ++n) read_one(0, 0, 0, n);
+
+  auto tile_body = [&](int t, auto stage_c) {
+    // stage_c 0..3: steady-state tile (t + 4 < nk: every refill exists, stage is a constant); -1: one of the last tiles (run-time checks)
+    constexpr int STC = decltype(stage_c)::value;
+    const int ST = STC >= 0 ? STC : (t & 3);
+    const bool HAS_NEXT = STC >= 0 || t + 1 < nk, DMA3 = STC >= 0 || t + 3 < nk, DMA4 = STC >= 0 || t + 4 < nk;
+#pragma unroll
+    for (int n = 0; n < 8; ++n) {   // k-step 0: fragments of k-step 1 come in, pieces 4..7 of tile t + 3 go out
+      __builtin_amdgcn_sched_barrier(0);
+      const int i = n >> 1, j0 = 2 * (n & 1);
+      acc[i][j0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][i], fb[0][j0], acc[i][j0], 0, 0, 0);
+      if (!(OPT & 2) && n < 4) read_one(ST, 1, 1, 2 * n);
+      if (n >= 4 && DMA3 && !(OPT & 4)) dma_piece(t + 3, (ST + 3) & 3, n);
+      acc[i][j0 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][i], fb[0][j0 + 1], acc[i][j0 + 1], 0, 0, 0);
+      if (!(OPT & 2) && n < 4) read_one(ST, 1, 1, 2 * n + 1);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if ((OPT & 16) && p.tl && blockIdx.x == 0 && t >= 16 && t < 24) {
+      const unsigned long long ts = __builtin_amdgcn_s_memtime();
+      if (lane == 0) p.tl[(wave * 8 + t - 16) * 4 + 0] = ts;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // tile t is read completely (lgkmcnt(0)); tile t + 1 has landed once at most the 16 younger pieces are outstanding
+    if (STC >= 0) asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else if (t + 3 < nk) asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else if (t + 2 < nk) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if ((OPT & 16) && p.tl && blockIdx.x == 0 && t >= 16 && t < 24) {
+      __builtin_amdgcn_sched_barrier(0);
+      const unsigned long long ts = __builtin_amdgcn_s_memtime();
+      if (lane == 0) p.tl[(wave * 8 + t - 16) * 4 + 1] = ts;
+    }
+#pragma unroll
+    for (int n = 0; n < 8; ++n) {   // k-step 1: first fragments of tile t + 1 come in, pieces 0..3 of tile t + 4 go into the stage just released
+      __builtin_amdgcn_sched_barrier(0);
+      const int i = n >> 1, j0 = 2 * (n & 1);
+      acc[i][j0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][i], fb[1][j0], acc[i][j0], 0, 0, 0);
+      if (!(OPT & 2) && HAS_NEXT && n < 4) read_one((ST + 1) & 3, 0, 0, 2 * n);
+      if (n >= 4 && DMA4 && !(OPT & 4)) dma_piece(t + 4, ST, n - 4);
+      acc[i][j0 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][i], fb[1][j0 + 1], acc[i][j0 + 1], 0, 0, 0);
+      if (!(OPT & 2) && HAS_NEXT && n < 4) read_one((ST + 1) & 3, 0, 0, 2 * n + 1);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if ((OPT & 16) && p.tl && blockIdx.x == 0 && t >= 16 && t < 24) {
+      const unsigned long long ts = __builtin_amdgcn_s_memtime();
+      if (lane == 0) p.tl[(wave * 8 + t - 16) * 4 + 2] = ts;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  int t = 0;
+  for (; t + 7 < nk; t += 4) {
+    tile_body(t, std::integral_constant<int, 0>{});
+    tile_body(t + 1, std::integral_constant<int, 1>{});
+    tile_body(t + 2, std::integral_constant<int, 2>{});
+    tile_body(t + 3, std::integral_constant<int, 3>{});
+  }
+  for (; t < nk; ++t) tile_body(t, std::integral_constant<int, -1>{});
+  __syncthreads();
+
+  float* patch0 = reinterpret_cast<float*>(smem) + wave * 2048;
+  const int er = lane >> 3, ec = (lane & 7) * 4;
+#pragma clang loop unroll(full)
+  for (int i = 0; i < 4; ++i)
+#pragma clang loop unroll(full)
+    for (int j = 0; j < 4; ++j) {
+      float* patch = patch0 + ((i * 4 + j) & 1) * 1024;
+#pragma clang loop unroll(full)
+      for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * hi) * 32 + l31] = acc[i][j][r];
+      const int gn = col0 + wn * 128 + j * 32 + ec;
+      const int gm0 = row0 + wm * 128 + i * 32 + er;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 v = *reinterpret_cast<const float4*>(patch + (q * 8 + er) * 32 + ec);
+        *reinterpret_cast<uint2*>(p.C + (long)(gm0 + q * 8) * p.ldc + gn) = make_uint2(pack2bf(v.x, v.y), pack2bf(v.z, v.w));
+      }
+    }
+}
+
+template <int OPT>
+int launch_ring(const XArgs& a0, hipStream_t stream) {
+  XArgs a = a0;
+  UDM_CHECK_ARG(a.M % 256 == 0 && a.N % 256 == 0 && a.K % 32 == 0, "udm_gemm_nt_bf16_variant(ring): M, N must be multiples of 256");
+  a.tiles_m = a.M / 256;
+  a.tiles_n = a.N / 256;
+  a.sg_mod = a.sg_mul = 0;
+  if (const char* e = getenv("UDM_RING_STAGGER")) sscanf(e, "%d,%d", &a.sg_mod, &a.sg_mul);
+  const size_t lds = 4 * 2 * 256 * 32 * 2;
+  auto kern = gemm_nt_ring_kernel<OPT>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  if (OPT & 16) {
+    static int calls = 0;
+    if (++calls == 3) {
+      unsigned long long* buf = nullptr;
+      (void)hipMalloc(&buf, 4 * 8 * 4 * 8);
+      (void)hipMemset(buf, 0, 4 * 8 * 4 * 8);
+      a.tl = buf;
+      hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n), dim3(256), lds, stream, a);
+      (void)hipStreamSynchronize(stream);
+      static unsigned long long h[4 * 8 * 4];
+      (void)hipMemcpy(h, buf, sizeof(h), hipMemcpyDeviceToHost);
+      for (int w = 0; w < 4; ++w)
+        for (int t = 0; t < 8; ++t)
+          fprintf(stderr, "RTL wave %d t %d: wait@%lld released@%lld end@%lld\n", w, t + 16, (long long)(h[(w * 8 + t) * 4] - h[0]), (long long)(h[(w * 8 + t) * 4 + 1] - h[0]),
+                  (long long)(h[(w * 8 + t) * 4 + 2] - h[0]));
+      (void)hipFree(buf);
+      return 0;
+    }
+  }
+  hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n), dim3(256), lds, stream, a);
+  UDM_CHECK_LAUNCH("udm_gemm_nt_bf16_variant(ring)");
+  return 0;
+}
+
 template <int BM, int BN, int WGM, int WGN, int STAGES>
 int launch(const XArgs& a0, hipStream_t stream) {
   XArgs a = a0;
@@ -600,8 +827,8 @@ int launch(const XArgs& a0, hipStream_t stream) {
 // variant ids: see scripts/bench_gemm_variants.py
 extern "C" int udm_gemm_nt_bf16_variant(int variant, const void* A, const void* B, void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb,
                                         int64_t ldc, hipStream_t stream) {
-  UDM_CHECK_ARG(A && B && C && M > 0 && N > 0 && K > 0 && K % 64 == 0, "udm_gemm_nt_bf16_variant: bad arguments (K %% 64 == 0 required)");
-  XArgs a{(const bf16_t*)A, (const bf16_t*)B, (bf16_t*)C, (long)lda, (long)ldb, (long)ldc, (int)M, (int)N, (int)K, 0, 0, nullptr};
+  UDM_CHECK_ARG(A && B && C && M > 0 && N > 0 && K > 0 && K % (variant >= 50 && variant < 60 ? 32 : 64) == 0, "udm_gemm_nt_bf16_variant: bad arguments (K %% 64 == 0 required)");
+  XArgs a{(const bf16_t*)A, (const bf16_t*)B, (bf16_t*)C, (long)lda, (long)ldb, (long)ldc, (int)M, (int)N, (int)K, 0, 0, nullptr, 0, 0};
   switch (variant) {
     case 0: return launch<128, 128, 2, 2, 2>(a, stream);
     case 1: return launch<128, 128, 2, 2, 3>(a, stream);
@@ -634,6 +861,13 @@ extern "C" int udm_gemm_nt_bf16_variant(int variant, const void* A, const void* 
     case 35: return launch_quad<15>(a, stream);   // neither, no barrier: bare MFMA stream
     case 36: return launch_quad<9>(a, stream);    // no barrier only
     case 37: return launch_quad<17>(a, stream);   // timeline
+    case 50: return launch_ring<0>(a, stream);
+    case 52: return launch_ring<2>(a, stream);    // no fragment reads
+    case 53: return launch_ring<4>(a, stream);    // no refills
+    case 57: return launch_ring<16>(a, stream);   // timeline
+    case 54: return launch_ring<32>(a, stream);   // buffer_load ... lds refills
+    case 58: return launch_ring<48>(a, stream);   // buffer_load ... lds refills, timeline
+    case 59: return launch_ring<48 + 64>(a, stream);   // timeline, only wave 0 refills (ablation)
     case 38: return launch_stagger<320, 256, 2, 4, 1, 5>(a, stream);   // production-like schedule with cycle stamps
     case 39: return launch_stagger<256, 256, 2, 4, 1, 1>(a, stream);   // 256-row tile, LDS-DMA inside the MFMA section
     case 40: return launch_stagger<256, 256, 2, 4, 1, 8>(a, stream);   // 256-row tile, register-staged refill (global_load + ds_write_b128)
