@@ -134,6 +134,13 @@ int udm_ddpm_sample_rows(const void* logits, int64_t ld, const int64_t* modality
                          uint64_t seed, int64_t* out, int64_t M, int64_t V, int64_t Vt, int64_t mask_id, int restrict_modality, int greedy,
                          hipStream_t stream);
 
+/* ---- token data path: joint-sequence assembly, `Diffusion.update_batch` token-dataset branch model.py:183-212 over the dataset
+ * schema of models/datasets/image_datasets.py:263-281.  txt [n, Lt] int32, txt_mask [n, Lt] bool bytes (nullable: all valid), img [n, Li] int16;
+ * idx [B] rows to gather (nullable: rows 0..B-1).  Writes input_ids int64 [B, Lt+Li] (image ids shifted by Vt), attention_mask bool bytes, modality
+ * int64 (0 text / 1 image).  The caller guarantees 0 <= idx[b] < n. */
+int udm_assemble_joint_tokens(const int32_t* txt, const uint8_t* txt_mask, const int16_t* img, const int64_t* idx, int64_t B, int64_t Lt, int64_t Li,
+                              int64_t Vt, int64_t* ids, uint8_t* mask, int64_t* modality, hipStream_t stream);
+
 /* ---- optimizer step: torch.optim.AdamW(fused=True) `model_setup.py:385-424` + accelerator.clip_grad_norm_ `model.py:1516-1520`.
  * fp32 masters and moments; `step` is the 1-based update count (bias corrections are computed from it); `grad_norm_sq` (nullable) is a DEVICE
  * scalar holding the sum of squares of ALL gradients (udm_sumsq_f32 over the engine's flat gradient buffer): g is scaled by

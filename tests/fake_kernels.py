@@ -384,3 +384,15 @@ def ddpm_sample_rows(logits, V, Vt, mask_id, *, t=None, s=None, modality=None, r
     if u is None:
         u = torch.rand(M, V, generator=torch.Generator().manual_seed(int(seed) & 0x7FFFFFFF))
     return (q / (1e-10 - (u[:, :V] + 1e-10).log())).argmax(-1)
+
+
+# ------------------------------------------------------------------------------------------------ token data path (csrc/tokens.hip)
+def assemble_joint_tokens(txt, txt_mask, img, Vt, idx=None):
+    if idx is not None:
+        txt, img = txt[idx], img[idx]
+        txt_mask = None if txt_mask is None else txt_mask[idx]
+    ids = torch.cat([txt.to(torch.int64), img.to(torch.int64) + int(Vt)], -1)
+    tm = torch.ones_like(txt, dtype=torch.bool) if txt_mask is None else txt_mask.to(torch.bool)
+    mask = torch.cat([tm, torch.ones_like(img, dtype=torch.bool)], -1)
+    modality = torch.cat([torch.zeros_like(txt, dtype=torch.int64), torch.ones_like(img, dtype=torch.int64)], -1)
+    return ids, mask, modality

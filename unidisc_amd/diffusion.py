@@ -147,7 +147,8 @@ class Diffusion:
                         modality = torch.zeros_like(batch["input_ids"], dtype=torch.int64)
                         modality[:, -img_input_ids.shape[-1]:] = 1
                     batch["modality"] = modality
-            elif cfg_get(tr, "multimodal_batches", False):  # :214-250 (pre-tokenised multimodal batches)
+            elif cfg_get(tr, "multimodal_batches", False) or ("input_ids" in batch and "modality" in batch and "img" not in batch):
+                # :214-250 (pre-tokenised multimodal batches); also batches already assembled on the device by token_data.TokenBatcher
                 if "img" in batch:
                     raise NotImplementedError("unidisc_amd: raw-image batches need the VQ tokenizer, which is outside the denoising hot path")
                 batch["input_ids"] = batch["input_ids"].to(torch.int64)

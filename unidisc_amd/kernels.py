@@ -116,6 +116,26 @@ def ddpm_sample_rows(logits, V, Vt, mask_id, *, t=None, s=None, modality=None, r
     return out
 
 
+def assemble_joint_tokens(txt, txt_mask, img, Vt, idx=None):
+    """(input_ids int64, attention_mask bool, modality int64), each [B, Lt + Li], from dataset fields txt int32 [n, Lt], txt_mask bool [n, Lt] (or None),
+    img int16 [n, Li]; idx int64 [B] selects rows (None: all n rows in order).  `update_batch` token-dataset branch in one pass."""
+    if txt.dtype != torch.int32 or img.dtype != torch.int16 or txt.dim() != 2 or img.dim() != 2 or not (txt.is_contiguous() and img.is_contiguous()):
+        raise TypeError("assemble_joint_tokens: txt must be contiguous int32 [n, Lt], img contiguous int16 [n, Li]")
+    if txt.shape[0] != img.shape[0] or not (txt.is_cuda and img.is_cuda):
+        raise ValueError("assemble_joint_tokens: txt / img must be device tensors with the same number of rows")
+    if txt_mask is not None and (txt_mask.dtype != torch.bool or txt_mask.shape != txt.shape or not txt_mask.is_contiguous() or not txt_mask.is_cuda):
+        raise TypeError("assemble_joint_tokens: txt_mask must be a contiguous bool device tensor shaped like txt")
+    if idx is not None and (idx.dtype != torch.int64 or idx.dim() != 1 or not idx.is_cuda):
+        raise TypeError("assemble_joint_tokens: idx must be a 1-D int64 device tensor")
+    B = txt.shape[0] if idx is None else idx.shape[0]
+    Lt, Li = txt.shape[1], img.shape[1]
+    ids = torch.empty(B, Lt + Li, dtype=torch.int64, device=txt.device)
+    mask = torch.empty(B, Lt + Li, dtype=torch.bool, device=txt.device)
+    modality = torch.empty(B, Lt + Li, dtype=torch.int64, device=txt.device)
+    _lib.call("udm_assemble_joint_tokens", _p(txt), _p(txt_mask), _p(img), _p(idx), B, Lt, Li, int(Vt), _p(ids), _p(mask), _p(modality), _s())
+    return ids, mask, modality
+
+
 def sumsq(x, out):
     """out[0] = sum(x**2) (fp32, 1-D contiguous x); two-phase reduction through the scratch buffer."""
     _chk(x, F32, "sumsq x"), _chk(out, F32, "sumsq out")
