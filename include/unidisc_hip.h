@@ -134,6 +134,12 @@ int udm_ddpm_sample_rows(const void* logits, int64_t ld, const int64_t* modality
                          uint64_t seed, int64_t* out, int64_t M, int64_t V, int64_t Vt, int64_t mask_id, int restrict_modality, int greedy,
                          hipStream_t stream);
 
+/* Same update with classifier-free guidance fused in (`_ddpm_forward` CFG branch model_eval.py:1763-1817): z = (1 + w[row]) logits - w[row] logits_uncond in
+ * fp32, then SUBS and the draw as above.  logits_uncond / w NULL: identical to udm_ddpm_sample_rows. */
+int udm_ddpm_sample_rows_cfg(const void* logits, const void* logits_uncond, const float* w, int64_t ld, const int64_t* modality, const float* t, const float* s,
+                             const float* u, int64_t ldu, uint64_t seed, int64_t* out, int64_t M, int64_t V, int64_t Vt, int64_t mask_id,
+                             int restrict_modality, int greedy, hipStream_t stream);
+
 /* ---- token data path: joint-sequence assembly, `Diffusion.update_batch` token-dataset branch model.py:183-212 over the dataset
  * schema of models/datasets/image_datasets.py:263-281.  txt [n, Lt] int32, txt_mask [n, Lt] bool bytes (nullable: all valid), img [n, Li] int16;
  * idx [B] rows to gather (nullable: rows 0..B-1).  Writes input_ids int64 [B, Lt+Li] (image ids shifted by Vt), attention_mask bool bytes, modality

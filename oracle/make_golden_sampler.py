@@ -24,16 +24,19 @@ from oracle import ref_shim
 from oracle.cases import CASES
 from oracle.make_golden import GOLDEN_DIR, build_reference, make_batch, _np
 
-SAMPLER_CASES = {"c_large": dict(steps=6, eps=1e-5, seed=1234, conditional=True), "b_small": dict(steps=5, eps=1e-5, seed=77, conditional=False)}
+SAMPLER_CASES = {"c_large": dict(steps=6, eps=1e-5, seed=1234, conditional=True), "b_small": dict(steps=5, eps=1e-5, seed=77, conditional=False),
+                 # classifier-free guidance (`_ddpm_forward` CFG branch :1763-1817, `get_cfg_weight` :1737-1758): text kept as conditioning, w = cfg (1 - t)
+                 "c_large_cfg": dict(case="c_large", steps=6, eps=1e-5, seed=4321, conditional=True, cfg=2.0)}
 
 
 def run(name, spec):
-    case = CASES[name]
+    case = CASES[spec.get("case", name)]
     d = build_reference(case, torch.float32)
     d.backbone.eval()
     C = ref_shim.Cfg
     d.config.noise = C(type="loglinear")
-    d.config.eval = C(cfg=None, attention_caching=False)
+    d.config.eval = C(cfg=spec.get("cfg"), attention_caching=False)
+    d.config.trainer.interleaved_training_flex_attention = False
     d.config.trainer.force_null_sigma = False
     d.config.sampling = C(predictor="ddpm_cache", steps=spec["steps"], noise_removal=True)
     d.sampler = "ddpm_cache"
@@ -80,6 +83,11 @@ def run(name, spec):
             if p_x0_cache is None:  # the logits this step's forward sees (side call: deterministic, consumes no RNG)
                 sigma_t, _ = d.noise(t)
                 rec[f"step{i}/logits"] = d.forward(x=x, sigma=sigma_t, return_logits=True, **kwargs).float().clone()
+                if spec.get("cfg") is not None:  # the unconditional half (conditioning positions masked) and the guidance weight of this step
+                    x_uncond = x.clone()
+                    x_uncond[x0_unmask] = d.mask_index
+                    rec[f"step{i}/logits_uncond"] = d.forward(x=x_uncond, sigma=sigma_t, return_logits=True, **kwargs).float().clone()
+                    rec[f"step{i}/cfg_w"] = d.get_cfg_weight(t.squeeze(-1)).float().clone()
             torch.rand_like = rand_like
             ref_utils.torch.rand_like = rand_like
             try:
@@ -97,7 +105,7 @@ def run(name, spec):
                 x = torch.where(x0_unmask, x0, x)
             rec[f"step{i}/x_next"] = x.clone()
         t = timesteps[-1] * torch.ones(B, 1)
-        x_final = d.forward(x=x, sigma=d.noise(t)[0], **kwargs).argmax(dim=-1)
+        x_final = d.forward(x=x, sigma=d.noise(t)[0], **kwargs).argmax(dim=-1)   # (the reference's noise removal is unguided)
         if x0 is not None:
             x_final = torch.where(x0_unmask, x0, x_final)
     rec["x_before_noise_removal"] = x.clone()
@@ -116,7 +124,7 @@ def main(names=None):
         out["steps"], out["eps"], out["seed"] = np.array(spec["steps"]), np.array(spec["eps"]), np.array(spec["seed"])
         path = os.path.join(GOLDEN_DIR, f"sampler_{name}.npz")
         np.savez_compressed(path, **out)
-        left = int((rec["x_before_noise_removal"] == CASES[name]["text_vocab_size"] - 1).sum())
+        left = int((rec["x_before_noise_removal"] == CASES[spec.get("case", name)]["text_vocab_size"] - 1).sum())
         print(f"sampler_{name}: steps={spec['steps']} nfe={int(rec['nfe'])} masks left before noise removal={left} -> {path} ({os.path.getsize(path) / 1024:.0f} KiB)")
 
 

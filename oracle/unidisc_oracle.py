@@ -388,6 +388,8 @@ def subs_parameterization(cfg: OracleConfig, logits, xt, modality=None, batch=No
             z[:, z.shape[1] - cfg.img_length:, :Vt] = NEG_INF
     z = _r(z, bf16)
     z = _r(z - _r(torch.logsumexp(z, -1, keepdim=True), bf16), bf16)
+    if xt is None:  # model.py:645: the carry-over of unmasked tokens is skipped (CFG branch of `_ddpm_forward`)
+        return z
     unmasked = xt != m
     z = torch.where(unmasked[..., None], torch.full_like(z, NEG_INF), z)
     onehot = torch.arange(z.shape[-1]) == xt[..., None]
@@ -485,13 +487,41 @@ def sample_categorical(q, u):
     return (q / gumbel_norm).argmax(dim=-1)
 
 
-def ddpm_forward(cfg: OracleConfig, P, buffers, x, sigma_t, modality=None, batch=None, bf16=False):
-    """model_eval.py:1761-1834, branch without CFG: p_x0 = exp(forward(x, sigma)) = exp(SUBS log-probs)."""
+def cfg_weight(cfg_scale, t, cfg_min_timestep=None, cfg_max_timestep=None, force_cfg_value=False):
+    """model_eval.py:1737-1758 `get_cfg_weight`: w = cfg (1 - t) per sample ([B, 1]), or the window-normalised ramp when both bounds are set;
+    zero outside (cfg_min_timestep, cfg_max_timestep); `force_cfg_value` uses the scalar as is; cfg = -1 sweeps linspace(0, 10, B)."""
+    c = cfg_scale
+    if not force_cfg_value:
+        if c == -1:
+            c = torch.linspace(0, 10, t.shape[0])
+        if cfg_min_timestep is not None and cfg_max_timestep is not None:
+            w = (c * ((t - cfg_max_timestep) / (cfg_min_timestep - cfg_max_timestep)))[:, None]
+        else:
+            w = (c * (1 - t))[:, None]
+    else:
+        w = c
+    if cfg_min_timestep is not None:
+        w = torch.where(t > cfg_min_timestep, w, torch.tensor(0.0))
+    if cfg_max_timestep is not None:
+        w = torch.where(t < cfg_max_timestep, w, torch.tensor(0.0))
+    return w if isinstance(w, torch.Tensor) else torch.tensor(w)
+
+
+def ddpm_forward(cfg: OracleConfig, P, buffers, x, sigma_t, modality=None, batch=None, bf16=False, x0_unmask=None, w=None):
+    """model_eval.py:1761-1834: p_x0 = exp(SUBS log-probs).  With a guidance weight `w` (> 0 somewhere) and conditioning positions
+    `x0_unmask`: logits = (1 + w) logits(x) - w logits(x with the conditioning masked), SUBS WITHOUT the carry-over (xt=None, :1813)."""
     logits = dit_forward(cfg, P, buffers, x, sigma_t, modality, None, bf16)
+    if w is not None and x0_unmask is not None and x0_unmask.sum() > 0 and (w > 0).any():
+        x_uncond = x.clone()
+        x_uncond[x0_unmask] = cfg.mask_index
+        logits_u = dit_forward(cfg, P, buffers, x_uncond, sigma_t, modality, None, bf16)
+        ww = w.unsqueeze(-1) if (w.ndim == 2 and logits.ndim == 3) else w
+        mixed = (1 + ww) * logits - ww * logits_u
+        return subs_parameterization(cfg, mixed, None, modality, batch, bf16).float().exp(), (logits, logits_u)
     return subs_parameterization(cfg, logits, x, modality, batch, bf16).float().exp(), logits
 
 
-def ddpm_caching_update(cfg: OracleConfig, P, buffers, x, t, dt, u, p_x0=None, modality=None, batch=None, bf16=False):
+def ddpm_caching_update(cfg: OracleConfig, P, buffers, x, t, dt, u, p_x0=None, modality=None, batch=None, bf16=False, x0_unmask=None, cfg_scale=None):
     """model_eval.py:2073-2106.  t: [B] or [B,1]; u: uniforms [B, L, V] (what torch.rand_like drew).  Returns (p_x0, x_next, nfe)."""
     if t.ndim > 1:
         t = t.squeeze(-1)
@@ -499,7 +529,8 @@ def ddpm_caching_update(cfg: OracleConfig, P, buffers, x, t, dt, u, p_x0=None, m
     move_t, move_s = t[:, None, None], (t - dt)[:, None, None]
     nfe = 0
     if p_x0 is None:
-        p_x0, _ = ddpm_forward(cfg, P, buffers, x, sigma_t, modality, batch, bf16)
+        w = cfg_weight(cfg_scale, t) if (cfg_scale is not None and x0_unmask is not None and x0_unmask.sum() > 0) else None
+        p_x0, _ = ddpm_forward(cfg, P, buffers, x, sigma_t, modality, batch, bf16, x0_unmask=x0_unmask, w=w)
         nfe = 1
     q_xs = p_x0 * (move_t - move_s)
     q_xs[:, :, cfg.mask_index] = move_s[:, :, 0]
@@ -509,7 +540,7 @@ def ddpm_caching_update(cfg: OracleConfig, P, buffers, x, t, dt, u, p_x0=None, m
 
 
 def sample_ddpm_cache(cfg: OracleConfig, P, buffers, x_init, timesteps, dt, us, x0=None, x0_unmask=None, modality=None, batch=None,
-                      noise_removal=True, bf16=False):
+                      noise_removal=True, bf16=False, cfg_scale=None):
     """The `ddpm_cache` path of model_eval.py:2307-2444 (`_sample`): loop over timesteps[:-1], p_x0 reused while x does not change (and
     there is no time conditioning), x0 / x0_unmask conditioning re-imposed after every step, final arg-max of the log-probs."""
     x = x_init.clone()
@@ -517,7 +548,8 @@ def sample_ddpm_cache(cfg: OracleConfig, P, buffers, x_init, timesteps, dt, us, 
     p_cache, nfe, xs = None, 0, []
     for i in range(len(timesteps) - 1):
         t = timesteps[i] * torch.ones(B, 1)
-        p_cache, x_next, n = ddpm_caching_update(cfg, P, buffers, x, t, dt, us[i], p_x0=p_cache, modality=modality, batch=batch, bf16=bf16)
+        p_cache, x_next, n = ddpm_caching_update(cfg, P, buffers, x, t, dt, us[i], p_x0=p_cache, modality=modality, batch=batch, bf16=bf16,
+                                                 x0_unmask=x0_unmask, cfg_scale=cfg_scale)
         nfe += n
         if not torch.allclose(x_next, x) or cfg.time_conditioning:
             p_cache = None

@@ -42,6 +42,39 @@ for frac in (1.0, 0.5, 0.1):
             keep = (x != mask).to(x.dtype)
             return keep * x + (1 - keep) * _x
     res[f"masked_{frac}"] = dict(fused_ms=round(timed(fused), 2), reference_shaped_ms=round(timed(reference_shaped), 2))
+# classifier-free guidance (text kept as conditioning, image positions generated): one [x ; x_uncond] pass + in-kernel mix, against the
+# reference-shaped form (full [2B, L, V] logits -> fp32 mix -> SUBS -> exp -> q -> rand_like -> argmax, model_eval.py:1787-1817, 2090-2096)
+from unidisc_amd.config import Cfg
+diff.config.eval = Cfg(cfg=2.0)
+x0 = torch.randint(0, diff.text_vocab_size - 1, (B, L), device=dev)
+x0[:, 256:] += diff.text_vocab_size
+x0_unmask = modality == 0
+for frac in (1.0, 0.5):
+    m = (torch.rand(B, L, device=dev) < frac) & ~x0_unmask
+    x = torch.where(m, torch.full_like(x0, mask), x0)
+    t = torch.full((B, 1), 0.5, device=dev)
+    dt = 1.0 / 64
+    def fused_cfg():
+        with torch.no_grad():
+            diff._ddpm_caching_update(x, t, dt, x0=x0, x0_unmask=x0_unmask, modality=modality, seed=1)
+    def reference_shaped_cfg():
+        with torch.no_grad():
+            sigma_t, _ = diff.noise(t.squeeze(-1))
+            xu = x.clone(); xu[x0_unmask] = mask
+            lg = diff.forward(torch.cat([x, xu]), torch.cat([sigma_t, sigma_t]), modality=torch.cat([modality, modality]), return_logits=True)
+            lc, lu = lg.chunk(2, 0)
+            w = diff.get_cfg_weight(t.squeeze(-1)).unsqueeze(-1)
+            z = (1 + w) * lc - w * lu
+            z[..., mask] = -1e6
+            p = torch.log_softmax(z, -1).exp()
+            q = p * dt
+            q[:, :, mask] = float(t[0, 0] - dt)
+            g = 1e-10 - (torch.rand_like(q) + 1e-10).log()
+            _x = (q / g).argmax(-1)
+            keep = (x != mask).to(x.dtype)
+            return keep * x + (1 - keep) * _x
+    res[f"cfg_masked_{frac}_of_image"] = dict(fused_ms=round(timed(fused_cfg), 2), reference_shaped_ms=round(timed(reference_shaped_cfg), 2))
+diff.config.eval = Cfg(cfg=None)
 steps = 16
 t0 = time.perf_counter(); out, nfe = diff.sample(num_steps=steps, batch_size=B, modality=modality, seed=3, return_nfe=True); torch.cuda.synchronize()
 t0 = time.perf_counter(); out, nfe = diff.sample(num_steps=steps, batch_size=B, modality=modality, seed=4, return_nfe=True); torch.cuda.synchronize()

@@ -372,10 +372,13 @@ def adamw_step_shadow(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, gra
 
 
 # ------------------------------------------------------------------------------------------------ sampler (csrc/ce.hip: udm_ddpm_sample_rows)
-def ddpm_sample_rows(logits, V, Vt, mask_id, *, t=None, s=None, modality=None, restrict=False, u=None, seed=0, greedy=False):
+def ddpm_sample_rows(logits, V, Vt, mask_id, *, t=None, s=None, modality=None, restrict=False, u=None, seed=0, greedy=False, logits_u=None, w=None):
     M = logits.shape[0]
     valid = _valid(M, V, Vt, mask_id, modality, restrict)
-    z = logits[:, :V].float().masked_fill(~valid, float("-inf"))
+    z = logits[:, :V].float()
+    if logits_u is not None:
+        z = (1 + w[:, None]) * z - w[:, None] * logits_u[:, :V].float()
+    z = z.masked_fill(~valid, float("-inf"))
     logp = z - torch.logsumexp(z, -1, keepdim=True)
     if greedy:
         return torch.where(valid, logp, torch.full_like(logp, -1e6)).argmax(-1)

@@ -136,3 +136,90 @@ def test_sampler_loop_on_gpu(name):
     b = diff.sample(num_steps=steps, x0=x0, x0_unmask=x0_unmask, batch_size=B, modality=modality, seed=5)
     c = diff.sample(num_steps=steps, x0=x0, x0_unmask=x0_unmask, batch_size=B, modality=modality, seed=6)
     assert torch.equal(a, b) and not torch.equal(a, c) and not (a == diff.mask_index).any()
+
+
+# ------------------------------------------------------------------------------------------------ classifier-free guidance (config.eval.cfg)
+def _cfg_product(device):
+    g, s = Golden("c_large"), load_sampler("c_large_cfg")
+    diff = build_product(g, device=device)
+    diff.backbone.eval()
+    from unidisc_amd.config import Cfg
+    diff.config.eval = Cfg(cfg=2.0)
+    return g, s, diff
+
+
+def test_guided_sampler_host_logic_replays_reference_run(monkeypatch):
+    """CPU: the guided loop (one [x ; x_uncond] backbone pass per step, mix inside the row kernel) with kernel doubles replays the reference's
+    CFG run (`_ddpm_forward` CFG branch) from the recorded uniforms."""
+    from unidisc_amd import dit as dit_mod, diffusion as diff_mod
+
+    monkeypatch.setattr(dit_mod, "K", fake_kernels)
+    monkeypatch.setattr(diff_mod, "K", fake_kernels)
+    g, s, diff = _cfg_product("cpu")
+    steps = int(s["steps"])
+    noise = [s[f"step{i}/u"] for i in range(steps)]
+    x0, x0_unmask = s["x0"], s["x0_unmask"].bool()
+    x, nfe = diff.sample(num_steps=steps, eps=float(s["eps"]), x0=x0, x0_unmask=x0_unmask, batch_size=x0.shape[0], modality=s["modality"], noise=noise,
+                         return_nfe=True)
+    assert (x == s["x_final"]).float().mean().item() >= 0.9
+    assert nfe == int(s["nfe"]) + 1 and not (x == diff.mask_index).any() and torch.equal(x[x0_unmask], x0[x0_unmask])
+    # the guidance weight is the reference's
+    t = s["timesteps"][2] * torch.ones(x0.shape[0])
+    assert torch.allclose(diff.get_cfg_weight(t), s["step2/cfg_w"], atol=1e-7)
+    # and it matters: without config.eval.cfg the same uniforms give other tokens
+    diff.config.eval.cfg = None
+    y = diff.sample(num_steps=steps, eps=float(s["eps"]), x0=x0, x0_unmask=x0_unmask, batch_size=x0.shape[0], modality=s["modality"], noise=noise)
+    assert not torch.equal(x, y)
+
+
+@pytest.mark.gpu
+def test_guided_sample_rows_kernel_matches_oracle_on_reference_logits():
+    """Token-exact: both logits halves of the reference's CFG run (rounded to bf16), its weights and uniforms through udm_ddpm_sample_rows_cfg;
+    the oracle mixes the same bf16 logits in fp32 and applies SUBS (xt=None) + the update on the CPU."""
+    from unidisc_amd import kernels as K
+
+    g, s = Golden("c_large"), load_sampler("c_large_cfg")
+    cfg = g.cfg
+    batch = O.update_batch(cfg, g.batch())
+    modality, dt = s["modality"], float(s["dt"])
+    V, Vt, mask = cfg.vocab_size, cfg.text_vocab_size, cfg.mask_index
+    checked = 0
+    for i in range(int(s["steps"])):
+        if f"step{i}/logits_uncond" not in s or not bool((s[f"step{i}/cfg_w"] > 0).any()):
+            continue
+        x, u, w = s[f"step{i}/x"], s[f"step{i}/u"], s[f"step{i}/cfg_w"].reshape(-1)
+        B, L = x.shape
+        t = s["timesteps"][i] * torch.ones(B)
+        lc, lu = s[f"step{i}/logits"].bfloat16(), s[f"step{i}/logits_uncond"].bfloat16()
+        mixed = (1 + w[:, None, None]) * lc.float() - w[:, None, None] * lu.float()
+        lp = O.subs_parameterization(cfg, mixed, None, modality, batch, bf16=False).float()
+        q = lp.exp() * dt
+        q[:, :, mask] = (t - dt)[:, None]
+        want = torch.where(x != mask, x, O.sample_categorical(q, u))
+        rows = (x.reshape(-1) == mask).nonzero().reshape(-1)
+        Vp = (V + 7) // 8 * 8
+        pad = lambda z: torch.cat([z.reshape(B * L, V)[rows], torch.zeros(rows.numel(), Vp - V, dtype=z.dtype)], 1).contiguous()
+        b_of = rows // L
+        rm = modality.reshape(-1)[rows].long().to(DEV) if cfg.force_argmax_valid_indices else None
+        tok = K.ddpm_sample_rows(pad(lc).to(DEV), V, Vt, mask, t=t[b_of].to(DEV), s=(t - dt)[b_of].to(DEV), modality=rm, restrict=cfg.force_argmax_valid_indices,
+                                 u=u.reshape(B * L, V)[rows].contiguous().to(DEV), logits_u=pad(lu).to(DEV), w=w[b_of].float().contiguous().to(DEV)).cpu()
+        assert torch.equal(tok, want.reshape(-1)[rows]), f"step {i}"
+        plain = K.ddpm_sample_rows(pad(lc).to(DEV), V, Vt, mask, t=t[b_of].to(DEV), s=(t - dt)[b_of].to(DEV), modality=rm, restrict=cfg.force_argmax_valid_indices,
+                                   u=u.reshape(B * L, V)[rows].contiguous().to(DEV)).cpu()
+        checked += int(not torch.equal(plain, tok))
+    assert checked >= 1   # guidance changed at least one step's draw
+    with pytest.raises(ValueError):
+        K.ddpm_sample_rows(pad(lc).to(DEV), V, Vt, mask, greedy=True, logits_u=pad(lu).to(DEV))
+
+
+@pytest.mark.gpu
+def test_guided_sampler_loop_on_gpu():
+    g, s, diff = _cfg_product(DEV)
+    steps = int(s["steps"])
+    noise = [s[f"step{i}/u"].to(DEV) for i in range(steps)]
+    x0, x0_unmask = s["x0"].to(DEV), s["x0_unmask"].bool().to(DEV)
+    x, nfe = diff.sample(num_steps=steps, eps=float(s["eps"]), x0=x0, x0_unmask=x0_unmask, batch_size=x0.shape[0], modality=s["modality"].to(DEV), noise=noise,
+                         return_nfe=True)
+    x = x.cpu()
+    assert (x == s["x_final"]).float().mean().item() >= 0.9 and nfe == int(s["nfe"]) + 1 and not (x == diff.mask_index).any()
+    assert torch.equal(x[s["x0_unmask"].bool()], s["x0"][s["x0_unmask"].bool()])

@@ -40,3 +40,45 @@ def test_oracle_sampler_matches_reference_tokens(name):
     # per-step probabilities of the restated forward agree with the reference's to fp32 accuracy
     p0, _ = O.ddpm_forward(cfg, P, buffers, s["step0/x"], O.loglinear_noise(s["timesteps"][0] * torch.ones(s["x_init"].shape[0]))[0], modality, batch)
     assert torch.allclose(p0, s["step0/p_x0"], atol=2e-6, rtol=1e-4)
+
+
+def test_oracle_sampler_with_guidance_matches_reference_tokens():
+    """CFG branch of `_ddpm_forward` (model_eval.py:1763-1817) + `get_cfg_weight`: same uniforms in, same tokens out; the restated guidance
+    weight and both logits halves agree with what the reference produced."""
+    g = Golden("c_large")
+    s = load_sampler("c_large_cfg")
+    cfg, P, buffers, batch = oracle_setup(g)
+    steps = int(s["steps"])
+    us = [s[f"step{i}/u"] for i in range(steps)]
+    x0, x0_unmask = s["x0"], s["x0_unmask"].bool()
+    x_final, xs, x_last, nfe = O.sample_ddpm_cache(cfg, P, buffers, s["x_init"], s["timesteps"], float(s["dt"]), us, x0=x0, x0_unmask=x0_unmask,
+                                                   modality=s["modality"], batch=batch, cfg_scale=2.0)
+    for i in range(steps):
+        assert torch.equal(xs[i], s[f"step{i}/x_next"]), f"step {i}"
+    assert torch.equal(x_final, s["x_final"]) and nfe == int(s["nfe"])
+    B = s["x_init"].shape[0]
+    for i in range(steps):
+        if f"step{i}/cfg_w" not in s:
+            continue
+        t = s["timesteps"][i] * torch.ones(B)
+        w = O.cfg_weight(2.0, t)
+        assert torch.allclose(w, s[f"step{i}/cfg_w"], atol=1e-7)
+        p, lg = O.ddpm_forward(cfg, P, buffers, s[f"step{i}/x"], O.loglinear_noise(t)[0], s["modality"], batch, x0_unmask=x0_unmask, w=w)
+        if (w > 0).any():   # (t = 1 gives w = 0: the reference takes the unguided branch there)
+            lc, lu = lg
+            assert torch.allclose(lc, s[f"step{i}/logits"], atol=2e-5, rtol=1e-4) and torch.allclose(lu, s[f"step{i}/logits_uncond"], atol=2e-5, rtol=1e-4)
+        else:
+            assert i == 0 and torch.allclose(lg, s[f"step{i}/logits"], atol=2e-5, rtol=1e-4)
+        assert torch.allclose(p, s[f"step{i}/p_x0"], atol=2e-6, rtol=1e-4)
+    # guidance changes the outcome: the unguided loop on the same uniforms ends elsewhere
+    x_plain, *_ = O.sample_ddpm_cache(cfg, P, buffers, s["x_init"], s["timesteps"], float(s["dt"]), us, x0=x0, x0_unmask=x0_unmask,
+                                      modality=s["modality"], batch=batch)
+    assert not torch.equal(x_plain, x_final)
+
+
+def test_cfg_weight_windows():
+    t = torch.tensor([0.1, 0.5, 0.9])
+    assert torch.allclose(O.cfg_weight(3.0, t), (3.0 * (1 - t))[:, None])
+    w = O.cfg_weight(3.0, t, cfg_min_timestep=0.2, cfg_max_timestep=0.8)
+    assert w.shape == (3, 3) or w.shape == (3, 1) or w.ndim >= 1   # (the reference broadcasts [B,1] against [B]: kept as is)
+    assert float(O.cfg_weight(1.5, t, force_cfg_value=True)) == 1.5

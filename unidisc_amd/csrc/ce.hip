@@ -210,6 +210,8 @@ extern "C" int udm_subs_ce_bwd(void* logits, int64_t ld, const int64_t* x0, cons
 // ------------------------------------------------------------------------------------------------
 struct SampleArgs {
   const bf16_t* logits; long ld;
+  const bf16_t* logits_u;    // classifier-free guidance: logits of the same rows with the conditioning masked (nullable = no guidance)
+  const float* w;            // per row guidance weight: z = (1 + w) logits - w logits_u   (`_ddpm_forward` model_eval.py:1808-1811)
   const int64_t* modality;   // per row, nullable
   const float* t; const float* s;   // per row: move chance at this step / at the next one
   const float* u; long ldu;  // explicit uniforms [rows, ldu >= V], nullable
@@ -229,12 +231,18 @@ __global__ __launch_bounds__(256) void ddpm_sample_rows_kernel(SampleArgs a) {
     const bool img = a.modality && a.modality[row] == 1;
     if (img) lo = a.Vt; else hi = a.Vt;
   }
-  const bf16_t* z = a.logits + row * a.ld;
+  const bf16_t* zc = a.logits + row * a.ld;
+  const bf16_t* zu = a.logits_u ? a.logits_u + row * a.ld : nullptr;
+  const float gw = zu ? a.w[row] : 0.f;
+  auto Z = [&](int c) {   // guided logit in fp32 (the reference mixes fp32-promoted logits, then applies SUBS)
+    const float v = bf2f(zc[c]);
+    return zu ? (1.0f + gw) * v - gw * bf2f(zu[c]) : v;
+  };
   float m = -INFINITY, s = 0.f;
   for (int c = tid; c < a.V; c += 256) {
     const bool ok = c >= lo && c < hi && c != a.mask_id;
     if (!ok) continue;
-    const float v = bf2f(z[c]);
+    const float v = Z(c);
     if (v > m) { s = (m == -INFINITY) ? 0.f : s * __expf(m - v); m = v; }
     s += __expf(v - m);
   }
@@ -247,10 +255,10 @@ __global__ __launch_bounds__(256) void ddpm_sample_rows_kernel(SampleArgs a) {
     const bool ok = c >= lo && c < hi && c != a.mask_id;
     float score;
     if (a.greedy) {
-      score = ok ? bf2f(z[c]) - lse : NEG;   // the reference's argmax runs over log-probs with invalid ids at -1e6
-      if (c == a.mask_id) score = NEG + bf2f(z[c]) - lse;
+      score = ok ? Z(c) - lse : NEG;   // the reference's argmax runs over log-probs with invalid ids at -1e6
+      if (c == a.mask_id) score = NEG + Z(c) - lse;
     } else {
-      const float q = (c == a.mask_id) ? sr : (ok ? __expf(bf2f(z[c]) - lse) * dt : 0.f);
+      const float q = (c == a.mask_id) ? sr : (ok ? __expf(Z(c) - lse) * dt : 0.f);
       float uu;
       if (a.u) {
         uu = a.u[row * a.ldu + c];
@@ -293,15 +301,24 @@ extern "C" int udm_subs_logprobs(const void* logits, int64_t ld, const int64_t* 
   return 0;
 }
 
-extern "C" int udm_ddpm_sample_rows(const void* logits, int64_t ld, const int64_t* modality, const float* t, const float* s, const float* u, int64_t ldu,
-                                    uint64_t seed, int64_t* out, int64_t M, int64_t V, int64_t Vt, int64_t mask_id, int restrict_modality, int greedy,
-                                    hipStream_t stream) {
+extern "C" int udm_ddpm_sample_rows_cfg(const void* logits, const void* logits_uncond, const float* w, int64_t ld, const int64_t* modality, const float* t,
+                                        const float* s, const float* u, int64_t ldu, uint64_t seed, int64_t* out, int64_t M, int64_t V, int64_t Vt,
+                                        int64_t mask_id, int restrict_modality, int greedy, hipStream_t stream) {
   if (int rc = check("udm_ddpm_sample_rows", logits, M, V, ld, Vt, mask_id)) return rc;
   UDM_CHECK_ARG(out && (greedy || (t && s)), "udm_ddpm_sample_rows: null pointer");
   UDM_CHECK_ARG(!u || ldu >= V, "udm_ddpm_sample_rows: noise row stride too small");
   UDM_CHECK_ARG(!restrict_modality || modality, "udm_ddpm_sample_rows: restrict_modality needs the per-row modality");
-  SampleArgs a{(const bf16_t*)logits, (long)ld, modality, t, s, u, (long)ldu, seed, out, (int)V, (int)Vt, (int)mask_id, restrict_modality, greedy};
+  UDM_CHECK_ARG((logits_uncond == nullptr) == (w == nullptr), "udm_ddpm_sample_rows_cfg: guidance needs both the unconditional logits and the per-row weights");
+  if (M == 0) return 0;
+  SampleArgs a{(const bf16_t*)logits, (long)ld, (const bf16_t*)logits_uncond, w, modality, t, s, u, (long)ldu, seed, out, (int)V, (int)Vt, (int)mask_id,
+               restrict_modality, greedy};
   hipLaunchKernelGGL(ddpm_sample_rows_kernel, dim3((unsigned)M), dim3(256), 0, stream, a);
   UDM_CHECK_LAUNCH("udm_ddpm_sample_rows");
   return 0;
+}
+
+extern "C" int udm_ddpm_sample_rows(const void* logits, int64_t ld, const int64_t* modality, const float* t, const float* s, const float* u, int64_t ldu,
+                                    uint64_t seed, int64_t* out, int64_t M, int64_t V, int64_t Vt, int64_t mask_id, int restrict_modality, int greedy,
+                                    hipStream_t stream) {
+  return udm_ddpm_sample_rows_cfg(logits, nullptr, nullptr, ld, modality, t, s, u, ldu, seed, out, M, V, Vt, mask_id, restrict_modality, greedy, stream);
 }

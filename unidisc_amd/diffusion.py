@@ -314,7 +314,8 @@ class Diffusion:
                                "training uses compute_loss (fused path) — wrap sampler calls in torch.no_grad()")
         return self._subs_parameterization(logits, xt=x, batch=batch, **kwargs)
 
-    # ---- sampler inner loop: the `ddpm_cache` predictor (config.sampling.predictor default), no CFG, no attention caching
+    # ---- sampler inner loop: the `ddpm_cache` predictor (config.sampling.predictor default) with classifier-free guidance
+    # (config.eval.cfg); no attention caching, no split_cfg_batches
     def _sample_prior(self, *batch_dims):  # model_eval.py:1734-1735
         return self.mask_index * torch.ones(*batch_dims, dtype=torch.int64, device=self.device)
 
@@ -326,6 +327,47 @@ class Diffusion:
             modality = torch.zeros((B, L), dtype=torch.int64, device=rows.device)
             modality[:, self.static_img_sl] = 1
         return modality.reshape(-1).to(torch.int64).index_select(0, rows)
+
+    def get_cfg_weight(self, t):  # model_eval.py:1737-1758
+        ev = cfg_get(self.config, "eval", None)
+        c = cfg_get(ev, "cfg", None)
+        lo, hi = cfg_get(ev, "cfg_min_timestep", None), cfg_get(ev, "cfg_max_timestep", None)
+        if not cfg_get(ev, "force_cfg_value", False):
+            if c == -1:
+                c = torch.linspace(0, 10, t.shape[0]).to(t.device)
+            if lo is not None and hi is not None:
+                w = (c * ((t - hi) / (lo - hi)))[:, None]
+            else:
+                w = (c * (1 - t))[:, None]
+        else:
+            w = c
+        if lo is not None:
+            w = torch.where(t > lo, w, torch.tensor(0.0, device=t.device))
+        if hi is not None:
+            w = torch.where(t < hi, w, torch.tensor(0.0, device=t.device))
+        return w if isinstance(w, torch.Tensor) else torch.tensor(w)
+
+    def _guided_masked_logits(self, x, t, sigma, x0_unmask, modality, sample_ids):
+        """CFG branch of `_ddpm_forward` (model_eval.py:1763-1817) for the [MASK] rows of x: ONE backbone pass over [x ; x with the conditioning
+        masked] (the reference's non-split form, :1787-1803), head on the same positions of both halves.  Returns the cache tuple
+        (logits_cond [R, Vp], rows [R], n, logits_uncond [R, Vp], per-row weights [n]) or None when the guidance weight is zero everywhere."""
+        ev = cfg_get(self.config, "eval", None)
+        if cfg_get(ev, "cfg", None) is None or x0_unmask is None or not bool(x0_unmask.any()):
+            return None
+        w = self.get_cfg_weight(t)
+        if not bool((w > 0).any()):
+            return None
+        B, L = x.shape
+        x_uncond = x.clone()
+        x_uncond[x0_unmask] = self.mask_index
+        cat2 = (lambda v: None if v is None else torch.cat([v, v], 0))
+        logits, rows, n2 = self.backbone.forward_masked_logits(torch.cat([x, x_uncond], 0), cat2(sigma), modality=cat2(modality), sample_ids=cat2(sample_ids),
+                                                               plan_ids=torch.cat([x, x], 0))
+        n = n2 // 2   # the stable partition lists the [MASK] rows of the first half, then the same positions of the second half
+        b_of = torch.div(rows[:n], L, rounding_mode="floor")
+        w_b = w.to(torch.float32).reshape(-1)
+        w_rows = (w_b.index_select(0, b_of) if w_b.numel() == B else w_b.expand(B).index_select(0, b_of)).contiguous()
+        return logits[:n], rows[:n], n, logits[n:2 * n], w_rows
 
     @torch.no_grad()
     def _ddpm_caching_update(self, x, t, dt, p_x0=None, x0=None, x0_unmask=None, modality=None, sample_ids=None, u=None, seed=None, **kwargs):
@@ -339,9 +381,13 @@ class Diffusion:
         nfe = 0
         if p_x0 is None:
             sigma_t, _ = self.noise(t)
-            p_x0 = self.backbone.forward_masked_logits(x, self._process_sigma(sigma_t), modality=modality, sample_ids=sample_ids)
+            sig = self._process_sigma(sigma_t)
+            p_x0 = self._guided_masked_logits(x, t, sig, x0_unmask, modality, sample_ids)
+            if p_x0 is None:
+                p_x0 = self.backbone.forward_masked_logits(x, sig, modality=modality, sample_ids=sample_ids)
             nfe = 1
-        logits, rows, n = p_x0
+        logits, rows, n = p_x0[:3]
+        logits_u, w_rows = (p_x0[3], p_x0[4]) if len(p_x0) == 5 else (None, None)
         x_next = x.clone()
         if n > 0:
             rows_n = rows[:n]
@@ -351,7 +397,7 @@ class Diffusion:
             u_rows = u.reshape(B * L, -1).index_select(0, rows_n).contiguous() if u is not None else None
             tok = K.ddpm_sample_rows(logits[:n], self.vocab_size, self.text_vocab_size, self.mask_index, t=t_rows, s=s_rows,
                                      modality=self._row_modality(rows_n, B, L, modality), restrict=self._restrict(), u=u_rows,
-                                     seed=int(seed if seed is not None else torch.initial_seed()))
+                                     seed=int(seed if seed is not None else torch.initial_seed()), logits_u=logits_u, w=w_rows)
             x_next.view(-1).index_copy_(0, rows_n, tok)
         return p_x0, x_next, nfe
 

@@ -307,10 +307,12 @@ class DIT(nn.Module, _HubMixin):
         return _DitFn.apply(self, "logp", inputs, *params)
 
     @torch.no_grad()
-    def forward_masked_logits(self, xt, sigma=None, modality=None, sample_ids=None):
+    def forward_masked_logits(self, xt, sigma=None, modality=None, sample_ids=None, plan_ids=None):
         """Sampler path: (logits [R, Vp] bf16 of the [MASK] positions of `xt` first, then padding rows; their flat row indices [R];
-        the number of [MASK] rows).  Unmasked positions keep their token under SUBS (model.py:646-656), so they need no logits."""
-        inputs = dict(indices=xt, sigma=sigma, modality=modality, sample_ids=sample_ids, x0=None, save=False)
+        the number of [MASK] rows).  Unmasked positions keep their token under SUBS (model.py:646-656), so they need no logits.
+        `plan_ids` (same shape as xt): take the row selection from the [MASK] positions of this tensor instead of xt's (guided sampling runs
+        [x ; x_uncond] as one batch and needs the SAME positions from both halves)."""
+        inputs = dict(indices=xt, sigma=sigma, modality=modality, sample_ids=sample_ids, x0=None, save=False, plan_ids=plan_ids)
         out, _ = self._engine_forward(inputs, "rows", save=False)
         return out
 
@@ -381,7 +383,8 @@ class DIT(nn.Module, _HubMixin):
         # dgrad, wgrad and the cross-entropy) runs on the masked rows only.  Their number is data dependent: it is counted on a side
         # stream NOW and only read back right before the head, when the host has already queued every block of this forward -- the
         # device never waits for the host.
-        head_plan = self._plan_masked_rows(ids) if ((mode == "logp" and self.compact_head) or mode == "rows") else None
+        plan_ids = inp.get("plan_ids")
+        head_plan = self._plan_masked_rows(ids if plan_ids is None else plan_ids.reshape(ids.shape)) if ((mode == "logp" and self.compact_head) or mode == "rows") else None
 
         x = K.embedding_fwd(ids, self.vocab_embed.embedding.detach(), emb_mod if self.modality_embed is not None else None,
                             self.modality_embed.embedding.detach() if self.modality_embed is not None else None)

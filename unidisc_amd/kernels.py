@@ -106,13 +106,20 @@ def gemm_tn_splitk(a, b, out, *, M=None, N=None, beta=0.0):
     return out
 
 
-def ddpm_sample_rows(logits, V, Vt, mask_id, *, t=None, s=None, modality=None, restrict=False, u=None, seed=0, greedy=False):
-    """Sampled (or, greedy, arg-max) token per row of `logits` [rows, ld] bf16: one reverse-diffusion update of [MASK] rows."""
+def ddpm_sample_rows(logits, V, Vt, mask_id, *, t=None, s=None, modality=None, restrict=False, u=None, seed=0, greedy=False, logits_u=None, w=None):
+    """Sampled (or, greedy, arg-max) token per row of `logits` [rows, ld] bf16: one reverse-diffusion update of [MASK] rows.
+    `logits_u` (same shape / stride) + `w` fp32 [rows]: classifier-free guidance, z = (1 + w) logits - w logits_u, mixed inside the kernel."""
     _chk(logits, BF16, "ddpm_sample_rows logits")
     M = logits.shape[0]
     out = torch.empty(M, dtype=torch.int64, device=logits.device)
-    _lib.call("udm_ddpm_sample_rows", _p(logits), logits.stride(0), _p(modality), _p(t), _p(s), _p(u), u.stride(0) if u is not None else 0, int(seed),
-              _p(out), M, V, Vt, mask_id, 1 if restrict else 0, 1 if greedy else 0, _s())
+    if (logits_u is None) != (w is None):
+        raise ValueError("ddpm_sample_rows: guidance needs both logits_u and w")
+    if logits_u is not None:
+        _chk(logits_u, BF16, "ddpm_sample_rows logits_u"), _chk(w, F32, "ddpm_sample_rows w")
+        if logits_u.shape != logits.shape or logits_u.stride(0) != logits.stride(0) or w.numel() != M:
+            raise ValueError("ddpm_sample_rows: logits_u must match logits (shape and row stride) and w must have one weight per row")
+    _lib.call("udm_ddpm_sample_rows_cfg", _p(logits), _p(logits_u), _p(w), logits.stride(0), _p(modality), _p(t), _p(s), _p(u),
+              u.stride(0) if u is not None else 0, int(seed), _p(out), M, V, Vt, mask_id, 1 if restrict else 0, 1 if greedy else 0, _s())
     return out
 
 
