@@ -13,7 +13,7 @@ fn.restype = ctypes.c_int
 src = torch.zeros(256 * 4 * 65536 + (1 << 20), dtype=torch.uint8, device="cuda")
 out = torch.zeros(4, dtype=torch.int64, device="cuda")
 sink = torch.zeros(4, dtype=torch.float32, device="cuda")
-KINDS = {0: "none", 1: "global_load_lds b128", 2: "buffer_load lds b128", 3: "buffer_load lds b32", 4: "global_load_dwordx4 -> VGPR", 5: "ds_read_b128", 6: "s_nop 15", 7: "buffer lds b128, wave 0 only"}
+KINDS = {0: "none", 1: "global_load_lds b128", 2: "buffer_load lds b128", 3: "buffer_load lds b32", 4: "global_load_dwordx4 -> VGPR", 5: "ds_read_b128", 6: "s_nop 15", 7: "buffer lds b128, wave 0 only", 8: "4 x v_fma_f32", 9: "2 x v_exp_f32"}
 iters = 200
 
 def run(mode, blocks, stride, win, bstride, wstride):
@@ -24,7 +24,7 @@ def run(mode, blocks, stride, win, bstride, wstride):
 
 part = sys.argv[1] if len(sys.argv) > 1 else "12"
 if "1" in part:
-    for mode in [0, 1000, 102, 104, 108, 116, 202, 204, 208, 216, 304, 308, 316, 404, 408, 504, 508, 516, 604, 608, 1204, 1208, 1216, 1508, 1516]:
+    for mode in [0, 1000, 102, 104, 108, 116, 202, 204, 208, 216, 304, 308, 316, 404, 408, 504, 508, 516, 604, 608, 804, 808, 816, 904, 908, 916, 1204, 1208, 1216, 1508, 1516]:
         kind, nops, m16 = (mode % 1000) // 100, mode % 100, mode // 1000
         c = run(mode, 1, 1024, 65536, 4 * 65536, 65536)
         print(f"idle  mfma {'16x16x32' if m16 else '32x32x16'} {KINDS[kind]:30s} x{nops:2d}: cycles/k-step {c[0]}", flush=True)

@@ -24,7 +24,7 @@ constexpr int BKV = 64;   // keys per tile
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
-template <int D, bool HAS_SID, bool USE_TR>
+template <int D, bool HAS_SID, bool USE_TR, int ABL = 0>   // ABL (timing-only ablations, wrong results): 1 = no softmax VALU, 2 = no MFMAs
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // K0 | K1 | V0 | V1 | sidk[2][64]   (one array: keeps LDS-DMA waits exact)
   constexpr int TB = BKV * D * 2;
@@ -45,6 +45,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
   for (int ks = 0; ks < KS; ++ks) qf[ks] = load_frag_global(a.q + (rowbase + qi) * a.q_stride + h * D + ks * 16 + hi * 8, q_ok);
   long sid_q = 0;
   if (HAS_SID) sid_q = q_ok ? a.sample_ids[rowbase + qi] : -1;
+  // Touch the Q fragments here so the compiler's wait for their global loads lands BEFORE the loop: inside it the only outstanding
+  // vector-memory operations are the inline-asm LDS-DMA refills, which it must not wait for (see DmaStager).
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[ks]));
+  if (HAS_SID) asm volatile("" : "+v"(sid_q));
 
   f32x16_t oT[DB];
 #pragma unroll
@@ -57,6 +62,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
   const bf16_t* kbase = a.k + rowbase * a.k_stride + h * D;
   const bf16_t* vbase = a.v + rowbase * a.v_stride + h * D;
   using Stg = DmaStager<D, BKV>;
+  DmaPlan<D, BKV> plank, planv;
+  plank.init(a.k_stride, wave, lane);
+  planv.init(a.v_stride, wave, lane);
   const int nkv = (a.L + BKV - 1) / BKV;
   Stg::issue(kbase, a.k_stride, 0, a.L, smem, wave, lane);
   Stg::issue(vbase, a.v_stride, 0, a.L, smem + 2 * TB, wave, lane);
@@ -68,20 +76,37 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
     if (HAS_SID && tid < BKV) sid_s[st * BKV + tid] = (kv0 + tid < a.L) ? a.sample_ids[rowbase + kv0 + tid] : -2;
     wait_all_vmem();   // this wave's share of tile t has landed
     __syncthreads();   // ... and everybody's; all waves are also done with tile t-1, so its stage may be refilled
-    if (t + 1 < nkv) {
+    if (kv0 + 2 * BKV <= a.L) {   // the next tile is a full one: offsets are precomputed, the tile base is wave-uniform
+      plank.issue_full(kbase + (long)(kv0 + BKV) * a.k_stride, smem + (st ^ 1) * TB, wave);
+      planv.issue_full(vbase + (long)(kv0 + BKV) * a.v_stride, smem + (2 + (st ^ 1)) * TB, wave);
+    } else if (t + 1 < nkv) {
       Stg::issue(kbase, a.k_stride, kv0 + BKV, a.L, smem + (st ^ 1) * TB, wave, lane);
       Stg::issue(vbase, a.v_stride, kv0 + BKV, a.L, smem + (2 + (st ^ 1)) * TB, wave, lane);
     }
-    // S^T = K Q^T : [64 keys] x [32 queries per wave]
+    // S^T = K Q^T : [64 keys] x [32 queries per wave].  The two 32-key chains alternate (consecutive MFMAs are independent) and the K
+    // fragments are read two k-steps ahead of their MFMAs, so neither the accumulator dependence nor the LDS latency stalls the pipe.
     f32x16_t sT[2];
 #pragma unroll
-    for (int f = 0; f < 2; ++f) {
+    for (int f = 0; f < 2; ++f)
 #pragma unroll
       for (int r = 0; r < 16; ++r) sT[f][r] = 0.f;
+    {
+      bf16x8_t kq[3][2];
+#pragma unroll
+      for (int pre = 0; pre < 2; ++pre)
+#pragma unroll
+        for (int f = 0; f < 2; ++f) kq[pre][f] = lds_frag(Ks, tile_off<D>(f * 32 + l31, pre * 2 + hi));
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
-        bf16x8_t kfr = lds_frag(Ks, tile_off<D>(f * 32 + l31, ks * 2 + hi));
-        sT[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr, qf[ks], sT[f], 0, 0, 0);
+        if (ks + 2 < KS) {
+#pragma unroll
+          for (int f = 0; f < 2; ++f) kq[(ks + 2) % 3][f] = lds_frag(Ks, tile_off<D>(f * 32 + l31, (ks + 2) * 2 + hi));
+        }
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+          if (ABL & 2) { sT[f][ks] += (float)kq[ks % 3][f][0]; continue; }
+          sT[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kq[ks % 3][f], qf[ks], sT[f], 0, 0, 0);
+        }
       }
     }
     if (HAS_SID || kv0 + BKV > a.L) {
@@ -95,6 +120,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
           if (!ok) sT[f][r] = -INFINITY;
         }
     }
+    float p[2][16];
+    if (ABL & 1) {
+#pragma unroll
+      for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) p[f][r] = sT[f][r];
+    } else {
     float mloc = -INFINITY;
 #pragma unroll
     for (int f = 0; f < 2; ++f)
@@ -118,7 +150,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
     }
     const float mc = (m == -INFINITY) ? 0.f : m * c;
     float psum = 0.f;
-    float p[2][16];
 #pragma unroll
     for (int f = 0; f < 2; ++f)
 #pragma unroll
@@ -127,6 +158,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
         psum += p[f][r];
       }
     lsum += psum;
+    }
     // O^T += V^T P^T
 #pragma unroll
     for (int cc = 0; cc < 4; ++cc) {
@@ -134,6 +166,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
       for (int i = 0; i < DB; ++i) {
         bf16x8_t vt = lds_frag_T<D, USE_TR>(Vs, cc * 16, i * 32, lane);
+        if (ABL & 2) { oT[i][cc] += (float)vt[0] * (float)pb[0]; continue; }
         oT[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vt, pb, oT[i], 0, 0, 0);
       }
     }
@@ -208,9 +241,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
   long sid_q = 0;
   if (HAS_SID) sid_q = q_ok ? a.sample_ids[rowbase + qi] : -1;
   const long sidx = ((long)b * a.H + h) * a.L + qi;
-  const float lse_q = q_ok ? a.lse[sidx] : INFINITY;
-  const float delta_q = q_ok ? a.delta[sidx] : 0.f;
+  float lse_q = q_ok ? a.lse[sidx] : INFINITY;
+  float delta_q = q_ok ? a.delta[sidx] : 0.f;
   const float c = a.scale_log2;
+  // (as in the forward kernel: the compiler's wait for these global loads must sit before the loop, not behind the inline-asm refills)
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[ks]), "+v"(dof[ks]));
+  asm volatile("" : "+v"(lse_q), "+v"(delta_q));
+  if (HAS_SID) asm volatile("" : "+v"(sid_q));
 
   f32x16_t dqT[DB];
 #pragma unroll
@@ -221,6 +259,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
   const bf16_t* kbase = a.k + rowbase * a.k_stride + h * D;
   const bf16_t* vbase = a.v + rowbase * a.v_stride + h * D;
   using Stg = DmaStager<D, BKV>;
+  DmaPlan<D, BKV> plank, planv;
+  plank.init(a.k_stride, wave, lane);
+  planv.init(a.v_stride, wave, lane);
   const int nkv = (a.L + BKV - 1) / BKV;
   Stg::issue(kbase, a.k_stride, 0, a.L, smem, wave, lane);
   Stg::issue(vbase, a.v_stride, 0, a.L, smem + 2 * TB, wave, lane);
@@ -232,7 +273,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
     if (HAS_SID && tid < BKV) sid_s[st * BKV + tid] = (kv0 + tid < a.L) ? a.sample_ids[rowbase + kv0 + tid] : -2;
     wait_all_vmem();   // this wave's share of tile t has landed
     __syncthreads();   // ... and everybody's; all waves are also done with tile t-1, so its stage may be refilled
-    if (t + 1 < nkv) {
+    if (kv0 + 2 * BKV <= a.L) {
+      plank.issue_full(kbase + (long)(kv0 + BKV) * a.k_stride, smem + (st ^ 1) * TB, wave);
+      planv.issue_full(vbase + (long)(kv0 + BKV) * a.v_stride, smem + (2 + (st ^ 1)) * TB, wave);
+    } else if (t + 1 < nkv) {
       Stg::issue(kbase, a.k_stride, kv0 + BKV, a.L, smem + (st ^ 1) * TB, wave, lane);
       Stg::issue(vbase, a.v_stride, kv0 + BKV, a.L, smem + (2 + (st ^ 1)) * TB, wave, lane);
     }
@@ -323,6 +367,12 @@ __global__ __launch_bounds__(256, WAVES) void attn_bwd_dkv_kernel(AttnArgs a) {
   long sid_k = 0;
   if (HAS_SID) sid_k = k_ok ? a.sample_ids[rowbase + ki] : -2;
   const float c = a.scale_log2;
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    asm volatile("" : "+v"(kf[ks]));
+    if (DO_DK) asm volatile("" : "+v"(vf[ks]));
+  }
+  if (HAS_SID) asm volatile("" : "+v"(sid_k));
 
   f32x16_t dkT[DB], dvT[DB];
 #pragma unroll
@@ -435,6 +485,11 @@ void launch_fwd(const AttnArgs& a, hipStream_t s) {
   auto kern = attn_fwd_kernel<D, SID, TR>;
   static bool once = false;
   if (!once) { set_lds(kern, lds); once = true; }
+  if (D == 128 && !SID && TR) {   // UDM_ATTN_ABL=1|2: timing-only ablations of the forward kernel (scripts/bench_attn.py)
+    static const int abl = [] { const char* e = getenv("UDM_ATTN_ABL"); return e ? atoi(e) : 0; }();
+    if (abl == 1) { auto k1 = attn_fwd_kernel<128, false, true, 1>; set_lds(k1, lds); hipLaunchKernelGGL(k1, grid, dim3(256), lds, s, a); return; }
+    if (abl == 2) { auto k2 = attn_fwd_kernel<128, false, true, 2>; set_lds(k2, lds); hipLaunchKernelGGL(k2, grid, dim3(256), lds, s, a); return; }
+  }
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
 }
 template <int D, bool SID, bool TR>

@@ -91,8 +91,40 @@ struct DmaStager {
       const int row = idx * RPI + lane / LPR;
       const int slot = (lane % LPR) ^ swz<D>(row);
       const int grow = min(row0 + row, L - 1);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + (long)grow * stride + slot * 8),
-                                       (UDM_LDS void*)(tile + idx * 1024), 16, 0, 0);
+      // Issued as inline asm ON PURPOSE: the compiler tracks LDS-DMA it knows about and puts s_waitcnt vmcnt(0) in front of every LDS read
+      // it cannot prove disjoint - which includes all ds_read_b64_tr_b16 - so the refill of the OTHER stage was waited for in the middle
+      // of the tile it should overlap with.  The waits that matter are explicit (wait_all_vmem before the barrier that publishes a stage).
+      const uint32_t dst = (uint32_t)(size_t)(UDM_LDS char*)(tile + idx * 1024);
+      asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(base + (long)grow * stride + slot * 8), "s"(dst) : "memory", "m0");
+    }
+  }
+};
+// Full tiles (every row < L) need no per-piece vector arithmetic: the per-lane byte offset of piece j inside a tile is fixed
+// (row-in-tile * stride + swizzled slot), the tile's first row goes into a wave-uniform 64-bit base (SALU), and the DMA takes the
+// (SGPR base + 32-bit VGPR offset) form.  The clamped general form above cost ~10 VALU instructions per piece, three of them quarter-rate
+// integer multiplies - about 600 cycles per 64-key tile and wave in the forward / dQ loops.
+template <int D, int ROWS>
+struct DmaPlan {
+  using Stg = DmaStager<D, ROWS>;
+  uint32_t off[Stg::PW];
+  __device__ __forceinline__ void init(long stride, int wave, int lane) {
+#pragma unroll
+    for (int j = 0; j < Stg::PW; ++j) {
+      const int idx = wave * Stg::PW + j;
+      const int row = idx * Stg::RPI + lane / Stg::LPR;
+      const int slot = (lane % Stg::LPR) ^ swz<D>(row);
+      off[j] = (uint32_t)((row * stride + slot * 8) * 2);
+    }
+  }
+  // tile_base: address of the tile's first row (wave-uniform); tile: LDS stage
+  __device__ __forceinline__ void issue_full(const bf16_t* tile_base, char* tile, int wave) const {
+    const uint64_t u = reinterpret_cast<uint64_t>(tile_base);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u), hi32 = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
+    const uint64_t sb = ((uint64_t)hi32 << 32) | lo;
+#pragma unroll
+    for (int j = 0; j < Stg::PW; ++j) {
+      const uint32_t dst = (uint32_t)(size_t)(UDM_LDS char*)(tile + (wave * Stg::PW + j) * 1024);
+      asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off[j]), "s"(sb), "s"(dst) : "memory", "m0");
     }
   }
 };

@@ -329,6 +329,12 @@ __device__ __forceinline__ void glds16(const void* gptr, char* lds_base) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gptr, (UDM_LDS void*)lds_base, 16, 0, 0);
 }
 
+// LDS-DMA issued as inline asm (see the TN branch of the stagger kernel): lane i lands at lds + 16 i; `lds` must be wave-uniform
+__device__ __forceinline__ void glds16_asm(const void* gptr, const char* lds) {
+  const uint32_t dst = (uint32_t)(size_t)(UDM_LDS const char*)lds;
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gptr), "s"(dst) : "memory", "m0");
+}
+
 // TN = true: both operands are K-major ("A^T B": A is [K, M], B is [K, N], rows = contraction index) — the wgrad
 // form dW = dY^T X read straight from the row-major activations.  Tiles are staged as [64 k-rows][columns] and the
 // MFMA operands are gathered with ds_read_b64_tr_b16 transposing reads; rows are rotated by (k & 3) 64-byte
@@ -418,7 +424,10 @@ __global__ __launch_bounds__(512) void gemm_nt_stagger_kernel(GemmArgs p) {
   const int nk_all = p.K / BK;
   const int kt0 = (int)((long)nk_all * slice / S), nk = (int)((long)nk_all * (slice + 1) / S);
 #pragma unroll
-  for (int j = 0; j < LOADS; ++j) glds16(src[j] + kt0 * (j < A_PW ? kstep_a : kstep_b), smem + dst[j] + (kt0 & 1) * STAGE_BYTES);
+  for (int j = 0; j < LOADS; ++j) {
+    if (TN) glds16_asm(src[j] + kt0 * (j < A_PW ? kstep_a : kstep_b), smem + dst[j] + (kt0 & 1) * STAGE_BYTES);
+    else glds16(src[j] + kt0 * (j < A_PW ? kstep_a : kstep_b), smem + dst[j] + (kt0 & 1) * STAGE_BYTES);
+  }
   wait_vmcnt<0>();
   __builtin_amdgcn_s_barrier();
   if (late) __builtin_amdgcn_s_barrier();
@@ -463,6 +472,34 @@ __global__ __launch_bounds__(512) void gemm_nt_stagger_kernel(GemmArgs p) {
       __builtin_amdgcn_sched_barrier(0);
       // The next tile's LDS-DMA is issued from INSIDE the MFMA section (an MFMA occupies the pipe for 32 cycles while the wave
       // itself is idle), so the read section stays short and the partner wave gets the matrix pipe back sooner.
+      if (TN) {
+        // The compiler puts s_waitcnt vmcnt(0) in front of every ds_read_b64_tr_b16 that follows an LDS-DMA it knows about (it cannot prove
+        // the stages disjoint), i.e. the refill was waited for one phase after its issue instead of at the end of the tile; and the
+        // sched_group_barrier interleave below did not take for this instantiation (all refills went out before the first MFMA).
+        // Here the refills are inline asm (invisible to that analysis; the waits that matter are the explicit ones) and their places
+        // between the MFMAs are written out and pinned.
+        constexpr int NMF = KKPP * FM * FN, NLD = PER, GAP = NMF / (NLD > 0 ? NLD : 1) > 0 ? NMF / (NLD > 0 ? NLD : 1) : 1;
+        const long knext = more ? kt + 1 : kt;   // last tile: re-stage the current tile into the free stage (harmless, waited for below) - no branches
+        int jd = ph * PER, cnt = 0;
+#pragma unroll
+        for (int q = 0; q < KKPP; ++q)
+#pragma unroll
+          for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[q][i], b[q][j], acc[i][j], 0, 0, 0);
+              ++cnt;
+              if (ph < ISSUE_PH && (cnt % GAP) == 1 && jd < (ph + 1) * PER && jd < LOADS) {
+                __builtin_amdgcn_sched_barrier(0);
+                glds16_asm(src[jd] + knext * (jd < A_PW ? kstep_a : kstep_b), nxt + dst[jd]);
+                __builtin_amdgcn_sched_barrier(0);
+                ++jd;
+              }
+            }
+#pragma unroll
+        for (; jd < (ph + 1) * PER && jd < LOADS && ph < ISSUE_PH; ++jd)
+          glds16_asm(src[jd] + knext * (jd < A_PW ? kstep_a : kstep_b), nxt + dst[jd]);
+      } else {
       if (ph < ISSUE_PH && more) {
 #pragma unroll
         for (int j = ph * PER; j < (ph + 1) * PER && j < LOADS; ++j) glds16(src[j] + (kt + 1) * (j < A_PW ? kstep_a : kstep_b), nxt + dst[j]);
@@ -479,6 +516,7 @@ __global__ __launch_bounds__(512) void gemm_nt_stagger_kernel(GemmArgs p) {
           __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
           __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
         }
+      }
       }
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();

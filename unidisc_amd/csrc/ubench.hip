@@ -42,6 +42,8 @@ __global__ __launch_bounds__(256, 1) void ubench_kernel(UArgs p) {
   const char* sbase = reinterpret_cast<const char*>(((uint64_t)uhi << 32) | ulo);
   __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)sbase, 0, 0x7ffff000, 0x00020000);
 #endif
+  float vv[4] = {1.f, 2.f, 3.f, 4.f}, vk = 0.999f, vc = 0.001f;
+  asm volatile("" : "+v"(vv[0]), "+v"(vv[1]), "+v"(vv[2]), "+v"(vv[3]), "+v"(vk), "+v"(vc));
   f32x4_t gsum = {};
   bf16x8_t lsum = {};
   const uint32_t lds0 = (uint32_t)(size_t)(UDM_LDS char*)smem;
@@ -65,6 +67,13 @@ __global__ __launch_bounds__(256, 1) void ubench_kernel(UArgs p) {
       lsum = v;
     }
     if (KIND == 6) asm volatile("s_nop 15" ::: "memory");
+    if (KIND == 8) {   // four independent fp32 FMAs (plain VALU) in the shadow of the MFMA just issued
+      asm volatile("v_fma_f32 %0, %0, %4, %5\n\tv_fma_f32 %1, %1, %4, %5\n\tv_fma_f32 %2, %2, %4, %5\n\tv_fma_f32 %3, %3, %4, %5"
+                   : "+v"(vv[0]), "+v"(vv[1]), "+v"(vv[2]), "+v"(vv[3]) : "v"(vk), "v"(vc));
+    }
+    if (KIND == 9) {   // two independent exp2 (quarter-rate transcendental)
+      asm volatile("v_exp_f32 %0, %0\n\tv_exp_f32 %1, %1" : "+v"(vv[0]), "+v"(vv[1]));
+    }
 #endif
     soff = (soff + p.stride) & p.win_mask;
   };
@@ -97,7 +106,7 @@ __global__ __launch_bounds__(256, 1) void ubench_kernel(UArgs p) {
   __builtin_amdgcn_sched_barrier(0);
   const unsigned long long t1 = __builtin_amdgcn_s_memtime();
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-  float s = gsum[0] + (float)lsum[0];
+  float s = gsum[0] + (float)lsum[0] + vv[0] + vv[1] + vv[2] + vv[3];
 #pragma unroll
   for (int i = 0; i < 16; ++i) s += acc[i][0];
 #pragma unroll
@@ -132,6 +141,7 @@ extern "C" int udm_ubench_issue(int mode, int blocks, int iters, int stride, int
     UB(0, 7, 4) UB(0, 7, 8)
     UB(1, 2, 4) UB(1, 2, 8) UB(1, 2, 16)
     UB(1, 5, 8) UB(1, 5, 16)
+    UB(0, 8, 4) UB(0, 8, 8) UB(0, 8, 16) UB(0, 9, 4) UB(0, 9, 8) UB(0, 9, 16)
     default: udm_set_error("udm_ubench_issue: unknown mode %d", mode); return 2;
   }
 #undef UB
