@@ -425,8 +425,7 @@ __global__ __launch_bounds__(512) void gemm_nt_stagger_kernel(GemmArgs p) {
   const int kt0 = (int)((long)nk_all * slice / S), nk = (int)((long)nk_all * (slice + 1) / S);
 #pragma unroll
   for (int j = 0; j < LOADS; ++j) {
-    if (TN) glds16_asm(src[j] + kt0 * (j < A_PW ? kstep_a : kstep_b), smem + dst[j] + (kt0 & 1) * STAGE_BYTES);
-    else glds16(src[j] + kt0 * (j < A_PW ? kstep_a : kstep_b), smem + dst[j] + (kt0 & 1) * STAGE_BYTES);
+    glds16_asm(src[j] + kt0 * (j < A_PW ? kstep_a : kstep_b), smem + dst[j] + (kt0 & 1) * STAGE_BYTES);
   }
   wait_vmcnt<0>();
   __builtin_amdgcn_s_barrier();
@@ -470,16 +469,16 @@ __global__ __launch_bounds__(512) void gemm_nt_stagger_kernel(GemmArgs p) {
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
-      // The next tile's LDS-DMA is issued from INSIDE the MFMA section (an MFMA occupies the pipe for 32 cycles while the wave
-      // itself is idle), so the read section stays short and the partner wave gets the matrix pipe back sooner.
-      if (TN) {
-        // The compiler puts s_waitcnt vmcnt(0) in front of every ds_read_b64_tr_b16 that follows an LDS-DMA it knows about (it cannot prove
-        // the stages disjoint), i.e. the refill was waited for one phase after its issue instead of at the end of the tile; and the
-        // sched_group_barrier interleave below did not take for this instantiation (all refills went out before the first MFMA).
-        // Here the refills are inline asm (invisible to that analysis; the waits that matter are the explicit ones) and their places
-        // between the MFMAs are written out and pinned.
-        constexpr int NMF = KKPP * FM * FN, NLD = PER, GAP = NMF / (NLD > 0 ? NLD : 1) > 0 ? NMF / (NLD > 0 ? NLD : 1) : 1;
-        const long knext = more ? kt + 1 : kt;   // last tile: re-stage the current tile into the free stage (harmless, waited for below) - no branches
+      {
+        // Refills of the next tile go out from INSIDE the MFMA section (an MFMA occupies the pipe for 32 cycles while the wave itself is
+        // idle), one per GAP MFMAs, at places that are written out and pinned: a sched_group_barrier recipe cannot reach across the
+        // `more` branch the refills used to sit behind (all of them went out in one burst before the first MFMA), so the last tile
+        // re-stages itself into the free stage instead (harmless, waited for below) and the section has no branch at all.
+        // They are inline asm on purpose: the compiler waits vmcnt(0) in front of every ds_read_b64_tr_b16 (TN form) that follows an
+        // LDS-DMA it knows about, because it cannot prove the stages disjoint - i.e. one phase after the issue instead of at the end
+        // of the tile.  The waits that matter are the explicit ones.
+        constexpr int NMF = KKPP * FM * FN, GAP = (NMF / PER) > 0 ? (NMF / PER) : 1;
+        const long knext = more ? kt + 1 : kt;
         int jd = ph * PER, cnt = 0;
 #pragma unroll
         for (int q = 0; q < KKPP; ++q)
@@ -489,7 +488,7 @@ __global__ __launch_bounds__(512) void gemm_nt_stagger_kernel(GemmArgs p) {
             for (int j = 0; j < FN; ++j) {
               acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[q][i], b[q][j], acc[i][j], 0, 0, 0);
               ++cnt;
-              if (ph < ISSUE_PH && (cnt % GAP) == 1 && jd < (ph + 1) * PER && jd < LOADS) {
+              if (ph < ISSUE_PH && ((cnt - 1) % GAP) == 0 && jd < (ph + 1) * PER && jd < LOADS) {
                 __builtin_amdgcn_sched_barrier(0);
                 glds16_asm(src[jd] + knext * (jd < A_PW ? kstep_a : kstep_b), nxt + dst[jd]);
                 __builtin_amdgcn_sched_barrier(0);
@@ -497,26 +496,7 @@ __global__ __launch_bounds__(512) void gemm_nt_stagger_kernel(GemmArgs p) {
               }
             }
 #pragma unroll
-        for (; jd < (ph + 1) * PER && jd < LOADS && ph < ISSUE_PH; ++jd)
-          glds16_asm(src[jd] + knext * (jd < A_PW ? kstep_a : kstep_b), nxt + dst[jd]);
-      } else {
-      if (ph < ISSUE_PH && more) {
-#pragma unroll
-        for (int j = ph * PER; j < (ph + 1) * PER && j < LOADS; ++j) glds16(src[j] + (kt + 1) * (j < A_PW ? kstep_a : kstep_b), nxt + dst[j]);
-      }
-#pragma unroll
-      for (int q = 0; q < KKPP; ++q)
-#pragma unroll
-        for (int i = 0; i < FM; ++i)
-#pragma unroll
-          for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[q][i], b[q][j], acc[i][j], 0, 0, 0);
-      if (ph < ISSUE_PH) {
-#pragma unroll
-        for (int q = 0; q < PER; ++q) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-        }
-      }
+        for (; jd < (ph + 1) * PER && jd < LOADS && ph < ISSUE_PH; ++jd) glds16_asm(src[jd] + knext * (jd < A_PW ? kstep_a : kstep_b), nxt + dst[jd]);
       }
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();
