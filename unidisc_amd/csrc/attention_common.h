@@ -128,6 +128,15 @@ struct DmaPlan {
     }
   }
 };
+// single LDS-DMA pieces as inline asm (same reason as in DmaStager): 16 or 4 bytes per lane, lane i lands at lds + 16 i / lds + 4 i
+__device__ __forceinline__ void dma16_asm(const void* gptr, const char* lds) {
+  const uint32_t dst = (uint32_t)(size_t)(UDM_LDS const char*)lds;
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gptr), "s"(dst) : "memory", "m0");
+}
+__device__ __forceinline__ void dma4_asm(const void* gptr, const char* lds) {
+  const uint32_t dst = (uint32_t)(size_t)(UDM_LDS const char*)lds;
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(gptr), "s"(dst) : "memory", "m0");
+}
 __device__ __forceinline__ void wait_all_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 }  // namespace
 

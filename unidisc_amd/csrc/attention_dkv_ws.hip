@@ -66,6 +66,8 @@ __device__ __forceinline__ void stamp(const Ctx& x, int j, int tag) {
   }
 }
 
+// (The refills are inline asm - dma16_asm / dma4_asm - because the compiler puts s_waitcnt vmcnt(0) in front of the transposing reads of the
+// Z section when it knows of an LDS-DMA in flight: the ring's prefetch depth was being waited away every step.)
 // Refill of one step, issued by the four accum waves (an LDS-DMA piece costs its issuer ~100 cycles; the accum stream has that slack
 // while the score wave is in its MFMA burst).  Full steps: wave-uniform base + precomputed 32-bit lane offset, no vector address math.
 __device__ __forceinline__ void issue_sub(const Ctx& x, char* smem, int sub, int stage) {
@@ -75,22 +77,22 @@ __device__ __forceinline__ void issue_sub(const Ctx& x, char* smem, int sub, int
   if ((sub + 1) * SUB <= x.L) {
 #pragma unroll
     for (int jj = 0; jj < 2; ++jj) {
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(x.qbase + sub * x.qstep + (size_t)x.offq[jj]), (UDM_LDS void*)(st + jj * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(x.dobase + sub * x.ostep + (size_t)x.offo[jj]), (UDM_LDS void*)(st + TQ + jj * 1024), 16, 0, 0);
+      dma16_asm(x.qbase + sub * x.qstep + (size_t)x.offq[jj], st + jj * 1024);
+      dma16_asm(x.dobase + sub * x.ostep + (size_t)x.offo[jj], st + TQ + jj * 1024);
     }
     // lse (lanes 0..31) | delta (lanes 32..63); every accum wave issues the same copy so that all of them carry identical vmcnt bookkeeping
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(x.ldp + sub * SUB), (UDM_LDS void*)ldst, 4, 0, 0);
+    dma4_asm(x.ldp + sub * SUB, ldst);
   } else {  // ragged last step: clamp rows to L-1 (finite data; the lse = +inf fix-up zeroes their probabilities)
 #pragma unroll
     for (int jj = 0; jj < 2; ++jj) {
       const int row = (kw * 2 + jj) * 4 + x.lane / 16;
       const int slot = (x.lane % 16) ^ swz<D>(row);
       const int grow = min(sub * SUB + row, x.L - 1);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(x.qb16 + (long)grow * x.q_stride + slot * 8), (UDM_LDS void*)(st + jj * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(x.ob16 + (long)grow * x.do_stride + slot * 8), (UDM_LDS void*)(st + TQ + jj * 1024), 16, 0, 0);
+      dma16_asm(x.qb16 + (long)grow * x.q_stride + slot * 8, st + jj * 1024);
+      dma16_asm(x.ob16 + (long)grow * x.do_stride + slot * 8, st + TQ + jj * 1024);
     }
     const int qrow = min(sub * SUB + (x.lane & 31), x.L - 1);
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(x.ldp - (x.lane & 31) + qrow), (UDM_LDS void*)ldst, 4, 0, 0);
+    dma4_asm(x.ldp - (x.lane & 31) + qrow, ldst);
   }
 }
 
