@@ -69,14 +69,17 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
   Stg::issue(kbase, a.k_stride, 0, a.L, smem, wave, lane);
   Stg::issue(vbase, a.v_stride, 0, a.L, smem + 2 * TB, wave, lane);
   for (int t = 0; t < nkv; ++t) {
-    const int kv0 = t * BKV, st = t & 1;
+    const int kv0 = t * BKV, st = (ABL & 4) ? 0 : (t & 1);
     const char* Ks = smem + st * TB;
     const char* Vs = smem + (2 + st) * TB;
     const long* sidk = sid_s + st * BKV;
     if (HAS_SID && tid < BKV) sid_s[st * BKV + tid] = (kv0 + tid < a.L) ? a.sample_ids[rowbase + kv0 + tid] : -2;
+    if (!(ABL & 4) || t == 0) {
     wait_all_vmem();   // this wave's share of tile t has landed
     __syncthreads();   // ... and everybody's; all waves are also done with tile t-1, so its stage may be refilled
-    if (kv0 + 2 * BKV <= a.L) {   // the next tile is a full one: offsets are precomputed, the tile base is wave-uniform
+    }
+    if (ABL & 4) {
+    } else if (kv0 + 2 * BKV <= a.L) {   // the next tile is a full one: offsets are precomputed, the tile base is wave-uniform
       plank.issue_full(kbase + (long)(kv0 + BKV) * a.k_stride, smem + (st ^ 1) * TB, wave);
       planv.issue_full(vbase + (long)(kv0 + BKV) * a.v_stride, smem + (2 + (st ^ 1)) * TB, wave);
     } else if (t + 1 < nkv) {
@@ -489,6 +492,8 @@ void launch_fwd(const AttnArgs& a, hipStream_t s) {
     static const int abl = [] { const char* e = getenv("UDM_ATTN_ABL"); return e ? atoi(e) : 0; }();
     if (abl == 1) { auto k1 = attn_fwd_kernel<128, false, true, 1>; set_lds(k1, lds); hipLaunchKernelGGL(k1, grid, dim3(256), lds, s, a); return; }
     if (abl == 2) { auto k2 = attn_fwd_kernel<128, false, true, 2>; set_lds(k2, lds); hipLaunchKernelGGL(k2, grid, dim3(256), lds, s, a); return; }
+    if (abl == 4) { auto k4 = attn_fwd_kernel<128, false, true, 4>; set_lds(k4, lds); hipLaunchKernelGGL(k4, grid, dim3(256), lds, s, a); return; }   // no refills / barriers
+    if (abl == 5) { auto k5 = attn_fwd_kernel<128, false, true, 5>; set_lds(k5, lds); hipLaunchKernelGGL(k5, grid, dim3(256), lds, s, a); return; }   // ... and no softmax
   }
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
 }
