@@ -300,6 +300,19 @@ def test_residual_dropout_mask_consistent(K):
     assert not torch.equal(xo2.cpu() != 0, keep)
 
 
+def test_residual_dropout_mask_statistics(K):
+    """16 random bits per decision: the keep rate is p rounded to 2^-16, neighbours (same Philox call, adjacent 16-bit halves) are independent."""
+    M, d, L, p = 1024, 2048, 128, 0.1
+    xo, _, _ = K.residual_fwd(torch.zeros(M, d, device=DEV), bf(torch.ones(M, d)).to(DEV), L, p_drop=p, seed=7)
+    keep = (xo != 0).float().cpu()
+    assert abs(keep.mean().item() - (1 - p)) < 1.5e-3          # 2.1 M draws: 3 sigma = 6e-4
+    a, b = keep[:, 0::2].reshape(-1), keep[:, 1::2].reshape(-1)
+    corr = ((a - a.mean()) * (b - b.mean())).mean() / (a.std() * b.std())
+    assert abs(corr.item()) < 5e-3
+    col = keep.mean(0)
+    assert (col - (1 - p)).abs().max().item() < 0.05           # no column is systematically kept / dropped (1024 draws each)
+
+
 # ------------------------------------------------------------------------------------------------ qk-norm + rope
 @pytest.mark.parametrize("d,D", [(64, 32), (768, 64), (2048, 128), (256, 64)])
 @pytest.mark.parametrize("qk_norm", [True, False])
