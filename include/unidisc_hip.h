@@ -158,6 +158,14 @@ int udm_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, floa
 int udm_adamw_step_shadow(float* p, const float* g, float* m, float* v, int64_t R, int64_t C, float lr, float beta1, float beta2, float eps,
                           float weight_decay, int64_t step, const float* grad_norm_sq, float max_grad_norm, void* w16, int64_t ld16, void* w16t,
                           int64_t ldt, hipStream_t stream);
+/* The same updates with the parameter EMA of models/ema.py:44-53 (`ExponentialMovingAverage.update`, called after optimizer.step at model.py:1541-1545)
+ * folded into the pass: ema <- ema - (1 - ema_decay) (ema - p_new).  `ema_decay` is the decay OF THIS UPDATE (the caller applies the reference's
+ * warm-up min(decay, (1 + n) / (10 + n))).  ema NULL: identical to the plain forms. */
+int udm_adamw_step_ema(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay,
+                       int64_t step, const float* grad_norm_sq, float max_grad_norm, float* ema, float ema_decay, hipStream_t stream);
+int udm_adamw_step_shadow_ema(float* p, const float* g, float* m, float* v, int64_t R, int64_t C, float lr, float beta1, float beta2, float eps,
+                              float weight_decay, int64_t step, const float* grad_norm_sq, float max_grad_norm, void* w16, int64_t ld16, void* w16t,
+                              int64_t ldt, float* ema, float ema_decay, hipStream_t stream);
 
 #ifdef __cplusplus
 }

@@ -358,12 +358,16 @@ def _adam(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_norm_sq, m
     p.sub_((lr / bc1) * (m / (v.sqrt() / (bc2 ** 0.5) + eps)))
 
 
-def adamw_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_norm_sq=None, max_grad_norm=None):
+def adamw_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_norm_sq=None, max_grad_norm=None, ema=None, ema_decay=0.0):
     _adam(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_norm_sq, max_grad_norm)
+    if ema is not None:
+        ema.sub_((1.0 - ema_decay) * (ema - p))
 
 
-def adamw_step_shadow(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_norm_sq, max_grad_norm, w16, w16t):
+def adamw_step_shadow(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_norm_sq, max_grad_norm, w16, w16t, ema=None, ema_decay=0.0):
     _adam(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_norm_sq, max_grad_norm)
+    if ema is not None:
+        ema.sub_((1.0 - ema_decay) * (ema - p))
     R, C = p.shape
     if w16 is not None:
         w16[:R, :C] = p.bfloat16()

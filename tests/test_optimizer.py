@@ -146,3 +146,90 @@ def test_training_steps_with_fused_adamw_match_torch_adamw_with_recast():
     assert all(abs(a - b) <= 2e-3 * abs(b) for a, b in zip(l1, l0)), (l1, l0)
     for n in p0:
         assert rel_err(p1[n], p0[n]) < 2e-3, n
+
+
+# ------------------------------------------------------------------------------------------------ parameter EMA (models/ema.py:44-53)
+class _RefEMA:
+    """The reference's ExponentialMovingAverage.update / copy_to / store / restore arithmetic, restated for the check."""
+
+    def __init__(self, params, decay, use_num_updates=True):
+        self.decay, self.n = decay, 0 if use_num_updates else None
+        self.shadow = [p.clone().detach() for p in params]
+
+    def update(self, params):
+        d = self.decay
+        if self.n is not None:
+            self.n += 1
+            d = min(d, (1 + self.n) / (10 + self.n))
+        for s, p in zip(self.shadow, params):
+            s.sub_((1.0 - d) * (s - p))
+
+
+def test_fused_adamw_ema_host_logic(fake_k):
+    from unidisc_amd import FusedAdamW
+
+    def net():
+        torch.manual_seed(3)
+        return torch.nn.Sequential(torch.nn.Linear(12, 20), torch.nn.LayerNorm(20), torch.nn.Linear(20, 7))
+
+    def grads(mod, seed):
+        g = torch.Generator().manual_seed(seed)
+        for p in mod.parameters():
+            p.grad = torch.randn(p.shape, generator=g)
+
+    model, ref = net(), net()
+    opt = FusedAdamW(model, lr=1e-2, weight_decay=0.01, max_grad_norm=0.05, maintain_shadows=False, ema_decay=0.999)
+    topt = torch.optim.AdamW(ref.parameters(), lr=1e-2, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01)
+    ema = _RefEMA(list(ref.parameters()), 0.999)
+    for it in range(12):
+        grads(model, 50 + it)
+        grads(ref, 50 + it)
+        opt.step()
+        torch.nn.utils.clip_grad_norm_(ref.parameters(), 0.05)
+        topt.step()
+        ema.update(list(ref.parameters()))
+    for p, s_ in zip(opt.params, ema.shadow):
+        torch.testing.assert_close(opt.ema[id(p)], s_, rtol=2e-5, atol=1e-7)
+    assert opt.ema_num_updates == 12
+    # store / copy_to / restore
+    before = [p.detach().clone() for p in opt.params]
+    opt.ema_store_and_copy()
+    for p in opt.params:
+        assert torch.equal(p, opt.ema[id(p)])
+    opt.ema_restore()
+    for p, b in zip(opt.params, before):
+        assert torch.equal(p, b)
+    # state dict round trip keeps the EMA and its warm-up counter
+    opt2 = FusedAdamW(model, lr=1e-2, maintain_shadows=False, ema_decay=0.999)
+    opt2.load_state_dict(opt.state_dict())
+    assert opt2.ema_num_updates == 12 and all(torch.equal(opt2.ema[id(p)], opt.ema[id(p)]) for p in opt.params)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [5, 4096, 100003])
+def test_adamw_kernel_ema(n):
+    from unidisc_amd import kernels as K
+    g = torch.Generator().manual_seed(n)
+    p, gr = torch.randn(n, generator=g), torch.randn(n, generator=g)
+    m, v, e = torch.zeros(n), torch.zeros(n), torch.randn(n, generator=g)
+    pd, gd, md, vd, ed = (t.clone().cuda() for t in (p, gr, m, v, e))
+    for step in (1, 2, 3):
+        K.adamw_step(pd, gd, md, vd, 1e-3, 0.9, 0.999, 1e-8, 0.01, step, ema=ed, ema_decay=0.9 + 0.03 * step)
+        fake_kernels.adamw_step(p, gr, m, v, 1e-3, 0.9, 0.999, 1e-8, 0.01, step, ema=e, ema_decay=0.9 + 0.03 * step)
+    torch.testing.assert_close(pd.cpu(), p, rtol=2e-6, atol=1e-7)
+    torch.testing.assert_close(ed.cpu(), e, rtol=2e-6, atol=1e-7)   # fp32 arithmetic in the same order: rounding-level agreement
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("R,C", [(64, 64), (200, 328), (97, 130)])
+def test_adamw_shadow_kernel_ema(R, C):
+    from unidisc_amd import kernels as K
+    g = torch.Generator().manual_seed(R * 1000 + C)
+    p, gr, e = torch.randn(R, C, generator=g), torch.randn(R, C, generator=g), torch.randn(R, C, generator=g)
+    m, v = torch.zeros(R, C), torch.zeros(R, C)
+    w16, w16t = torch.zeros(R, C, dtype=torch.bfloat16), torch.zeros(C, R, dtype=torch.bfloat16)
+    pd, gd, md, vd, ed, w16d, w16td = (t.clone().cuda() for t in (p, gr, m, v, e, w16, w16t))
+    K.adamw_step_shadow(pd, gd, md, vd, 1e-3, 0.9, 0.999, 1e-8, 0.0, 1, None, None, w16d, w16td, ema=ed, ema_decay=0.95)
+    fake_kernels.adamw_step_shadow(p, gr, m, v, 1e-3, 0.9, 0.999, 1e-8, 0.0, 1, None, None, w16, w16t, ema=e, ema_decay=0.95)
+    torch.testing.assert_close(ed.cpu(), e, rtol=2e-6, atol=1e-7)
+    assert torch.equal(w16d.cpu(), pd.cpu().bfloat16()) and torch.equal(w16td.cpu(), pd.cpu().t().bfloat16())

@@ -24,7 +24,14 @@ struct AdamArgs {
   float lr, b1, b2, eps, decay, bc1, rsqrt_bc2;   // decay = 1 - lr * wd; bc1 = 1 - b1^t; rsqrt_bc2 = 1 / sqrt(1 - b2^t)
   const float* gnorm_sq;                          // nullable: sum of squares of ALL gradients (device scalar)
   float max_norm;
+  float* ema;                                     // nullable: exponential moving average of p (models/ema.py:44-53), updated in the same pass
+  float ema_omd;                                  // 1 - decay of this update
 };
+__device__ __forceinline__ void ema4(const AdamArgs& a, long i4, const float4& p) {   // s <- s - (1 - decay) (s - p)
+  float4 e = reinterpret_cast<float4*>(a.ema)[i4];
+  e.x -= a.ema_omd * (e.x - p.x); e.y -= a.ema_omd * (e.y - p.y); e.z -= a.ema_omd * (e.z - p.z); e.w -= a.ema_omd * (e.w - p.w);
+  reinterpret_cast<float4*>(a.ema)[i4] = e;
+}
 
 __device__ __forceinline__ float clip_coef(const AdamArgs& a) {
   if (!a.gnorm_sq) return 1.f;
@@ -51,12 +58,15 @@ __global__ __launch_bounds__(256) void adamw_kernel(AdamArgs a, long n) {
     p.z = adam_update(a, p.z, g.z * clip, m.z, v.z);
     p.w = adam_update(a, p.w, g.w * clip, m.w, v.w);
     reinterpret_cast<float4*>(a.p)[i] = p; reinterpret_cast<float4*>(a.m)[i] = m; reinterpret_cast<float4*>(a.v)[i] = v;
+    if (a.ema) ema4(a, i, p);
   }
   if (blockIdx.x == 0 && threadIdx.x < n - n4 * 4) {  // tail (n not a multiple of 4)
     const long i = n4 * 4 + threadIdx.x;
     float m = a.m[i], v = a.v[i];
-    a.p[i] = adam_update(a, a.p[i], a.g[i] * clip, m, v);
+    const float pn = adam_update(a, a.p[i], a.g[i] * clip, m, v);
+    a.p[i] = pn;
     a.m[i] = m; a.v[i] = v;
+    if (a.ema) a.ema[i] -= a.ema_omd * (a.ema[i] - pn);
   }
 }
 
@@ -83,6 +93,7 @@ __global__ __launch_bounds__(256) void adamw_shadow_kernel(AdamArgs a, int R, in
         p.z = adam_update(a, p.z, g.z * clip, m.z, v.z);
         p.w = adam_update(a, p.w, g.w * clip, m.w, v.w);
         *reinterpret_cast<float4*>(a.p + base) = p; *reinterpret_cast<float4*>(a.m + base) = m; *reinterpret_cast<float4*>(a.v + base) = v;
+        if (a.ema) ema4(a, base / 4, p);
         b[0] = f2bf(p.x); b[1] = f2bf(p.y); b[2] = f2bf(p.z); b[3] = f2bf(p.w);
         if (w16) {
           bf16_t* op = w16 + (long)(r0 + r) * ld16 + c0 + cs;
@@ -95,6 +106,7 @@ __global__ __launch_bounds__(256) void adamw_shadow_kernel(AdamArgs a, int R, in
           float m = a.m[base + k], v = a.v[base + k];
           const float p = adam_update(a, a.p[base + k], a.g[base + k] * clip, m, v);
           a.p[base + k] = p; a.m[base + k] = m; a.v[base + k] = v;
+          if (a.ema) a.ema[base + k] -= a.ema_omd * (a.ema[base + k] - p);
           b[k] = f2bf(p);
           if (w16) w16[(long)(r0 + r) * ld16 + c0 + cs + k] = b[k];
         }
@@ -156,6 +168,14 @@ int fill_args(AdamArgs& a, const char* name, float* p, const float* g, float* m,
   a.bc1 = (float)(1.0 - pow((double)beta1, (double)step));
   a.rsqrt_bc2 = (float)(1.0 / sqrt(1.0 - pow((double)beta2, (double)step)));
   a.gnorm_sq = grad_norm_sq; a.max_norm = max_grad_norm;
+  a.ema = nullptr; a.ema_omd = 0.f;
+  return 0;
+}
+int set_ema(AdamArgs& a, const char* name, float* ema, float ema_decay) {
+  if (!ema) return 0;
+  UDM_CHECK_ARG(ema_decay >= 0.f && ema_decay <= 1.f, "%s: EMA decay must be in [0, 1]", name);
+  UDM_CHECK_ARG((uintptr_t)ema % 16 == 0, "%s: ema must be 16-byte aligned", name);
+  a.ema = ema; a.ema_omd = 1.f - ema_decay;
   return 0;
 }
 }  // namespace
@@ -173,10 +193,11 @@ extern "C" int udm_sumsq_f32(const float* x, int64_t n, float* out, float* ws, i
   return 0;
 }
 
-extern "C" int udm_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay,
-                              int64_t step, const float* grad_norm_sq, float max_grad_norm, hipStream_t stream) {
+extern "C" int udm_adamw_step_ema(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay,
+                                  int64_t step, const float* grad_norm_sq, float max_grad_norm, float* ema, float ema_decay, hipStream_t stream) {
   AdamArgs a;
   if (int rc = fill_args(a, "udm_adamw_step", p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_norm_sq, max_grad_norm)) return rc;
+  if (int rc = set_ema(a, "udm_adamw_step", ema, ema_decay)) return rc;
   UDM_CHECK_ARG(n > 0, "udm_adamw_step: empty tensor");
   UDM_CHECK_ARG(((uintptr_t)p % 16 == 0) && ((uintptr_t)g % 16 == 0) && ((uintptr_t)m % 16 == 0) && ((uintptr_t)v % 16 == 0), "udm_adamw_step: tensors must be 16-byte aligned");
   long grid = (n / 4 + 255) / 256;
@@ -187,11 +208,17 @@ extern "C" int udm_adamw_step(float* p, const float* g, float* m, float* v, int6
   return 0;
 }
 
-extern "C" int udm_adamw_step_shadow(float* p, const float* g, float* m, float* v, int64_t R, int64_t C, float lr, float beta1, float beta2, float eps,
-                                     float weight_decay, int64_t step, const float* grad_norm_sq, float max_grad_norm, void* w16, int64_t ld16, void* w16t,
-                                     int64_t ldt, hipStream_t stream) {
+extern "C" int udm_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay,
+                              int64_t step, const float* grad_norm_sq, float max_grad_norm, hipStream_t stream) {
+  return udm_adamw_step_ema(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, step, grad_norm_sq, max_grad_norm, nullptr, 0.f, stream);
+}
+
+extern "C" int udm_adamw_step_shadow_ema(float* p, const float* g, float* m, float* v, int64_t R, int64_t C, float lr, float beta1, float beta2, float eps,
+                                         float weight_decay, int64_t step, const float* grad_norm_sq, float max_grad_norm, void* w16, int64_t ld16, void* w16t,
+                                         int64_t ldt, float* ema, float ema_decay, hipStream_t stream) {
   AdamArgs a;
   if (int rc = fill_args(a, "udm_adamw_step_shadow", p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_norm_sq, max_grad_norm)) return rc;
+  if (int rc = set_ema(a, "udm_adamw_step_shadow", ema, ema_decay)) return rc;
   UDM_CHECK_ARG(R > 0 && C > 0 && (w16 || w16t), "udm_adamw_step_shadow: bad shape / no shadow requested");
   UDM_CHECK_ARG((!w16 || ld16 >= C) && (!w16t || ldt >= R), "udm_adamw_step_shadow: shadow strides too small");
   UDM_CHECK_ARG(((uintptr_t)p % 16 == 0) && ((uintptr_t)g % 16 == 0) && ((uintptr_t)m % 16 == 0) && ((uintptr_t)v % 16 == 0), "udm_adamw_step_shadow: tensors must be 16-byte aligned");
@@ -199,4 +226,11 @@ extern "C" int udm_adamw_step_shadow(float* p, const float* g, float* m, float* 
   hipLaunchKernelGGL(adamw_shadow_kernel, grid, dim3(256), 0, stream, a, (int)R, (int)C, (bf16_t*)w16, (long)ld16, (bf16_t*)w16t, (long)ldt);
   UDM_CHECK_LAUNCH("udm_adamw_step_shadow");
   return 0;
+}
+
+extern "C" int udm_adamw_step_shadow(float* p, const float* g, float* m, float* v, int64_t R, int64_t C, float lr, float beta1, float beta2, float eps,
+                                     float weight_decay, int64_t step, const float* grad_norm_sq, float max_grad_norm, void* w16, int64_t ld16, void* w16t,
+                                     int64_t ldt, hipStream_t stream) {
+  return udm_adamw_step_shadow_ema(p, g, m, v, R, C, lr, beta1, beta2, eps, weight_decay, step, grad_norm_sq, max_grad_norm, w16, ld16, w16t, ldt, nullptr, 0.f,
+                                   stream);
 }

@@ -151,22 +151,27 @@ def sumsq(x, out):
     return out
 
 
-def adamw_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_norm_sq=None, max_grad_norm=None):
-    """In-place AdamW update of a flat fp32 tensor (torch.optim.AdamW arithmetic); optional device-side global-norm clipping."""
+def adamw_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_norm_sq=None, max_grad_norm=None, ema=None, ema_decay=0.0):
+    """In-place AdamW update of a flat fp32 tensor (torch.optim.AdamW arithmetic); optional device-side global-norm clipping; optional parameter
+    EMA (ema <- ema - (1 - ema_decay) (ema - p_new)) in the same pass."""
     for t, n in ((p, "p"), (g, "g"), (m, "m"), (v, "v")):
         _chk(t, F32, f"adamw_step {n}")
-    _lib.call("udm_adamw_step", _p(p), _p(g), _p(m), _p(v), p.numel(), float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), int(step),
-              _p(grad_norm_sq), float(max_grad_norm or 0.0), _s())
+    if ema is not None:
+        _chk(ema, F32, "adamw_step ema")
+    _lib.call("udm_adamw_step_ema", _p(p), _p(g), _p(m), _p(v), p.numel(), float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), int(step),
+              _p(grad_norm_sq), float(max_grad_norm or 0.0), _p(ema), float(ema_decay), _s())
 
 
-def adamw_step_shadow(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_norm_sq, max_grad_norm, w16, w16t):
-    """AdamW update of a 2-D GEMM weight [R, C] that also writes its bf16 shadow w16 [>=R, C] and transposed shadow w16t [C, >=R]."""
+def adamw_step_shadow(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_norm_sq, max_grad_norm, w16, w16t, ema=None, ema_decay=0.0):
+    """AdamW update of a 2-D GEMM weight [R, C] that also writes its bf16 shadow w16 [>=R, C] and transposed shadow w16t [C, >=R] (+ EMA)."""
     for t, n in ((p, "p"), (g, "g"), (m, "m"), (v, "v")):
         _chk(t, F32, f"adamw_step_shadow {n}")
+    if ema is not None:
+        _chk(ema, F32, "adamw_step_shadow ema")
     R, C = p.shape
-    _lib.call("udm_adamw_step_shadow", _p(p), _p(g), _p(m), _p(v), R, C, float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), int(step),
+    _lib.call("udm_adamw_step_shadow_ema", _p(p), _p(g), _p(m), _p(v), R, C, float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), int(step),
               _p(grad_norm_sq), float(max_grad_norm or 0.0), _p(w16), w16.stride(0) if w16 is not None else 0, _p(w16t),
-              w16t.stride(0) if w16t is not None else 0, _s())
+              w16t.stride(0) if w16t is not None else 0, _p(ema), float(ema_decay), _s())
 
 
 def colsum(x, out):

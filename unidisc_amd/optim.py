@@ -22,7 +22,8 @@ class FusedAdamW:
     norm of the last step as a device tensor (no host synchronisation anywhere in ``step``)."""
 
     def __init__(self, backbone: torch.nn.Module, lr: float = 3e-4, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0,
-                 max_grad_norm: Optional[float] = None, maintain_shadows: bool = True, params: Optional[Iterable[torch.nn.Parameter]] = None):
+                 max_grad_norm: Optional[float] = None, maintain_shadows: bool = True, params: Optional[Iterable[torch.nn.Parameter]] = None,
+                 ema_decay: Optional[float] = None, ema_use_num_updates: bool = True):
         self.backbone = backbone
         self.params = [p for p in (params if params is not None else backbone.parameters()) if p.requires_grad]
         for p in self.params:
@@ -35,6 +36,40 @@ class FusedAdamW:
         self.state = {id(p): (torch.zeros_like(p), torch.zeros_like(p)) for p in self.params}
         self._gsq = None
         self.grad_norm = None
+        # parameter EMA (reference models/ema.py `ExponentialMovingAverage`, stepped right after optimizer.step at model.py:1541-1545; config
+        # trainer.ema, 0 = off): the shadow starts as a copy of the parameters and is updated inside the optimizer kernels
+        self.ema_decay = float(ema_decay) if ema_decay else None
+        self.ema_num_updates = 0 if ema_use_num_updates else None
+        self.ema = {id(p): p.detach().clone() for p in self.params} if self.ema_decay else None
+        self._ema_backup = None
+
+    def _ema_decay_now(self):   # models/ema.py:46-49
+        d = self.ema_decay
+        if self.ema_num_updates is not None:
+            self.ema_num_updates += 1
+            d = min(d, (1 + self.ema_num_updates) / (10 + self.ema_num_updates))
+        return d
+
+    @torch.no_grad()
+    def ema_store_and_copy(self):
+        """`ema.store(params); ema.copy_to(params)` (model.py evaluation with EMA weights): parameters <- EMA, originals kept for `ema_restore`."""
+        if self.ema is None:
+            raise RuntimeError("FusedAdamW: no EMA (ema_decay not set)")
+        self._ema_backup = [p.detach().clone() for p in self.params]
+        for p in self.params:
+            p.copy_(self.ema[id(p)])
+        if hasattr(self.backbone, "refresh_weight_shadows"):
+            self.backbone.refresh_weight_shadows(force=True)
+
+    @torch.no_grad()
+    def ema_restore(self):
+        if self._ema_backup is None:
+            raise RuntimeError("FusedAdamW: ema_restore without ema_store_and_copy")
+        for p, b in zip(self.params, self._ema_backup):
+            p.copy_(b)
+        self._ema_backup = None
+        if hasattr(self.backbone, "refresh_weight_shadows"):
+            self.backbone.refresh_weight_shadows(force=True)
 
     # ------------------------------------------------------------------------------------------------
     def _grad_sumsq(self, grads):
@@ -77,13 +112,16 @@ class FusedAdamW:
                 self.backbone.refresh_weight_shadows(force=True)
             lins = {id(l.weight): l for l in self.backbone._lins.values()}
         b1, b2 = self.betas
+        ed = self._ema_decay_now() if self.ema is not None else 0.0
         for p in todo:
             m, v = self.state[id(p)]
             lin = lins.get(id(p))
+            e = self.ema[id(p)] if self.ema is not None else None
             if lin is not None and lin.w16 is not None:
-                K.adamw_step_shadow(p, p.grad, m, v, self.lr, b1, b2, self.eps, self.weight_decay, self.step_count, gsq, self.max_grad_norm, lin.w16, lin.w16t)
+                K.adamw_step_shadow(p, p.grad, m, v, self.lr, b1, b2, self.eps, self.weight_decay, self.step_count, gsq, self.max_grad_norm, lin.w16, lin.w16t,
+                                    ema=e, ema_decay=ed)
             else:
-                K.adamw_step(p, p.grad, m, v, self.lr, b1, b2, self.eps, self.weight_decay, self.step_count, gsq, self.max_grad_norm)
+                K.adamw_step(p, p.grad, m, v, self.lr, b1, b2, self.eps, self.weight_decay, self.step_count, gsq, self.max_grad_norm, ema=e, ema_decay=ed)
         if self.maintain_shadows:
             # the shadows are current: the next forward must not re-cast (kernel writes do not bump tensor versions, so record them)
             self.backbone.recast_every_forward = False
@@ -99,10 +137,16 @@ class FusedAdamW:
 
     def state_dict(self):
         return dict(step=self.step_count, lr=self.lr, betas=self.betas, eps=self.eps, weight_decay=self.weight_decay, max_grad_norm=self.max_grad_norm,
-                    exp_avg=[self.state[id(p)][0] for p in self.params], exp_avg_sq=[self.state[id(p)][1] for p in self.params])
+                    exp_avg=[self.state[id(p)][0] for p in self.params], exp_avg_sq=[self.state[id(p)][1] for p in self.params],
+                    ema_decay=self.ema_decay, ema_num_updates=self.ema_num_updates,
+                    ema=[self.ema[id(p)] for p in self.params] if self.ema is not None else None)
 
     def load_state_dict(self, sd):
         self.step_count, self.lr = int(sd["step"]), float(sd["lr"])
         for p, m, v in zip(self.params, sd["exp_avg"], sd["exp_avg_sq"]):
             self.state[id(p)][0].copy_(m)
             self.state[id(p)][1].copy_(v)
+        if self.ema is not None and sd.get("ema") is not None:
+            self.ema_num_updates = sd.get("ema_num_updates", self.ema_num_updates)
+            for p, e in zip(self.params, sd["ema"]):
+                self.ema[id(p)].copy_(e)
