@@ -140,6 +140,13 @@ int udm_ddpm_sample_rows_cfg(const void* logits, const void* logits_uncond, cons
                              const float* u, int64_t ldu, uint64_t seed, int64_t* out, int64_t M, int64_t V, int64_t Vt, int64_t mask_id,
                              int restrict_modality, int greedy, hipStream_t stream);
 
+/* `maskgit` predictor, per [MASK] row (`_maskgit_update` model_eval.py:3069-3074): x ~ Categorical(exp(SUBS log-probs)) - the exponential race
+ * argmax p_i / (1e-10 - log(u_i + 1e-10)), explicit uniforms or Philox(seed) - or x = given[row] (replay of a recorded draw), and out_logp[row] =
+ * log p(x).  Guidance (logits_uncond, w) as in udm_ddpm_sample_rows_cfg. */
+int udm_categorical_sample_rows(const void* logits, const void* logits_uncond, const float* w, int64_t ld, const int64_t* modality, const float* u, int64_t ldu,
+                                uint64_t seed, const int64_t* given, int64_t* out, float* out_logp, int64_t M, int64_t V, int64_t Vt, int64_t mask_id,
+                                int restrict_modality, hipStream_t stream);
+
 /* ---- token data path: joint-sequence assembly, `Diffusion.update_batch` token-dataset branch model.py:183-212 over the dataset
  * schema of models/datasets/image_datasets.py:263-281.  txt [n, Lt] int32, txt_mask [n, Lt] bool bytes (nullable: all valid), img [n, Li] int16;
  * idx [B] rows to gather (nullable: rows 0..B-1).  Writes input_ids int64 [B, Lt+Li] (image ids shifted by Vt), attention_mask bool bytes, modality

@@ -565,3 +565,72 @@ def sample_ddpm_cache(cfg: OracleConfig, P, buffers, x_init, timesteps, dt, us, 
         if x0 is not None:
             x = torch.where(x0_unmask, x0, x)
     return x, xs, x_last, nfe
+
+
+# ------------------------------------------------------------------------------------------------
+# sampler inner loop: `maskgit` predictor
+# ------------------------------------------------------------------------------------------------
+def adap_sche(x, step, mask_index, mode="arccos"):
+    """model_eval.py:2964-3001: per-sample unmasking schedule [B, step] (how many tokens each step reveals), rounded, zeros lifted to 1,
+    the last step absorbs the remainder (never negative)."""
+    num_masked = (x == mask_index).sum(dim=-1)
+    r = torch.linspace(1, 0, step)
+    val = {"root": lambda: 1 - r ** 0.5, "linear": lambda: 1 - r, "square": lambda: 1 - r ** 2, "cosine": lambda: torch.cos(r * math.pi * 0.5),
+           "arccos": lambda: torch.arccos(r) / (math.pi * 0.5)}[mode]()
+    out = []
+    for n in num_masked:
+        s = ((val / val.sum()) * n).round()
+        s[s == 0] = 1
+        s[-1] += n - s.sum()
+        s[-1] = max(s[-1], 0)
+        out.append(s.int())
+    return torch.stack(out, 0)
+
+
+def maskgit_update(cfg: OracleConfig, P, buffers, x, t, schedule, step, pred, gumbel, r_temp, modality=None, batch=None, bf16=False):
+    """model_eval.py:3046-3114 with the two random draws passed in: `pred` [B, L] = what torch.multinomial(p_x0) returned per position,
+    `gumbel` [B, L] = np.random.gumbel.  conf = log p(pred) + r_temp * gumbel * t on [MASK] positions (-inf elsewhere); every sample keeps
+    its num_unmask = min(schedule[:, step], #masked) most confident predictions (threshold = k-th largest, ties included)."""
+    if t.ndim > 1:
+        t_col = t
+        t1 = t.squeeze(-1)
+    else:
+        t_col, t1 = t[:, None], t
+    copy_flag = x != cfg.mask_index
+    num_unmask = torch.minimum(schedule[:, step].to(torch.int64), (~copy_flag).sum(-1))
+    if torch.all(num_unmask <= 0):
+        return x, 0
+    sigma_t, _ = loglinear_noise(t1)
+    p_x0, _ = ddpm_forward(cfg, P, buffers, x, sigma_t, modality, batch, bf16)
+    conf = torch.gather(p_x0, -1, pred.unsqueeze(-1)).squeeze(-1).log() + r_temp * gumbel * t_col
+    conf = torch.where(copy_flag, torch.full_like(conf, float("-inf")), conf)
+    k = int(num_unmask.max())
+    top, _ = torch.topk(conf, k=k, dim=-1)
+    thr = top.gather(-1, torch.clamp(num_unmask - 1, min=0)[:, None])
+    thr = torch.where((num_unmask <= 0)[:, None], torch.full_like(thr, float("inf")), thr)
+    return torch.where(conf >= thr, pred, x), 1
+
+
+def sample_maskgit(cfg: OracleConfig, P, buffers, x_init, timesteps, dt, preds, gumbels, r_temp, x0=None, x0_unmask=None, modality=None, batch=None,
+                   noise_removal=True, bf16=False):
+    """The `maskgit` path of model_eval.py:2274-2447: arccos schedule from the initial x, one update per step, final arg-max of the log-probs."""
+    x = x_init.clone()
+    B = x.shape[0]
+    schedule = adap_sche(x, len(timesteps) - 1, cfg.mask_index, "arccos")
+    nfe, xs = 0, []
+    for i in range(len(timesteps) - 1):
+        t = timesteps[i] * torch.ones(B, 1)
+        if preds[i] is None:
+            xs.append(x.clone())
+            continue
+        x, n = maskgit_update(cfg, P, buffers, x, t, schedule, i, preds[i], gumbels[i], r_temp, modality, batch, bf16)
+        nfe += n
+        xs.append(x.clone())
+    x_last = x
+    if noise_removal:
+        t = timesteps[-1] * torch.ones(B)
+        logits = dit_forward(cfg, P, buffers, x, loglinear_noise(t)[0], modality, None, bf16)
+        x = subs_parameterization(cfg, logits, x, modality, batch, bf16).float().argmax(dim=-1)
+    if x0 is not None:
+        x = torch.where(x0_unmask, x0, x)
+    return x, xs, x_last, nfe, schedule

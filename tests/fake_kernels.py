@@ -393,6 +393,23 @@ def ddpm_sample_rows(logits, V, Vt, mask_id, *, t=None, s=None, modality=None, r
     return (q / (1e-10 - (u[:, :V] + 1e-10).log())).argmax(-1)
 
 
+def categorical_sample_rows(logits, V, Vt, mask_id, *, modality=None, restrict=False, u=None, seed=0, given=None, logits_u=None, w=None):
+    M = logits.shape[0]
+    valid = _valid(M, V, Vt, mask_id, modality, restrict)
+    z = logits[:, :V].float()
+    if logits_u is not None:
+        z = (1 + w[:, None]) * z - w[:, None] * logits_u[:, :V].float()
+    z = z.masked_fill(~valid, float("-inf"))
+    logp = z - torch.logsumexp(z, -1, keepdim=True)
+    if given is not None:
+        tok = given
+    else:
+        if u is None:
+            u = torch.rand(M, V, generator=torch.Generator().manual_seed(int(seed) & 0x7FFFFFFF))
+        tok = (logp.exp() / (1e-10 - (u[:, :V] + 1e-10).log())).argmax(-1)
+    return tok, logp.gather(-1, tok[:, None]).squeeze(-1)
+
+
 # ------------------------------------------------------------------------------------------------ token data path (csrc/tokens.hip)
 def assemble_joint_tokens(txt, txt_mask, img, Vt, idx=None):
     if idx is not None:

@@ -223,3 +223,111 @@ def test_guided_sampler_loop_on_gpu():
     x = x.cpu()
     assert (x == s["x_final"]).float().mean().item() >= 0.9 and nfe == int(s["nfe"]) + 1 and not (x == diff.mask_index).any()
     assert torch.equal(x[s["x0_unmask"].bool()], s["x0"][s["x0_unmask"].bool()])
+
+
+# ------------------------------------------------------------------------------------------------ `maskgit` predictor
+def _maskgit_golden(name):
+    z = np.load(os.path.join(GOLDEN_DIR, f"maskgit_{name}.npz"))
+    return {k: torch.from_numpy(np.asarray(z[k])) for k in z.files}
+
+
+def _maskgit_run(diff, s, device):
+    steps = int(s["steps"])
+    from unidisc_amd.config import Cfg
+    diff.config.eval = Cfg(maskgit_r_temp=float(s["r_temp"]))
+    replay = [(s[f"step{i}/pred"].to(device), s[f"step{i}/gumbel"].float().to(device)) if f"step{i}/pred" in s else (None, None) for i in range(steps)]
+    modality = s["modality"].to(device) if "modality" in s else None
+    x0, x0_unmask = (s["x0"].to(device), s["x0_unmask"].bool().to(device)) if "x0" in s else (None, None)
+    B = s["x_init"].shape[0]
+    return diff.sample(num_steps=steps, eps=float(s["eps"]), x0=x0, x0_unmask=x0_unmask, batch_size=B, modality=modality, predictor="maskgit", replay=replay,
+                       return_nfe=True)
+
+
+@pytest.mark.parametrize("name", ["c_large", "b_small"])
+def test_maskgit_host_logic_replays_reference_run(name, monkeypatch):
+    """CPU: the maskgit loop with kernel doubles, fed the reference's multinomial draws and Gumbel noise, reveals the reference's tokens."""
+    from unidisc_amd import dit as dit_mod, diffusion as diff_mod
+
+    monkeypatch.setattr(dit_mod, "K", fake_kernels)
+    monkeypatch.setattr(diff_mod, "K", fake_kernels)
+    g, s = Golden(name), _maskgit_golden(name)
+    diff = build_product(g, device="cpu")
+    diff.backbone.eval()
+    assert torch.equal(diff.adap_sche(s["x_init"], int(s["steps"]), diff.mask_index), s["schedule"].to(torch.int32))
+    x, nfe = _maskgit_run(diff, s, "cpu")
+    assert (x == s["x_final"]).float().mean().item() >= 0.9     # bf16 backbone vs fp32 reference: a near-tie in the top-k may flip
+    assert nfe == int(s["nfe"]) + 1 and not (x == diff.mask_index).any()
+    if "x0" in s:
+        assert torch.equal(x[s["x0_unmask"].bool()], s["x0"][s["x0_unmask"].bool()])
+    with pytest.raises(NotImplementedError):
+        diff.sample(num_steps=2, batch_size=2, predictor="first_hitting")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["c_large", "b_small"])
+def test_categorical_rows_kernel_logp_matches_oracle(name):
+    """udm_categorical_sample_rows with replayed tokens: log p(token) equals the oracle's SUBS log-prob of the same bf16 logits (fp32 rounding)."""
+    from unidisc_amd import kernels as K
+
+    g, s = Golden(name), _maskgit_golden(name)
+    cfg = g.cfg
+    batch = O.update_batch(cfg, g.batch())
+    modality = s["modality"] if "modality" in s else None
+    V, Vt, mask = cfg.vocab_size, cfg.text_vocab_size, cfg.mask_index
+    for i in range(int(s["steps"])):
+        if f"step{i}/pred" not in s:
+            continue
+        x, pred = s[f"step{i}/x"], s[f"step{i}/pred"]
+        B, L = x.shape
+        lb = s[f"step{i}/logits"].bfloat16()
+        lp = O.subs_parameterization(cfg, lb.float(), x, modality, batch, bf16=False).float()
+        rows = (x.reshape(-1) == mask).nonzero().reshape(-1)
+        Vp = (V + 7) // 8 * 8
+        lg = torch.zeros((rows.numel(), Vp), dtype=torch.bfloat16)
+        lg[:, :V] = lb.reshape(B * L, V)[rows]
+        rm = None
+        if cfg.force_argmax_valid_indices:
+            mod = modality if modality is not None else torch.cat([torch.zeros(B, cfg.txt_length), torch.ones(B, L - cfg.txt_length)], 1).long()
+            rm = mod.reshape(-1)[rows].long().to(DEV)
+        given = pred.reshape(-1)[rows].contiguous()
+        tok, logp = K.categorical_sample_rows(lg.to(DEV), V, Vt, mask, modality=rm, restrict=cfg.force_argmax_valid_indices, given=given.to(DEV))
+        assert torch.equal(tok.cpu(), given)
+        want = lp.reshape(B * L, V)[rows].gather(-1, given[:, None]).squeeze(-1)
+        assert torch.allclose(logp.cpu(), want, atol=2e-5, rtol=1e-5), f"step {i}"
+
+
+@pytest.mark.gpu
+def test_categorical_rows_kernel_draws_follow_p():
+    from unidisc_amd import kernels as K
+
+    V, Vt, mask = 24, 24, 23
+    z = torch.tensor([2.0, 1.0, 0.0, -1.0, 0.5] + [-3.0] * (V - 5))
+    R = 40000
+    lg = z.bfloat16()[None].repeat(R, 1).contiguous().to(DEV)
+    tok, logp = K.categorical_sample_rows(lg, V, Vt, mask, seed=11)
+    zz = z.bfloat16().float().clone()
+    zz[mask] = float("-inf")
+    want = torch.softmax(zz, -1)
+    freq = torch.bincount(tok.cpu(), minlength=V).float() / R
+    assert torch.allclose(freq, want, atol=0.01) and freq[mask] == 0
+    assert torch.allclose(logp.cpu(), torch.log_softmax(zz, -1)[tok.cpu()], atol=1e-5)
+    tok2, _ = K.categorical_sample_rows(lg, V, Vt, mask, seed=12)
+    assert not torch.equal(tok, tok2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["c_large", "b_small"])
+def test_maskgit_loop_on_gpu(name):
+    g, s = Golden(name), _maskgit_golden(name)
+    diff = build_product(g, device=DEV)
+    diff.backbone.eval()
+    x, nfe = _maskgit_run(diff, s, DEV)
+    x = x.cpu()
+    assert (x == s["x_final"]).float().mean().item() >= 0.9 and nfe == int(s["nfe"]) + 1 and not (x == diff.mask_index).any()
+    # free-running (Philox draws + device Gumbel noise): complete, reproducible for a seed
+    modality = s["modality"].to(DEV) if "modality" in s else None
+    B = s["x_init"].shape[0]
+    a = diff.sample(num_steps=int(s["steps"]), batch_size=B, modality=modality, predictor="maskgit", seed=3)
+    b = diff.sample(num_steps=int(s["steps"]), batch_size=B, modality=modality, predictor="maskgit", seed=3)
+    c = diff.sample(num_steps=int(s["steps"]), batch_size=B, modality=modality, predictor="maskgit", seed=4)
+    assert torch.equal(a, b) and not torch.equal(a, c) and not (a == diff.mask_index).any()

@@ -82,3 +82,40 @@ def test_cfg_weight_windows():
     w = O.cfg_weight(3.0, t, cfg_min_timestep=0.2, cfg_max_timestep=0.8)
     assert w.shape == (3, 3) or w.shape == (3, 1) or w.ndim >= 1   # (the reference broadcasts [B,1] against [B]: kept as is)
     assert float(O.cfg_weight(1.5, t, force_cfg_value=True)) == 1.5
+
+
+@pytest.mark.parametrize("name", ["c_large", "b_small"])
+def test_oracle_maskgit_matches_reference_tokens(name):
+    """`maskgit` predictor (model_eval.py:3046-3114, schedule :2964-3001): with the reference's multinomial draws and Gumbel noise replayed,
+    the restated update reveals exactly the same tokens at every step."""
+    g = Golden(name)
+    z = np.load(os.path.join(GOLDEN_DIR, f"maskgit_{name}.npz"))
+    s = {k: torch.from_numpy(np.asarray(z[k])) for k in z.files}
+    cfg, P, buffers, batch = oracle_setup(g)
+    steps = int(s["steps"])
+    preds = [s.get(f"step{i}/pred") for i in range(steps)]
+    gums = [s[f"step{i}/gumbel"].float() if f"step{i}/gumbel" in s else None for i in range(steps)]
+    modality = s["modality"] if "modality" in s else None
+    x0, x0_unmask = (s["x0"], s["x0_unmask"].bool()) if "x0" in s else (None, None)
+    x_final, xs, x_last, nfe, schedule = O.sample_maskgit(cfg, P, buffers, s["x_init"], s["timesteps"], float(s["dt"]), preds, gums, float(s["r_temp"]),
+                                                          x0=x0, x0_unmask=x0_unmask, modality=modality, batch=batch)
+    assert torch.equal(schedule, s["schedule"].to(schedule.dtype))
+    for i in range(steps):
+        assert torch.equal(xs[i], s[f"step{i}/x_next"]), f"step {i}"
+    assert torch.equal(x_final, s["x_final"]) and nfe == int(s["nfe"])
+    # the number of tokens revealed per step follows the schedule
+    m = cfg.mask_index
+    prev = s["x_init"]
+    for i in range(steps):
+        revealed = ((prev == m) & (xs[i] != m)).sum(-1)
+        assert torch.equal(revealed, torch.minimum(schedule[:, i].long(), (prev == m).sum(-1)))
+        prev = xs[i]
+
+
+def test_adap_sche_modes_and_edges():
+    x = torch.tensor([[9, 9, 9, 9, 9, 9, 9, 9, 9, 9], [1, 9, 2, 9, 3, 9, 4, 5, 6, 7], [1, 2, 3, 4, 5, 6, 7, 8, 1, 2]])
+    for mode in ("arccos", "linear", "cosine", "root", "square"):
+        s = O.adap_sche(x, 4, 9, mode)
+        assert s.shape == (3, 4) and (s >= 0).all()
+    s = O.adap_sche(x, 4, 9, "arccos")
+    assert int(s[0].sum()) == 10 and int(s[2, -1]) == 0      # nothing masked: the lifted ones are paid back by the last step (clamped at 0)

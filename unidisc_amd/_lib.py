@@ -39,6 +39,7 @@ PROTOTYPES = {
     "udm_attention_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _P],
     "udm_attention_set_tr_read": [_I],
     "udm_assemble_joint_tokens": [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _P, _P, _P, _P],
+    "udm_categorical_sample_rows": [_P, _P, _P, _I64, _P, _P, _I64, _U64, _P, _P, _P, _I64, _I64, _I64, _I64, _I, _P],
     "udm_ddpm_sample_rows_cfg": [_P, _P, _P, _I64, _P, _P, _P, _P, _I64, _U64, _P, _I64, _I64, _I64, _I64, _I, _I, _P],
     "udm_ddpm_sample_rows": [_P, _I64, _P, _P, _P, _P, _I64, _U64, _P, _I64, _I64, _I64, _I64, _I, _I, _P],
     "udm_sumsq_f32": [_P, _I64, _P, _P, _I64, _P],

@@ -218,6 +218,11 @@ struct SampleArgs {
   uint64_t seed;
   int64_t* out;
   int V, Vt, mask_id, restrict_modality, greedy;
+  // categorical mode (`_maskgit_update` model_eval.py:3069-3071): draw x ~ p (mask id has probability 0) - i.e. t - s = 1, s = 0 - or take the
+  // token from `given` (replay), and report log p(x) in out_logp
+  int categorical;
+  const int64_t* given;
+  float* out_logp;
 };
 
 __global__ __launch_bounds__(256) void ddpm_sample_rows_kernel(SampleArgs a) {
@@ -248,9 +253,17 @@ __global__ __launch_bounds__(256) void ddpm_sample_rows_kernel(SampleArgs a) {
   }
   block_reduce_ms(m, s, sm, ss);
   const float lse = m + __logf(s);
-  const float dt = a.greedy ? 0.f : a.t[row] - a.s[row], sr = a.greedy ? 0.f : a.s[row];
+  const float dt = a.categorical ? 1.f : (a.greedy ? 0.f : a.t[row] - a.s[row]), sr = (a.greedy || a.categorical) ? 0.f : a.s[row];
   float best = -INFINITY;
   int besti = 0x7fffffff;
+  if (a.given) {   // replayed draw: only its log-probability is wanted
+    if (tid == 0) {
+      const int c = (int)a.given[row];
+      a.out[row] = c;
+      if (a.out_logp) a.out_logp[row] = (c >= lo && c < hi && c != a.mask_id) ? Z(c) - lse : -INFINITY;
+    }
+    return;
+  }
   for (int c = tid; c < a.V; c += 256) {
     const bool ok = c >= lo && c < hi && c != a.mask_id;
     float score;
@@ -284,6 +297,7 @@ __global__ __launch_bounds__(256) void ddpm_sample_rows_kernel(SampleArgs a) {
     for (int w = 1; w < 4; ++w)
       if (bs[w] > best || (bs[w] == best && bi[w] < besti)) { best = bs[w]; besti = bi[w]; }
     a.out[row] = besti;
+    if (a.out_logp) a.out_logp[row] = Z(besti) - lse;
   }
 }
 
@@ -311,9 +325,25 @@ extern "C" int udm_ddpm_sample_rows_cfg(const void* logits, const void* logits_u
   UDM_CHECK_ARG((logits_uncond == nullptr) == (w == nullptr), "udm_ddpm_sample_rows_cfg: guidance needs both the unconditional logits and the per-row weights");
   if (M == 0) return 0;
   SampleArgs a{(const bf16_t*)logits, (long)ld, (const bf16_t*)logits_uncond, w, modality, t, s, u, (long)ldu, seed, out, (int)V, (int)Vt, (int)mask_id,
-               restrict_modality, greedy};
+               restrict_modality, greedy, 0, nullptr, nullptr};
   hipLaunchKernelGGL(ddpm_sample_rows_kernel, dim3((unsigned)M), dim3(256), 0, stream, a);
   UDM_CHECK_LAUNCH("udm_ddpm_sample_rows");
+  return 0;
+}
+
+extern "C" int udm_categorical_sample_rows(const void* logits, const void* logits_uncond, const float* w, int64_t ld, const int64_t* modality, const float* u,
+                                           int64_t ldu, uint64_t seed, const int64_t* given, int64_t* out, float* out_logp, int64_t M, int64_t V, int64_t Vt,
+                                           int64_t mask_id, int restrict_modality, hipStream_t stream) {
+  if (int rc = check("udm_categorical_sample_rows", logits, M, V, ld, Vt, mask_id)) return rc;
+  UDM_CHECK_ARG(out && out_logp, "udm_categorical_sample_rows: null output");
+  UDM_CHECK_ARG(!u || ldu >= V, "udm_categorical_sample_rows: noise row stride too small");
+  UDM_CHECK_ARG(!restrict_modality || modality, "udm_categorical_sample_rows: restrict_modality needs the per-row modality");
+  UDM_CHECK_ARG((logits_uncond == nullptr) == (w == nullptr), "udm_categorical_sample_rows: guidance needs both the unconditional logits and the per-row weights");
+  if (M == 0) return 0;
+  SampleArgs a{(const bf16_t*)logits, (long)ld, (const bf16_t*)logits_uncond, w, modality, nullptr, nullptr, u, (long)ldu, seed, out, (int)V, (int)Vt, (int)mask_id,
+               restrict_modality, 0, 1, given, out_logp};
+  hipLaunchKernelGGL(ddpm_sample_rows_kernel, dim3((unsigned)M), dim3(256), 0, stream, a);
+  UDM_CHECK_LAUNCH("udm_categorical_sample_rows");
   return 0;
 }
 

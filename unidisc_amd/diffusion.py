@@ -13,6 +13,8 @@ given generator state.  All O(B·L·d) and O(B·L·V) work goes through ``unidis
 """
 from __future__ import annotations
 
+import math
+
 from dataclasses import dataclass
 from typing import Optional
 
@@ -401,9 +403,77 @@ class Diffusion:
             x_next.view(-1).index_copy_(0, rows_n, tok)
         return p_x0, x_next, nfe
 
+    # ---- `maskgit` predictor (model_eval.py:2964-3001 schedule, :3046-3114 update)
+    @staticmethod
+    def adap_sche(x, step, mask_index, mode="arccos"):
+        """Per-sample unmasking schedule [B, step]: how many tokens each step reveals (model_eval.py:2964-3001)."""
+        num_masked = (x == mask_index).sum(dim=-1)
+        r = torch.linspace(1, 0, step)
+        if mode == "root":
+            val = 1 - r ** 0.5
+        elif mode == "linear":
+            val = 1 - r
+        elif mode == "square":
+            val = 1 - r ** 2
+        elif mode == "cosine":
+            val = torch.cos(r * math.pi * 0.5)
+        elif mode == "arccos":
+            val = torch.arccos(r) / (math.pi * 0.5)
+        else:
+            return None
+        val = val.to(x.device)
+        out = []
+        for n in num_masked:
+            sche = ((val / val.sum()) * n).round()
+            sche[sche == 0] = 1
+            sche[-1] += n - sche.sum()
+            sche[-1] = max(sche[-1], 0)
+            out.append(sche.int())
+        return torch.stack(out, dim=0)
+
+    @torch.no_grad()
+    def _maskgit_update(self, x, t, dt, schedule=None, step=None, x0=None, x0_unmask=None, modality=None, sample_ids=None, pred=None, gumbel=None, seed=None,
+                        **kwargs):
+        """One `maskgit` step on the [MASK] rows only: token ~ p (or the replayed `pred`) and its log-probability from the fused row kernel
+        (`udm_categorical_sample_rows`), confidence = log p + r_temp * gumbel * t, each sample keeps its num_unmask most confident predictions
+        (threshold = k-th largest, as the reference).  `gumbel` [B, L]: explicit noise (replay); otherwise drawn on the device."""
+        B, L = x.shape
+        t_col = t if t.ndim > 1 else t[:, None]
+        copy_flag = x != self.mask_index
+        num_unmask = torch.minimum(schedule[:, step].to(torch.int64).to(x.device), (~copy_flag).sum(dim=-1))
+        if bool(torch.all(num_unmask <= 0)):
+            return x, 0
+        r_temp = float(cfg_get(cfg_get(self.config, "eval", None), "maskgit_r_temp", 10))
+        sigma_t, _ = self.noise(t_col.squeeze(-1))
+        sig = self._process_sigma(sigma_t)
+        cache = self._guided_masked_logits(x, t_col.squeeze(-1), sig, x0_unmask, modality, sample_ids)
+        if cache is None:
+            cache = self.backbone.forward_masked_logits(x, sig, modality=modality, sample_ids=sample_ids)
+        logits, rows, n = cache[:3]
+        logits_u, w_rows = (cache[3], cache[4]) if len(cache) == 5 else (None, None)
+        rows_n = rows[:n]
+        given = pred.reshape(-1).index_select(0, rows_n).contiguous() if pred is not None else None
+        tok, logp = K.categorical_sample_rows(logits[:n], self.vocab_size, self.text_vocab_size, self.mask_index,
+                                              modality=self._row_modality(rows_n, B, L, modality), restrict=self._restrict(), given=given,
+                                              seed=int(seed if seed is not None else torch.initial_seed()), logits_u=logits_u, w=w_rows)
+        if gumbel is None:
+            g = torch.Generator(device=x.device).manual_seed(int(seed if seed is not None else torch.initial_seed()) + 1)
+            u = torch.rand(B, L, device=x.device, generator=g).clamp_(1e-20, 1.0)
+            gumbel = -torch.log(-torch.log(u))
+        conf = torch.full((B * L,), float("-inf"), dtype=torch.float32, device=x.device)
+        conf.index_copy_(0, rows_n, logp)
+        conf = conf.view(B, L) + torch.where(copy_flag, torch.zeros((), device=x.device), r_temp * gumbel.to(torch.float32) * t_col.to(torch.float32))
+        conf = torch.where(copy_flag, torch.full_like(conf, float("-inf")), conf)
+        top, _ = torch.topk(conf, k=int(num_unmask.max()), dim=-1)
+        thr = top.gather(-1, torch.clamp(num_unmask - 1, min=0)[:, None])
+        thr = torch.where((num_unmask <= 0)[:, None], torch.full_like(thr, float("inf")), thr)
+        pred_full = x.clone()
+        pred_full.view(-1).index_copy_(0, rows_n, tok)
+        return torch.where(conf >= thr, pred_full, x), 1
+
     @torch.no_grad()
     def sample(self, num_steps=None, eps=1e-5, x0=None, x0_unmask=None, batch_size=None, modality=None, sample_ids=None, seed=None, noise=None,
-               noise_removal=True, return_nfe=False):
+               noise_removal=True, return_nfe=False, predictor=None, replay=None):
         """Token sampler: the `ddpm_cache` path of `_sample` (model_eval.py:2109-2455) without the decode / logging stack: prior = all [MASK]
         (x0 / x0_unmask conditioning kept fixed), timesteps = linspace(1, eps, steps + 1), one fused update per step with the logits
         cache reused while nothing changes, final arg-max of the log-probs (`noise_removal`).  Returns token ids [B, L]
@@ -425,8 +495,19 @@ class Diffusion:
         dt = (1 - eps) / num_steps
         base_seed = int(seed if seed is not None else torch.initial_seed())
         cache, nfe = None, 0
+        if predictor is None:
+            predictor = cfg_get(sampling, "predictor", "ddpm_cache") if sampling is not None else "ddpm_cache"
+        if predictor not in ("ddpm_cache", "maskgit"):
+            raise NotImplementedError(f"unidisc_amd.Diffusion.sample: predictor {predictor!r} is not built (ddpm_cache, maskgit)")
+        schedule = self.adap_sche(x, num_steps, self.mask_index, "arccos") if predictor == "maskgit" else None
         for i in range(num_steps):
             t = timesteps[i] * torch.ones(B, 1, device=self.device)
+            if predictor == "maskgit":   # replay: list of (pred [B, L] or None, gumbel [B, L] or None) per step
+                pr, gm = replay[i] if replay is not None else (None, None)
+                x, n = self._maskgit_update(x, t, dt, schedule=schedule, step=i, x0=x0, x0_unmask=x0_unmask, modality=modality, sample_ids=sample_ids,
+                                            pred=pr, gumbel=gm, seed=base_seed + 7919 * i)
+                nfe += n
+                continue
             cache, x_next, n = self._ddpm_caching_update(x, t, dt, p_x0=cache, x0=x0, x0_unmask=x0_unmask, modality=modality, sample_ids=sample_ids,
                                                          u=noise[i] if noise is not None else None, seed=base_seed + 7919 * i)
             nfe += n

@@ -143,6 +143,24 @@ def assemble_joint_tokens(txt, txt_mask, img, Vt, idx=None):
     return ids, mask, modality
 
 
+def categorical_sample_rows(logits, V, Vt, mask_id, *, modality=None, restrict=False, u=None, seed=0, given=None, logits_u=None, w=None):
+    """(token, log p(token)) per row of `logits` [rows, ld] bf16 under the SUBS distribution: the `maskgit` predictor's multinomial draw + confidence.
+    `given` int64 [rows]: take these tokens instead of drawing (replay)."""
+    _chk(logits, BF16, "categorical_sample_rows logits")
+    M = logits.shape[0]
+    if (logits_u is None) != (w is None):
+        raise ValueError("categorical_sample_rows: guidance needs both logits_u and w")
+    if logits_u is not None and (logits_u.shape != logits.shape or logits_u.stride(0) != logits.stride(0) or w.numel() != M):
+        raise ValueError("categorical_sample_rows: logits_u must match logits and w must have one weight per row")
+    if given is not None and (given.dtype != torch.int64 or given.numel() != M):
+        raise TypeError("categorical_sample_rows: given must be int64 [rows]")
+    tok = torch.empty(M, dtype=torch.int64, device=logits.device)
+    logp = torch.empty(M, dtype=torch.float32, device=logits.device)
+    _lib.call("udm_categorical_sample_rows", _p(logits), _p(logits_u), _p(w), logits.stride(0), _p(modality), _p(u), u.stride(0) if u is not None else 0,
+              int(seed), _p(given), _p(tok), _p(logp), M, V, Vt, mask_id, 1 if restrict else 0, _s())
+    return tok, logp
+
+
 def sumsq(x, out):
     """out[0] = sum(x**2) (fp32, 1-D contiguous x); two-phase reduction through the scratch buffer."""
     _chk(x, F32, "sumsq x"), _chk(out, F32, "sumsq out")
