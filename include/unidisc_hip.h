@@ -33,8 +33,8 @@ typedef struct ihipStream_t* hipStream_t;
 /* GEMM epilogues */
 #define UDM_EPI_NONE 0      /* C = A·Bᵀ                                                   */
 #define UDM_EPI_BIAS 1      /* C = A·Bᵀ + bias[n]                                          */
-#define UDM_EPI_BIAS_GELU 2 /* aux = bf16(A·Bᵀ + bias); C = gelu_tanh(aux)   (mlp.0 + GELU) */
-#define UDM_EPI_DGELU 3     /* C = (A·Bᵀ) ⊙ gelu_tanh'(aux)                  (GELU backward); a non-NULL `bias` is then an fp32 [N]
+#define UDM_EPI_BIAS_GELU 2 /* u = bf16(A·Bᵀ + bias); C = gelu_tanh(u); aux = bf16(gelu_tanh'(u))   (mlp.0 + GELU: the derivative is saved, not u) */
+#define UDM_EPI_DGELU 3     /* C = (A·Bᵀ) ⊙ aux                              (GELU backward); a non-NULL `bias` is then an fp32 [N]
                                OUTPUT accumulating the column sums of C (the bias gradient of the upstream Linear)         */
 
 const char* udm_last_error(void);

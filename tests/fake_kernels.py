@@ -31,14 +31,14 @@ def gemm_nt(a, b, out=None, *, out_dtype=BF16, M=None, N=None, K=None, lda=None,
     acc = a[:M, :K].float() @ b[:N, :K].float().t()
     if epilogue in (EPI_BIAS, EPI_BIAS_GELU):
         acc = acc + bias[:N].float()
-    if epilogue == EPI_BIAS_GELU:
-        pre = acc.bfloat16()
-        aux[:M, :N] = pre
-        acc = F.gelu(pre.float(), approximate="tanh")
+    if epilogue == EPI_BIAS_GELU:   # aux receives bf16(gelu'(u)), u = bf16(pre-activation)
+        u = acc.bfloat16().float().requires_grad_()
+        y = F.gelu(u, approximate="tanh")
+        (gr,) = torch.autograd.grad(y.sum(), u)
+        aux[:M, :N] = gr.bfloat16()
+        acc = y.detach()
     if epilogue == EPI_DGELU:
-        u = aux[:M, :N].float().requires_grad_()
-        (gr,) = torch.autograd.grad(F.gelu(u, approximate="tanh").sum(), u)
-        acc = acc * gr
+        acc = acc * aux[:M, :N].float()
         if bias is not None:  # EPI_DGELU: `bias` is the bias-gradient OUTPUT (column sums of the result)
             bias[:N] += acc.detach().bfloat16().float().sum(0)
     if out is None:

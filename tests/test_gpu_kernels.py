@@ -62,14 +62,15 @@ def test_gemm_large_tile_kernels(K, tile, M, N, K_):
         aux = torch.zeros((M, ldc), dtype=torch.bfloat16, device=DEV)
         g = torch.zeros((M, ldc), dtype=torch.bfloat16, device=DEV)
         K.gemm_nt(ga, gb, out=g, N=N, epilogue=K.EPI_BIAS_GELU, bias=gbias, aux=aux)
-        assert rel_err(aux.float().cpu()[:, :N], (acc + bias).bfloat16().float()) < 4e-3
-        assert rel_err(g.float().cpu()[:, :N], torch.nn.functional.gelu(aux.float().cpu()[:, :N], approximate="tanh")) < 4e-3
-        u = aux.float().cpu()[:, :N].requires_grad_()
-        (gp,) = torch.autograd.grad(torch.nn.functional.gelu(u, approximate="tanh").sum(), u)
+        u = (acc + bias).bfloat16().float().requires_grad_()
+        y = torch.nn.functional.gelu(u, approximate="tanh")
+        (gp,) = torch.autograd.grad(y.sum(), u)
+        assert rel_err(g.float().cpu()[:, :N], y.detach()) < 6e-3
+        assert rel_err(aux.float().cpu()[:, :N], gp) < 6e-3     # aux = bf16(gelu'(u))
         dg = torch.zeros((M, ldc), dtype=torch.bfloat16, device=DEV)
         dbias = torch.zeros(N, dtype=torch.float32, device=DEV)
         K.gemm_nt(ga, gb, out=dg, N=N, epilogue=K.EPI_DGELU, aux=aux, bias=dbias)
-        assert rel_err(dg.float().cpu()[:, :N], acc * gp) < 5e-3
+        assert rel_err(dg.float().cpu()[:, :N], acc * gp) < 8e-3
         assert torch.allclose(dbias.cpu(), dg.float().cpu()[:, :N].sum(0), atol=2e-2, rtol=2e-3)  # fused bias gradient = column sums
         c0 = rnd(M, N, seed=83)
         c = c0.clone().to(DEV)
@@ -119,14 +120,15 @@ def test_gemm_gelu_epilogues_extreme_preactivations(K, M, N):
     bias = vals.repeat(N // vals.numel() + 1)[:N].clone()
     aux = torch.empty((M, N), dtype=torch.bfloat16, device=DEV)
     g = K.gemm_nt(a.to(DEV), b.to(DEV), epilogue=K.EPI_BIAS_GELU, bias=(bias - 1.0).to(DEV), aux=aux).float().cpu()
-    pre = aux.float().cpu()
-    assert torch.equal(pre[0], bias.bfloat16().float())
+    pre = bias.bfloat16().float()[None].expand(M, N)            # accumulator 1.0 + (bias - 1.0), rounded to bf16 like the reference's mlp.0 output
     ref = torch.nn.functional.gelu(pre.double(), approximate="tanh").float()
     assert torch.isfinite(g).all() and torch.allclose(g, ref, atol=2e-3, rtol=8e-3)
-    u = pre.double().requires_grad_()
+    u = pre.double().clone().requires_grad_()
     (gp,) = torch.autograd.grad(torch.nn.functional.gelu(u, approximate="tanh").sum(), u)
+    saved = aux.float().cpu()                                     # aux holds bf16(gelu'(u))
+    assert torch.isfinite(saved).all() and torch.allclose(saved, gp.float(), atol=2e-3, rtol=8e-3)
     dg = K.gemm_nt(a.to(DEV), b.to(DEV), epilogue=K.EPI_DGELU, aux=aux).float().cpu()
-    assert torch.isfinite(dg).all() and torch.allclose(dg, gp.float(), atol=2e-3, rtol=8e-3)
+    assert torch.isfinite(dg).all() and torch.allclose(dg, gp.float(), atol=2e-3, rtol=1.2e-2)
 
 
 def test_gemm_identity_asymmetric(K):
@@ -147,12 +149,13 @@ def test_gemm_epilogues(K):
     aux = torch.empty((M, N), dtype=torch.bfloat16, device=DEV)
     g = K.gemm_nt(a.to(DEV), b.to(DEV), epilogue=K.EPI_BIAS_GELU, bias=bias.to(DEV), aux=aux).float().cpu()
     pre = (acc + bias).bfloat16()
-    assert rel_err(aux.float().cpu(), pre.float()) < 4e-3
-    assert rel_err(g, torch.nn.functional.gelu(aux.float().cpu(), approximate="tanh")) < 4e-3
-    u = aux.float().cpu().requires_grad_()
-    (gp,) = torch.autograd.grad(torch.nn.functional.gelu(u, approximate="tanh").sum(), u)
+    u = pre.float().requires_grad_()
+    y = torch.nn.functional.gelu(u, approximate="tanh")
+    (gp,) = torch.autograd.grad(y.sum(), u)
+    assert rel_err(g, y.detach()) < 6e-3
+    assert rel_err(aux.float().cpu(), gp) < 6e-3                  # the saved GELU derivative (bf16)
     dg = K.gemm_nt(a.to(DEV), b.to(DEV), epilogue=K.EPI_DGELU, aux=aux).float().cpu()
-    assert rel_err(dg, acc * gp) < 5e-3
+    assert rel_err(dg, acc * gp) < 8e-3
     c0 = rnd(M, N, seed=6)
     c = c0.clone().to(DEV)
     K.gemm_nt(a.to(DEV), b.to(DEV), out=c, beta=1.0)

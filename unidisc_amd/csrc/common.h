@@ -60,6 +60,18 @@ __device__ __forceinline__ float gelu_tanh_grad(float x) {
   return s + (2.0f * x * du) * (e * s) * s;                  // 1 - sigma = e sigma
 }
 
+// gelu(x) and gelu'(x) from ONE exp2 and ONE rcp (the forward epilogue of mlp.0 stores the derivative for the backward epilogue, which then
+// is a single multiply): with s = sigma(2u), e = exp(-2u):  gelu = x s,  gelu' = s + (x s)(e s)(2 u'),  2u' = 2 k0 + 6 k0 k1 x^2.
+__device__ __forceinline__ void gelu_tanh_both(float x, float& g, float& dg) {
+  const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+  const float c0 = -2.0f * 1.4426950408889634f * k0, c1 = c0 * k1;
+  const float x2 = x * x;
+  const float e = __builtin_amdgcn_exp2f(fminf(x * (c0 + c1 * x2), 80.0f));
+  const float s = __builtin_amdgcn_rcpf(1.0f + e);
+  g = x * s;
+  dg = s + (g * (e * s)) * (2.0f * k0 + 6.0f * k0 * k1 * x2);
+}
+
 // Philox4x32-10 counter RNG for dropout masks: (seed, 64-bit element-group counter) -> 4 uniform uint32.
 __device__ __forceinline__ uint4 philox4x32(uint64_t seed, uint64_t ctr) {
   uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);

@@ -163,12 +163,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(GemmArgs p) {
         if (e < nvalid) x[e] += p.bias[gn + e];
     }
     if (EPI == UDM_EPI_BIAS_GELU) {
-      // pre-activation is materialised in bf16 (as the reference's mlp.0 output is), GELU evaluated on it
+      // the pre-activation is rounded to bf16 (as the reference's mlp.0 output is) and GELU evaluated on it; aux receives bf16(gelu'(pre))
       bf16_t pre[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        pre[e] = f2bf(x[e]);
-        x[e] = gelu_tanh(bf2f(pre[e]));
+        float dg;
+        gelu_tanh_both(bf2f(f2bf(x[e])), x[e], dg);
+        pre[e] = f2bf(dg);
       }
       bf16_t* ap = p.aux + (long)gm * p.ldaux + gn;
       if (nvalid == 4 && (p.ldaux % 4 == 0)) {
@@ -182,7 +183,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(GemmArgs p) {
 #pragma unroll
       for (int e = 0; e < 4; ++e)
         if (e < nvalid) {
-          x[e] *= gelu_tanh_grad(bf2f(ap[e]));
+          x[e] *= bf2f(ap[e]);
           if (p.bias) atomicAdd(const_cast<float*>(p.bias) + gn + e, OUT_F32 ? x[e] : bf2f(f2bf(x[e])));  // bias-gradient output (see header)
         }
     }
@@ -556,12 +557,12 @@ __global__ __launch_bounds__(512) void gemm_nt_stagger_kernel(GemmArgs p) {
           if (EPI == UDM_EPI_BIAS_GELU) {
             bf16_t pre[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { pre[e] = f2bf(x[e]); x[e] = gelu_tanh(bf2f(pre[e])); }
+            for (int e = 0; e < 4; ++e) { float dg; gelu_tanh_both(bf2f(f2bf(x[e])), x[e], dg); pre[e] = f2bf(dg); }
             *reinterpret_cast<uint2*>(p.aux + gm * p.ldaux + gn) = make_uint2((uint32_t)pre[0] | ((uint32_t)pre[1] << 16), (uint32_t)pre[2] | ((uint32_t)pre[3] << 16));
           }
           if (EPI == UDM_EPI_DGELU) {
-            x[0] *= gelu_tanh_grad(__uint_as_float(au[q].x << 16)); x[1] *= gelu_tanh_grad(__uint_as_float(au[q].x & 0xffff0000u));
-            x[2] *= gelu_tanh_grad(__uint_as_float(au[q].y << 16)); x[3] *= gelu_tanh_grad(__uint_as_float(au[q].y & 0xffff0000u));
+            x[0] *= __uint_as_float(au[q].x << 16); x[1] *= __uint_as_float(au[q].x & 0xffff0000u);
+            x[2] *= __uint_as_float(au[q].y << 16); x[3] *= __uint_as_float(au[q].y & 0xffff0000u);
           }
           if (EPI == UDM_EPI_DGELU && colsum) {
 #pragma unroll
@@ -590,12 +591,12 @@ __global__ __launch_bounds__(512) void gemm_nt_stagger_kernel(GemmArgs p) {
           const int nvalid = min(4, p.N - gn);
           for (int e = 0; e < nvalid; ++e) {
             if (EPI == UDM_EPI_BIAS_GELU) {
-              const bf16_t pre = f2bf(x[e]);
-              p.aux[gm * p.ldaux + gn + e] = pre;
-              x[e] = gelu_tanh(bf2f(pre));
+              float dg;
+              gelu_tanh_both(bf2f(f2bf(x[e])), x[e], dg);
+              p.aux[gm * p.ldaux + gn + e] = f2bf(dg);
             }
             if (EPI == UDM_EPI_DGELU) {
-              x[e] *= gelu_tanh_grad(bf2f(p.aux[gm * p.ldaux + gn + e]));
+              x[e] *= bf2f(p.aux[gm * p.ldaux + gn + e]);
               if (colsum) atomicAdd(colsum + gn + e, OUT_F32 ? x[e] : bf2f(f2bf(x[e])));
             }
             if (OUT_F32 && S > 1) {
@@ -705,7 +706,7 @@ extern "C" int udm_gemm_nt_bf16(const void* A, const void* B, void* C, int64_t M
   a.slice_stride = 0;
   if (epilogue == UDM_EPI_BIAS || epilogue == UDM_EPI_BIAS_GELU) UDM_CHECK_ARG(bias, "udm_gemm_nt_bf16: bias epilogue without bias");
   if (epilogue == UDM_EPI_BIAS_GELU) UDM_CHECK_ARG(aux && !out_f32, "udm_gemm_nt_bf16: EPI_BIAS_GELU needs aux and bf16 output");
-  if (epilogue == UDM_EPI_DGELU) UDM_CHECK_ARG(aux, "udm_gemm_nt_bf16: EPI_DGELU needs aux (saved pre-activation)");
+  if (epilogue == UDM_EPI_DGELU) UDM_CHECK_ARG(aux, "udm_gemm_nt_bf16: EPI_DGELU needs aux (the saved GELU derivative)");
   UDM_CHECK_ARG(epilogue >= 0 && epilogue <= 3, "udm_gemm_nt_bf16: unknown epilogue %d", epilogue);
   switch (choose_tile(M, N, K, lda, ldb)) {
     case 192: return launch_big<192>(a, epilogue, out_f32, stream);
@@ -722,7 +723,7 @@ extern "C" int udm_gemm_nt_bf16(const void* A, const void* B, void* C, int64_t M
       UDM_CHECK_ARG(bias && aux && !out_f32, "udm_gemm_nt_bf16: EPI_BIAS_GELU needs bias, aux and bf16 output");
       return launch_gemm<UDM_EPI_BIAS_GELU>(a, out_f32, stream);
     case UDM_EPI_DGELU:
-      UDM_CHECK_ARG(aux, "udm_gemm_nt_bf16: EPI_DGELU needs aux (saved pre-activation)");
+      UDM_CHECK_ARG(aux, "udm_gemm_nt_bf16: EPI_DGELU needs aux (the saved GELU derivative)");
       return launch_gemm<UDM_EPI_DGELU>(a, out_f32, stream);
     default: udm_set_error("udm_gemm_nt_bf16: unknown epilogue %d", epilogue); return 2;
   }
