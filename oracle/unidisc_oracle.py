@@ -634,3 +634,46 @@ def sample_maskgit(cfg: OracleConfig, P, buffers, x_init, timesteps, dt, preds, 
     if x0 is not None:
         x = torch.where(x0_unmask, x0, x)
     return x, xs, x_last, nfe, schedule
+
+
+# ------------------------------------------------------------------------------------------------
+# sampler inner loop: `first_hitting` predictor
+# ------------------------------------------------------------------------------------------------
+def first_hitting_update(cfg: OracleConfig, P, buffers, x, t, schedule, step, u, pos_u, modality=None, batch=None, bf16=False):
+    """model_eval.py:3005-3043 with the two torch.rand_like draws passed in: u [B, L, V] (token race of `_sample_categorical(p_x0)`),
+    pos_u [B, L] (which [MASK] positions are revealed: the num_unmask largest values among the masked positions)."""
+    t1 = t.squeeze(-1) if t.ndim > 1 else t
+    sigma_t, _ = loglinear_noise(t1)
+    p_x0, _ = ddpm_forward(cfg, P, buffers, x, sigma_t, modality, batch, bf16)
+    copy_flag = x != cfg.mask_index
+    _x = sample_categorical(p_x0, u)
+    num_unmask = torch.minimum(schedule[:, step].to(torch.int64), (~copy_flag).sum(-1))
+    if torch.all(num_unmask <= 0):
+        return x, 1
+    rv = torch.where(~copy_flag, pos_u, torch.full_like(pos_u, -1.0))
+    _, indices = torch.sort(rv, dim=-1, descending=True)
+    final = torch.arange(x.shape[-1]).expand(x.shape) < num_unmask[:, None]
+    result = torch.zeros_like(copy_flag)
+    result.scatter_(-1, indices, final)
+    return torch.where(result, _x, x), 1
+
+
+def sample_first_hitting(cfg: OracleConfig, P, buffers, x_init, timesteps, dt, us, pos_us, x0=None, x0_unmask=None, modality=None, batch=None,
+                         noise_removal=True, bf16=False):
+    x = x_init.clone()
+    B = x.shape[0]
+    schedule = adap_sche(x, len(timesteps) - 1, cfg.mask_index, "linear")
+    nfe, xs = 0, []
+    for i in range(len(timesteps) - 1):
+        t = timesteps[i] * torch.ones(B, 1)
+        x, n = first_hitting_update(cfg, P, buffers, x, t, schedule, i, us[i], pos_us[i], modality, batch, bf16)
+        nfe += n
+        xs.append(x.clone())
+    x_last = x
+    if noise_removal:
+        t = timesteps[-1] * torch.ones(B)
+        logits = dit_forward(cfg, P, buffers, x, loglinear_noise(t)[0], modality, None, bf16)
+        x = subs_parameterization(cfg, logits, x, modality, batch, bf16).float().argmax(dim=-1)
+    if x0 is not None:
+        x = torch.where(x0_unmask, x0, x)
+    return x, xs, x_last, nfe, schedule

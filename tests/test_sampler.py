@@ -260,7 +260,7 @@ def test_maskgit_host_logic_replays_reference_run(name, monkeypatch):
     if "x0" in s:
         assert torch.equal(x[s["x0_unmask"].bool()], s["x0"][s["x0_unmask"].bool()])
     with pytest.raises(NotImplementedError):
-        diff.sample(num_steps=2, batch_size=2, predictor="first_hitting")
+        diff.sample(num_steps=2, batch_size=2, predictor="maskgit_nucleus")
 
 
 @pytest.mark.gpu
@@ -331,3 +331,82 @@ def test_maskgit_loop_on_gpu(name):
     b = diff.sample(num_steps=int(s["steps"]), batch_size=B, modality=modality, predictor="maskgit", seed=3)
     c = diff.sample(num_steps=int(s["steps"]), batch_size=B, modality=modality, predictor="maskgit", seed=4)
     assert torch.equal(a, b) and not torch.equal(a, c) and not (a == diff.mask_index).any()
+
+
+# ------------------------------------------------------------------------------------------------ `first_hitting` predictor
+def _fh_run(diff, name, device):
+    z = np.load(os.path.join(GOLDEN_DIR, f"first_hitting_{name}.npz"))
+    s = {k: torch.from_numpy(np.asarray(z[k])) for k in z.files}
+    steps = int(s["steps"])
+    replay = [(s[f"step{i}/u"].to(device), s[f"step{i}/pos_u"].to(device) if f"step{i}/pos_u" in s else None) for i in range(steps)]
+    modality = s["modality"].to(device) if "modality" in s else None
+    x0, x0_unmask = (s["x0"].to(device), s["x0_unmask"].bool().to(device)) if "x0" in s else (None, None)
+    out = diff.sample(num_steps=steps, eps=float(s["eps"]), x0=x0, x0_unmask=x0_unmask, batch_size=s["x_init"].shape[0], modality=modality,
+                      predictor="first_hitting", replay=replay, return_nfe=True)
+    return s, out
+
+
+@pytest.mark.parametrize("name", ["c_large", "b_small"])
+def test_first_hitting_host_logic_replays_reference_run(name, monkeypatch):
+    from unidisc_amd import dit as dit_mod, diffusion as diff_mod
+
+    monkeypatch.setattr(dit_mod, "K", fake_kernels)
+    monkeypatch.setattr(diff_mod, "K", fake_kernels)
+    diff = build_product(Golden(name), device="cpu")
+    diff.backbone.eval()
+    s, (x, nfe) = _fh_run(diff, name, "cpu")
+    assert torch.equal(diff.adap_sche(s["x_init"], int(s["steps"]), diff.mask_index, "linear"), s["schedule"].to(torch.int32))
+    assert (x == s["x_final"]).float().mean().item() >= 0.9 and nfe == int(s["nfe"]) + 1 and not (x == diff.mask_index).any()
+    # the revealed POSITIONS are exact at every step (integer lottery); only near-tie token draws may differ under bf16
+    if "x0" in s:
+        assert torch.equal(x[s["x0_unmask"].bool()], s["x0"][s["x0_unmask"].bool()])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["c_large", "b_small"])
+def test_first_hitting_loop_on_gpu(name):
+    diff = build_product(Golden(name), device=DEV)
+    diff.backbone.eval()
+    s, (x, nfe) = _fh_run(diff, name, DEV)
+    x = x.cpu()
+    assert (x == s["x_final"]).float().mean().item() >= 0.9 and nfe == int(s["nfe"]) + 1 and not (x == diff.mask_index).any()
+    modality = s["modality"].to(DEV) if "modality" in s else None
+    B = s["x_init"].shape[0]
+    a = diff.sample(num_steps=int(s["steps"]), batch_size=B, modality=modality, predictor="first_hitting", seed=3)
+    b = diff.sample(num_steps=int(s["steps"]), batch_size=B, modality=modality, predictor="first_hitting", seed=3)
+    assert torch.equal(a, b) and not (a == diff.mask_index).any()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["c_large", "b_small"])
+def test_categorical_rows_kernel_token_exact_on_reference_uniforms(name):
+    """`_sample_categorical(p_x0)` of the first-hitting update: the reference's logits (rounded to bf16) and its [B, L, V] uniforms through
+    udm_categorical_sample_rows give exactly the tokens the oracle's fp32 restatement picks from the same bf16 logits."""
+    from unidisc_amd import kernels as K
+
+    g = Golden(name)
+    z = np.load(os.path.join(GOLDEN_DIR, f"first_hitting_{name}.npz"))
+    s = {k: torch.from_numpy(np.asarray(z[k])) for k in z.files}
+    cfg = g.cfg
+    batch = O.update_batch(cfg, g.batch())
+    modality = s["modality"] if "modality" in s else None
+    V, Vt, mask = cfg.vocab_size, cfg.text_vocab_size, cfg.mask_index
+    for i in range(int(s["steps"])):
+        x, u = s[f"step{i}/x"], s[f"step{i}/u"]
+        B, L = x.shape
+        lb = s[f"step{i}/logits"].bfloat16()
+        p = O.subs_parameterization(cfg, lb.float(), x, modality, batch, bf16=False).float().exp()
+        want = O.sample_categorical(p, u)
+        rows = (x.reshape(-1) == mask).nonzero().reshape(-1)
+        if rows.numel() == 0:
+            continue
+        Vp = (V + 7) // 8 * 8
+        lg = torch.zeros((rows.numel(), Vp), dtype=torch.bfloat16)
+        lg[:, :V] = lb.reshape(B * L, V)[rows]
+        rm = None
+        if cfg.force_argmax_valid_indices:
+            mod = modality if modality is not None else torch.cat([torch.zeros(B, cfg.txt_length), torch.ones(B, L - cfg.txt_length)], 1).long()
+            rm = mod.reshape(-1)[rows].long().to(DEV)
+        tok, _ = K.categorical_sample_rows(lg.to(DEV), V, Vt, mask, modality=rm, restrict=cfg.force_argmax_valid_indices,
+                                           u=u.reshape(B * L, V)[rows].contiguous().to(DEV))
+        assert torch.equal(tok.cpu(), want.reshape(-1)[rows]), f"step {i}"

@@ -119,3 +119,23 @@ def test_adap_sche_modes_and_edges():
         assert s.shape == (3, 4) and (s >= 0).all()
     s = O.adap_sche(x, 4, 9, "arccos")
     assert int(s[0].sum()) == 10 and int(s[2, -1]) == 0      # nothing masked: the lifted ones are paid back by the last step (clamped at 0)
+
+
+@pytest.mark.parametrize("name", ["c_large", "b_small"])
+def test_oracle_first_hitting_matches_reference_tokens(name):
+    """`first_hitting` predictor (model_eval.py:3005-3043, linear schedule): both rand_like draws replayed, identical tokens at every step."""
+    g = Golden(name)
+    z = np.load(os.path.join(GOLDEN_DIR, f"first_hitting_{name}.npz"))
+    s = {k: torch.from_numpy(np.asarray(z[k])) for k in z.files}
+    cfg, P, buffers, batch = oracle_setup(g)
+    steps = int(s["steps"])
+    us = [s[f"step{i}/u"] for i in range(steps)]
+    pos = [s.get(f"step{i}/pos_u") for i in range(steps)]
+    modality = s["modality"] if "modality" in s else None
+    x0, x0_unmask = (s["x0"], s["x0_unmask"].bool()) if "x0" in s else (None, None)
+    x_final, xs, x_last, nfe, schedule = O.sample_first_hitting(cfg, P, buffers, s["x_init"], s["timesteps"], float(s["dt"]), us, pos, x0=x0,
+                                                                x0_unmask=x0_unmask, modality=modality, batch=batch)
+    assert torch.equal(schedule, s["schedule"].to(schedule.dtype))
+    for i in range(steps):
+        assert torch.equal(xs[i], s[f"step{i}/x_next"]), f"step {i}"
+    assert torch.equal(x_final, s["x_final"]) and nfe == int(s["nfe"])

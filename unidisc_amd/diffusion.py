@@ -472,6 +472,41 @@ class Diffusion:
         return torch.where(conf >= thr, pred_full, x), 1
 
     @torch.no_grad()
+    def _first_hitting_update(self, x, t, dt, schedule=None, step=None, x0=None, x0_unmask=None, modality=None, sample_ids=None, u=None, pos_u=None, seed=None,
+                              **kwargs):
+        """`_first_hitting_update` (model_eval.py:3005-3043) on the [MASK] rows: token = `_sample_categorical(p_x0)` through the fused row kernel (explicit
+        uniforms `u` [B, L, V] replay the reference's draw, else Philox), then the num_unmask [MASK] positions with the largest lottery values
+        `pos_u` [B, L] are revealed."""
+        B, L = x.shape
+        t_col = t if t.ndim > 1 else t[:, None]
+        copy_flag = x != self.mask_index
+        sigma_t, _ = self.noise(t_col.squeeze(-1))
+        sig = self._process_sigma(sigma_t)
+        cache = self._guided_masked_logits(x, t_col.squeeze(-1), sig, x0_unmask, modality, sample_ids)
+        if cache is None:
+            cache = self.backbone.forward_masked_logits(x, sig, modality=modality, sample_ids=sample_ids)
+        num_unmask = torch.minimum(schedule[:, step].to(torch.int64).to(x.device), (~copy_flag).sum(dim=-1))
+        if bool(torch.all(num_unmask <= 0)):
+            return x, 1
+        logits, rows, n = cache[:3]
+        logits_u, w_rows = (cache[3], cache[4]) if len(cache) == 5 else (None, None)
+        rows_n = rows[:n]
+        u_rows = u.reshape(B * L, -1).index_select(0, rows_n).contiguous() if u is not None else None
+        base = int(seed if seed is not None else torch.initial_seed())
+        tok, _ = K.categorical_sample_rows(logits[:n], self.vocab_size, self.text_vocab_size, self.mask_index, modality=self._row_modality(rows_n, B, L, modality),
+                                           restrict=self._restrict(), u=u_rows, seed=base, logits_u=logits_u, w=w_rows)
+        if pos_u is None:
+            pos_u = torch.rand(B, L, device=x.device, generator=torch.Generator(device=x.device).manual_seed(base + 1))
+        rv = torch.where(~copy_flag, pos_u.to(torch.float32), torch.full((), -1.0, device=x.device))
+        _, indices = torch.sort(rv, dim=-1, descending=True)
+        final = torch.arange(L, device=x.device).expand(B, L) < num_unmask[:, None]
+        result = torch.zeros_like(copy_flag)
+        result.scatter_(-1, indices, final)
+        pred_full = x.clone()
+        pred_full.view(-1).index_copy_(0, rows_n, tok)
+        return torch.where(result, pred_full, x), 1
+
+    @torch.no_grad()
     def sample(self, num_steps=None, eps=1e-5, x0=None, x0_unmask=None, batch_size=None, modality=None, sample_ids=None, seed=None, noise=None,
                noise_removal=True, return_nfe=False, predictor=None, replay=None):
         """Token sampler: the `ddpm_cache` path of `_sample` (model_eval.py:2109-2455) without the decode / logging stack: prior = all [MASK]
@@ -497,15 +532,23 @@ class Diffusion:
         cache, nfe = None, 0
         if predictor is None:
             predictor = cfg_get(sampling, "predictor", "ddpm_cache") if sampling is not None else "ddpm_cache"
-        if predictor not in ("ddpm_cache", "maskgit"):
-            raise NotImplementedError(f"unidisc_amd.Diffusion.sample: predictor {predictor!r} is not built (ddpm_cache, maskgit)")
-        schedule = self.adap_sche(x, num_steps, self.mask_index, "arccos") if predictor == "maskgit" else None
+        if predictor not in ("ddpm_cache", "maskgit", "first_hitting"):
+            raise NotImplementedError(f"unidisc_amd.Diffusion.sample: predictor {predictor!r} is not built (ddpm_cache, maskgit, first_hitting)")
+        schedule = None
+        if predictor in ("maskgit", "first_hitting"):   # model_eval.py:2274-2290
+            schedule = self.adap_sche(x, num_steps, self.mask_index, "arccos" if predictor == "maskgit" else "linear")
         for i in range(num_steps):
             t = timesteps[i] * torch.ones(B, 1, device=self.device)
             if predictor == "maskgit":   # replay: list of (pred [B, L] or None, gumbel [B, L] or None) per step
                 pr, gm = replay[i] if replay is not None else (None, None)
                 x, n = self._maskgit_update(x, t, dt, schedule=schedule, step=i, x0=x0, x0_unmask=x0_unmask, modality=modality, sample_ids=sample_ids,
                                             pred=pr, gumbel=gm, seed=base_seed + 7919 * i)
+                nfe += n
+                continue
+            if predictor == "first_hitting":   # replay: list of (u [B, L, V] or None, pos_u [B, L] or None) per step
+                uu, pu = replay[i] if replay is not None else (None, None)
+                x, n = self._first_hitting_update(x, t, dt, schedule=schedule, step=i, x0=x0, x0_unmask=x0_unmask, modality=modality, sample_ids=sample_ids,
+                                                  u=uu, pos_u=pu, seed=base_seed + 7919 * i)
                 nfe += n
                 continue
             cache, x_next, n = self._ddpm_caching_update(x, t, dt, p_x0=cache, x0=x0, x0_unmask=x0_unmask, modality=modality, sample_ids=sample_ids,
