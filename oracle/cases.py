@@ -71,3 +71,16 @@ CASES = {
         set_max_txt_loss_ratio=1.0, mask_entire_modality=0.4, step_seed=17,
     ),
 }
+
+
+# Interleaved / packed batches (fixture made by oracle/make_golden_interleaved.py).  Kept out of CASES: the generic suites
+# iterate over CASES with token-dataset batches, this one has its own batch layout (sample ids, padding, two images in one sample).
+INTERLEAVED_CASES = {
+    "f_interleaved": _case(
+        txt_length=48, img_length=512, rope_2d=True, linear_factor=1.0, mask_entire_modality=0.6, softmin_snr=5, text_loss_weight=1.0, img_loss_weight=0.5,
+        batch_size=2, step_seed=23, data_seed=101, interleaved=True,
+        # rows of (sample id, modality, length); -1 = padding
+        layout=[[(0, 0, 12), (0, 1, 256), (0, 0, 8), (1, 0, 10), (1, 1, 256), (1, 0, 6), (-1, -1, 12)],
+                [(0, 0, 16), (0, 1, 256), (0, 0, 8), (0, 1, 256), (0, 0, 12), (-1, -1, 12)]],
+    ),
+}

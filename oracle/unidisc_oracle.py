@@ -60,6 +60,7 @@ class OracleConfig:
     set_max_txt_loss_ratio: Optional[float] = None
     antithetic_sampling: bool = True
     sampling_eps: float = 1e-3
+    interleaved: bool = False          # trainer.interleaved + data.require_sample_ids + interleaved_training_flex_attention
     extra: dict = field(default_factory=dict)
 
     @property
@@ -211,15 +212,77 @@ def select_rotary(cfg: OracleConfig, buffers: Dict[str, torch.Tensor], modality,
     return buffers["rotary_cos_emb"][:L], buffers["rotary_sin_emb"][:L]
 
 
+def interleaved_indices(modality_mask):
+    """unidisc/utils/tensor_utils.py:4-22: maximal runs of image tokens per row -> (batch index, start, end) in row-major order."""
+    out = []
+    for b in range(modality_mask.shape[0]):
+        row, start = modality_mask[b].tolist(), None
+        for i, v in enumerate(row + [False]):
+            if v and start is None:
+                start = i
+            elif not v and start is not None:
+                out.append((b, start, i))
+                start = None
+    return out
+
+
+def contiguous_blocks(ids, extra=None):
+    """tensor_utils.py:24-44 (and :46-69 with `extra` = modality): maximal runs of equal sample id (and equal modality) with id >= 0."""
+    out = []
+    for b in range(ids.shape[0]):
+        row = ids[b].tolist()
+        ex = extra[b].tolist() if extra is not None else [0] * len(row)
+        start = 0
+        for i in range(1, len(row) + 1):
+            if i == len(row) or row[i] != row[start] or ex[i] != ex[start]:
+                if row[start] >= 0:
+                    out.append((b, start, i))
+                start = i
+    return out
+
+
+def interleaved_rotary(cfg: OracleConfig, P, buffers, x, modality, sample_ids):
+    """models/dit.py:1421-1444 with :122-191.  cos = sin = 0 [B, L, D/2]; every image run whose length is one of the supported block sizes gets
+    that size's 2-D table and `img_count_embedding[j]` added to its embeddings (j = number of earlier image runs of the same row that start in
+    the same packed sample); then inside every run of one sample id the TEXT positions get the 1-D table indexed from the start of the run.
+    Image runs of any other length keep cos = sin = 0.  Returns (x, cos, sin)."""
+    B, L = modality.shape
+    D2 = cfg.head_dim // 2
+    cos, sin = torch.zeros(B, L, D2), torch.zeros(B, L, D2)
+    is_img = modality.bool()
+    runs = interleaved_indices(is_img)
+    x = x.clone()
+    for i, (b, s, e) in enumerate(runs):
+        n = e - s
+        j = sum(1 for (b2, s2, _) in runs[:i] if b2 == b and int(sample_ids[b2, s2]) == int(sample_ids[b, s]))
+        if n in (256, 1024, 2304, 4096):
+            x[b, s:e] = x[b, s:e] + P["img_count_embedding"][j]
+            cos[b, s:e] = buffers[f"rotary_cos_emb_img_{n}"][:n]
+            sin[b, s:e] = buffers[f"rotary_sin_emb_img_{n}"][:n]
+    ct, st = buffers["rotary_cos_emb_txt"], buffers["rotary_sin_emb_txt"]
+    for (b, s, e) in contiguous_blocks(sample_ids):
+        txt = ~is_img[b, s:e, None]
+        cos[b, s:e] = torch.where(txt, ct[: e - s], cos[b, s:e])
+        sin[b, s:e] = torch.where(txt, st[: e - s], sin[b, s:e])
+    return x, cos, sin
+
+
 def make_buffers(cfg: OracleConfig, lumina_fn=None):
     """Non-persistent rotary buffers registered by DIT.__init__ (models/dit.py:1203-1239)."""
     D = cfg.head_dim
     out = {}
     if cfg.rope_2d:
-        side = int(math.sqrt(cfg.img_length))
-        emb = lumina_fn(D, side, side, linear_factor=cfg.linear_factor, ntk_factor=1.0)
-        out["rotary_cos_emb_img"] = emb.flatten(0, 1).real.contiguous()
-        out["rotary_sin_emb_img"] = emb.flatten(0, 1).imag.contiguous()
+        if cfg.interleaved:  # dit.py:1209-1213: one 2-D table per supported image block size (tokens, linear factor)
+            for n_img, lf in ((256, 1), (1024, 2), (2304, 3), (4096, 4)):
+                side = int(math.sqrt(n_img))
+                emb = lumina_fn(D, side, side, linear_factor=lf, ntk_factor=1.0)
+                out[f"rotary_cos_emb_img_{n_img}"] = emb.flatten(0, 1).real.contiguous()
+                out[f"rotary_sin_emb_img_{n_img}"] = emb.flatten(0, 1).imag.contiguous()
+        else:
+            side = int(math.sqrt(cfg.img_length))
+            emb = lumina_fn(D, side, side, linear_factor=cfg.linear_factor, ntk_factor=1.0)
+            out["rotary_cos_emb_img"] = emb.flatten(0, 1).real.contiguous()
+            out["rotary_sin_emb_img"] = emb.flatten(0, 1).imag.contiguous()
         n = cfg.length if cfg.multimodal_batches else cfg.txt_length
         c, s = rotary_table_1d(n, D)
         out["rotary_cos_emb_txt"], out["rotary_sin_emb_txt"] = c, s
@@ -287,7 +350,10 @@ def dit_forward(cfg: OracleConfig, P: Dict[str, torch.Tensor], buffers, indices,
             x = x + torch.where((modality == 0).unsqueeze(-1), Em[0][None, None], Em[1][None, None])
         else:
             x = torch.cat([x[:, :cfg.txt_length] + Em[0], x[:, cfg.txt_length:] + Em[1]], 1)
-    cos, sin = select_rotary(cfg, buffers, modality, L)
+    if cfg.interleaved:
+        x, cos, sin = interleaved_rotary(cfg, P, buffers, x, modality, sample_ids)
+    else:
+        cos, sin = select_rotary(cfg, buffers, modality, L)
     for i in range(cfg.n_blocks):
         x = dit_block(cfg, P, f"blocks.{i}.", x, cos, sin, c, modality, sample_ids, bf16)
     norm = get_norm(cfg)
@@ -328,6 +394,13 @@ def update_batch(cfg: OracleConfig, batch: dict):
         b["img_sl"] = b["modality_mask"][..., 1]
     if cfg.force_full_attention_mask:
         b["attention_mask"] = torch.ones_like(b["attention_mask"], dtype=torch.bool)
+    if cfg.interleaved:  # model.py:350-353 (+ :375-376 default ids)
+        b["attention_mask"] = b["attention_mask"].to(torch.bool).clone()
+        if "sample_ids" not in b:
+            b["sample_ids"] = torch.zeros_like(b["modality"])
+        b["sample_ids"] = b["sample_ids"].to(torch.int64).clone()
+        b["sample_ids"][~b["attention_mask"]] = -1
+        b["attention_mask"][b["sample_ids"] == -1] = False
     b["attention_mask"] = b["attention_mask"].to(torch.bool)
     return b
 
@@ -358,16 +431,31 @@ def q_xt(cfg: OracleConfig, x0, move_chance, batch, training=True, generator=Non
         else:
             smt = torch.rand(B, 1, generator=generator) < pm / 2
             smi = torch.rand(B, 1, generator=generator) < pm / 2
-        both = smt & smi
-        smt, smi = smt & ~both, smi & ~both
-        if cfg.multimodal_batches:
+        if not (cfg.multimodal_batches and cfg.interleaved):
+            both = smt & smi
+            smt, smi = smt & ~both, smi & ~both
+        if cfg.multimodal_batches and cfg.interleaved:
+            # model.py:483-522: per (modality, sample) block of more than 4 tokens, masked as a whole with probability
+            # 2 pm (k + 1) / n, k = index of the block inside its packed sample, n = number of such blocks in that sample
+            blocks = [blk for blk in contiguous_blocks(batch["sample_ids"], batch["modality"]) if blk[2] - blk[1] > 4]
+            sid_of = [int(batch["sample_ids"][b, s]) for (b, s, _) in blocks]
+            r = torch.rand(len(blocks), 1, generator=generator)
+            ignore = torch.zeros(B, dtype=torch.bool)
+            for i, (b, s, e) in enumerate(blocks):
+                k = sum(1 for i2 in range(i) if blocks[i2][0] == b and sid_of[i2] == sid_of[i])
+                n = sum(1 for i2 in range(len(blocks)) if blocks[i2][0] == b and sid_of[i2] == sid_of[i])
+                if bool(r[i, 0] < pm * ((k + 1) / n) * 2):
+                    move[b, s:e] = True
+                    ignore[b] = True
+        elif cfg.multimodal_batches:
             move = torch.where(smt, batch["modality_mask"][..., 0], move)
             move = torch.where(smi, batch["modality_mask"][..., 1], move)
         else:
             smi = smi & ~batch["txt_sl"].all(-1, keepdim=True)
             move[:, :cfg.txt_length] |= smt
             move[:, L - cfg.img_length:] |= smi
-        ignore = smi | smt
+        if not (cfg.multimodal_batches and cfg.interleaved):
+            ignore = smi | smt
     xt = torch.where(move, cfg.mask_index, x0)
     return xt, ignore, smt, smi, move
 
@@ -469,7 +557,7 @@ def compute_loss(cfg: OracleConfig, P, buffers, batch, generator=None, bf16=Fals
     move_chance = 1 - torch.exp(-sigma[:, None])
     xt, ignore, smt, smi, move = q_xt(cfg, x0, move_chance, batch, training, generator)
     modality = batch["modality"] if cfg.multimodal_batches else None
-    logits = dit_forward(cfg, P, buffers, xt, sigma, modality, None, bf16)
+    logits = dit_forward(cfg, P, buffers, xt, sigma, modality, batch["sample_ids"] if cfg.interleaved else None, bf16)
     lp = subs_parameterization(cfg, logits, xt, modality, batch, bf16).float()
     log_p = torch.gather(lp, -1, x0[:, :, None]).squeeze(-1)
     out = reduce_loss(cfg, log_p, sigma, dsigma, am, modality_mask, ignore)
