@@ -394,7 +394,7 @@ def update_batch(cfg: OracleConfig, batch: dict):
         b["img_sl"] = b["modality_mask"][..., 1]
     if cfg.force_full_attention_mask:
         b["attention_mask"] = torch.ones_like(b["attention_mask"], dtype=torch.bool)
-    if cfg.interleaved:  # model.py:350-353 (+ :375-376 default ids)
+    if getattr(cfg, "interleaved", False):  # model.py:350-353 (+ :375-376 default ids)
         b["attention_mask"] = b["attention_mask"].to(torch.bool).clone()
         if "sample_ids" not in b:
             b["sample_ids"] = torch.zeros_like(b["modality"])

@@ -16,6 +16,11 @@ def product_config(case):
         kw[k] = case.get(k)
     cfg = make_config(**kw)
     cfg.model.force_text_vocab_size = case["text_vocab_size"] - 1  # tokenizer-less: len(tokenizer) stand-in (model_setup.py:90-92)
+    if case.get("interleaved"):  # configs of the interleaved checkpoints: packed samples, document mask from sample ids
+        cfg.trainer.interleaved = True
+        cfg.trainer.interleaved_training_flex_attention = True
+        cfg.data.require_sample_ids = True
+        cfg.model.use_flex_attention = True
     return cfg
 
 

@@ -54,3 +54,66 @@ def test_oracle_interleaved_rotary_layout():
     # padding: zero tables (q, k rotate to zero), no embedding
     assert (cos[:, -12:] == 0).all() and (sin[:, -12:] == 0).all() and (x2[:, -12:] == 0).all()
     assert sum(n for row in lay for (_, _, n) in row) == 2 * cfg.length
+
+
+# ------------------------------------------------------------------------------------------------ product (host logic here, HIP kernels under -m gpu)
+def _product_step(g, device):
+    from product_utils import build_product
+
+    diff = build_product(g, device)
+    diff.rng_device = "cpu"   # replay the reference's CPU generator stream
+    torch.manual_seed(g.case["step_seed"])
+    out = diff.training_step(g.batch(), 1)
+    assert torch.equal(diff._last["xt"].cpu(), g.t("fp32/xt")) and torch.equal(diff._last["move_indices"].cpu(), g.t("fp32/move_indices"))   # bit-exact
+    assert torch.equal(out.token_mask.cpu(), g.t("fp32/token_mask"))
+    return diff, out
+
+
+def _check_step(g, diff, out, loss_tol, nll_tol, grad_tol):
+    l32 = float(g.t("fp32/loss"))
+    assert abs(float(out.loss) - l32) <= loss_tol * abs(l32), (float(out.loss), l32)
+    assert rel_err(out.nlls.cpu(), g.t("fp32/nlls")) < nll_tol
+    assert torch.all(out.nlls.cpu()[~g.t("fp32/move_indices")] == 0)
+    out.loss.backward()
+    named = dict(diff.backbone.named_parameters())
+    gref = g.grads("fp32")
+    assert set(gref) == {k for k, p in named.items() if p.grad is not None}
+    bad = [(k, rel_err(named[k].grad.cpu(), v)) for k, v in gref.items() if rel_err(named[k].grad.cpu(), v) > grad_tol]
+    assert not bad, bad[:6]
+
+
+def test_product_rotary_layout_matches_oracle():
+    """`DIT._rotary_interleaved` (tensor form) against the oracle's block loop: tables, and the image-count embedding row of every position."""
+    from product_utils import build_product
+
+    g = Golden(NAME)
+    diff = build_product(g, "cpu")
+    b = O.update_batch(g.cfg, g.batch())
+    P, buf = g.params(), g.buffers()
+    x = torch.zeros(*b["input_ids"].shape, g.cfg.hidden_size)
+    x2, cos, sin = O.interleaved_rotary(g.cfg, P, buf, x, b["modality"], b["sample_ids"])
+    c, s, cnt = diff.backbone._rotary_interleaved(b["modality"], b["sample_ids"])
+    assert torch.equal(c, cos) and torch.equal(s, sin)
+    want = torch.where(cnt[..., None] >= 0, P["img_count_embedding"][cnt.clamp(min=0)], torch.zeros(()))
+    assert torch.equal(want, x2)
+
+
+def test_product_interleaved_host_logic_with_kernel_doubles(monkeypatch):
+    import unidisc_amd.dit as dit_mod
+    import unidisc_amd.diffusion as diff_mod
+
+    monkeypatch.setattr(dit_mod, "K", fake_kernels)
+    monkeypatch.setattr(diff_mod, "K", fake_kernels)
+    g = Golden(NAME)
+    diff, out = _product_step(g, "cpu")
+    _check_step(g, diff, out, loss_tol=1e-2, nll_tol=3e-2, grad_tol=8e-2)   # the doubles round to bf16 where the kernels do
+
+
+@pytest.mark.gpu
+def test_product_interleaved_training_step_gpu():
+    """HIP path on packed samples: document-masked attention from sample ids, per-block rotary tables, image-count embedding and its gradient."""
+    g = Golden(NAME)
+    diff, out = _product_step(g, "cuda")
+    _check_step(g, diff, out, loss_tol=4e-3, nll_tol=1e-2, grad_tol=6e-2)
+    gc = dict(diff.backbone.named_parameters())["img_count_embedding"].grad.cpu()
+    assert (gc[2:] == 0).all()

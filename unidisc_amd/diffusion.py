@@ -229,7 +229,36 @@ class Diffusion:
                 should_mask_img = self._rand(batch_size, 1, device=x.device) < mask_prob / 2
             if cfg_get(tr, "multimodal_batches", False):
                 if cfg_get(tr, "interleaved", False):
-                    raise NotImplementedError("unidisc_amd: per-block modality masking for interleaved batches (SURVEY §8 row a19) is not built yet")
+                    # model.py:483-522: every (modality, packed sample) block of more than 4 tokens is masked as a whole with probability
+                    # 2 p (k + 1) / n  (k: index of the block inside its sample, n: blocks of that sample); one uniform per block, drawn after
+                    # the two per-row draws above (same call order as the reference).  Block boundaries are found on the host: a handful per row.
+                    mod_h, sid_h = batch["modality"].cpu(), batch["sample_ids"].cpu()
+                    blocks = []
+                    for b in range(batch_size):
+                        mrow, srow = mod_h[b].tolist(), sid_h[b].tolist()
+                        st = 0
+                        for i in range(1, seq_len + 1):
+                            if i == seq_len or mrow[i] != mrow[st] or srow[i] != srow[st]:
+                                if srow[st] >= 0 and i - st > 4:
+                                    blocks.append((b, st, i, srow[st]))
+                                st = i
+                    r = self._rand(len(blocks), 1, device=x.device).reshape(-1).tolist() if blocks else []
+                    accum = torch.zeros_like(move_indices)
+                    ignore_batch_mask_for_metrics = torch.zeros((batch_size,), device=x.device, dtype=torch.bool)
+                    for i, (b, st, en, sidv) in enumerate(blocks):
+                        k = sum(1 for (b2, _, _, s2) in blocks[:i] if b2 == b and s2 == sidv)
+                        n = sum(1 for (b2, _, _, s2) in blocks if b2 == b and s2 == sidv)
+                        thr = mask_prob * (torch.tensor(k + 1) / torch.tensor(n)) * 2   # fp32, in the reference's order of operations
+                        if r[i] < float(thr):
+                            accum[b, st:en] = True
+                            ignore_batch_mask_for_metrics[b] = True
+                    move_indices = move_indices | accum
+                    xt = torch.where(move_indices, self.mask_index, x)
+                    if allow_move_mask is not None:
+                        raise NotImplementedError("unidisc_amd: allow_move_mask with interleaved batches")
+                    if return_ignore_batch_mask_for_metrics:
+                        return xt, ignore_batch_mask_for_metrics, None, should_mask_txt, should_mask_img, move_indices
+                    return xt
                 both_mask = should_mask_txt & should_mask_img
                 should_mask_txt = torch.where(both_mask, False, should_mask_txt)
                 should_mask_img = torch.where(both_mask, False, should_mask_img)

@@ -199,15 +199,21 @@ class DIT(nn.Module, _HubMixin):
         assert (self.txt_length + self.img_length == self.total_length) or self.multimodal_batches
         D = self.head_dim
         if self.rope_2d:  # models/dit.py:1203-1232
-            if self.require_sample_ids:
-                raise NotImplementedError("unidisc_amd.DIT: per-image-block 2-D RoPE for interleaved batches (SURVEY §8 row a19) is not built yet")
             if not (self.multimodal_batches and self.modality_embed is not None):
                 raise NotImplementedError("unidisc_amd.DIT: rope_2d needs multimodal_batches and modality_embed (as in every shipped config)")
-            side = int(math.sqrt(self.img_length))
-            assert side * side == self.img_length, f"seq_len_2d must be a square number, got {self.img_length}"
-            emb = self._lumina(D, side, side, cfg_get(m, "linear_factor", 1.0))
-            self.register_buffer("rotary_cos_emb_img", emb.flatten(0, 1).real.contiguous(), persistent=False)
-            self.register_buffer("rotary_sin_emb_img", emb.flatten(0, 1).imag.contiguous(), persistent=False)
+            if self.require_sample_ids:  # interleaved / packed batches (:1209-1216): one table per supported image block, image-count embedding
+                for n_img, lf in self.IMG_BLOCKS:
+                    side = int(math.sqrt(n_img))
+                    emb = self._lumina(D, side, side, lf)
+                    self.register_buffer(f"rotary_cos_emb_img_{n_img}", emb.flatten(0, 1).real.contiguous(), persistent=False)
+                    self.register_buffer(f"rotary_sin_emb_img_{n_img}", emb.flatten(0, 1).imag.contiguous(), persistent=False)
+                self.img_count_embedding = nn.Parameter(torch.zeros((16, d)))
+            else:
+                side = int(math.sqrt(self.img_length))
+                assert side * side == self.img_length, f"seq_len_2d must be a square number, got {self.img_length}"
+                emb = self._lumina(D, side, side, cfg_get(m, "linear_factor", 1.0))
+                self.register_buffer("rotary_cos_emb_img", emb.flatten(0, 1).real.contiguous(), persistent=False)
+                self.register_buffer("rotary_sin_emb_img", emb.flatten(0, 1).imag.contiguous(), persistent=False)
             c, s = rotary_table_1d(self.total_length, D)
             self.register_buffer("rotary_cos_emb_txt", c, persistent=False)
             self.register_buffer("rotary_sin_emb_txt", s, persistent=False)
@@ -250,6 +256,8 @@ class DIT(nn.Module, _HubMixin):
         raise NotImplementedError("unidisc_amd.DIT: modality KV cache is an inference feature outside the denoising hot path")
 
     # -------------------------------------------------------------------------------------------- parameters / shadows
+    IMG_BLOCKS = ((256, 1), (1024, 2), (2304, 3), (4096, 4))   # (tokens of an image block, Lumina linear factor), models/dit.py:1210
+
     def _ordered_params(self) -> List[nn.Parameter]:
         """Parameters in the order their gradients become final during backward (head first, embeddings last)."""
         out = list(self.output_layer.parameters())
@@ -258,6 +266,8 @@ class DIT(nn.Module, _HubMixin):
         out += list(self.vocab_embed.parameters())
         if self.modality_embed is not None:
             out += list(self.modality_embed.parameters())
+        if getattr(self, "img_count_embedding", None) is not None:
+            out.append(self.img_count_embedding)
         if self.sigma_map is not None:
             out += list(self.sigma_map.parameters())
         seen = {id(p) for p in out}
@@ -332,6 +342,54 @@ class DIT(nn.Module, _HubMixin):
                                       "document masks are derived from sample_ids")
 
     # -------------------------------------------------------------------------------------------- engine: forward
+    def _rotary_interleaved(self, modality, sample_ids):
+        """models/dit.py:1421-1444 with `add_img_data_to_blocks` / `add_txt_data_to_blocks` (:122-191), as tensor operations on the device (the
+        reference loops over blocks on the host): cos, sin fp32 [B, L, D/2] and, per position, the row of `img_count_embedding` to add (-1: none).
+        Image runs whose length is a supported block size get that size's 2-D table and count embedding j = number of earlier image runs of the row
+        that start in the same packed sample; text positions inside a run of one sample id >= 0 get the 1-D table from the start of that run;
+        everything else (padding, image runs of other lengths) keeps cos = sin = 0."""
+        B, L = modality.shape
+        dev = modality.device
+        ar = torch.arange(L, device=dev)[None].expand(B, L)
+        is_img = modality.bool()
+        prev = torch.nn.functional.pad(is_img[:, :-1], (1, 0))
+        start = is_img & ~prev
+        run_start = torch.cummax(torch.where(start, ar, torch.full_like(ar, -1)), dim=1).values
+        rows = torch.arange(B, device=dev)[:, None].expand(B, L)
+        key = (rows * L + run_start.clamp(min=0))
+        counts = torch.bincount(key[is_img], minlength=B * L)
+        run_len = torch.where(is_img, counts[key], torch.zeros_like(key))
+        pos_in_run = ar - run_start
+        if getattr(self, "_img_tab_cos", None) is None or self._img_tab_cos.device != dev:
+            self._img_tab_cos = torch.cat([getattr(self, f"rotary_cos_emb_img_{n}") for n, _ in self.IMG_BLOCKS], 0).to(dev)
+            self._img_tab_sin = torch.cat([getattr(self, f"rotary_sin_emb_img_{n}") for n, _ in self.IMG_BLOCKS], 0).to(dev)
+        off = torch.full_like(run_len, -1)
+        base = 0
+        for n, _ in self.IMG_BLOCKS:
+            off = torch.where(run_len == n, torch.full_like(off, base), off)
+            base += n
+        valid_img = is_img & (off >= 0)
+        idx = (off + pos_in_run).clamp(min=0)
+        cos_img, sin_img = self._img_tab_cos[idx], self._img_tab_sin[idx]
+        # image index inside its packed sample: running count of image-run starts per (row, sample id)
+        sid = sample_ids
+        nsid = int(sid.max().item()) + 1 if sid.numel() else 1
+        onehot = start[:, :, None] & (sid[:, :, None] == torch.arange(max(nsid, 1), device=dev)[None, None])
+        cum = onehot.cumsum(1)                                                   # [B, L, nsid] starts with that id up to and including l
+        j_at = (cum.gather(2, sid.clamp(min=0)[:, :, None]).squeeze(2) - 1)      # at a run start: earlier runs with the same id
+        j_run = j_at.gather(1, run_start.clamp(min=0))
+        count_idx = torch.where(valid_img, j_run, torch.full_like(j_run, -1))
+        # text: positions restart at every run of one sample id
+        sprev = torch.nn.functional.pad(sid[:, :-1], (1, 0), value=-2)
+        sstart = sid != sprev
+        s_run_start = torch.cummax(torch.where(sstart, ar, torch.full_like(ar, -1)), dim=1).values
+        tpos = (ar - s_run_start).clamp(min=0, max=self.rotary_cos_emb_txt.shape[0] - 1)
+        is_txt = (~is_img) & (sid >= 0)
+        zero = torch.zeros((), dtype=cos_img.dtype, device=dev)
+        cos = torch.where(valid_img[:, :, None], cos_img, torch.where(is_txt[:, :, None], self.rotary_cos_emb_txt[tpos], zero))
+        sin = torch.where(valid_img[:, :, None], sin_img, torch.where(is_txt[:, :, None], self.rotary_sin_emb_txt[tpos], zero))
+        return cos.contiguous(), sin.contiguous(), count_idx
+
     def _rotary(self, modality, L):
         """models/dit.py:1413-1460 (non-interleaved branches) → fp32 [L, D/2] or per-sample [B, L, D/2]."""
         if self.modality_embed is not None and self.rope_2d and self.multimodal_batches:
@@ -388,7 +446,17 @@ class DIT(nn.Module, _HubMixin):
 
         x = K.embedding_fwd(ids, self.vocab_embed.embedding.detach(), emb_mod if self.modality_embed is not None else None,
                             self.modality_embed.embedding.detach() if self.modality_embed is not None else None)
-        cos, sin = self._rotary(modality, L)
+        if self.rope_2d and self.require_sample_ids:
+            if sid is None:
+                raise ValueError("unidisc_amd.DIT: data.require_sample_ids needs sample_ids")
+            cos, sin, count_idx = self._rotary_interleaved(modality.to(torch.int64), sid)
+            cnt_rows = (count_idx.view(-1) >= 0).nonzero().view(-1)
+            cnt_j = count_idx.view(-1).index_select(0, cnt_rows)
+            if cnt_rows.numel():  # x[b, l] += img_count_embedding[j] on the positions of supported image blocks
+                x.index_add_(0, cnt_rows, self.img_count_embedding.detach().to(x.dtype).index_select(0, cnt_j))
+            S["cnt_rows"], S["cnt_j"] = cnt_rows, cnt_j
+        else:
+            cos, sin = self._rotary(modality, L)
         S["cos"], S["sin"] = cos, sin
 
         any_img = None
@@ -697,10 +765,14 @@ class DIT(nn.Module, _HubMixin):
             self._notify(flat, list(blk.parameters()))
 
         # ---- embeddings
+        if S.get("cnt_rows") is not None and S["cnt_rows"].numel():
+            G[id(self.img_count_embedding)].index_add_(0, S["cnt_j"], dx.index_select(0, S["cnt_rows"]))
         K.embedding_bwd(S["ids"], dx, G[id(self.vocab_embed.embedding)], self.mask_index,
                         modality=S["emb_mod"] if self.modality_embed is not None else None,
                         dEm=G[id(self.modality_embed.embedding)] if self.modality_embed is not None else None)
         tail = list(self.vocab_embed.parameters()) + (list(self.modality_embed.parameters()) if self.modality_embed is not None else [])
+        if getattr(self, "img_count_embedding", None) is not None:
+            tail.append(self.img_count_embedding)
         if tc:  # c = silu(W2 silu(W0 te + b0) + b2)
             dc16 = torch.empty((Bp, self.cond_dim), dtype=BF16, device=dev)
             K.cast_f32_bf16(dc, dc16)
