@@ -184,13 +184,18 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU path)")
+    local_rank %= torch.cuda.device_count()  # one rank per GPU on a node; wraps only in the single-GPU rehearsal of the N > 1 path (below)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     import torch.distributed as dist
 
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)  # "nccl" is RCCL on ROCm
+        backend = os.environ.get("UDM_DIST_BACKEND", "nccl")  # "nccl" is RCCL on ROCm; "gloo" only to rehearse the N > 1 path with two ranks on one GPU
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     w = WORKLOADS[args.workload]
     B = args.batch or w["batch"]
