@@ -30,6 +30,11 @@ WORKLOADS = {
     "unidisc-1.4b-l1280": dict(preset="extra_large", txt_length=256, img_length=1024, text_vocab=32001, image_vocab=16384, batch=8,
                                desc="UniDisc 1.4B non-interleaved, seq_len=1280 (256 text + 1024 image), bf16"),
     # BASELINE.json configs[1]: UniDisc-S
+    # BASELINE.json configs[4] in bf16 (no fp8 attention yet): large_scale_train_high_res_interleaved with model.length=4608:
+    # every row packs 4 samples of 128 text + 1024 image tokens; attention stays inside a sample (document mask from sample_ids)
+    "unidisc-1.4b-interleaved-l4608": dict(preset="extra_large", txt_length=512, img_length=4096, text_vocab=32001, image_vocab=16384, batch=2,
+                                           packed=dict(samples=4, txt=128, img=1024),
+                                           desc="UniDisc 1.4B interleaved, seq_len=4608 (4 packed samples of 128 text + 1024 image), bf16 attention"),
     "unidisc-s-l384": dict(preset="small", txt_length=128, img_length=256, text_vocab=32001, image_vocab=8192, batch=64,
                            desc="UniDisc-S (~115M) DiT, joint 128 text + 256 image VQ tokens, bf16"),
 }
@@ -70,6 +75,12 @@ def build(workload, device, dropout):
                       img_loss_weight=0.5 if large else None, force_full_attention_mask=True if large else None,
                       force_full_attention_mask_loss_only=None if large else True)
     cfg.model.force_text_vocab_size = w["text_vocab"] - 1
+    if "packed" in w:  # large_scale_train_high_res_interleaved.yaml
+        cfg.trainer.interleaved = True
+        cfg.trainer.interleaved_training_flex_attention = True
+        cfg.data.require_sample_ids = True
+        cfg.model.use_flex_attention = True
+        cfg.trainer.img_loss_weight, cfg.trainer.mask_entire_modality = 0.2, 0.2
     diff = Diffusion(cfg, None, device)
     diff.backbone.train()
     return cfg, diff
@@ -78,6 +89,15 @@ def build(workload, device, dropout):
 def synthetic_batch(workload, B, seed):
     w = WORKLOADS[workload]
     g = torch.Generator().manual_seed(seed)
+    if "packed" in w:
+        pk = w["packed"]
+        ids, mod, sid = [], [], []
+        for s_ in range(pk["samples"]):
+            ids += [torch.randint(0, w["text_vocab"] - 1, (B, pk["txt"]), generator=g), torch.randint(w["text_vocab"], w["text_vocab"] + w["image_vocab"], (B, pk["img"]), generator=g)]
+            mod += [torch.zeros(B, pk["txt"], dtype=torch.int64), torch.ones(B, pk["img"], dtype=torch.int64)]
+            sid += [torch.full((B, pk["txt"] + pk["img"]), s_, dtype=torch.int64)]
+        ids = torch.cat(ids, 1)
+        return dict(input_ids=ids, modality=torch.cat(mod, 1), sample_ids=torch.cat(sid, 1), attention_mask=torch.ones_like(ids, dtype=torch.bool))
     return dict(txt_input_ids=torch.randint(0, w["text_vocab"] - 1, (B, w["txt_length"]), generator=g, dtype=torch.int32),
                 img_input_ids=torch.randint(0, w["image_vocab"], (B, w["img_length"]), generator=g, dtype=torch.int32).to(torch.int16),
                 txt_attention_mask=torch.ones(B, w["txt_length"], dtype=torch.bool))
@@ -245,7 +265,8 @@ def main():
     tokens = world * B * L * args.steps
     value = tokens / dt
     m = cfg.model
-    f_tok = flops_per_token(m.n_blocks, m.hidden_size, diff.vocab_size, L)
+    L_att = (w["packed"]["txt"] + w["packed"]["img"]) if "packed" in w else L   # keys a query attends to
+    f_tok = flops_per_token(m.n_blocks, m.hidden_size, diff.vocab_size, L_att)
     result = {
         "metric": "denoising tokens/sec (fwd+bwd), 1.4B DiT seq_len=1280" if args.workload == "unidisc-1.4b-l1280" else f"denoising tokens/sec (fwd+bwd), {args.workload}",
         "value": value, "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
@@ -264,7 +285,7 @@ def main():
                               "avg_launch_ms": gs["total_ms"] / gs["launches"], "share_of_step_time": gs["total_ms"] * 1e-3 / dt}
     if sync is not None:
         result["allreduce_bytes_per_step"] = sync.bytes_on_wire // (args.steps + args.warmup)
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and "packed" not in w:
         try:
             result["cpu_baseline"] = cpu_baseline(args.workload, cfg, diff, seed)
         except Exception as e:  # the GPU number stands on its own; say why the comparator is missing

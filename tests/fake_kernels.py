@@ -233,14 +233,28 @@ def _attn(q, k, v, B, L, H, D, sid):
     return (p @ v).transpose(1, 2).reshape(B * L, H * D)
 
 
-def attention_fwd(qkr, qkv, B, L, H, D, sample_ids=None):
+def attention_doc_ranges(sample_ids):
+    B, L = sample_ids.shape
+    nT = (L + 63) // 64
+    r = torch.zeros(B, nT, 2, dtype=torch.int32)
+    for b in range(B):
+        for t in range(nT):
+            ids = sample_ids[b, t * 64:(t + 1) * 64]
+            ids = ids[ids >= 0]
+            if ids.numel():
+                hit = ((sample_ids[b] >= ids.min()) & (sample_ids[b] <= ids.max())).nonzero().flatten()
+                r[b, t, 0], r[b, t, 1] = int(hit[0]), int(hit[-1]) + 1
+    return r
+
+
+def attention_fwd(qkr, qkv, B, L, H, D, sample_ids=None, doc_ranges=None):
     d = H * D
     o = _attn(qkr[:, :d].float(), qkr[:, d:].float(), qkv[:, 2 * d:].float(), B, L, H, D, sample_ids)
     return o.bfloat16(), torch.zeros(B, H, L)
 
 
 @torch.enable_grad()
-def attention_bwd(qkr, qkv, o, do, lse, dqkr, dqkv, B, L, H, D, sample_ids=None):
+def attention_bwd(qkr, qkv, o, do, lse, dqkr, dqkv, B, L, H, D, sample_ids=None, doc_ranges=None):
     d = H * D
     q, k, v = (t.float().clone().requires_grad_() for t in (qkr[:, :d], qkr[:, d:], qkv[:, 2 * d:]))
     _attn(q, k, v, B, L, H, D, sample_ids).backward(do.float())

@@ -407,6 +407,62 @@ def test_attention_d128_wave_specialised_backward_ragged_lengths(K, L, B, H):
     assert rel_err(dk.float().cpu(), dk_r) < 1.5e-2
 
 
+def _doc_layouts(B, L):
+    """Packed-sample id layouts: contiguous documents with a padding tail, one document, non-contiguous ids, a row of padding only, padding inside."""
+    g = torch.Generator().manual_seed(L)
+    out = {}
+    sid = torch.zeros(B, L, dtype=torch.int64)
+    cuts = sorted(torch.randint(1, L, (3,), generator=g).tolist())
+    for i, c in enumerate(cuts):
+        sid[:, c:] = i + 1
+    sid[1 % B, -(L // 5 + 1):] = -1
+    out["contiguous"] = sid
+    out["single"] = torch.zeros(B, L, dtype=torch.int64)
+    nc = (torch.arange(L) // 37 % 3)[None].repeat(B, 1)          # ids 0 1 2 0 1 2 ... : spans overlap, nothing may be skipped wrongly
+    out["interleaved_ids"] = nc
+    pad = sid.clone()
+    pad[0] = -1                                                     # a whole row of padding
+    pad[B - 1, L // 2:L // 2 + 70] = -1                             # padding in the middle of a row (whole 64-tile of padding when L is large)
+    out["padding"] = pad
+    return out
+
+
+@pytest.mark.parametrize("L", [100, 640, 1500])
+def test_attention_doc_ranges_kernel_matches_definition(K, L):
+    import fake_kernels
+
+    for name, sid in _doc_layouts(3, L).items():
+        r = K.attention_doc_ranges(sid.to(DEV)).cpu()
+        assert torch.equal(r, fake_kernels.attention_doc_ranges(sid)), name
+
+
+@pytest.mark.parametrize("D,H", [(64, 3), (128, 2)])
+@pytest.mark.parametrize("L", [100, 640, 1500])
+def test_attention_tile_skipping_is_exact(K, D, H, L):
+    """With `doc_ranges` the kernels walk only the tiles that can hold a matching sample id; results must be BIT-identical to the unskipped run
+    (the per-element id test stays) and match the fp32 reference."""
+    B = 3
+    M, d = B * L, H * D
+    q, k, v, do = (bf(rnd(M, d, seed=s)) for s in (230, 231, 232, 233))
+    g = lambda t: t.to(DEV)
+    for name, sid in _doc_layouts(B, L).items():
+        sd = sid.to(DEV)
+        r = K.attention_doc_ranges(sd)
+        o0, lse0 = K.attention_fwd_generic(g(q), g(k), g(v), B, L, H, D, sd)
+        o1, lse1 = K.attention_fwd_generic(g(q), g(k), g(v), B, L, H, D, sd, r)
+        assert torch.equal(o0, o1) and torch.equal(lse0, lse1), name
+        g0 = K.attention_bwd_generic(g(q), g(k), g(v), o0, g(do), lse0, B, L, H, D, sd)
+        g1 = K.attention_bwd_generic(g(q), g(k), g(v), o1, g(do), lse1, B, L, H, D, sd, r)
+        for a, b_, nm in zip(g0, g1, "qkv"):
+            assert torch.equal(a, b_), (name, nm)
+        o_r, dq_r, dk_r, dv_r = _attn_ref(q, k, v, B, L, H, D, sid, do)
+        assert rel_err(o1.float().cpu(), o_r) < 1e-2, name
+        for a, b_, nm in zip(g1, (dq_r, dk_r, dv_r), "qkv"):
+            assert rel_err(a.float().cpu(), b_) < 1.5e-2, (name, nm)
+        pad_rows = (sid.reshape(-1) < 0)
+        assert (o1.float().cpu()[pad_rows] == 0).all() and all((t.float().cpu()[pad_rows] == 0).all() for t in g1), name   # padding rows: zeros
+
+
 def test_attention_online_softmax_rescale_branch(K):
     # a key far above the others late in the sequence forces the running max to jump (rule: test the rare branch)
     B, H, L, D = 1, 1, 256, 64

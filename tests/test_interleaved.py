@@ -117,3 +117,32 @@ def test_product_interleaved_training_step_gpu():
     _check_step(g, diff, out, loss_tol=4e-3, nll_tol=1e-2, grad_tol=6e-2)
     gc = dict(diff.backbone.named_parameters())["img_count_embedding"].grad.cpu()
     assert (gc[2:] == 0).all()
+
+
+@pytest.mark.gpu
+def test_packed_samples_equal_separate_rows_gpu():
+    """Size-independent property of the document mask + per-sample rotary positions: a sample gets the same logits packed behind another sample
+    as alone in its own row (up to bf16 summation order: its key tiles start at a different offset)."""
+    from product_utils import build_product
+
+    g = Golden(NAME)
+    diff = build_product(g, "cuda")
+    diff.backbone.eval()
+    b = O.update_batch(g.cfg, g.batch())
+    ids, mod, sid = b["input_ids"][0], b["modality"][0], b["sample_ids"][0]
+    L = ids.numel()
+    n0, n1 = int((sid == 0).sum()), int((sid == 1).sum())
+    assert n0 > 0 and n1 > 0 and bool((sid[:n0] == 0).all()) and bool((sid[n0:n0 + n1] == 1).all())
+
+    def alone(lo, n):
+        i, m, s_ = torch.zeros(L, dtype=torch.int64), torch.zeros(L, dtype=torch.int64), torch.full((L,), -1, dtype=torch.int64)
+        i[:n], m[:n], s_[:n] = ids[lo:lo + n], mod[lo:lo + n], 0
+        return i, m, s_
+
+    rows = [alone(0, n0), alone(n0, n1)]
+    with torch.no_grad():
+        packed = diff.backbone(ids[None].cuda(), None, modality=mod[None].cuda(), sample_ids=sid[None].cuda()).float().cpu()[0]
+        sep = diff.backbone(torch.stack([r[0] for r in rows]).cuda(), None, modality=torch.stack([r[1] for r in rows]).cuda(),
+                            sample_ids=torch.stack([r[2] for r in rows]).cuda()).float().cpu()
+    assert rel_err(sep[0, :n0], packed[:n0]) < 1e-2
+    assert rel_err(sep[1, :n1], packed[n0:n0 + n1]) < 1e-2

@@ -21,6 +21,69 @@ namespace {
 constexpr int BQ = 128;   // query rows per block (4 waves x 32)
 constexpr int BKV = 64;   // keys per tile
 
+// Document masks (packed samples): a 128-row block only has to walk the 64-row tiles of the other side that can hold one of its sample ids.
+// `doc_ranges` (udm_attention_doc_ranges) gives, per 64-row tile, the [lo, hi) span of positions whose id lies inside the tile's [min, max]
+// of valid ids (lo = hi = 0 for a tile of padding only).  The span is conservative for any id layout and exact for contiguous documents; the
+// per-element id comparison inside the kernels stays, so skipping tiles never changes a result.
+__device__ __forceinline__ void doc_tile_span(const int* doc_ranges, int b, int L, int blk128, int ntiles, int& t_begin, int& t_end) {
+  t_begin = 0;
+  t_end = ntiles;
+  if (doc_ranges == nullptr) return;
+  const int nT = (L + 63) / 64;
+  int lo = L, hi = 0;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int t = blk128 * 2 + j;
+    if (t < nT) {
+      const int l = doc_ranges[((long)b * nT + t) * 2], h = doc_ranges[((long)b * nT + t) * 2 + 1];
+      if (h > l) { lo = min(lo, l); hi = max(hi, h); }
+    }
+  }
+  if (hi <= lo) { t_begin = 0; t_end = 0; return; }
+  t_begin = __builtin_amdgcn_readfirstlane(lo / 64);
+  t_end = __builtin_amdgcn_readfirstlane((hi + 63) / 64);
+}
+
+__global__ __launch_bounds__(256) void attn_doc_ranges_kernel(const int64_t* __restrict__ sid, int* __restrict__ ranges, int L) {
+  __shared__ long s_mn[4], s_mx[4];
+  __shared__ int s_lo[4], s_hi[4];
+  const int nT = (L + 63) / 64;
+  const int b = blockIdx.x / nT, t = blockIdx.x % nT, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t* row = sid + (long)b * L;
+  long mn = INT64_MAX, mx = -1;
+  if (tid < 64 && t * 64 + tid < L) {
+    const long v = row[t * 64 + tid];
+    if (v >= 0) { mn = v; mx = v; }
+  }
+  for (int off = 32; off; off >>= 1) {
+    mn = min(mn, __shfl_xor(mn, off, 64));
+    mx = max(mx, __shfl_xor(mx, off, 64));
+  }
+  if (lane == 0) { s_mn[wave] = mn; s_mx[wave] = mx; }
+  __syncthreads();
+  mn = s_mn[0];   // only wave 0 read ids
+  mx = s_mx[0];
+  int lo = L, hi = 0;
+  if (mx >= 0)
+    for (int j = tid; j < L; j += 256) {
+      const long v = row[j];
+      if (v >= mn && v <= mx) { lo = min(lo, j); hi = max(hi, j + 1); }
+    }
+  for (int off = 32; off; off >>= 1) {
+    lo = min(lo, __shfl_xor(lo, off, 64));
+    hi = max(hi, __shfl_xor(hi, off, 64));
+  }
+  if (lane == 0) { s_lo[wave] = lo; s_hi[wave] = hi; }
+  __syncthreads();
+  if (tid == 0) {
+    lo = min(min(s_lo[0], s_lo[1]), min(s_lo[2], s_lo[3]));
+    hi = max(max(s_hi[0], s_hi[1]), max(s_hi[2], s_hi[3]));
+    if (hi <= lo) { lo = 0; hi = 0; }
+    ranges[((long)b * nT + t) * 2] = lo;
+    ranges[((long)b * nT + t) * 2 + 1] = hi;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
@@ -66,9 +129,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
   plank.init(a.k_stride, wave, lane);
   planv.init(a.v_stride, wave, lane);
   const int nkv = (a.L + BKV - 1) / BKV;
-  Stg::issue(kbase, a.k_stride, 0, a.L, smem, wave, lane);
-  Stg::issue(vbase, a.v_stride, 0, a.L, smem + 2 * TB, wave, lane);
-  for (int t = 0; t < nkv; ++t) {
+  int t_begin = 0, t_end = nkv;
+  if (HAS_SID) doc_tile_span(a.doc_ranges, b, a.L, tile_x, nkv, t_begin, t_end);
+  if (t_begin < t_end) {
+    Stg::issue(kbase, a.k_stride, t_begin * BKV, a.L, smem + (t_begin & 1) * TB, wave, lane);
+    Stg::issue(vbase, a.v_stride, t_begin * BKV, a.L, smem + (2 + (t_begin & 1)) * TB, wave, lane);
+  }
+  for (int t = t_begin; t < t_end; ++t) {
     const int kv0 = t * BKV, st = (ABL & 4) ? 0 : (t & 1);
     const char* Ks = smem + st * TB;
     const char* Vs = smem + (2 + st) * TB;
@@ -78,11 +145,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
     wait_all_vmem();   // this wave's share of tile t has landed
     __syncthreads();   // ... and everybody's; all waves are also done with tile t-1, so its stage may be refilled
     }
-    if (ABL & 4) {
+    if ((ABL & 4) || t + 1 >= t_end) {
     } else if (kv0 + 2 * BKV <= a.L) {   // the next tile is a full one: offsets are precomputed, the tile base is wave-uniform
       plank.issue_full(kbase + (long)(kv0 + BKV) * a.k_stride, smem + (st ^ 1) * TB, wave);
       planv.issue_full(vbase + (long)(kv0 + BKV) * a.v_stride, smem + (2 + (st ^ 1)) * TB, wave);
-    } else if (t + 1 < nkv) {
+    } else {
       Stg::issue(kbase, a.k_stride, kv0 + BKV, a.L, smem + (st ^ 1) * TB, wave, lane);
       Stg::issue(vbase, a.v_stride, kv0 + BKV, a.L, smem + (2 + (st ^ 1)) * TB, wave, lane);
     }
@@ -266,9 +333,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
   plank.init(a.k_stride, wave, lane);
   planv.init(a.v_stride, wave, lane);
   const int nkv = (a.L + BKV - 1) / BKV;
-  Stg::issue(kbase, a.k_stride, 0, a.L, smem, wave, lane);
-  Stg::issue(vbase, a.v_stride, 0, a.L, smem + 2 * TB, wave, lane);
-  for (int t = 0; t < nkv; ++t) {
+  int t_begin = 0, t_end = nkv;
+  if (HAS_SID) doc_tile_span(a.doc_ranges, b, a.L, tile_x, nkv, t_begin, t_end);
+  if (t_begin < t_end) {
+    Stg::issue(kbase, a.k_stride, t_begin * BKV, a.L, smem + (t_begin & 1) * TB, wave, lane);
+    Stg::issue(vbase, a.v_stride, t_begin * BKV, a.L, smem + (2 + (t_begin & 1)) * TB, wave, lane);
+  }
+  for (int t = t_begin; t < t_end; ++t) {
     const int kv0 = t * BKV, st = t & 1;
     const char* Ks = smem + st * TB;
     const char* Vs = smem + (2 + st) * TB;
@@ -276,10 +347,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
     if (HAS_SID && tid < BKV) sid_s[st * BKV + tid] = (kv0 + tid < a.L) ? a.sample_ids[rowbase + kv0 + tid] : -2;
     wait_all_vmem();   // this wave's share of tile t has landed
     __syncthreads();   // ... and everybody's; all waves are also done with tile t-1, so its stage may be refilled
-    if (kv0 + 2 * BKV <= a.L) {
+    if (t + 1 >= t_end) {
+    } else if (kv0 + 2 * BKV <= a.L) {
       plank.issue_full(kbase + (long)(kv0 + BKV) * a.k_stride, smem + (st ^ 1) * TB, wave);
       planv.issue_full(vbase + (long)(kv0 + BKV) * a.v_stride, smem + (2 + (st ^ 1)) * TB, wave);
-    } else if (t + 1 < nkv) {
+    } else {
       Stg::issue(kbase, a.k_stride, kv0 + BKV, a.L, smem + (st ^ 1) * TB, wave, lane);
       Stg::issue(vbase, a.v_stride, kv0 + BKV, a.L, smem + (2 + (st ^ 1)) * TB, wave, lane);
     }
@@ -388,9 +460,13 @@ __global__ __launch_bounds__(256, WAVES) void attn_bwd_dkv_kernel(AttnArgs a) {
   const long sbase = ((long)b * a.H + h) * a.L;
   using Stg = DmaStager<D, BQT>;
   const int nq = (a.L + BQT - 1) / BQT;
-  Stg::issue(qbase, a.q_stride, 0, a.L, smem, wave, lane);
-  Stg::issue(dobase, a.do_stride, 0, a.L, smem + 2 * TB, wave, lane);
-  for (int t = 0; t < nq; ++t) {
+  int t_begin = 0, t_end = nq;
+  if (HAS_SID) doc_tile_span(a.doc_ranges, b, a.L, tile_x, nq, t_begin, t_end);
+  if (t_begin < t_end) {
+    Stg::issue(qbase, a.q_stride, t_begin * BQT, a.L, smem + (t_begin & 1) * TB, wave, lane);
+    Stg::issue(dobase, a.do_stride, t_begin * BQT, a.L, smem + (2 + (t_begin & 1)) * TB, wave, lane);
+  }
+  for (int t = t_begin; t < t_end; ++t) {
     const int q0 = t * BQT, st = t & 1;
     const char* Qs = smem + st * TB;
     const char* Os = smem + (2 + st) * TB;
@@ -405,7 +481,7 @@ __global__ __launch_bounds__(256, WAVES) void attn_bwd_dkv_kernel(AttnArgs a) {
     }
     wait_all_vmem();
     __syncthreads();
-    if (t + 1 < nq) {
+    if (t + 1 < t_end) {
       Stg::issue(qbase, a.q_stride, q0 + BQT, a.L, smem + (st ^ 1) * TB, wave, lane);
       Stg::issue(dobase, a.do_stride, q0 + BQT, a.L, smem + (2 + (st ^ 1)) * TB, wave, lane);
     }
@@ -538,12 +614,22 @@ extern "C" int udm_attention_set_tr_read(int enable) {
   return 0;
 }
 
-extern "C" int udm_attention_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const int64_t* sample_ids, int64_t B, int64_t H, int64_t L,
+extern "C" int udm_attention_doc_ranges(const int64_t* sample_ids, int64_t B, int64_t L, int32_t* ranges, hipStream_t stream) {
+  UDM_CHECK_ARG(sample_ids && ranges, "udm_attention_doc_ranges: null pointer");
+  UDM_CHECK_ARG(B > 0 && L > 0 && B * ((L + 63) / 64) < (1LL << 31) && L < (1LL << 31), "udm_attention_doc_ranges: bad shape");
+  hipLaunchKernelGGL(attn_doc_ranges_kernel, dim3((unsigned)(B * ((L + 63) / 64))), dim3(256), 0, stream, sample_ids, ranges, (int)L);
+  UDM_CHECK_LAUNCH("udm_attention_doc_ranges");
+  return 0;
+}
+
+extern "C" int udm_attention_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const int64_t* sample_ids, const int32_t* doc_ranges, int64_t B, int64_t H, int64_t L,
                                  int64_t D, int64_t q_stride, int64_t k_stride, int64_t v_stride, int64_t o_stride, hipStream_t stream) {
   UDM_CHECK_ARG(q && k && v && o && lse, "udm_attention_fwd: null pointer");
   if (int rc = check_common("udm_attention_fwd", B, H, L, D, q_stride, k_stride, v_stride)) return rc;
   UDM_CHECK_ARG(o_stride % 4 == 0, "udm_attention_fwd: o_stride must be a multiple of 4");
+  UDM_CHECK_ARG(sample_ids || !doc_ranges, "udm_attention_fwd: doc_ranges without sample_ids");
   AttnArgs a{};
+  a.doc_ranges = doc_ranges;
   a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.out = (bf16_t*)o; a.lse = lse; a.sample_ids = sample_ids;
   a.q_stride = q_stride; a.k_stride = k_stride; a.v_stride = v_stride; a.out_stride = o_stride;
   a.B = (int)B; a.H = (int)H; a.L = (int)L;
@@ -555,13 +641,15 @@ extern "C" int udm_attention_fwd(const void* q, const void* k, const void* v, vo
 }
 
 extern "C" int udm_attention_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse, float* delta, void* dq, void* dk,
-                                 void* dv, const int64_t* sample_ids, int64_t B, int64_t H, int64_t L, int64_t D, int64_t q_stride, int64_t k_stride,
+                                 void* dv, const int64_t* sample_ids, const int32_t* doc_ranges, int64_t B, int64_t H, int64_t L, int64_t D, int64_t q_stride, int64_t k_stride,
                                  int64_t v_stride, int64_t o_stride, int64_t do_stride, int64_t dq_stride, int64_t dk_stride, int64_t dv_stride,
                                  hipStream_t stream) {
   UDM_CHECK_ARG(q && k && v && o && dout && lse && delta && dq && dk && dv, "udm_attention_bwd: null pointer");
   if (int rc = check_common("udm_attention_bwd", B, H, L, D, q_stride, k_stride, v_stride)) return rc;
   UDM_CHECK_ARG(o_stride % 8 == 0 && do_stride % 8 == 0 && dq_stride % 4 == 0 && dk_stride % 4 == 0 && dv_stride % 4 == 0, "udm_attention_bwd: bad strides");
+  UDM_CHECK_ARG(sample_ids || !doc_ranges, "udm_attention_bwd: doc_ranges without sample_ids");
   AttnArgs a{};
+  a.doc_ranges = doc_ranges;
   a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.o = (const bf16_t*)o; a.dout = (const bf16_t*)dout;
   a.out = (bf16_t*)dq; a.out2 = (bf16_t*)dk; a.out3 = (bf16_t*)dv; a.lse = const_cast<float*>(lse); a.delta = delta; a.sample_ids = sample_ids;
   a.q_stride = q_stride; a.k_stride = k_stride; a.v_stride = v_stride; a.o_stride = o_stride; a.do_stride = do_stride;

@@ -68,6 +68,7 @@ struct AttnArgs {
   float* lse;           // [B,H,L] log2-domain log-sum-exp of scaled scores
   const float* delta;   // [B,H,L] rowsum(dO * O)
   const int64_t* sample_ids;  // [B,L] or null
+  const int* doc_ranges;      // [B, ceil(L/64), 2] or null: per 64-row tile, the [lo, hi) span of positions whose sample id can match one of the tile's
   long q_stride, k_stride, v_stride, o_stride, do_stride, out_stride, out2_stride, out3_stride;
   int B, H, L;
   float scale_log2;     // log2(e) / sqrt(D)

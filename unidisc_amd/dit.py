@@ -437,6 +437,7 @@ class DIT(nn.Module, _HubMixin):
         else:
             emb_mod = mod_flat
         S = dict(B=B, L=L, ids=ids, modality=mod_flat, emb_mod=emb_mod, sid=sid, p_drop=p_drop, seed0=seed0, blocks=[])
+        S["doc_ranges"] = K.attention_doc_ranges(sid) if sid is not None else None   # once per step, shared by every block's forward and backward
         # SUBS: only [MASK] rows have a non-zero log-probability (model.py:621-658), so in "logp" mode the vocabulary head (GEMM fwd,
         # dgrad, wgrad and the cross-entropy) runs on the masked rows only.  Their number is data dependent: it is counted on a side
         # stream NOW and only read back right before the head, when the host has already queued every block of this forward -- the
@@ -493,7 +494,7 @@ class DIT(nn.Module, _HubMixin):
             qkr, qstats = K.qknorm_rope_fwd(qkv, cos, sin, L, D, gq=at.q_norm.weight.detach() if self.qk_norm else None,
                                             bq=at.q_norm.bias.detach() if self.qk_norm else None, gk=at.k_norm.weight.detach() if self.qk_norm else None,
                                             bk=at.k_norm.bias.detach() if self.qk_norm else None)
-            o, lse = K.attention_fwd(qkr, qkv, B, L, H, D, sid)
+            o, lse = K.attention_fwd(qkr, qkv, B, L, H, D, sid, S["doc_ranges"])
             a_out = K.gemm_nt(o, lin[f"{i}.out"].w16, N=d)
             # Without adaLN the next pre-norm is unmodulated and is fused into the residual add (x_out is normalised while in registers)
             fuse_w2 = None if tc else blk.norm2.weight.detach()
@@ -749,7 +750,7 @@ class DIT(nn.Module, _HubMixin):
             self._wgrad(da, R["o"], lo, G)
             dqkr = torch.empty((M, 2 * d), dtype=BF16, device=dev)
             dqkv = torch.empty((M, 3 * d), dtype=BF16, device=dev)
-            K.attention_bwd(R["qkr"], R["qkv"], R["o"], do, R["lse"], dqkr, dqkv, B, L, H, D, S["sid"])
+            K.attention_bwd(R["qkr"], R["qkv"], R["o"], do, R["lse"], dqkr, dqkv, B, L, H, D, S["sid"], S["doc_ranges"])
             qn = self.qk_norm
             K.qknorm_rope_bwd(dqkr, R["qkv"], dqkv, S["cos"], S["sin"], L, D, gq=at.q_norm.weight.detach() if qn else None,
                               gk=at.k_norm.weight.detach() if qn else None, stats=R["qstats"], dgq=G[id(at.q_norm.weight)] if qn else None,

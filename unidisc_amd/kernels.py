@@ -320,41 +320,49 @@ def qknorm_rope_bwd(dqkr, qkv, dqkv, cos, sin, L, D, *, gq=None, gk=None, stats=
               _p(dbk), M, d, L, D, _p(ws), ws.numel() if ws is not None else 0, _s())
 
 
-def attention_fwd(qkr, qkv, B, L, H, D, sample_ids=None):
+def attention_doc_ranges(sample_ids):
+    """int32 [B, ceil(L/64), 2]: per 64-row tile the span of positions that can share a sample id with it (tile skipping for packed samples)."""
+    B, L = sample_ids.shape
+    r = torch.empty((B, (L + 63) // 64, 2), dtype=torch.int32, device=sample_ids.device)
+    _lib.call("udm_attention_doc_ranges", _p(sample_ids), B, L, _p(r), _s())
+    return r
+
+
+def attention_fwd(qkr, qkv, B, L, H, D, sample_ids=None, doc_ranges=None):
     """q, k from qkr [M,2d] (normalised+rotated), v from qkv [M,3d] columns [2d,3d)."""
     d = H * D
     M = B * L
     o = torch.empty((M, d), dtype=BF16, device=qkr.device)
     lse = torch.empty((B, H, L), dtype=F32, device=qkr.device)
     q_ptr, k_ptr, v_ptr = qkr.data_ptr(), qkr.data_ptr() + 2 * d, qkv.data_ptr() + 4 * d
-    _lib.call("udm_attention_fwd", q_ptr, k_ptr, v_ptr, _p(o), _p(lse), _p(sample_ids), B, H, L, D, 2 * d, 2 * d, 3 * d, d, _s())
+    _lib.call("udm_attention_fwd", q_ptr, k_ptr, v_ptr, _p(o), _p(lse), _p(sample_ids), _p(doc_ranges), B, H, L, D, 2 * d, 2 * d, 3 * d, d, _s())
     return o, lse
 
 
-def attention_bwd(qkr, qkv, o, do, lse, dqkr, dqkv, B, L, H, D, sample_ids=None):
+def attention_bwd(qkr, qkv, o, do, lse, dqkr, dqkv, B, L, H, D, sample_ids=None, doc_ranges=None):
     """Writes dq|dk (wrt rotated q,k) into dqkr [M,2d] and dv into dqkv[:, 2d:3d]."""
     d = H * D
     delta = torch.empty((B, H, L), dtype=F32, device=qkr.device)
     q_ptr, k_ptr, v_ptr = qkr.data_ptr(), qkr.data_ptr() + 2 * d, qkv.data_ptr() + 4 * d
     dq_ptr, dk_ptr, dv_ptr = dqkr.data_ptr(), dqkr.data_ptr() + 2 * d, dqkv.data_ptr() + 4 * d
-    _lib.call("udm_attention_bwd", q_ptr, k_ptr, v_ptr, _p(o), _p(do), _p(lse), _p(delta), dq_ptr, dk_ptr, dv_ptr, _p(sample_ids), B, H, L, D, 2 * d,
+    _lib.call("udm_attention_bwd", q_ptr, k_ptr, v_ptr, _p(o), _p(do), _p(lse), _p(delta), dq_ptr, dk_ptr, dv_ptr, _p(sample_ids), _p(doc_ranges), B, H, L, D, 2 * d,
               2 * d, 3 * d, d, do.stride(0), 2 * d, 2 * d, 3 * d, _s())
 
 
-def attention_fwd_generic(q, k, v, B, L, H, D, sample_ids=None):
+def attention_fwd_generic(q, k, v, B, L, H, D, sample_ids=None, doc_ranges=None):
     """q, k, v: separate contiguous bf16 [B*L, H*D] (unit tests)."""
     d = H * D
     o = torch.empty((B * L, d), dtype=BF16, device=q.device)
     lse = torch.empty((B, H, L), dtype=F32, device=q.device)
-    _lib.call("udm_attention_fwd", _p(q), _p(k), _p(v), _p(o), _p(lse), _p(sample_ids), B, H, L, D, d, d, d, d, _s())
+    _lib.call("udm_attention_fwd", _p(q), _p(k), _p(v), _p(o), _p(lse), _p(sample_ids), _p(doc_ranges), B, H, L, D, d, d, d, d, _s())
     return o, lse
 
 
-def attention_bwd_generic(q, k, v, o, do, lse, B, L, H, D, sample_ids=None):
+def attention_bwd_generic(q, k, v, o, do, lse, B, L, H, D, sample_ids=None, doc_ranges=None):
     d = H * D
     dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
     delta = torch.empty((B, H, L), dtype=F32, device=q.device)
-    _lib.call("udm_attention_bwd", _p(q), _p(k), _p(v), _p(o), _p(do), _p(lse), _p(delta), _p(dq), _p(dk), _p(dv), _p(sample_ids), B, H, L, D, d, d, d, d,
+    _lib.call("udm_attention_bwd", _p(q), _p(k), _p(v), _p(o), _p(do), _p(lse), _p(delta), _p(dq), _p(dk), _p(dv), _p(sample_ids), _p(doc_ranges), B, H, L, D, d, d, d, d,
               d, d, d, d, _s())
     return dq, dk, dv
 
