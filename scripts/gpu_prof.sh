@@ -2,7 +2,7 @@
 # rocprofv3 kernel-trace summary of the bench command (short run, no CPU baseline).  Usage: bash scripts/gpu_prof.sh <tag>
 TAG=${1:-x}; mkdir -p gpurun_out; export TMPDIR=/tmp; R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$TAG -o trace -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-timing > $R/gpurun_out/prof_$TAG.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$TAG -o trace -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-timing $EXTRA > $R/gpurun_out/prof_$TAG.log 2>&1
 cd $R
 F=$(find gpurun_out/prof_$TAG -name "*kernel_stats.csv" | head -1)
 [ -n "$F" ] && head -45 "$F" > gpurun_out/kernel_stats_$TAG.csv

@@ -236,14 +236,16 @@ def _attn(q, k, v, B, L, H, D, sid):
 def attention_doc_ranges(sample_ids):
     B, L = sample_ids.shape
     nT = (L + 63) // 64
-    r = torch.zeros(B, nT, 2, dtype=torch.int32)
+    r = torch.zeros(B, nT, 4, dtype=torch.int32)
     for b in range(B):
         for t in range(nT):
-            ids = sample_ids[b, t * 64:(t + 1) * 64]
-            ids = ids[ids >= 0]
+            tile = sample_ids[b, t * 64:(t + 1) * 64]
+            ids = tile[tile >= 0]
+            r[b, t, 2], r[b, t, 3] = -1, -2
             if ids.numel():
                 hit = ((sample_ids[b] >= ids.min()) & (sample_ids[b] <= ids.max())).nonzero().flatten()
                 r[b, t, 0], r[b, t, 1] = int(hit[0]), int(hit[-1]) + 1
+                r[b, t, 2], r[b, t, 3] = (int(ids.min()) if ids.numel() == tile.numel() else -1), int(ids.max())
     return r
 
 

@@ -15,6 +15,7 @@
 // flight under the current tile's MFMAs.  The same swizzle is conflict-free for the ds_read_b128
 // fragment reads and for the transposing reads.
 #include "attention_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -22,44 +23,62 @@ constexpr int BQ = 128;   // query rows per block (4 waves x 32)
 constexpr int BKV = 64;   // keys per tile
 
 // Document masks (packed samples): a 128-row block only has to walk the 64-row tiles of the other side that can hold one of its sample ids.
-// `doc_ranges` (udm_attention_doc_ranges) gives, per 64-row tile, the [lo, hi) span of positions whose id lies inside the tile's [min, max]
-// of valid ids (lo = hi = 0 for a tile of padding only).  The span is conservative for any id layout and exact for contiguous documents; the
-// per-element id comparison inside the kernels stays, so skipping tiles never changes a result.
-__device__ __forceinline__ void doc_tile_span(const int* doc_ranges, int b, int L, int blk128, int ntiles, int& t_begin, int& t_end) {
-  t_begin = 0;
-  t_end = ntiles;
-  if (doc_ranges == nullptr) return;
+// `doc_ranges` (udm_attention_doc_ranges) gives, per 64-row tile, {lo, hi, idmin, idmax}: the [lo, hi) span of positions whose id lies inside the
+// tile's [idmin, idmax] of valid ids (lo = hi = 0 for a tile of padding only), and that id interval itself - with idmin = -1 when the tile holds
+// any padding, so that idmin == idmax >= 0 means "every row of this tile belongs to the one document idmin".  The span is conservative for any id
+// layout and exact for contiguous documents.  A tile pair that is uniform on both sides with the same id needs no per-element id test; every other
+// pair keeps it, so neither skipping tiles nor skipping the test changes a result.
+struct DocSpan {
+  int t_begin, t_end;   // tiles of the other side to walk
+  int blk_id;           // the one document all rows of this 128-row block belong to, or -1
+};
+__device__ __forceinline__ DocSpan doc_tile_span(const int* doc_ranges, int b, int L, int blk128, int ntiles) {
+  DocSpan d{0, ntiles, -1};
+  if (doc_ranges == nullptr) return d;
   const int nT = (L + 63) / 64;
-  int lo = L, hi = 0;
+  int lo = L, hi = 0, id = -2;
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int t = blk128 * 2 + j;
     if (t < nT) {
-      const int l = doc_ranges[((long)b * nT + t) * 2], h = doc_ranges[((long)b * nT + t) * 2 + 1];
-      if (h > l) { lo = min(lo, l); hi = max(hi, h); }
+      const int4 r = *reinterpret_cast<const int4*>(doc_ranges + ((long)b * nT + t) * 4);
+      if (r.y > r.x) { lo = min(lo, r.x); hi = max(hi, r.y); }
+      const int tid_ = (r.z == r.w) ? r.z : -1;
+      id = (id == -2 || id == tid_) ? tid_ : -1;
     }
   }
-  if (hi <= lo) { t_begin = 0; t_end = 0; return; }
-  t_begin = __builtin_amdgcn_readfirstlane(lo / 64);
-  t_end = __builtin_amdgcn_readfirstlane((hi + 63) / 64);
+  d.blk_id = __builtin_amdgcn_readfirstlane(id < 0 ? -1 : id);
+  if (hi <= lo) { d.t_begin = 0; d.t_end = 0; return d; }
+  d.t_begin = __builtin_amdgcn_readfirstlane(lo / 64);
+  d.t_end = __builtin_amdgcn_readfirstlane((hi + 63) / 64);
+  return d;
+}
+// does the pair (this block, tile t of the other side) need the per-element id test?
+__device__ __forceinline__ bool doc_pair_needs_mask(const int* doc_ranges, int b, int L, int t, int blk_id) {
+  if (doc_ranges == nullptr || blk_id < 0) return true;
+  const int nT = (L + 63) / 64;
+  const int2 r = *reinterpret_cast<const int2*>(doc_ranges + ((long)b * nT + t) * 4 + 2);
+  return !(r.x == blk_id && r.y == blk_id);
 }
 
 __global__ __launch_bounds__(256) void attn_doc_ranges_kernel(const int64_t* __restrict__ sid, int* __restrict__ ranges, int L) {
   __shared__ long s_mn[4], s_mx[4];
-  __shared__ int s_lo[4], s_hi[4];
+  __shared__ int s_lo[4], s_hi[4], s_pad;
   const int nT = (L + 63) / 64;
   const int b = blockIdx.x / nT, t = blockIdx.x % nT, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t* row = sid + (long)b * L;
   long mn = INT64_MAX, mx = -1;
+  int pad = 0;   // rows past L do not count as padding: nothing is ever computed for them
   if (tid < 64 && t * 64 + tid < L) {
     const long v = row[t * 64 + tid];
-    if (v >= 0) { mn = v; mx = v; }
+    if (v >= 0) { mn = v; mx = v; } else pad = 1;
   }
   for (int off = 32; off; off >>= 1) {
     mn = min(mn, __shfl_xor(mn, off, 64));
     mx = max(mx, __shfl_xor(mx, off, 64));
+    pad |= __shfl_xor(pad, off, 64);
   }
-  if (lane == 0) { s_mn[wave] = mn; s_mx[wave] = mx; }
+  if (lane == 0) { s_mn[wave] = mn; s_mx[wave] = mx; if (wave == 0) s_pad = pad; }
   __syncthreads();
   mn = s_mn[0];   // only wave 0 read ids
   mx = s_mx[0];
@@ -79,8 +98,12 @@ __global__ __launch_bounds__(256) void attn_doc_ranges_kernel(const int64_t* __r
     lo = min(min(s_lo[0], s_lo[1]), min(s_lo[2], s_lo[3]));
     hi = max(max(s_hi[0], s_hi[1]), max(s_hi[2], s_hi[3]));
     if (hi <= lo) { lo = 0; hi = 0; }
-    ranges[((long)b * nT + t) * 2] = lo;
-    ranges[((long)b * nT + t) * 2 + 1] = hi;
+    const bool small = mx >= 0 && mx < (1L << 30);   // ids that do not fit are simply never "uniform"
+    int4 r;
+    r.x = lo; r.y = hi;
+    r.z = (small && !s_pad) ? (int)mn : -1;
+    r.w = small ? (int)mx : -2;
+    *reinterpret_cast<int4*>(ranges + ((long)b * nT + t) * 4) = r;
   }
 }
 
@@ -129,8 +152,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
   plank.init(a.k_stride, wave, lane);
   planv.init(a.v_stride, wave, lane);
   const int nkv = (a.L + BKV - 1) / BKV;
-  int t_begin = 0, t_end = nkv;
-  if (HAS_SID) doc_tile_span(a.doc_ranges, b, a.L, tile_x, nkv, t_begin, t_end);
+  int t_begin = 0, t_end = nkv, blk_id = -1;
+  if (HAS_SID) { const DocSpan sp = doc_tile_span(a.doc_ranges, b, a.L, tile_x, nkv); t_begin = sp.t_begin; t_end = sp.t_end; blk_id = sp.blk_id; }
   if (t_begin < t_end) {
     Stg::issue(kbase, a.k_stride, t_begin * BKV, a.L, smem + (t_begin & 1) * TB, wave, lane);
     Stg::issue(vbase, a.v_stride, t_begin * BKV, a.L, smem + (2 + (t_begin & 1)) * TB, wave, lane);
@@ -140,6 +163,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
     const char* Ks = smem + st * TB;
     const char* Vs = smem + (2 + st) * TB;
     const long* sidk = sid_s + st * BKV;
+    const bool id_test = HAS_SID && doc_pair_needs_mask(a.doc_ranges, b, a.L, t, blk_id);   // block-uniform
     if (HAS_SID && tid < BKV) sid_s[st * BKV + tid] = (kv0 + tid < a.L) ? a.sample_ids[rowbase + kv0 + tid] : -2;
     if (!(ABL & 4) || t == 0) {
     wait_all_vmem();   // this wave's share of tile t has landed
@@ -179,14 +203,14 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
         }
       }
     }
-    if (HAS_SID || kv0 + BKV > a.L) {
+    if (id_test || kv0 + BKV > a.L) {
 #pragma unroll
       for (int f = 0; f < 2; ++f)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int kl = f * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
           bool ok = kv0 + kl < a.L;
-          if (HAS_SID) ok = ok && (sidk[kl] == sid_q) && (sid_q >= 0);
+          if (HAS_SID) ok = ok && (!id_test || ((sidk[kl] == sid_q) && (sid_q >= 0)));
           if (!ok) sT[f][r] = -INFINITY;
         }
     }
@@ -207,7 +231,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
     // rescaled: 64 + 2 VALU per lane) when some query of the wave saw a score more than 2^8 above its reference; otherwise
     // p = exp2(s c - m c) simply exceeds 1 by at most 2^8, which fp32 sums and bf16 operands hold without loss.  O / l and the
     // LSE m c + log2(l) are exact for any reference.  After the first key tile the branch is practically never taken.
-    const bool move = mloc * c > m * c + 8.0f;
+    const bool move = q_ok && (mloc * c > m * c + 8.0f);   // (lanes of query rows past L never vote: their scores depend on the masking path taken)
     if (__builtin_amdgcn_ballot_w64(move) != 0) {
       const float m_new = fmaxf(m, mloc);
       const float alpha = __builtin_amdgcn_exp2f((m - ((m_new == -INFINITY) ? 0.f : m_new)) * c);
@@ -333,8 +357,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
   plank.init(a.k_stride, wave, lane);
   planv.init(a.v_stride, wave, lane);
   const int nkv = (a.L + BKV - 1) / BKV;
-  int t_begin = 0, t_end = nkv;
-  if (HAS_SID) doc_tile_span(a.doc_ranges, b, a.L, tile_x, nkv, t_begin, t_end);
+  int t_begin = 0, t_end = nkv, blk_id = -1;
+  if (HAS_SID) { const DocSpan sp = doc_tile_span(a.doc_ranges, b, a.L, tile_x, nkv); t_begin = sp.t_begin; t_end = sp.t_end; blk_id = sp.blk_id; }
   if (t_begin < t_end) {
     Stg::issue(kbase, a.k_stride, t_begin * BKV, a.L, smem + (t_begin & 1) * TB, wave, lane);
     Stg::issue(vbase, a.v_stride, t_begin * BKV, a.L, smem + (2 + (t_begin & 1)) * TB, wave, lane);
@@ -344,6 +368,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
     const char* Ks = smem + st * TB;
     const char* Vs = smem + (2 + st) * TB;
     const long* sidk = sid_s + st * BKV;
+    const bool id_test = HAS_SID && doc_pair_needs_mask(a.doc_ranges, b, a.L, t, blk_id);   // block-uniform
     if (HAS_SID && tid < BKV) sid_s[st * BKV + tid] = (kv0 + tid < a.L) ? a.sample_ids[rowbase + kv0 + tid] : -2;
     wait_all_vmem();   // this wave's share of tile t has landed
     __syncthreads();   // ... and everybody's; all waves are also done with tile t-1, so its stage may be refilled
@@ -369,12 +394,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
       }
       // per-element masks only for document masks and the ragged last tile: full tiles have no out-of-range keys, and an out-of-range
       // QUERY has lse = +inf (p = 0) and zero operands
-      if (HAS_SID || kv0 + BKV > a.L) {
+      if (id_test || kv0 + BKV > a.L) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int kl = f * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
           bool ok = (kv0 + kl < a.L) && q_ok;
-          if (HAS_SID) ok = ok && (sidk[kl] == sid_q) && (sid_q >= 0);
+          if (HAS_SID) ok = ok && (!id_test || ((sidk[kl] == sid_q) && (sid_q >= 0)));
           const float pv = ok ? __builtin_amdgcn_exp2f(sT[r] * c - lse_q) : 0.f;
           ds[f][r] = pv * (dpT[r] - delta_q);
         }
@@ -460,8 +485,8 @@ __global__ __launch_bounds__(256, WAVES) void attn_bwd_dkv_kernel(AttnArgs a) {
   const long sbase = ((long)b * a.H + h) * a.L;
   using Stg = DmaStager<D, BQT>;
   const int nq = (a.L + BQT - 1) / BQT;
-  int t_begin = 0, t_end = nq;
-  if (HAS_SID) doc_tile_span(a.doc_ranges, b, a.L, tile_x, nq, t_begin, t_end);
+  int t_begin = 0, t_end = nq, blk_id = -1;
+  if (HAS_SID) { const DocSpan sp = doc_tile_span(a.doc_ranges, b, a.L, tile_x, nq); t_begin = sp.t_begin; t_end = sp.t_end; blk_id = sp.blk_id; }
   if (t_begin < t_end) {
     Stg::issue(qbase, a.q_stride, t_begin * BQT, a.L, smem + (t_begin & 1) * TB, wave, lane);
     Stg::issue(dobase, a.do_stride, t_begin * BQT, a.L, smem + (2 + (t_begin & 1)) * TB, wave, lane);
@@ -473,6 +498,7 @@ __global__ __launch_bounds__(256, WAVES) void attn_bwd_dkv_kernel(AttnArgs a) {
     const float* lse_s = lse_all + st * BQT;
     const float* delta_s = delta_all + st * BQT;
     const long* sidq = sid_all + st * BQT;
+    const bool id_test = HAS_SID && doc_pair_needs_mask(a.doc_ranges, b, a.L, t, blk_id);   // block-uniform
     if (tid < BQT) {
       const bool ok = q0 + tid < a.L;
       lse_all[st * BQT + tid] = ok ? a.lse[sbase + q0 + tid] : INFINITY;
@@ -503,21 +529,24 @@ __global__ __launch_bounds__(256, WAVES) void attn_bwd_dkv_kernel(AttnArgs a) {
       }
       __builtin_amdgcn_sched_barrier(0);
       float p[16], ds[16];
+      auto softmax_bwd = [&](auto IDT) {
 #pragma unroll
-      for (int rg = 0; rg < 4; ++rg) {
-        const int ql0 = qs * 32 + 8 * rg + 4 * hi;
-        const float4 l4 = *reinterpret_cast<const float4*>(lse_s + ql0);
-        const float4 d4 = *reinterpret_cast<const float4*>(delta_s + ql0);
-        const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dv[4] = {d4.x, d4.y, d4.z, d4.w};
+        for (int rg = 0; rg < 4; ++rg) {
+          const int ql0 = qs * 32 + 8 * rg + 4 * hi;
+          const float4 l4 = *reinterpret_cast<const float4*>(lse_s + ql0);
+          const float4 d4 = *reinterpret_cast<const float4*>(delta_s + ql0);
+          const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dv[4] = {d4.x, d4.y, d4.z, d4.w};
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int r = rg * 4 + e;
-          bool ok = k_ok && (q0 + ql0 + e < a.L);
-          if (HAS_SID) ok = ok && (sidq[ql0 + e] == sid_k) && (sid_k >= 0);
-          p[r] = ok ? __builtin_amdgcn_exp2f(s[r] * c - lv[e]) : 0.f;
-          ds[r] = p[r] * (dp[r] - dv[e]);
+          for (int e = 0; e < 4; ++e) {
+            const int r = rg * 4 + e;
+            bool ok = k_ok && (q0 + ql0 + e < a.L);
+            if (decltype(IDT)::value) ok = ok && (sidq[ql0 + e] == sid_k) && (sid_k >= 0);
+            p[r] = ok ? __builtin_amdgcn_exp2f(s[r] * c - lv[e]) : 0.f;
+            ds[r] = p[r] * (dp[r] - dv[e]);
+          }
         }
-      }
+      };
+      if (HAS_SID && id_test) softmax_bwd(std::true_type{}); else softmax_bwd(std::false_type{});
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int c2 = 0; c2 < 2; ++c2) {
