@@ -161,3 +161,72 @@ def test_assemble_kernel_rejects_host_tensors_and_wrong_dtypes():
 @pytest.mark.parametrize("resident", [True, False])
 def test_batcher_on_device(resident):
     _check_batcher("cuda", resident)
+
+# ------------------------------------------------------------------------------------------------ packing collate (dataloader.py:564-678)
+def _packing_case(name):
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "packing_collate.npz"))
+    def group(prefix):
+        items = {}
+        for k in z.files:
+            if k.startswith(prefix):
+                idx, field = k[len(prefix):].rsplit("/", 1)
+                items.setdefault(idx, {})[field] = torch.from_numpy(z[k])
+        return items
+    first = group(f"{name}/first/")
+    first = [first[str(i)] for i in range(len(first))]
+    ds_flat = group(f"{name}/ds/")
+    nds = 1 + max(int(k.split("/")[0]) for k in ds_flat)
+    datasets = [[ds_flat[f"{d}/{i}"] for i in range(sum(1 for k in ds_flat if k.startswith(f"{d}/")))] for d in range(nds)]
+    return z, first, datasets
+
+
+@pytest.mark.parametrize("name", ["mixed", "long_samples", "no_packing"])
+def test_packing_collate_matches_reference(name):
+    from unidisc_amd.token_data import PackingCollate
+
+    z, first, datasets = _packing_case(name)
+
+    class DS:
+        def __init__(self):
+            self.datasets = datasets
+
+        def __getitem__(self, k):
+            return {n: v.clone() for n, v in self.datasets[k[0]][k[1]].items()}
+
+    class Cfg:
+        class data:
+            disable_packing = bool(z[f"{name}/disable_packing"])
+
+    gen = torch.Generator().manual_seed(int(z[f"{name}/seed"]))
+    collate = PackingCollate(Cfg, DS(), int(z[f"{name}/seq_length"]), gen, pad_token_id=0, eos_token_id=2, image_token_id=7)
+    out = collate([{k: v.clone() for k, v in s.items()} for s in first])
+    for k in PackingCollate.KEYS:
+        ref = torch.from_numpy(z[f"{name}/out/{k}"])
+        assert out[k].dtype == ref.dtype and torch.equal(out[k], ref), (name, k)
+    assert int(torch.randint(1 << 30, (1,), generator=gen)) == int(z[f"{name}/next_draw"])   # same number of draws from the generator
+
+
+def test_packing_collate_derives_sample_ids_and_feeds_update_batch():
+    """Samples without `sample_ids` (valid prefix = everything before the first pad token), then the packed rows through `update_batch`'s
+    interleaved tail (padding gets sample id -1 / attention False) - the batch layout the a19 path consumes."""
+    from unidisc_amd.token_data import PackingCollate
+
+    z, first, datasets = _packing_case("mixed")
+    strip = lambda s: {k: v.clone() for k, v in s.items() if k != "sample_ids"}
+
+    class DS:
+        def __init__(self):
+            self.datasets = [[strip(s) for s in d] for d in datasets]
+
+        def __getitem__(self, k):
+            return strip(self.datasets[k[0]][k[1]])
+
+    gen = torch.Generator().manual_seed(int(z["mixed/seed"]))
+    out = PackingCollate(None, DS(), int(z["mixed/seq_length"]), gen, pad_token_id=0, eos_token_id=2, image_token_id=7)([strip(s) for s in first])
+    for k in PackingCollate.KEYS:
+        assert torch.equal(out[k], torch.from_numpy(z[f"mixed/out/{k}"])), k
+    valid = out["sample_ids"] >= 0
+    assert torch.equal(valid, out["attention_mask"].bool()) and torch.equal(out["modality"] >= 0, valid)
+    for b in range(valid.shape[0]):   # documents are contiguous and numbered 0, 1, 2, ... along the row
+        s = out["sample_ids"][b][valid[b]]
+        assert bool((s[1:] - s[:-1] >= 0).all()) and int(s[0]) == 0 and set(s.tolist()) == set(range(int(s.max()) + 1))

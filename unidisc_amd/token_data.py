@@ -15,8 +15,11 @@ MI355X-first layout: a shard is uploaded to HBM once (`TokenShard.to_device`; 2.
 whole stage-1 token set) and a batch is B row indices + one gather kernel; nothing but 8 B per sample crosses PCIe per step.  Shards that
 should stay on the host go through a pinned staging buffer and an async copy on a side stream instead (`resident=False`).
 
-Not built (out of this row's scope, stated in DESIGN.md): `PackingCollate` / interleaved samples, raw-image and webdataset branches,
-tokenizer setup, fault-tolerant distributed samplers.
+  * `PackingCollate` (`dataloader.py:564-678`): interleaved samples packed into fixed-length rows with per-row sample ids (what the document
+    mask, the per-sample rotary positions and the per-block masking of SURVEY §8 row a19 consume) - host integer logic with data-dependent
+    control flow over a handful of samples per row; the finished [B, L] rows go to HBM in one copy.  Pinned by `tests/golden/packing_collate.npz`.
+
+Not built (out of this row's scope, stated in DESIGN.md): raw-image and webdataset branches, tokenizer setup, fault-tolerant distributed samplers.
 """
 from __future__ import annotations
 
@@ -286,3 +289,98 @@ class _NullCtx:
 
     def __exit__(self, *a):
         return False
+
+
+class PackingCollate:
+    """Pack variable-length interleaved samples into rows of `seq_length` tokens (reference: `PackingCollate`, dataloader.py:564-678).
+
+    A sample is a dict of 1-D tensors `input_ids`, `attention_mask`, `modality` (0 text / 1 image) and optionally `sample_ids` (0 on its valid
+    prefix, -1 on its padding; derived from the first pad token when absent).  Row i starts with the i-th sample of the incoming batch and is
+    topped up with samples drawn from `dataset` - (dataset index, element index), two `torch.randint` draws from `generator` each, the same
+    draws in the same order as the reference - until it is full, or until what is left is shorter than a quarter of the next sample.  Each
+    packed sample gets the next sample id of its row; a sample that does not fit is truncated.  A row that ends inside an image loses that
+    image (and its `<image>` token), after an EOS has been put behind the text before it.  Unused positions: pad id, attention 0,
+    modality -1, sample id -1.  Returns a dict of [B, seq_length] tensors with the dtypes of the first sample.
+    """
+
+    KEYS = ("input_ids", "attention_mask", "modality", "sample_ids")
+
+    def __init__(self, config, dataset, seq_length, generator, tensor_collate=None, tokenizer=None, *, pad_token_id=None, eos_token_id=None,
+                 image_token_id=None):
+        self.dataset, self.seq_length, self.generator, self.tensor_collate = dataset, int(seq_length), generator, tensor_collate
+        if tokenizer is not None:
+            pad_token_id, eos_token_id = tokenizer.pad_token_id, tokenizer.eos_token_id
+            toks = tokenizer("<image>", add_special_tokens=False)["input_ids"]
+            if len(toks) != 1:
+                raise ValueError("PackingCollate: '<image>' must be a single token")
+            image_token_id = toks[0]
+        if pad_token_id is None or eos_token_id is None or image_token_id is None:
+            raise ValueError("PackingCollate needs a tokenizer or pad_token_id / eos_token_id / image_token_id")
+        self.padding_token_id, self.eos_token_id, self.image_token_id = int(pad_token_id), int(eos_token_id), int(image_token_id)
+        data = getattr(config, "data", None)
+        self.disable_packing = bool(getattr(data, "disable_packing", False)) if data is not None else False
+
+    @staticmethod
+    def _clean(sample):
+        return {k: v for k, v in sample.items() if k not in ("write_flag", "dataset_idx")}
+
+    def _draw(self):
+        d = int(torch.randint(len(self.dataset.datasets), (1,), generator=self.generator).item())
+        e = int(torch.randint(len(self.dataset.datasets[d]), (1,), generator=self.generator).item())
+        return self._clean(self.dataset[(d, e)])
+
+    def _valid_length(self, sample):
+        """Number of leading positions that belong to the sample (everything before its first sample id of -1)."""
+        if "sample_ids" not in sample:   # before the first pad token: the sample; from it on: padding
+            seen_pad = torch.cumsum((sample["input_ids"] == self.padding_token_id).long(), 0) > 0
+            sample["sample_ids"] = torch.where(seen_pad, -1, 0).to(sample["input_ids"].dtype)
+        sid = sample["sample_ids"]
+        if not bool(((sid == 0) | (sid == -1)).all()):   # already packed text (several documents per sample): text only
+            assert bool((sample["modality"] == 0).all())
+        neg = (sid == -1).nonzero()
+        if neg.numel():
+            return int(neg[0])
+        assert bool(sample["attention_mask"].all())
+        return sid.numel()
+
+    def __call__(self, batch):
+        if self.tensor_collate is not None:
+            batch = [self.tensor_collate(b) for b in batch] if isinstance(batch, list) else self.tensor_collate(batch)
+        batch = [self._clean(dict(b)) for b in batch]
+        B, S = len(batch), self.seq_length
+        proto = batch[0]
+        dt = lambda k: proto[k].dtype if k in proto else proto["input_ids"].dtype
+        ids = torch.full((B, S), self.padding_token_id, dtype=dt("input_ids"))
+        att = torch.zeros((B, S), dtype=dt("attention_mask"))
+        mod = torch.full((B, S), -1, dtype=dt("modality"))
+        sids = torch.full((B, S), -1, dtype=dt("sample_ids"))
+        for i in range(B):
+            used, n_packed, queue = 0, 0, [batch[i]]
+            while used < S and not (self.disable_packing and n_packed > 0):
+                sample = queue.pop(0) if queue else self._draw()
+                room = S - used
+                if room < sample["input_ids"].shape[0] // 4:
+                    if used > 0:
+                        break
+                    continue
+                n = min(self._valid_length(sample), room)
+                ids[i, used:used + n], att[i, used:used + n], mod[i, used:used + n] = sample["input_ids"][:n], sample["attention_mask"][:n], sample["modality"][:n]
+                sids[i, used:used + n] = n_packed
+                used += n
+                n_packed += 1
+            if mod[i, -1] == 1:   # the row ends inside an image: drop that image
+                is_img = mod[i] == 1
+                changes = (is_img[:-1] != is_img[1:]).nonzero().flatten() + 1
+                if changes.numel():
+                    start = int(changes[-1])
+                    if start > 0 and ids[i, start - 1] == self.image_token_id:
+                        start -= 1
+                    if start > 0 and ids[i, start - 1] != self.eos_token_id:
+                        ids[i, start], att[i, start], mod[i, start] = self.eos_token_id, 1, 0
+                        start += 1
+                    ids[i, start:], att[i, start:], mod[i, start:], sids[i, start:] = self.padding_token_id, 0, -1, -1
+        return dict(input_ids=ids, attention_mask=att, modality=mod, sample_ids=sids)
+
+    def to_device(self, packed, device):
+        """One host-to-device copy per field of the finished rows."""
+        return {k: v.to(device, non_blocking=True) for k, v in packed.items()}
