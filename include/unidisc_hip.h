@@ -109,6 +109,14 @@ int udm_attention_fwd(const void* q, const void* k, const void* v, void* o, floa
 int udm_attention_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse, float* delta, void* dq, void* dk,
                       void* dv, const int64_t* sample_ids, const int32_t* doc_ranges, int64_t B, int64_t H, int64_t L, int64_t D, int64_t q_stride, int64_t k_stride, int64_t v_stride,
                       int64_t o_stride, int64_t do_stride, int64_t dq_stride, int64_t dk_stride, int64_t dv_stride, hipStream_t stream);
+/* fp8 (OCP e4m3) forward, BASELINE config E; no reference counterpart - parity target is udm_attention_fwd under a looser tolerance.
+ * udm_attention_quantize_fp8: q, k, v bf16 (same addressing as above) -> q8, k8 [B*L, H*D] bytes, v8t [B*H, D, Lp] bytes (Lp = ceil(L/64)*64, per-head
+ * transposed, keys of each 16-chunk in the order 0-3, 8-11, 4-7, 12-15, zero padded), scales fp32 [3] = amax/448 of q, k, v; amax_ws: 3 x uint32 scratch.
+ * udm_attention_fwd_fp8: O bf16 and lse as udm_attention_fwd; S and PV through v_mfma_f32_32x32x16_fp8_fp8, softmax in fp32, P scaled by 2^8. */
+int udm_attention_quantize_fp8(const void* q, const void* k, const void* v, void* q8, void* k8, void* v8t, float* scales, uint32_t* amax_ws, int64_t B,
+                               int64_t H, int64_t L, int64_t D, int64_t q_stride, int64_t k_stride, int64_t v_stride, hipStream_t stream);
+int udm_attention_fwd_fp8(const void* q8, const void* k8, const void* v8t, const float* scales, void* o, float* lse, const int64_t* sample_ids,
+                          const int32_t* doc_ranges, int64_t B, int64_t H, int64_t L, int64_t D, int64_t o_stride, hipStream_t stream);
 int udm_attention_set_tr_read(int enable); /* diagnostics: 0 = gather Vᵀ fragments with scalar LDS reads */
 
 /* ---- embeddings: EmbeddingLayer models/dit.py:1036-1043 (+modality embedding :1402-1411) ------------- */

@@ -463,6 +463,72 @@ def test_attention_tile_skipping_is_exact(K, D, H, L):
         assert (o1.float().cpu()[pad_rows] == 0).all() and all((t.float().cpu()[pad_rows] == 0).all() for t in g1), name   # padding rows: zeros
 
 
+# ------------------------------------------------------------------------------------------------ fp8 attention forward (config E; no reference counterpart)
+def _fp8_dequant(quant, B, L, H, D):
+    """(q8, k8, v8t, scales) of the quantize kernel -> fp32 q, k, v [B*L, H*D] (undoing the per-head transpose and the 16-key permutation)."""
+    q8, k8, v8t, scales = (t.cpu() for t in quant)
+    sq, sk, sv = scales.tolist()
+    q = q8.view(torch.float8_e4m3fn).float() * sq
+    k = k8.view(torch.float8_e4m3fn).float() * sk
+    Lp = v8t.shape[-1]
+    pos = torch.arange(Lp)
+    j = pos & 15
+    src = (pos & ~15) + ((j & 3) | ((j & 4) << 1) | ((j & 8) >> 1))     # storage position of key `pos`
+    vt = v8t.view(torch.float8_e4m3fn).float()[:, :, src] * sv          # [B*H, D, Lp] in key order
+    v = vt[:, :, :L].reshape(B, H, D, L).permute(0, 3, 1, 2).reshape(B * L, H * D)
+    return q, k, v, (sq, sk, sv), vt[:, :, L:]
+
+
+@pytest.mark.parametrize("D,H", [(64, 3), (128, 2)])
+@pytest.mark.parametrize("L", [100, 640, 1500])
+def test_attention_fp8_quantize(K, D, H, L):
+    B = 2
+    M, d = B * L, H * D
+    q, k, v = (bf(rnd(M, d, seed=s)) for s in (330, 331, 332))
+    v = bf(v.float() * 3.0)
+    o, lse, quant = K.attention_fwd_fp8_generic(q.to(DEV), k.to(DEV), v.to(DEV), B, L, H, D, return_quantized=True)
+    qd, kd, vd, (sq, sk, sv), tail = _fp8_dequant(quant, B, L, H, D)
+    for src, deq, s in ((q, qd, sq), (k, kd, sk), (v, vd, sv)):
+        assert abs(s - src.float().abs().max().item() / 448.0) < 1e-6 * s
+        ref = (src.float() / s).to(torch.float8_e4m3fn).float() * s          # round-to-nearest-even e4m3, as v_cvt_pk_fp8_f32
+        # bf16 inputs sit exactly half-way between two e4m3 values about once in 32; x * (1/s) (kernel) and x / s (here) break those ties differently
+        assert (deq != ref).float().mean().item() < 2e-2 and rel_err(deq, ref) < 1e-2
+        assert ((deq - ref).abs() <= 0.13 * ref.abs().clamp_min(s * 2.0 ** -6)).all()          # ... and never by more than one e4m3 step
+        assert rel_err(deq, src.float()) < 4e-2                                            # 3 mantissa bits
+    assert (tail == 0).all()                                                               # keys past L are zero
+
+
+@pytest.mark.parametrize("D,H", [(64, 3), (128, 2)])
+@pytest.mark.parametrize("L", [100, 640, 1500])
+@pytest.mark.parametrize("use_sid", [False, True])
+def test_attention_fp8_forward(K, D, H, L, use_sid):
+    """Tolerances (stated): against fp32 attention on the SAME quantised operands 3e-2 rel-RMS (what the e4m3 rounding of P
+    costs); against the bf16 kernel 8e-2 (adds the e4m3 rounding of q, k, v); log-sum-exp (log2 units) within 0.25 of the bf16 kernel's and
+    within 5e-3 of the exact one of the quantised operands."""
+    B = 3
+    M, d = B * L, H * D
+    q, k, v = (bf(rnd(M, d, seed=s)) for s in (340, 341, 342))
+    g = lambda t: t.to(DEV) if t is not None else None
+    layouts = _doc_layouts(B, L) if use_sid else {"none": None}
+    for name, sid in layouts.items():
+        r = K.attention_doc_ranges(g(sid)) if sid is not None else None
+        o, lse, quant = K.attention_fwd_fp8_generic(g(q), g(k), g(v), B, L, H, D, g(sid), r, return_quantized=True)
+        qd, kd, vd, _, _ = _fp8_dequant(quant, B, L, H, D)
+        o_ref = R._attn(qd, kd, vd, B, L, H, D, sid)
+        assert rel_err(o.float().cpu(), o_ref) < 3e-2, name
+        o16, lse16 = K.attention_fwd_generic(g(q), g(k), g(v), B, L, H, D, g(sid), r)
+        assert rel_err(o.float().cpu(), o16.float().cpu()) < 8e-2, name
+        fin = torch.isfinite(lse16)
+        assert torch.equal(torch.isfinite(lse), fin) and torch.allclose(lse[fin], lse16[fin], atol=0.25, rtol=0), name      # log2 units; q, k rounding
+        if sid is None:   # the softmax statistics themselves are fp32: tight against the exact scores of the quantised operands
+            sc = (qd.reshape(B, L, H, D).transpose(1, 2) @ kd.reshape(B, L, H, D).transpose(1, 2).transpose(-1, -2)) / math.sqrt(D)
+            assert torch.allclose(lse.cpu() * math.log(2.0), torch.logsumexp(sc, -1), atol=5e-3, rtol=1e-4), name
+        if sid is not None:
+            o_noskip, _ = K.attention_fwd_fp8_generic(g(q), g(k), g(v), B, L, H, D, g(sid), None)
+            assert torch.equal(o, o_noskip), name                       # tile skipping changes nothing
+            assert (o.float().cpu()[sid.reshape(-1) < 0] == 0).all(), name
+
+
 def test_attention_online_softmax_rescale_branch(K):
     # a key far above the others late in the sequence forces the running max to jump (rule: test the rare branch)
     B, H, L, D = 1, 1, 256, 64

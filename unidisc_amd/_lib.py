@@ -38,6 +38,8 @@ PROTOTYPES = {
     "udm_attention_doc_ranges": [_P, _I64, _I64, _P, _P],
     "udm_attention_fwd": [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _P],
     "udm_attention_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _P],
+    "udm_attention_quantize_fp8": [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _P],
+    "udm_attention_fwd_fp8": [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _P],
     "udm_attention_set_tr_read": [_I],
     "udm_assemble_joint_tokens": [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _P, _P, _P, _P],
     "udm_categorical_sample_rows": [_P, _P, _P, _I64, _P, _P, _I64, _U64, _P, _P, _P, _I64, _I64, _I64, _I64, _I, _P],

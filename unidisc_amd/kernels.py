@@ -340,6 +340,34 @@ def attention_fwd(qkr, qkv, B, L, H, D, sample_ids=None, doc_ranges=None):
     return o, lse
 
 
+def _attention_fwd_fp8(q_ptr, k_ptr, v_ptr, qs, ks, vs, B, L, H, D, device, sample_ids, doc_ranges):
+    d, M, Lp = H * D, B * L, (L + 63) // 64 * 64
+    q8 = torch.empty((M, d), dtype=torch.uint8, device=device)
+    k8 = torch.empty((M, d), dtype=torch.uint8, device=device)
+    v8t = torch.empty((B * H, D, Lp), dtype=torch.uint8, device=device)
+    scales = torch.empty(3, dtype=F32, device=device)
+    amax = torch.empty(3, dtype=torch.int32, device=device)
+    _lib.call("udm_attention_quantize_fp8", q_ptr, k_ptr, v_ptr, _p(q8), _p(k8), _p(v8t), _p(scales), _p(amax), B, H, L, D, qs, ks, vs, _s())
+    o = torch.empty((M, d), dtype=BF16, device=device)
+    lse = torch.empty((B, H, L), dtype=F32, device=device)
+    _lib.call("udm_attention_fwd_fp8", _p(q8), _p(k8), _p(v8t), _p(scales), _p(o), _p(lse), _p(sample_ids), _p(doc_ranges), B, H, L, D, d, _s())
+    return o, lse, (q8, k8, v8t, scales)
+
+
+def attention_fwd_fp8(qkr, qkv, B, L, H, D, sample_ids=None, doc_ranges=None):
+    """fp8 (e4m3) forward on q, k from qkr [M,2d] and v from qkv [M,3d] (config E; no reference counterpart).  Returns o bf16 [M,d], lse."""
+    d = H * D
+    o, lse, _ = _attention_fwd_fp8(qkr.data_ptr(), qkr.data_ptr() + 2 * d, qkv.data_ptr() + 4 * d, 2 * d, 2 * d, 3 * d, B, L, H, D, qkr.device, sample_ids, doc_ranges)
+    return o, lse
+
+
+def attention_fwd_fp8_generic(q, k, v, B, L, H, D, sample_ids=None, doc_ranges=None, return_quantized=False):
+    """q, k, v: separate contiguous bf16 [B*L, H*D] (unit tests)."""
+    d = H * D
+    o, lse, quant = _attention_fwd_fp8(q.data_ptr(), k.data_ptr(), v.data_ptr(), d, d, d, B, L, H, D, q.device, sample_ids, doc_ranges)
+    return (o, lse, quant) if return_quantized else (o, lse)
+
+
 def attention_bwd(qkr, qkv, o, do, lse, dqkr, dqkv, B, L, H, D, sample_ids=None, doc_ranges=None):
     """Writes dq|dk (wrt rotated q,k) into dqkr [M,2d] and dv into dqkv[:, 2d:3d]."""
     d = H * D
