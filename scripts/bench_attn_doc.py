@@ -26,3 +26,20 @@ for B in (1, 2):
         b = t(lambda: K.attention_bwd_generic(q, k, v, o, do, lse, B, L, H, D, ss, rr))
         print(f"B={B} {name:22s} fwd {f:8.1f} us  bwd {b:8.1f} us", flush=True)
     print(f"B={B} doc_ranges kernel {t(lambda: K.attention_doc_ranges(sid)):.1f} us")
+
+# fp8 forward (quantise pass and kernel timed separately) against the bf16 forward, config C shape and the packed config E shape
+from unidisc_amd import _lib
+for (B, L, docs) in ((8, 1280, 1), (2, 4608, 4)):
+    H, D = 16, 128
+    d = H * D
+    g = torch.Generator().manual_seed(0)
+    q, k, v = (torch.randn(B * L, d, generator=g).bfloat16().cuda() for _ in range(3))
+    sid = (torch.arange(L) // (L // docs))[None].repeat(B, 1).cuda() if docs > 1 else None
+    r = K.attention_doc_ranges(sid) if sid is not None else None
+    f16 = t(lambda: K.attention_fwd_generic(q, k, v, B, L, H, D, sid, r))
+    o, lse, (q8, k8, v8t, scales) = K.attention_fwd_fp8_generic(q, k, v, B, L, H, D, sid, r, return_quantized=True)
+    amax = torch.empty(3, dtype=torch.int32, device="cuda")
+    p_ = lambda x: x.data_ptr() if x is not None else 0
+    tq = t(lambda: _lib.call("udm_attention_quantize_fp8", p_(q), p_(k), p_(v), p_(q8), p_(k8), p_(v8t), p_(scales), p_(amax), B, H, L, D, d, d, d, K._s()))
+    tf = t(lambda: _lib.call("udm_attention_fwd_fp8", p_(q8), p_(k8), p_(v8t), p_(scales), p_(o), p_(lse), p_(sid), p_(r), B, H, L, D, d, K._s()))
+    print(f"B={B} L={L} docs={docs}: bf16 fwd {f16:7.1f} us | fp8 quantise {tq:6.1f} us + fp8 fwd {tf:7.1f} us", flush=True)

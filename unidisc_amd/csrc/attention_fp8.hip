@@ -32,12 +32,6 @@ struct Fp8Args {
   float scale_log2;
 };
 
-// 16-byte slot swizzle of a [rows][ROWB bytes] tile: conflict-free for the 8-byte fragment reads of 32 consecutive rows
-template <int ROWB>
-__device__ __forceinline__ int swz8(int row) { return (row / (128 / ROWB)) & (ROWB / 16 - 1); }
-template <int ROWB>
-__device__ __forceinline__ int off8(int row, int slot16) { return row * ROWB + ((slot16 ^ swz8<ROWB>(row)) << 4); }
-
 __device__ __forceinline__ long pack8_fp8(const float* p) {
   int lo = 0, hi = 0;
   lo = __builtin_amdgcn_cvt_pk_fp8_f32(p[0], p[1], lo, false);
@@ -79,8 +73,11 @@ template <int D, bool HAS_SID>
 __global__ __launch_bounds__(256, 2) void attn_fwd_fp8_kernel(Fp8Args a) {
   constexpr int KS = D / 16, DB = D / 32;
   constexpr int KT = BKV8 * D, VT = D * BKV8;          // bytes per K8 / V8T tile
-  constexpr int PPT = D / 64;                          // 16-byte staging pieces per thread and operand
-  __shared__ __attribute__((aligned(16))) char smem[2 * (KT + VT)];
+  // Byte geometry of the tiles = bf16 tiles of half the width, so the LDS-DMA stager and the XOR swizzle of the bf16 kernels are reused as is:
+  // K8 [64 keys][D bytes] = [64][D/2 bf16], V8T [D rows][64 bytes] = [D][32 bf16].  A fragment is the 8-byte half `hi` of a 16-byte slot.
+  using StgK = DmaStager<D / 2, BKV8>;
+  using StgV = DmaStager<32, D>;
+  __shared__ __attribute__((aligned(16))) char smem[2 * (KT + VT)];   // K0 | K1 | V0 | V1
   __shared__ long sid_s[2][BKV8];
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -96,8 +93,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_fp8_kernel(Fp8Args a) {
   for (int ks = 0; ks < KS; ++ks) qf[ks] = q_ok ? *reinterpret_cast<const long*>(a.q8 + (rowbase + qi) * d + h * D + ks * 16 + hi * 8) : 0L;
   long sid_q = 0;
   if (HAS_SID) sid_q = q_ok ? a.sample_ids[rowbase + qi] : -1;
-  const float sq = a.scales[0], sk = a.scales[1], sv = a.scales[2];
-  const float c = a.scale_log2 * sq * sk;
+  float c = a.scale_log2 * a.scales[0] * a.scales[1];
+  float sv = a.scales[2];
+  // (as in the bf16 kernel: the waits for these global loads must land before the loop, whose only vector-memory traffic is the inline-asm DMA)
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[ks]));
+  asm volatile("" : "+v"(c), "+v"(sv));
+  if (HAS_SID) asm volatile("" : "+v"(sid_q));
 
   f32x16_t oT[DB];
 #pragma unroll
@@ -106,47 +108,28 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_fp8_kernel(Fp8Args a) {
     for (int r = 0; r < 16; ++r) oT[i][r] = 0.f;
   float m = -INFINITY, lsum = 0.f;
 
-  const uint8_t* kbase = a.k8 + rowbase * d + h * D;
-  const uint8_t* vbase = a.v8t + (long)bh * D * a.Lp;
+  const bf16_t* kbase = reinterpret_cast<const bf16_t*>(a.k8 + rowbase * d + h * D);     // row stride d bytes = d / 2 "bf16"
+  const uint8_t* vbase = a.v8t + (long)bh * D * a.Lp;                                     // row stride Lp bytes
+  const long kstride = d / 2, vstride = a.Lp / 2;
   const int nkv = (a.L + BKV8 - 1) / BKV8;
   int t_begin = 0, t_end = nkv, blk_id = -1;
   if (HAS_SID) doc_span8(a.doc_ranges, b, a.L, tile_x, nkv, t_begin, t_end, blk_id);
-
-  // staging: thread -> PPT 16-byte pieces of the K8 tile (row = key, D bytes) and of the V8T tile (row = d, 64 bytes)
-  uint4 kreg[PPT], vreg[PPT];
-  auto load_tile = [&](int t) {
-    const int kv0 = t * BKV8;
-#pragma unroll
-    for (int j = 0; j < PPT; ++j) {
-      const int p = tid * PPT + j;
-      const int krow = p / (D / 16), kslot = p % (D / 16);
-      kreg[j] = *reinterpret_cast<const uint4*>(kbase + (long)min(kv0 + krow, a.L - 1) * d + kslot * 16);
-      const int vrow = p / 4, vslot = p % 4;
-      vreg[j] = *reinterpret_cast<const uint4*>(vbase + (long)vrow * a.Lp + kv0 + vslot * 16);
-    }
-  };
-  auto store_tile = [&](int st) {
-    char* Ks = smem + st * (KT + VT);
-    char* Vs = Ks + KT;
-#pragma unroll
-    for (int j = 0; j < PPT; ++j) {
-      const int p = tid * PPT + j;
-      *reinterpret_cast<uint4*>(Ks + off8<D>(p / (D / 16), p % (D / 16))) = kreg[j];
-      *reinterpret_cast<uint4*>(Vs + off8<64>(p / 4, p % 4)) = vreg[j];
-    }
-  };
   if (t_begin < t_end) {
-    load_tile(t_begin);
-    store_tile(t_begin & 1);
+    StgK::issue(kbase, kstride, t_begin * BKV8, a.L, smem + (t_begin & 1) * KT, wave, lane);
+    StgV::issue(reinterpret_cast<const bf16_t*>(vbase + t_begin * BKV8), vstride, 0, D, smem + 2 * KT + (t_begin & 1) * VT, wave, lane);
   }
   for (int t = t_begin; t < t_end; ++t) {
     const int kv0 = t * BKV8, st = t & 1;
-    const char* Ks = smem + st * (KT + VT);
-    const char* Vs = Ks + KT;
+    const char* Ks = smem + st * KT;
+    const char* Vs = smem + 2 * KT + st * VT;
     const bool id_test = HAS_SID && doc_needs_mask8(a.doc_ranges, b, a.L, t, blk_id);
     if (HAS_SID && tid < BKV8) sid_s[st][tid] = (kv0 + tid < a.L) ? a.sample_ids[rowbase + kv0 + tid] : -2;
-    __syncthreads();                       // stage st is complete; everybody is done with stage st^1 (tile t-1)
-    if (t + 1 < t_end) load_tile(t + 1);   // global loads in flight under this tile's MFMAs
+    wait_all_vmem();   // this wave's share of tile t has landed
+    __syncthreads();   // ... and everybody's; all waves are done with tile t-1, so its stage may be refilled
+    if (t + 1 < t_end) {
+      StgK::issue(kbase, kstride, kv0 + BKV8, a.L, smem + (st ^ 1) * KT, wave, lane);
+      StgV::issue(reinterpret_cast<const bf16_t*>(vbase + kv0 + BKV8), vstride, 0, D, smem + 2 * KT + (st ^ 1) * VT, wave, lane);
+    }
 
     f32x16_t sT[2];
 #pragma unroll
@@ -157,7 +140,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_fp8_kernel(Fp8Args a) {
     for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
       for (int f = 0; f < 2; ++f) {
-        const long kf = *reinterpret_cast<const long*>(Ks + off8<D>(f * 32 + l31, ks) + hi * 8);
+        const long kf = *reinterpret_cast<const long*>(Ks + tile_off<D / 2>(f * 32 + l31, ks) + hi * 8);
         sT[f] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(kf, qf[ks], sT[f], 0, 0, 0);
       }
     if (id_test || kv0 + BKV8 > a.L) {
@@ -189,27 +172,27 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_fp8_kernel(Fp8Args a) {
         for (int r = 0; r < 16; ++r) oT[i][r] *= alpha;
     }
     const float mc = (m == -INFINITY) ? 0.f : m * c;
-    float p[2][16];
     float psum = 0.f;
-#pragma unroll
-    for (int f = 0; f < 2; ++f)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float pv = __builtin_amdgcn_exp2f(sT[f][r] * c - mc);
-        psum += pv;
-        p[f][r] = pv * P_SCALE;
-      }
-    lsum += psum;
+    long pb[4];
 #pragma unroll
     for (int cc = 0; cc < 4; ++cc) {
-      const long pb = pack8_fp8(&p[cc >> 1][8 * (cc & 1)]);
+      float pq[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float pv = __builtin_amdgcn_exp2f(sT[cc >> 1][8 * (cc & 1) + j] * c - mc);
+        psum += pv;
+        pq[j] = pv * P_SCALE;
+      }
+      pb[cc] = pack8_fp8(pq);
+    }
+    lsum += psum;
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc)
 #pragma unroll
       for (int i = 0; i < DB; ++i) {
-        const long vt = *reinterpret_cast<const long*>(Vs + off8<64>(i * 32 + l31, cc) + hi * 8);
-        oT[i] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(vt, pb, oT[i], 0, 0, 0);
+        const long vt = *reinterpret_cast<const long*>(Vs + tile_off<32>(i * 32 + l31, cc) + hi * 8);
+        oT[i] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(vt, pb[cc], oT[i], 0, 0, 0);
       }
-    }
-    if (t + 1 < t_end) store_tile(st ^ 1);   // stage st^1 was last read in iteration t-1: every wave is past this iteration's barrier
   }
   const float ltot = lsum + __shfl_xor(lsum, 32, 64);
   const float inv = ltot > 0.f ? sv / (ltot * P_SCALE) : 0.f;
@@ -244,10 +227,16 @@ __global__ __launch_bounds__(256) void fp8_amax_kernel(const bf16_t* __restrict_
       for (int j = 0; j < 4; ++j) mx[s] = fmaxf(mx[s], fmaxf(fabsf(__uint_as_float(w[j] << 16)), fabsf(__uint_as_float(w[j] & 0xffff0000u))));
     }
   }
+  __shared__ float red[3][4];
 #pragma unroll
   for (int s = 0; s < 3; ++s) {
     const float r = wave_max(mx[s]);
-    if ((threadIdx.x & 63) == 0) atomicMax(amax + s, __float_as_uint(r));
+    if ((threadIdx.x & 63) == 0) red[s][threadIdx.x >> 6] = r;
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) {   // one atomic per block and tensor: tens of thousands of same-address atomics cost more than the pass itself
+    const float r = fmaxf(fmaxf(red[threadIdx.x][0], red[threadIdx.x][1]), fmaxf(red[threadIdx.x][2], red[threadIdx.x][3]));
+    atomicMax(amax + threadIdx.x, __float_as_uint(r));
   }
 }
 
@@ -280,31 +269,43 @@ __global__ __launch_bounds__(256) void fp8_quant_qk_kernel(const bf16_t* __restr
   }
 }
 
-// v8t[bh][dd][Lp]: block = (bh, 64-key tile); keys of each 16-chunk stored as 0-3, 8-11, 4-7, 12-15; keys past L are zero
+// v8t[bh][dd][Lp]: block = (bh, 64-key tile); keys of each 16-chunk stored as 0-3, 8-11, 4-7, 12-15 (groups of 4 stay together); keys past L are
+// zero.  A thread takes 4 consecutive keys x 8 head dims, quantises, transposes the 4 x 8 bytes in registers and writes 8 dwords (4 keys of one dim).
 template <int D>
 __global__ __launch_bounds__(256) void fp8_quant_vt_kernel(const bf16_t* __restrict__ v, long vs, int B, int H, int L, int Lp, const float* __restrict__ scales,
                                                           uint8_t* __restrict__ v8t) {
-  __shared__ uint8_t tile[D][64 + 4];
+  __shared__ __attribute__((aligned(16))) uint8_t tile[D][64 + 4];
   const int ntile = Lp / 64;
   const int bh = blockIdx.x / ntile, t = blockIdx.x % ntile;
   const int b = bh / H, h = bh % H;
   const float iv = 1.0f / scales[2];
   constexpr int VPR = D / 8;   // 16-byte vectors per key row
-  for (int i = threadIdx.x; i < 64 * VPR; i += 256) {
-    const int key = i / VPR, c8 = (i % VPR) * 8;
-    const int l = t * 64 + key;
-    uint2 r = make_uint2(0u, 0u);
-    if (l < L) r = quant8(*reinterpret_cast<const uint4*>(v + ((long)b * L + l) * vs + h * D + c8), iv);
-    const int j = key & 15;
-    const int pos = (key & ~15) + ((j & 3) | ((j & 8) >> 1) | ((j & 4) << 1));   // 0-3 -> 0-3, 8-11 -> 4-7, 4-7 -> 8-11, 12-15 -> 12-15
-    const uint32_t w[2] = {r.x, r.y};
+  for (int i = threadIdx.x; i < 16 * VPR; i += 256) {
+    const int kg = i / VPR, c8 = (i % VPR) * 8;   // key group (4 keys), first head dim
+    uint32_t w[4][2];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) tile[c8 + e][pos] = (uint8_t)(w[e >> 2] >> (8 * (e & 3)));
+    for (int kk = 0; kk < 4; ++kk) {
+      const int l = t * 64 + kg * 4 + kk;
+      uint2 r = make_uint2(0u, 0u);
+      if (l < L) r = quant8(*reinterpret_cast<const uint4*>(v + ((long)b * L + l) * vs + h * D + c8), iv);
+      w[kk][0] = r.x; w[kk][1] = r.y;
+    }
+    const int g = kg & 3;                                              // group inside its 16-key chunk: 0, 1, 2, 3 -> stored 0, 2, 1, 3
+    const int pos = (kg & ~3) * 4 + (((g & 1) << 1) | (g >> 1)) * 4;   // byte position of the group inside the 64-key row
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int sh = 8 * (e & 3);
+      const uint32_t o = ((w[0][e >> 2] >> sh) & 0xffu) | (((w[1][e >> 2] >> sh) & 0xffu) << 8) | (((w[2][e >> 2] >> sh) & 0xffu) << 16) | (((w[3][e >> 2] >> sh) & 0xffu) << 24);
+      *reinterpret_cast<uint32_t*>(&tile[c8 + e][pos]) = o;
+    }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < D * 16; i += 256) {
-    const int dd = i / 16, w4 = (i % 16) * 4;
-    *reinterpret_cast<uint32_t*>(v8t + ((long)bh * D + dd) * Lp + t * 64 + w4) = *reinterpret_cast<const uint32_t*>(&tile[dd][w4]);
+  for (int i = threadIdx.x; i < D * 4; i += 256) {
+    const int dd = i / 4, w16 = (i % 4) * 16;
+    uint4 o;
+    o.x = *reinterpret_cast<const uint32_t*>(&tile[dd][w16]); o.y = *reinterpret_cast<const uint32_t*>(&tile[dd][w16 + 4]);
+    o.z = *reinterpret_cast<const uint32_t*>(&tile[dd][w16 + 8]); o.w = *reinterpret_cast<const uint32_t*>(&tile[dd][w16 + 12]);
+    *reinterpret_cast<uint4*>(v8t + ((long)bh * D + dd) * Lp + t * 64 + w16) = o;
   }
 }
 
@@ -318,7 +319,7 @@ extern "C" int udm_attention_quantize_fp8(const void* q, const void* k, const vo
   const long M = B * L;
   const int d = (int)(H * D), Lp = (int)((L + 63) / 64 * 64);
   if (hipMemsetAsync(amax_ws, 0, 3 * sizeof(uint32_t), stream) != hipSuccess) { udm_set_error("udm_attention_quantize_fp8: memset failed"); return 1; }
-  const int grid = (int)std::min<long>((M * (d / 8) + 255) / 256, 4096);
+  const int grid = (int)std::min<long>((M * (d / 8) + 255) / 256, 2048);
   hipLaunchKernelGGL(fp8_amax_kernel, dim3(grid), dim3(256), 0, stream, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (long)q_stride, (long)k_stride,
                      (long)v_stride, M, d, amax_ws);
   hipLaunchKernelGGL(fp8_scales_kernel, dim3(1), dim3(64), 0, stream, amax_ws, scales);
