@@ -191,6 +191,7 @@ def main():
     ap.add_argument("--workload", default="unidisc-1.4b-l1280", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: workload's)")
     ap.add_argument("--dropout", type=float, default=0.1, help="model.dropout (reference extra_large.yaml: 0.1)")
+    ap.add_argument("--fp8-attention", action="store_true", help="attention forward through the fp8 kernel (config E option; changes numerics, not the headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     args = ap.parse_args()
@@ -223,6 +224,7 @@ def main():
     seed = 42 + rank  # reference seeding: main.py:1058-1068
     torch.manual_seed(seed)
     cfg, diff = build(args.workload, device, args.dropout)
+    diff.backbone.fp8_attention = bool(args.fp8_attention)
     sync = None
     if world > 1:
         from unidisc_amd import ddp
@@ -272,7 +274,8 @@ def main():
         "value": value, "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "config": {"workload": w["desc"], "per_gpu_batch": B, "global_batch": B * world, "seq_len": L, "parallelism": f"dp{world}",
-                   "dropout": args.dropout, "weights": "random init (zero_linear_init=false)"},
+                   "dropout": args.dropout, "weights": "random init (zero_linear_init=false)",
+                   "attention_forward": "fp8 e4m3" if args.fp8_attention else "bf16"},
         "tokens_per_s_per_gpu": value / world, "loss": loss, "flops_per_token": f_tok,
         "step_mfu": (value / world) * f_tok / (PEAK_BF16_DENSE_TFLOPS * 1e12),
     }

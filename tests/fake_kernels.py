@@ -255,6 +255,14 @@ def attention_fwd(qkr, qkv, B, L, H, D, sample_ids=None, doc_ranges=None):
     return o.bfloat16(), torch.zeros(B, H, L)
 
 
+def attention_fwd_fp8(qkr, qkv, B, L, H, D, sample_ids=None, doc_ranges=None):
+    """Stand-in for the fp8 forward: per-tensor amax / 448 scales, round to e4m3, fp32 attention (P is not quantised here)."""
+    d = H * D
+    f8 = lambda t: (lambda s_: (t / s_).to(torch.float8_e4m3fn).float() * s_)(t.abs().max().clamp_min(1e-30) / 448.0)
+    o = _attn(f8(qkr[:, :d].float()), f8(qkr[:, d:].float()), f8(qkv[:, 2 * d:].float()), B, L, H, D, sample_ids)
+    return o.bfloat16(), torch.zeros(B, H, L)
+
+
 @torch.enable_grad()
 def attention_bwd(qkr, qkv, o, do, lse, dqkr, dqkv, B, L, H, D, sample_ids=None, doc_ranges=None):
     d = H * D

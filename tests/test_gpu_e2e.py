@@ -144,3 +144,46 @@ def test_subs_logprobs_forward_contract():
     finite = ref > -1e5
     assert torch.equal(lp.float().cpu() > -1e5, finite)
     assert torch.allclose(lp.float().cpu()[finite], ref[finite], atol=0.12, rtol=0.02)
+
+
+@pytest.mark.parametrize("heads", [12, 6])
+def test_fp8_attention_forward_training_step(heads):
+    """model.fp8_attention (BASELINE config E; no reference counterpart): the same step with the attention forward in fp8, at width 768 with head
+    dim 64 / 128 (the fp8 kernel's head dims), 2 blocks.  Stated tolerances against this repository's bf16 path on the same inputs: masks
+    bit-exact, loss 2e-2 relative, per-token nll 5e-2 rel-RMS, gradients 0.25 rel-RMS (forward e4m3 noise on q, k, v and P; the bf16 backward
+    reuses the fp8 forward's log-sum-exp)."""
+    case = dict(hidden_size=768, n_heads=heads, cond_dim=128, n_blocks=2, batch_size=2, txt_length=64, img_length=64, text_vocab_size=32001,
+                vocab_size=40193, norm_type="rms", qk_norm=True, sandwich_normalization=True, modality_embed=True, rope_2d=False,
+                time_conditioning=False, multimodal_batches=True, force_argmax_valid_indices=True, mask_entire_modality=0.1, softmin_snr=5,
+                text_loss_weight=1.0, img_loss_weight=None, force_full_attention_mask_loss_only=True)
+    from unidisc_amd import Diffusion
+
+    gen = torch.Generator().manual_seed(5)
+    B, Lt, Li = 2, 64, 64
+    batch = dict(txt_input_ids=torch.randint(0, 32000, (B, Lt), generator=gen, dtype=torch.int32),
+                 img_input_ids=torch.randint(0, 8192, (B, Li), generator=gen, dtype=torch.int32).to(torch.int16),
+                 txt_attention_mask=torch.ones(B, Lt, dtype=torch.bool))
+    res = []
+    for fp8 in (False, True):
+        torch.manual_seed(0)
+        diff = Diffusion(product_config(case), None, DEV)
+        diff.backbone.train()
+        diff.backbone.fp8_attention = fp8
+        diff.rng_device = "cpu"
+        wg = torch.Generator().manual_seed(7)
+        with torch.no_grad():
+            for n, p in sorted(diff.backbone.named_parameters()):
+                if n.endswith("linear.weight"):
+                    p.copy_((torch.randn(p.shape, generator=wg) / p.shape[-1] ** 0.5).to(DEV))
+        torch.manual_seed(123)
+        out = diff.training_step({k: v.clone() for k, v in batch.items()}, 1)
+        out.loss.backward()
+        torch.cuda.synchronize()
+        res.append((diff._last["xt"].cpu(), float(out.loss), out.nlls.detach().cpu(), {k: p.grad.cpu() for k, p in diff.backbone.named_parameters() if p.grad is not None}))
+    (x0, l0, n0, g0), (x1, l1, n1, g1) = res
+    assert torch.equal(x0, x1)
+    assert abs(l1 - l0) <= 2e-2 * abs(l0), (l0, l1)
+    assert rel_err(n1, n0) < 5e-2
+    assert l1 != l0                                             # the fp8 kernel really ran
+    bad = [(k, rel_err(g1[k], g0[k])) for k in g0 if rel_err(g1[k], g0[k]) > 0.25]
+    assert not bad, bad[:6]

@@ -196,6 +196,9 @@ class DIT(nn.Module, _HubMixin):
         self.txt_length, self.img_length, self.total_length = cfg_get(m, "txt_length"), cfg_get(m, "img_length"), cfg_get(m, "length")
         self.multimodal_batches = bool(cfg_get(tr, "multimodal_batches", False))
         self.rope_2d = bool(cfg_get(m, "rope_2d", False))
+        # BASELINE config E: attention FORWARD through the fp8 (e4m3) MFMA kernel (no reference counterpart).  The backward stays
+        # bf16 and reuses the forward's log-sum-exp, so gradients carry the forward's quantisation noise (tolerances in tests/test_gpu_e2e.py).
+        self.fp8_attention = bool(cfg_get(m, "fp8_attention", False))
         self.require_sample_ids = bool(cfg_get(data, "require_sample_ids", False))
         assert (self.txt_length + self.img_length == self.total_length) or self.multimodal_batches
         D = self.head_dim
@@ -526,7 +529,10 @@ class DIT(nn.Module, _HubMixin):
             qkr, qstats = K.qknorm_rope_fwd(qkv, cos, sin, L, D, gq=at.q_norm.weight.detach() if self.qk_norm else None,
                                             bq=at.q_norm.bias.detach() if self.qk_norm else None, gk=at.k_norm.weight.detach() if self.qk_norm else None,
                                             bk=at.k_norm.bias.detach() if self.qk_norm else None)
-            o, lse = K.attention_fwd(qkr, qkv, B, L, H, D, sid, S["doc_ranges"])
+            if self.fp8_attention:
+                o, lse = K.attention_fwd_fp8(qkr, qkv, B, L, H, D, sid, S["doc_ranges"])
+            else:
+                o, lse = K.attention_fwd(qkr, qkv, B, L, H, D, sid, S["doc_ranges"])
             a_out = K.gemm_nt(o, lin[f"{i}.out"].w16, N=d)
             # Without adaLN the next pre-norm is unmodulated and is fused into the residual add (x_out is normalised while in registers)
             fuse_w2 = None if tc else blk.norm2.weight.detach()
