@@ -84,3 +84,34 @@ def test_masked_row_head_compaction_is_exact(name, fake_k):
     assert set(g0) == set(g1)
     for k in g0:
         assert torch.allclose(g0[k], g1[k], rtol=1e-5, atol=1e-7), k
+
+
+def test_val_and_test_prefixes_update_attached_metrics(fake_k):
+    """model.py:1163-1171: prefix 'val' / 'test' feed (nlls, token_mask) - and the per-modality pairs - to the metric collections on the trainer."""
+    class Mean:
+        def __init__(self):
+            self.s, self.n = 0.0, 0.0
+
+        def update(self, value, weight):
+            self.s += float((value * weight).sum())
+            self.n += float(weight.sum())
+
+    g = Golden("c_large")
+    diff = build_product(g, device="cpu")
+    diff.rng_device = "cpu"
+    with pytest.raises(RuntimeError):
+        diff.compute_loss(diff.update_batch(g.batch()), prefix="val")
+    diff.valid_metrics, diff.valid_txt_metrics, diff.valid_img_metrics, diff.test_metrics = Mean(), Mean(), Mean(), Mean()
+    torch.manual_seed(g.case["step_seed"])
+    ref = diff.training_step(g.batch(), 1)
+    torch.manual_seed(g.case["step_seed"])
+    with torch.no_grad():
+        assert diff.compute_loss(diff.update_batch(g.batch()), prefix="val") is None
+    assert diff.valid_metrics.n == float(ref.token_mask.sum()) and abs(diff.valid_metrics.s - float((ref.nlls * ref.token_mask).sum())) < 1e-3
+    assert abs(diff.valid_txt_metrics.s + diff.valid_img_metrics.s - diff.valid_metrics.s) < 1e-3
+    torch.manual_seed(g.case["step_seed"])
+    with torch.no_grad():
+        diff.compute_loss(diff.update_batch(g.batch()), prefix="test")
+    assert diff.test_metrics.n == diff.valid_metrics.n
+    with pytest.raises(ValueError):
+        diff.compute_loss(diff.update_batch(g.batch()), prefix="bogus")

@@ -683,7 +683,22 @@ class Diffusion:
         losses = Loss(loss=loss_dict["loss"], img_loss=loss_dict.get("img_loss", 0), txt_loss=loss_dict.get("txt_loss", 0), nlls=std_nlls,
                       txt_nlls=loss_dict.get("std_txt_loss", 0), img_nlls=loss_dict.get("std_img_loss", 0), token_mask=attention_mask,
                       modality_mask=modality_mask, extra_losses=loss_dict.get("extra_losses", None))
+        if cfg_get(tr, "disable_torchmetrics", False):
+            raise NotImplementedError("Torchmetrics disabled")
         if prefix == "train":
             return losses
-        raise NotImplementedError(f"unidisc_amd.compute_loss: prefix={prefix!r} drives torchmetrics bookkeeping, which is outside the hot path; "
-                                  "call with prefix='train' and feed Loss.nlls / Loss.token_mask to your metrics")
+        # model.py:1163-1171: validation / test update the metric collections the trainer attached (any object with .update(values, mask))
+        if prefix == "val":
+            if getattr(self, "valid_metrics", None) is None:
+                raise RuntimeError("unidisc_amd.compute_loss(prefix='val'): attach `valid_metrics` (and optionally `valid_txt_metrics` / `valid_img_metrics`) first")
+            self.valid_metrics.update(losses.nlls, losses.token_mask)
+            if getattr(self, "valid_txt_metrics", None) is not None:
+                self.valid_txt_metrics.update(losses.txt_nlls, losses.modality_mask[..., 0] & losses.token_mask)
+                self.valid_img_metrics.update(losses.img_nlls, losses.modality_mask[..., 1] & losses.token_mask)
+            return None
+        if prefix == "test":
+            if getattr(self, "test_metrics", None) is None:
+                raise RuntimeError("unidisc_amd.compute_loss(prefix='test'): attach `test_metrics` first")
+            self.test_metrics.update(losses.nlls, losses.token_mask)
+            return None
+        raise ValueError(f"Invalid prefix: {prefix}")
