@@ -99,10 +99,11 @@ int udm_qknorm_rope_bwd(const void* dqkr, const void* qkv, void* dqkv, const flo
 /* ---- attention core: flash_attn_qkvpacked_func models/dit.py:843 / SDPA :826-829 / FlexAttention doc mask :784-812
  * bidirectional softmax(QKᵀ/√D)V; element (b,l,h,:) of a tensor lives at base + (b*L+l)*stride + h*D.
  * sample_ids [B,L] (or NULL): attend iff ids equal and != -1 (model_utils.py:740-771).  lse/delta fp32 [B,H,L].
- * doc_ranges int32 [B, ceil(L/64), 4] (or NULL), from udm_attention_doc_ranges on the same sample_ids: per 64-row tile {lo, hi, idmin, idmax} - the
- * [lo, hi) span of positions that can share a sample id with the tile, so the kernels walk only those tiles, and the tile's id interval (idmin = -1
+ * doc_ranges int32 [B, ceil(L/64), 8] (or NULL), from udm_attention_doc_ranges on the same sample_ids: per 64-row tile {lo, hi, idmin, idmax, exact, 0, 0, 0}
+ * - the [lo, hi) span of positions that can share a sample id with the tile, so the kernels walk only those tiles; the tile's id interval (idmin = -1
  * when it holds padding), so that tile pairs inside one document skip the per-element id test (FlexAttention's BlockMask does both: empty / full /
- * partial blocks, model_utils.py:716-771); results are identical with and without it. */
+ * partial blocks, model_utils.py:716-771); exact = the tile's one document occupies exactly [lo, hi) (such key blocks take the wave-specialised dK/dV
+ * kernel).  The forward and dQ are bit-identical with and without it; dK/dV agree to summation order at head dim 128. */
 int udm_attention_doc_ranges(const int64_t* sample_ids, int64_t B, int64_t L, int32_t* ranges, hipStream_t stream);
 int udm_attention_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const int64_t* sample_ids, const int32_t* doc_ranges, int64_t B, int64_t H, int64_t L, int64_t D,
                       int64_t q_stride, int64_t k_stride, int64_t v_stride, int64_t o_stride, hipStream_t stream);

@@ -236,7 +236,7 @@ def _attn(q, k, v, B, L, H, D, sid):
 def attention_doc_ranges(sample_ids):
     B, L = sample_ids.shape
     nT = (L + 63) // 64
-    r = torch.zeros(B, nT, 4, dtype=torch.int32)
+    r = torch.zeros(B, nT, 8, dtype=torch.int32)
     for b in range(B):
         for t in range(nT):
             tile = sample_ids[b, t * 64:(t + 1) * 64]
@@ -246,6 +246,7 @@ def attention_doc_ranges(sample_ids):
                 hit = ((sample_ids[b] >= ids.min()) & (sample_ids[b] <= ids.max())).nonzero().flatten()
                 r[b, t, 0], r[b, t, 1] = int(hit[0]), int(hit[-1]) + 1
                 r[b, t, 2], r[b, t, 3] = (int(ids.min()) if ids.numel() == tile.numel() else -1), int(ids.max())
+                r[b, t, 4] = int(r[b, t, 2] >= 0 and r[b, t, 2] == r[b, t, 3] and hit.numel() == int(hit[-1]) + 1 - int(hit[0]))
     return r
 
 

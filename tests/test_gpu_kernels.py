@@ -424,6 +424,12 @@ def _doc_layouts(B, L):
     pad[0] = -1                                                     # a whole row of padding
     pad[B - 1, L // 2:L // 2 + 70] = -1                             # padding in the middle of a row (whole 64-tile of padding when L is large)
     out["padding"] = pad
+    if L >= 512:                                                    # documents that start and end on 128-row block boundaries, then a padding tail
+        al = torch.full((B, L), -1, dtype=torch.int64)
+        n = (L // 128) * 128
+        al[:, :n] = (torch.arange(n) // 256)[None]
+        al[B - 1, n - 128:n] = -1
+        out["aligned"] = al
     return out
 
 
@@ -454,7 +460,10 @@ def test_attention_tile_skipping_is_exact(K, D, H, L):
         g0 = K.attention_bwd_generic(g(q), g(k), g(v), o0, g(do), lse0, B, L, H, D, sd)
         g1 = K.attention_bwd_generic(g(q), g(k), g(v), o1, g(do), lse1, B, L, H, D, sd, r)
         for a, b_, nm in zip(g0, g1, "qkv"):
-            assert torch.equal(a, b_), (name, nm)
+            if D == 128 and nm != "q":   # document-pure key blocks take the wave-specialised dK/dV kernel: same math, another summation order
+                assert rel_err(a.float(), b_.float()) < 4e-3, (name, nm)
+            else:
+                assert torch.equal(a, b_), (name, nm)
         o_r, dq_r, dk_r, dv_r = _attn_ref(q, k, v, B, L, H, D, sid, do)
         assert rel_err(o1.float().cpu(), o_r) < 1e-2, name
         for a, b_, nm in zip(g1, (dq_r, dk_r, dv_r), "qkv"):

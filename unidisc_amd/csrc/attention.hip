@@ -22,48 +22,9 @@ namespace {
 constexpr int BQ = 128;   // query rows per block (4 waves x 32)
 constexpr int BKV = 64;   // keys per tile
 
-// Document masks (packed samples): a 128-row block only has to walk the 64-row tiles of the other side that can hold one of its sample ids.
-// `doc_ranges` (udm_attention_doc_ranges) gives, per 64-row tile, {lo, hi, idmin, idmax}: the [lo, hi) span of positions whose id lies inside the
-// tile's [idmin, idmax] of valid ids (lo = hi = 0 for a tile of padding only), and that id interval itself - with idmin = -1 when the tile holds
-// any padding, so that idmin == idmax >= 0 means "every row of this tile belongs to the one document idmin".  The span is conservative for any id
-// layout and exact for contiguous documents.  A tile pair that is uniform on both sides with the same id needs no per-element id test; every other
-// pair keeps it, so neither skipping tiles nor skipping the test changes a result.
-struct DocSpan {
-  int t_begin, t_end;   // tiles of the other side to walk
-  int blk_id;           // the one document all rows of this 128-row block belong to, or -1
-};
-__device__ __forceinline__ DocSpan doc_tile_span(const int* doc_ranges, int b, int L, int blk128, int ntiles) {
-  DocSpan d{0, ntiles, -1};
-  if (doc_ranges == nullptr) return d;
-  const int nT = (L + 63) / 64;
-  int lo = L, hi = 0, id = -2;
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int t = blk128 * 2 + j;
-    if (t < nT) {
-      const int4 r = *reinterpret_cast<const int4*>(doc_ranges + ((long)b * nT + t) * 4);
-      if (r.y > r.x) { lo = min(lo, r.x); hi = max(hi, r.y); }
-      const int tid_ = (r.z == r.w) ? r.z : -1;
-      id = (id == -2 || id == tid_) ? tid_ : -1;
-    }
-  }
-  d.blk_id = __builtin_amdgcn_readfirstlane(id < 0 ? -1 : id);
-  if (hi <= lo) { d.t_begin = 0; d.t_end = 0; return d; }
-  d.t_begin = __builtin_amdgcn_readfirstlane(lo / 64);
-  d.t_end = __builtin_amdgcn_readfirstlane((hi + 63) / 64);
-  return d;
-}
-// does the pair (this block, tile t of the other side) need the per-element id test?
-__device__ __forceinline__ bool doc_pair_needs_mask(const int* doc_ranges, int b, int L, int t, int blk_id) {
-  if (doc_ranges == nullptr || blk_id < 0) return true;
-  const int nT = (L + 63) / 64;
-  const int2 r = *reinterpret_cast<const int2*>(doc_ranges + ((long)b * nT + t) * 4 + 2);
-  return !(r.x == blk_id && r.y == blk_id);
-}
-
 __global__ __launch_bounds__(256) void attn_doc_ranges_kernel(const int64_t* __restrict__ sid, int* __restrict__ ranges, int L) {
   __shared__ long s_mn[4], s_mx[4];
-  __shared__ int s_lo[4], s_hi[4], s_pad;
+  __shared__ int s_lo[4], s_hi[4], s_cnt[4], s_pad;
   const int nT = (L + 63) / 64;
   const int b = blockIdx.x / nT, t = blockIdx.x % nT, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t* row = sid + (long)b * L;
@@ -82,17 +43,18 @@ __global__ __launch_bounds__(256) void attn_doc_ranges_kernel(const int64_t* __r
   __syncthreads();
   mn = s_mn[0];   // only wave 0 read ids
   mx = s_mx[0];
-  int lo = L, hi = 0;
+  int lo = L, hi = 0, cnt = 0;
   if (mx >= 0)
     for (int j = tid; j < L; j += 256) {
       const long v = row[j];
-      if (v >= mn && v <= mx) { lo = min(lo, j); hi = max(hi, j + 1); }
+      if (v >= mn && v <= mx) { lo = min(lo, j); hi = max(hi, j + 1); ++cnt; }
     }
   for (int off = 32; off; off >>= 1) {
     lo = min(lo, __shfl_xor(lo, off, 64));
     hi = max(hi, __shfl_xor(hi, off, 64));
+    cnt += __shfl_xor(cnt, off, 64);
   }
-  if (lane == 0) { s_lo[wave] = lo; s_hi[wave] = hi; }
+  if (lane == 0) { s_lo[wave] = lo; s_hi[wave] = hi; s_cnt[wave] = cnt; }
   __syncthreads();
   if (tid == 0) {
     lo = min(min(s_lo[0], s_lo[1]), min(s_lo[2], s_lo[3]));
@@ -103,7 +65,12 @@ __global__ __launch_bounds__(256) void attn_doc_ranges_kernel(const int64_t* __r
     r.x = lo; r.y = hi;
     r.z = (small && !s_pad) ? (int)mn : -1;
     r.w = small ? (int)mx : -2;
-    *reinterpret_cast<int4*>(ranges + ((long)b * nT + t) * 4) = r;
+    // exact: one document (no padding in the tile) whose rows are exactly the positions [lo, hi) - nothing of another id in between
+    const int cnt_all = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+    const int exact = (r.z >= 0 && r.z == r.w && cnt_all == hi - lo) ? 1 : 0;
+    int* out = ranges + ((long)b * nT + t) * DOC_STRIDE;
+    *reinterpret_cast<int4*>(out) = r;
+    *reinterpret_cast<int4*>(out + 4) = make_int4(exact, 0, 0, 0);
   }
 }
 
@@ -486,7 +453,11 @@ __global__ __launch_bounds__(256, WAVES) void attn_bwd_dkv_kernel(AttnArgs a) {
   using Stg = DmaStager<D, BQT>;
   const int nq = (a.L + BQT - 1) / BQT;
   int t_begin = 0, t_end = nq, blk_id = -1;
-  if (HAS_SID) { const DocSpan sp = doc_tile_span(a.doc_ranges, b, a.L, tile_x, nq); t_begin = sp.t_begin; t_end = sp.t_end; blk_id = sp.blk_id; }
+  if (HAS_SID) {
+    const DocSpan sp = doc_tile_span(a.doc_ranges, b, a.L, tile_x, nq);
+    if (sp.pure && a.doc_pure_split) return;   // block-uniform: this key block belongs to attn_bwd_dkv_ws_kernel (launched beside this one)
+    t_begin = sp.t_begin; t_end = sp.t_end; blk_id = sp.blk_id;
+  }
   if (t_begin < t_end) {
     Stg::issue(qbase, a.q_stride, t_begin * BQT, a.L, smem + (t_begin & 1) * TB, wave, lane);
     Stg::issue(dobase, a.do_stride, t_begin * BQT, a.L, smem + (2 + (t_begin & 1)) * TB, wave, lane);
@@ -617,7 +588,14 @@ void launch_bwd(const AttnArgs& a, hipStream_t s) {
   if (!once) { set_lds(kq, lds_q); set_lds(kk, lds_k); once = true; }
   hipLaunchKernelGGL(kq, gq, dim3(256), lds_q, s, a);
   if (D == 128 && !SID && TR && g_dkv_ws) udm_launch_attn_bwd_dkv_ws(&a, s);
-  else hipLaunchKernelGGL(kk, gk, dim3(256), lds_k, s, a);
+  else if (D == 128 && SID && TR && g_dkv_ws && a.doc_ranges) {
+    // packed documents: key blocks that lie inside one document and whose query span is exactly that document go to the wave-specialised
+    // kernel (no id test needed anywhere); the blocks at document boundaries / with padding stay with the single-role kernel
+    AttnArgs a2 = a;
+    a2.doc_pure_split = 1;
+    udm_launch_attn_bwd_dkv_ws(&a2, s);
+    hipLaunchKernelGGL(kk, gk, dim3(256), lds_k, s, a2);
+  } else hipLaunchKernelGGL(kk, gk, dim3(256), lds_k, s, a);
 }
 
 #define ATTN_DISPATCH(FN, a, D, sid, tr, s)                                    \

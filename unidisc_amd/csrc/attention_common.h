@@ -68,12 +68,59 @@ struct AttnArgs {
   float* lse;           // [B,H,L] log2-domain log-sum-exp of scaled scores
   const float* delta;   // [B,H,L] rowsum(dO * O)
   const int64_t* sample_ids;  // [B,L] or null
-  const int* doc_ranges;      // [B, ceil(L/64), 2] or null: per 64-row tile, the [lo, hi) span of positions whose sample id can match one of the tile's
+  const int* doc_ranges;      // [B, ceil(L/64), 8] or null: per 64-row tile {lo, hi, idmin, idmax, exact, -, -, -} (udm_attention_doc_ranges)
+  int doc_pure_split;         // dK/dV with documents: 1 = document-pure key blocks are computed by the wave-specialised kernel, the rest by the other
   long q_stride, k_stride, v_stride, o_stride, do_stride, out_stride, out2_stride, out3_stride;
   int B, H, L;
   float scale_log2;     // log2(e) / sqrt(D)
   float scale;          // 1 / sqrt(D)
 };
+
+constexpr int DOC_STRIDE = 8;   // ints per tile in doc_ranges: {lo, hi, idmin, idmax, exact, 0, 0, 0}
+// Document masks (packed samples): a 128-row block only has to walk the 64-row tiles of the other side that can hold one of its sample ids.
+// `doc_ranges` (udm_attention_doc_ranges) gives, per 64-row tile, {lo, hi, idmin, idmax, exact}: the [lo, hi) span of positions whose id lies inside the
+// tile's [idmin, idmax] of valid ids (lo = hi = 0 for a tile of padding only), and that id interval itself - with idmin = -1 when the tile holds
+// any padding, so that idmin == idmax >= 0 means "every row of this tile belongs to the one document idmin".  The span is conservative for any id
+// layout and exact for contiguous documents.  A tile pair that is uniform on both sides with the same id needs no per-element id test; every other
+// pair keeps it, so neither skipping tiles nor skipping the test changes a result.
+struct DocSpan {
+  int t_begin, t_end;   // tiles of the other side to walk
+  int blk_id;           // the one document all rows of this 128-row block belong to, or -1
+  int lo, hi;           // the same span in positions
+  bool pure;            // blk_id >= 0 and every position of [lo, hi) belongs to that document: no per-element test anywhere in the block's walk
+};
+__device__ __forceinline__ DocSpan doc_tile_span(const int* doc_ranges, int b, int L, int blk128, int ntiles) {
+  DocSpan d{0, ntiles, -1, 0, L, false};
+  if (doc_ranges == nullptr) return d;
+  const int nT = (L + 63) / 64;
+  int lo = L, hi = 0, id = -2, exact = 1;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int t = blk128 * 2 + j;
+    if (t < nT) {
+      const int4 r = *reinterpret_cast<const int4*>(doc_ranges + ((long)b * nT + t) * DOC_STRIDE);
+      if (r.y > r.x) { lo = min(lo, r.x); hi = max(hi, r.y); }
+      const int tid_ = (r.z == r.w) ? r.z : -1;
+      id = (id == -2 || id == tid_) ? tid_ : -1;
+      exact &= doc_ranges[((long)b * nT + t) * DOC_STRIDE + 4];
+    }
+  }
+  d.blk_id = __builtin_amdgcn_readfirstlane(id < 0 ? -1 : id);
+  if (hi <= lo) { d.t_begin = 0; d.t_end = 0; d.lo = 0; d.hi = 0; return d; }
+  d.lo = __builtin_amdgcn_readfirstlane(lo);
+  d.hi = __builtin_amdgcn_readfirstlane(hi);
+  d.t_begin = d.lo / 64;
+  d.t_end = (d.hi + 63) / 64;
+  d.pure = d.blk_id >= 0 && __builtin_amdgcn_readfirstlane(exact) != 0;
+  return d;
+}
+// does the pair (this block, tile t of the other side) need the per-element id test?
+__device__ __forceinline__ bool doc_pair_needs_mask(const int* doc_ranges, int b, int L, int t, int blk_id) {
+  if (doc_ranges == nullptr || blk_id < 0) return true;
+  const int nT = (L + 63) / 64;
+  const int2 r = *reinterpret_cast<const int2*>(doc_ranges + ((long)b * nT + t) * DOC_STRIDE + 2);
+  return !(r.x == blk_id && r.y == blk_id);
+}
 
 // stage a [ROWS][D] bf16 tile with LDS-DMA (global_load_lds_dwordx4: no VGPR round trip, no ds_write).  One wave
 // instruction moves 1 KiB = 1024/(2D) rows; lane i lands at +16*i, so the XOR swizzle is applied on the per-lane SOURCE

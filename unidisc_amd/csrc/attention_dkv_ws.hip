@@ -1,4 +1,4 @@
-// Attention backward, dK/dV, head dim 128, no document mask: WAVE-SPECIALISED kernel, two waves per SIMD with different roles.
+// Attention backward, dK/dV, head dim 128, no document mask or document-pure key blocks: WAVE-SPECIALISED kernel, two waves per SIMD with different roles.
 // (reference: the backward of flash_attn_qkvpacked_func / SDPA, models/dit.py:826-829, :843)
 //
 // Why: both accumulators dK^T, dV^T (128 registers) plus the K/V operands (64) only fit ONE wave per SIMD when one wave does the
@@ -224,14 +224,24 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_ws_kernel(AttnArgs a) {
   const bool k_ok = ki < a.L;
   const long rowbase = (long)b * a.L;
   const long sbase = ((long)b * a.H + h) * a.L;
+  // Packed documents (a.doc_ranges, launched by attention.hip::launch_bwd beside the single-role kernel): this kernel takes the key blocks that lie
+  // inside ONE document whose rows are exactly the positions [lo, hi) - then no (query, key) pair of the walk needs an id test, and the walk is this
+  // kernel's ordinary one over the `hi - lo` queries starting at `lo`.  Every other key block returns here and is computed by the other kernel.
+  int q_lo = 0, q_n = a.L;
+  if (a.doc_ranges != nullptr) {
+    const DocSpan sp = doc_tile_span(a.doc_ranges, b, a.L, tile_x, (a.L + 63) / 64);
+    if (!sp.pure) return;   // block-uniform
+    q_lo = sp.lo;
+    q_n = sp.hi - sp.lo;
+  }
 
   Ctx x;
-  x.qb16 = a.q + rowbase * a.q_stride + h * D; x.ob16 = a.dout + rowbase * a.do_stride + h * D;
+  x.qb16 = a.q + (rowbase + q_lo) * a.q_stride + h * D; x.ob16 = a.dout + (rowbase + q_lo) * a.do_stride + h * D;
   x.qbase = reinterpret_cast<const char*>(x.qb16); x.dobase = reinterpret_cast<const char*>(x.ob16);
   x.q_stride = a.q_stride; x.do_stride = a.do_stride;
   x.qstep = (long)SUB * a.q_stride * 2; x.ostep = (long)SUB * a.do_stride * 2;
-  x.ldp = (lane < 32 ? a.lse : a.delta) + sbase + l31;
-  x.L = a.L; x.nsub = (a.L + SUB - 1) / SUB; x.wave = wave; x.lane = lane; x.c = a.scale_log2;
+  x.ldp = (lane < 32 ? a.lse : a.delta) + sbase + q_lo + l31;
+  x.L = q_n; x.nsub = (q_n + SUB - 1) / SUB; x.wave = wave; x.lane = lane; x.c = a.scale_log2;
   {
 #pragma unroll
     for (int jj = 0; jj < 2; ++jj) {

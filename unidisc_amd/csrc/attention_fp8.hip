@@ -41,34 +41,6 @@ __device__ __forceinline__ long pack8_fp8(const float* p) {
   return (long)(((unsigned long)(unsigned)hi << 32) | (unsigned)lo);
 }
 
-// (the document-range helpers of attention.hip, restated for this translation unit: same doc_ranges layout {lo, hi, idmin, idmax})
-__device__ __forceinline__ void doc_span8(const int* doc_ranges, int b, int L, int blk128, int ntiles, int& t_begin, int& t_end, int& blk_id) {
-  t_begin = 0; t_end = ntiles; blk_id = -1;
-  if (doc_ranges == nullptr) return;
-  const int nT = (L + 63) / 64;
-  int lo = L, hi = 0, id = -2;
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int t = blk128 * 2 + j;
-    if (t < nT) {
-      const int4 r = *reinterpret_cast<const int4*>(doc_ranges + ((long)b * nT + t) * 4);
-      if (r.y > r.x) { lo = min(lo, r.x); hi = max(hi, r.y); }
-      const int tid_ = (r.z == r.w) ? r.z : -1;
-      id = (id == -2 || id == tid_) ? tid_ : -1;
-    }
-  }
-  blk_id = __builtin_amdgcn_readfirstlane(id < 0 ? -1 : id);
-  if (hi <= lo) { t_begin = 0; t_end = 0; return; }
-  t_begin = __builtin_amdgcn_readfirstlane(lo / 64);
-  t_end = __builtin_amdgcn_readfirstlane((hi + 63) / 64);
-}
-__device__ __forceinline__ bool doc_needs_mask8(const int* doc_ranges, int b, int L, int t, int blk_id) {
-  if (doc_ranges == nullptr || blk_id < 0) return true;
-  const int nT = (L + 63) / 64;
-  const int2 r = *reinterpret_cast<const int2*>(doc_ranges + ((long)b * nT + t) * 4 + 2);
-  return !(r.x == blk_id && r.y == blk_id);
-}
-
 template <int D, bool HAS_SID>
 __global__ __launch_bounds__(256, 2) void attn_fwd_fp8_kernel(Fp8Args a) {
   constexpr int KS = D / 16, DB = D / 32;
@@ -113,7 +85,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_fp8_kernel(Fp8Args a) {
   const long kstride = d / 2, vstride = a.Lp / 2;
   const int nkv = (a.L + BKV8 - 1) / BKV8;
   int t_begin = 0, t_end = nkv, blk_id = -1;
-  if (HAS_SID) doc_span8(a.doc_ranges, b, a.L, tile_x, nkv, t_begin, t_end, blk_id);
+  if (HAS_SID) { const DocSpan sp = doc_tile_span(a.doc_ranges, b, a.L, tile_x, nkv); t_begin = sp.t_begin; t_end = sp.t_end; blk_id = sp.blk_id; }
   if (t_begin < t_end) {
     StgK::issue(kbase, kstride, t_begin * BKV8, a.L, smem + (t_begin & 1) * KT, wave, lane);
     StgV::issue(reinterpret_cast<const bf16_t*>(vbase + t_begin * BKV8), vstride, 0, D, smem + 2 * KT + (t_begin & 1) * VT, wave, lane);
@@ -122,7 +94,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_fp8_kernel(Fp8Args a) {
     const int kv0 = t * BKV8, st = t & 1;
     const char* Ks = smem + st * KT;
     const char* Vs = smem + 2 * KT + st * VT;
-    const bool id_test = HAS_SID && doc_needs_mask8(a.doc_ranges, b, a.L, t, blk_id);
+    const bool id_test = HAS_SID && doc_pair_needs_mask(a.doc_ranges, b, a.L, t, blk_id);
     if (HAS_SID && tid < BKV8) sid_s[st][tid] = (kv0 + tid < a.L) ? a.sample_ids[rowbase + kv0 + tid] : -2;
     wait_all_vmem();   // this wave's share of tile t has landed
     __syncthreads();   // ... and everybody's; all waves are done with tile t-1, so its stage may be refilled

@@ -321,10 +321,11 @@ def qknorm_rope_bwd(dqkr, qkv, dqkv, cos, sin, L, D, *, gq=None, gk=None, stats=
 
 
 def attention_doc_ranges(sample_ids):
-    """int32 [B, ceil(L/64), 4] = {lo, hi, idmin, idmax} per 64-row tile: the span of positions that can share a sample id with it (tile skipping
-    for packed samples) and the tile's id interval (idmin = -1 if it holds padding; idmin == idmax: one document, no per-element id test needed)."""
+    """int32 [B, ceil(L/64), 8] = {lo, hi, idmin, idmax, exact, 0, 0, 0} per 64-row tile: the span of positions that can share a sample id with it
+    (tile skipping for packed samples), the tile's id interval (idmin = -1 if it holds padding; idmin == idmax: one document, no per-element id
+    test needed) and whether that document's rows are exactly [lo, hi) (then its key blocks take the wave-specialised dK/dV kernel)."""
     B, L = sample_ids.shape
-    r = torch.empty((B, (L + 63) // 64, 4), dtype=torch.int32, device=sample_ids.device)
+    r = torch.empty((B, (L + 63) // 64, 8), dtype=torch.int32, device=sample_ids.device)
     _lib.call("udm_attention_doc_ranges", _p(sample_ids), B, L, _p(r), _s())
     return r
 
