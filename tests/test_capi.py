@@ -64,3 +64,20 @@ def test_state_dict_schema_matches_reference():
         sd = diff.backbone.state_dict()
         assert set(sd) == set(g.params()), name
         assert all(v.dtype == torch.float32 for v in sd.values())
+
+
+def test_bench_flops_per_token_match_survey():
+    """F_tok = 6 P_mm + 12 n L_att d -> 0.737 (UniDisc-S, L=384), 8.597 (1.4 B, L=1280), 8.522 GFLOP/token (interleaved, L_att=1152)."""
+    import importlib.util
+    import os
+
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert abs(bench.flops_per_token(12, 768, 40193, 384) / 1e9 - 0.737) < 1e-3
+    assert abs(bench.flops_per_token(24, 2048, 48385, 1280) / 1e9 - 8.597) < 1e-3
+    assert abs(bench.flops_per_token(24, 2048, 48385, 1152) / 1e9 - 8.522) < 1e-3
+    for name, w in bench.WORKLOADS.items():   # every workload names a configuration of BASELINE.json
+        assert w["desc"] and w["batch"] > 0 and w["txt_length"] + w["img_length"] > 0, name
+    b = bench.synthetic_batch("unidisc-1.4b-interleaved-l4608", 2, 0)
+    assert b["input_ids"].shape == (2, 4608) and int(b["sample_ids"].max()) == 3 and int((b["modality"] == 1).sum()) == 2 * 4096
