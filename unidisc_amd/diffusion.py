@@ -643,7 +643,7 @@ class Diffusion:
             loss_dict.update(dict(std_txt_loss=(std_loss.detach() * modality_mask[..., 0] * attention_mask),
                                   std_img_loss=(std_loss.detach() * modality_mask[..., 1] * attention_mask)))
         if cfg_get(tr, "mask_entire_modality", None) is not None and self.backbone.training:
-            loss_dict["batch_ignore_loss"] = ignore_batch_mask_for_metrics.squeeze(-1)
+            loss_dict["batch_ignore_loss"] = ignore_batch_mask_for_metrics.reshape(-1)  # (reference: .squeeze(-1), which breaks its own interleaved branch at B = 1)
         weighted = cfg_get(tr, "text_loss_weight", None) is not None and cfg_get(tr, "img_loss_weight", None) is not None
         if cfg_get(tr, "multimodal_batches", False) or weighted:
             txt_mask = modality_mask[..., 0] & attention_mask
