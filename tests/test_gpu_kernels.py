@@ -98,7 +98,8 @@ def test_gemm_tn_kmajor(K, Kc, M, N):
     assert torch.allclose(cs.cpu()[:M], a[:, :M].float().sum(0), atol=2e-3, rtol=1e-4)
 
 
-@pytest.mark.parametrize("Kc,M,N", [(10240, 2048, 2048), (2048, 512, 768), (4096, 256, 256), (256, 2048, 2048), (1024, 304, 264)])
+@pytest.mark.parametrize("Kc,M,N", [(10240, 2048, 2048), (2048, 512, 768), (4096, 256, 256), (256, 2048, 2048), (1024, 304, 264),
+                                    (24576, 768, 768), (24576, 3072, 768), (24576, 768, 2304), (6464, 520, 264)])  # UniDisc-S wgrads: 28 / 7 / 9 uneven slices
 def test_gemm_tn_splitk_workspace(K, Kc, M, N):
     """few tiles x long K: K split across CUs through a workspace + reduce pass (falls back to the plain kernel when it cannot split)."""
     a, b = bf(rnd(Kc, M, seed=93, scale=0.5)), bf(rnd(Kc, N, seed=94, scale=0.5))

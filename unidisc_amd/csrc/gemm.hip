@@ -788,8 +788,11 @@ extern "C" int udm_gemm_tn_splitk_bf16(const void* A, const void* B, void* C, in
   UDM_CHECK_ARG(M > 0 && N > 0 && K > 0 && K % 64 == 0, "udm_gemm_tn_splitk_bf16: K must be a positive multiple of 64 (got M=%ld N=%ld K=%ld)", (long)M, (long)N, (long)K);
   const long tiles = ((M + 255) / 256) * ((N + 255) / 256);
   const long nkt = K / 64;
-  int sk = 1;
-  while (tiles * sk * 2 <= 256 && nkt / (sk * 2) >= 16 && sk < 16) sk *= 2;
+  // as many slices as fill the 256 CUs once (any count: slices may be uneven), each at least 8 K tiles deep, at most 32
+  long skl = 256 / tiles;
+  if (skl > nkt / 8) skl = nkt / 8;
+  if (skl > 32) skl = 32;
+  const int sk = skl < 2 ? 1 : (int)skl;
   if (sk == 1 || !ws || ws_elems < (int64_t)sk * M * N || ldc != N || (M * N) % 4 != 0)
     return udm_gemm_tn_bf16(A, B, C, M, N, K, lda, ldb, ldc, beta, stream);
   UDM_CHECK_ARG(lda % 8 == 0 && ldb % 8 == 0 && lda >= M && ldb >= N, "udm_gemm_tn_splitk_bf16: lda/ldb must be multiples of 8 and cover the rows");

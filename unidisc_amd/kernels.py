@@ -97,9 +97,7 @@ def gemm_tn_splitk(a, b, out, *, M=None, N=None, beta=0.0):
     M = a.shape[1] if M is None else M
     N = b.shape[1] if N is None else N
     tiles = ((M + 255) // 256) * ((N + 255) // 256)
-    sk = 1
-    while tiles * sk * 2 <= 256 and (K // 64) // (sk * 2) >= 16 and sk < 16:
-        sk *= 2
+    sk = max(1, min(256 // tiles, (K // 64) // 8, 32))   # the rule of udm_gemm_tn_splitk_bf16 (sizes the workspace)
     ws = _scratch(sk * M * N, a.device) if sk > 1 else None
     _lib.call("udm_gemm_tn_splitk_bf16", _p(a), _p(b), _p(out), M, N, K, a.stride(0), b.stride(0), out.stride(0), float(beta), _p(ws),
               ws.numel() if ws is not None else 0, _s())
