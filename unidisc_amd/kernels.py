@@ -257,7 +257,7 @@ def norm_bwd(dy, x, rstd, mean, w, norm_type, L, dx, dw, *, accumulate=True, mod
     M, d = x.shape
     (shift, scale), ms = _mod_ptrs(mod, mod_idx, d)
     (dshift, dscale), _ = _mod_ptrs(dmod, mod_idx, d)
-    ws = _scratch(512 * d, x.device) if M >= 2048 else None
+    ws = _scratch(1024 * d, x.device) if M >= 2048 else None
     _lib.call("udm_norm_bwd", _p(dy), _p(x), _p(rstd), _p(mean), _p(w), shift, scale, ms, _p(modality) if mod is not None else None,
               _p(any_img) if mod is not None else None, _p(dx), _p(dw), dshift, dscale, M, d, L, norm_type, 1 if accumulate else 0,
               _p(ws), ws.numel() if ws is not None else 0, _s())
@@ -291,7 +291,7 @@ def residual_bwd(dx, branch, L, *, w_b=None, rstd=None, mean=None, norm_type=NOR
     use = gate_idx is not None and mod is not None
     (gate,), ms = _mod_ptrs(mod if use else None, (gate_idx,), d)
     (dgate,), _ = _mod_ptrs(dmod if use else None, (gate_idx,), d)
-    ws = _scratch(1536 * d, dx.device) if (w_b is not None and d >= 2048) else None
+    ws = _scratch(1536 * d, dx.device) if w_b is not None else None
     _lib.call("udm_residual_bwd", _p(dx), _p(branch), _p(dbranch), _p(w_b), _p(rstd), _p(mean), gate, ms, _p(modality), _p(dw_b), dgate, M, d, L,
               norm_type, float(p_drop), int(seed), _p(ws), ws.numel() if ws is not None else 0, _s())
     return dbranch
@@ -313,7 +313,7 @@ def qknorm_rope_bwd(dqkr, qkv, dqkv, cos, sin, L, D, *, gq=None, gk=None, stats=
     d = d3 // 3
     per_sample = 1 if cos.dim() == 3 else 0
     contig = gq is not None and dbq.data_ptr() == dgq.data_ptr() + 4 * d and dgk.data_ptr() == dgq.data_ptr() + 8 * d and dbk.data_ptr() == dgq.data_ptr() + 12 * d
-    ws = _scratch(4096 * d, qkv.device) if (contig and d >= 2048) else None
+    ws = _scratch(4096 * d, qkv.device) if contig else None
     _lib.call("udm_qknorm_rope_bwd", _p(dqkr), _p(qkv), _p(dqkv), _p(gq), _p(gk), _p(stats), _p(cos), _p(sin), per_sample, _p(dgq), _p(dbq), _p(dgk),
               _p(dbk), M, d, L, D, _p(ws), ws.numel() if ws is not None else 0, _s())
 
