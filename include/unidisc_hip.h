@@ -55,6 +55,7 @@ int udm_gemm_tn_bf16(const void* A, const void* B, void* C, int64_t M, int64_t N
 int udm_gemm_tn_splitk_bf16(const void* A, const void* B, void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, float beta,
                             float* ws, int64_t ws_elems, hipStream_t stream);
 int udm_gemm_set_tile(int tile); /* diagnostics: force the tile family (-1 auto, 0 = 128x128 kernel, 192/256/320 = BMx256 kernel) */
+int udm_gemm_set_persist(int enable); /* diagnostics: 0 = one block per output tile (default 1: persistent blocks for multi-round NT shapes) */
 /* out[C,R] = in[R,C]ᵀ (bf16); optional colsum[c] += Σ_r in[r,c] (bias gradient).  Feeds the wgrad GEMMs. */
 int udm_transpose_bf16(const void* in, void* out, int64_t R, int64_t C, int64_t ld_in, int64_t ld_out, float* colsum, hipStream_t stream);
 /* fp32 master weights -> bf16 shadow (and Kᵀ-major shadow for dgrad): the per-forward autocast weight cast. */

@@ -80,6 +80,45 @@ def test_gemm_large_tile_kernels(K, tile, M, N, K_):
         K.gemm_set_tile(-1)
 
 
+@pytest.mark.parametrize("M,N,K_", [(5120, 8192, 128), (5120, 8192, 192), (10240, 8192, 320), (2560, 6144, 256), (5120, 2304 + 256, 64 * 5)])
+def test_gemm_persistent_blocks_every_epilogue(K, M, N, K_):
+    """More than 256 whole tiles: 256 persistent blocks walk them, each staging the next output tile's first K tile from inside the last K
+    iteration (even and odd K-tile counts flip the stage parity between tiles), epilogue patches in the stage consumed last.  Every epilogue, and
+    bit-identical to the one-block-per-tile launch (UDM_GEMM_PERSIST=0 path via gemm_set_persist)."""
+    a, b, bias = bf(rnd(M, K_, seed=180, scale=0.5)), bf(rnd(N, K_, seed=181, scale=0.3)), rnd(N, seed=182)
+    acc = a.float() @ b.float().t()
+    ga, gb, gbias = a.to(DEV), b.to(DEV), bias.to(DEV)
+
+    def run_all():
+        out = K.gemm_nt(ga, gb, N=N)
+        o32 = K.gemm_nt(ga, gb, out_dtype=torch.float32, epilogue=K.EPI_BIAS, bias=gbias)
+        aux = torch.zeros((M, N), dtype=torch.bfloat16, device=DEV)
+        g = torch.zeros((M, N), dtype=torch.bfloat16, device=DEV)
+        K.gemm_nt(ga, gb, out=g, N=N, epilogue=K.EPI_BIAS_GELU, bias=gbias, aux=aux)
+        dg = torch.zeros((M, N), dtype=torch.bfloat16, device=DEV)
+        dbias = torch.zeros(N, dtype=torch.float32, device=DEV)
+        K.gemm_nt(ga, gb, out=dg, N=N, epilogue=K.EPI_DGELU, aux=aux, bias=dbias)
+        return out, o32, aux, g, dg, dbias
+
+    res_p = run_all()
+    K.gemm_set_persist(0)
+    try:
+        res_1 = run_all()
+    finally:
+        K.gemm_set_persist(1)
+    for x, y, name in zip(res_p[:5], res_1[:5], ("plain", "bias f32", "aux", "gelu", "dgelu")):
+        assert torch.equal(x, y), name
+    assert torch.allclose(res_p[5], res_1[5], rtol=1e-4, atol=1e-3)   # column sums are fp32 atomics: order differs
+    out, o32, aux, g, dg, dbias = res_p
+    assert rel_err(out.float().cpu(), acc) < 4e-3
+    assert rel_err(o32.cpu(), acc + bias) < 1e-5
+    u = (acc + bias).bfloat16().float().requires_grad_()
+    y = torch.nn.functional.gelu(u, approximate="tanh")
+    (gp,) = torch.autograd.grad(y.sum(), u)
+    assert rel_err(g.float().cpu(), y.detach()) < 6e-3 and rel_err(aux.float().cpu(), gp) < 6e-3
+    assert rel_err(dg.float().cpu(), acc * gp) < 8e-3
+
+
 @pytest.mark.parametrize("Kc,M,N", [(256, 192, 256), (1280, 2048, 2048), (128, 64, 200), (640, 1001, 328), (2560, 6144, 2048), (192, 320, 8192), (10240, 512, 512), (4096, 300, 260)])
 def test_gemm_tn_kmajor(K, Kc, M, N):
     """wgrad form C = A^T B with both operands K-major (transposing LDS reads), incl. ragged M/N and padded strides."""

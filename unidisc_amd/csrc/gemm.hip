@@ -340,7 +340,11 @@ __device__ __forceinline__ void glds16_asm(const void* gptr, const char* lds) {
 // form dW = dY^T X read straight from the row-major activations.  Tiles are staged as [64 k-rows][columns] and the
 // MFMA operands are gathered with ds_read_b64_tr_b16 transposing reads; rows are rotated by (k & 3) 64-byte
 // granules (applied on the LDS-DMA source address) so the four k-rows of one transposing read hit different banks.
-template <int BMX, int EPI, bool OUT_F32, bool TN, int KKPP = (TN ? 2 : 1)>  // KKPP = 16-deep k-steps per phase
+// PERSIST = true (NT form, whole tiles only, no split-K; grid = 256): a block walks its XCD's tiles instead of ending after one.  The last K
+// iteration of a tile stages the FIRST K tile of the block's next output tile (the slot where a lone tile harmlessly re-stages itself), the
+// epilogue's patches live in the stage that was consumed last, and the next main loop starts on data that is already in LDS: no block
+// dispatch, no cold first load, and the epilogue's stores drain under the next tile's MFMAs.
+template <int BMX, int EPI, bool OUT_F32, bool TN, int KKPP = (TN ? 2 : 1), bool PERSIST = false>  // KKPP = 16-deep k-steps per phase
 __global__ __launch_bounds__(512) void gemm_nt_stagger_kernel(GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int BNX = 256, WGM = 2, WGN = 4, NWAVES = 8;
@@ -352,23 +356,40 @@ __global__ __launch_bounds__(512) void gemm_nt_stagger_kernel(GemmArgs p) {
   constexpr int NPH = 4 / KKPP, ISSUE_PH = NPH > 2 ? 2 : 1, PER = (LOADS + ISSUE_PH - 1) / ISSUE_PH;
   static_assert(WM % 32 == 0 && (A_BYTES / 1024) % NWAVES == 0, "bad tile");
 
+  static_assert(!PERSIST || !TN, "the persistent form is built for the NT kernels");
   const int S = p.splitk > 1 ? p.splitk : 1;
   const int nwg = p.tiles_m * p.tiles_n;
-  int pid = xcd_remap(blockIdx.x, nwg * S);
-  const int slice = pid % S;  // slices of one tile are neighbours in the remapped order: same XCD, shared operand panels
-  pid /= S;
-  const int per_group = GROUP_M * p.tiles_n;
-  const int grp = pid / per_group, first_m = grp * GROUP_M;
-  const int gsz = min(p.tiles_m - first_m, GROUP_M);
-  const int tm = first_m + (pid % per_group) % gsz, tn = (pid % per_group) / gsz;
-  const int row0 = tm * BMX, col0 = tn * BNX;
-
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int late = __builtin_amdgcn_readfirstlane(wave >= NWAVES / 2 ? 1 : 0);
   const int wm = wave / WGN, wn = wave % WGN;
   const int l31 = lane & 31, hi = lane >> 5;
   const int lrow = lane >> 3, lslot = lane & 7;
+  const int per_group = GROUP_M * p.tiles_n;
+  int par = 0;           // PERSIST: stage that holds the first K tile of the current output tile
+  bool primed = false;   // PERSIST: ... and it is already there (staged by the previous output tile's last K iteration)
+  for (int wi = blockIdx.x;; wi += gridDim.x) {   // one pass unless PERSIST
+  int pid = xcd_remap(wi, nwg * S);
+  const int slice = pid % S;  // slices of one tile are neighbours in the remapped order: same XCD, shared operand panels
+  pid /= S;
+  const int grp = pid / per_group, first_m = grp * GROUP_M;
+  const int gsz = min(p.tiles_m - first_m, GROUP_M);
+  const int tm = first_m + (pid % per_group) % gsz, tn = (pid % per_group) / gsz;
+  const int row0 = tm * BMX, col0 = tn * BNX;
+  bool has_next = false;
+  long next_da = 0, next_db = 0;   // element offsets from this tile's operand rows to the next tile's (whole tiles: no clamping in src[])
+  if (PERSIST) {
+    const int wn_i = wi + gridDim.x;
+    has_next = wn_i < nwg;
+    if (has_next) {
+      const int pid2 = xcd_remap(wn_i, nwg);
+      const int grp2 = pid2 / per_group, first2 = grp2 * GROUP_M;
+      const int gsz2 = min(p.tiles_m - first2, GROUP_M);
+      const int tm2 = first2 + (pid2 % per_group) % gsz2, tn2 = (pid2 % per_group) / gsz2;
+      next_da = (long)(tm2 - tm) * BMX * p.lda;
+      next_db = (long)(tn2 - tn) * BNX * p.ldb;
+    }
+  }
   const bf16_t* src[LOADS];
   int dst[LOADS];
   constexpr int RB_A = BMX * 2, RB_B = BNX * 2, NG_A = RB_A / 64, NG_B = RB_B / 64;  // TN: row bytes / 64-byte granules per k-row
@@ -424,18 +445,20 @@ __global__ __launch_bounds__(512) void gemm_nt_stagger_kernel(GemmArgs p) {
 
   const int nk_all = p.K / BK;
   const int kt0 = (int)((long)nk_all * slice / S), nk = (int)((long)nk_all * (slice + 1) / S);
+  if (!(PERSIST && primed)) {
 #pragma unroll
-  for (int j = 0; j < LOADS; ++j) {
-    glds16_asm(src[j] + kt0 * (j < A_PW ? kstep_a : kstep_b), smem + dst[j] + (kt0 & 1) * STAGE_BYTES);
+    for (int j = 0; j < LOADS; ++j) {
+      glds16_asm(src[j] + kt0 * (j < A_PW ? kstep_a : kstep_b), smem + dst[j] + ((kt0 + par) & 1) * STAGE_BYTES);
+    }
+    wait_vmcnt<0>();
   }
-  wait_vmcnt<0>();
   __builtin_amdgcn_s_barrier();
   if (late) __builtin_amdgcn_s_barrier();
 
   for (int kt = kt0; kt < nk; ++kt) {
-    const char* As = smem + (kt & 1) * STAGE_BYTES;
+    const char* As = smem + ((kt + par) & 1) * STAGE_BYTES;
     const char* Bs = As + A_BYTES;
-    char* nxt = smem + ((kt + 1) & 1) * STAGE_BYTES;
+    char* nxt = smem + ((kt + 1 + par) & 1) * STAGE_BYTES;
     const bool more = kt + 1 < nk;
 #pragma unroll
     for (int ph = 0; ph < NPH; ++ph) {
@@ -480,6 +503,10 @@ __global__ __launch_bounds__(512) void gemm_nt_stagger_kernel(GemmArgs p) {
         // of the tile.  The waits that matter are the explicit ones.
         constexpr int NMF = KKPP * FM * FN, GAP = (NMF / PER) > 0 ? (NMF / PER) : 1;
         const long knext = more ? kt + 1 : kt;
+        // element offset of the refill's source from src[]: the next K tile; on the last K tile of a PERSIST block with another output tile
+        // to do, the first K tile of THAT tile (kt0 = 0 there); otherwise the lone tile re-stages itself
+        const long ref_a = (PERSIST && !more && has_next) ? next_da : knext * kstep_a;
+        const long ref_b = (PERSIST && !more && has_next) ? next_db : knext * kstep_b;
         int jd = ph * PER, cnt = 0;
 #pragma unroll
         for (int q = 0; q < KKPP; ++q)
@@ -491,13 +518,13 @@ __global__ __launch_bounds__(512) void gemm_nt_stagger_kernel(GemmArgs p) {
               ++cnt;
               if (ph < ISSUE_PH && ((cnt - 1) % GAP) == 0 && jd < (ph + 1) * PER && jd < LOADS) {
                 __builtin_amdgcn_sched_barrier(0);
-                glds16_asm(src[jd] + knext * (jd < A_PW ? kstep_a : kstep_b), nxt + dst[jd]);
+                glds16_asm(src[jd] + (jd < A_PW ? ref_a : ref_b), nxt + dst[jd]);
                 __builtin_amdgcn_sched_barrier(0);
                 ++jd;
               }
             }
 #pragma unroll
-        for (; jd < (ph + 1) * PER && jd < LOADS && ph < ISSUE_PH; ++jd) glds16_asm(src[jd] + knext * (jd < A_PW ? kstep_a : kstep_b), nxt + dst[jd]);
+        for (; jd < (ph + 1) * PER && jd < LOADS && ph < ISSUE_PH; ++jd) glds16_asm(src[jd] + (jd < A_PW ? ref_a : ref_b), nxt + dst[jd]);
       }
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();
@@ -508,7 +535,10 @@ __global__ __launch_bounds__(512) void gemm_nt_stagger_kernel(GemmArgs p) {
   __syncthreads();  // all LDS tile reads are done: the wave-private epilogue patches may overwrite stage memory
 
   // ---- epilogue ----
-  float* patch0 = reinterpret_cast<float*>(smem) + wave * 2048;  // two 32 x 32 fp32 patches per wave (ping-pong)
+  // two 32 x 32 fp32 patches per wave (ping-pong), 64 KiB per block.  PERSIST: inside the stage of the LAST K tile - the other stage already
+  // holds the next output tile's first K tile (needs 64 KiB <= STAGE_BYTES: BMX >= 256)
+  static_assert(!PERSIST || STAGE_BYTES >= NWAVES * 8192, "persistent form: the epilogue patches must fit one stage");
+  float* patch0 = reinterpret_cast<float*>(smem + (PERSIST ? ((nk - 1 + par) & 1) * STAGE_BYTES : 0)) + wave * 2048;
   const int er = lane >> 3, ec = (lane & 7) * 4;               // read side: this lane's row (within 8) and 4-column chunk
   const bool interior = (row0 + BMX <= p.M) && (col0 + BNX <= p.N) && (p.ldc % 4 == 0) && (EPI < UDM_EPI_BIAS_GELU || p.ldaux % 4 == 0);
   float bias4[FN][4];
@@ -625,7 +655,13 @@ __global__ __launch_bounds__(512) void gemm_nt_stagger_kernel(GemmArgs p) {
         if (er == 0) atomicAdd(colsum + col0 + wn * WN + j * 32 + ec + e, v);
       }
   }
+  if (!PERSIST || !has_next) break;
+  par = (nk + par) & 1;   // where the last K iteration put the next tile's first K tile
+  primed = true;
+  }  // output tiles of this block
 }
+
+int g_gemm_persist = 1;   // diagnostics (UDM_GEMM_PERSIST=0): 0 = one block per output tile everywhere
 
 template <int BMX, int EPI, bool OUT_F32, bool TN = false>
 int launch_big_t(const GemmArgs& a0, hipStream_t stream) {
@@ -638,6 +674,22 @@ int launch_big_t(const GemmArgs& a0, hipStream_t stream) {
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
+  }
+  if constexpr (!TN && BMX >= 256) {
+    // more than one round of whole tiles: 256 persistent blocks walk them (see PERSIST above)
+    static const bool env_once = [] { if (const char* e = getenv("UDM_GEMM_PERSIST")) g_gemm_persist = atoi(e); return true; }();
+    (void)env_once;
+    if (g_gemm_persist && a.splitk <= 1 && a.tiles_m * a.tiles_n > 256 && a.M % BMX == 0 && a.N % 256 == 0 && a.K / BK >= 2) {
+      auto kp = gemm_nt_stagger_kernel<BMX, EPI, OUT_F32, false, 1, true>;
+      static bool attr_p = false;
+      if (!attr_p) {
+        (void)hipFuncSetAttribute((const void*)kp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_p = true;
+      }
+      hipLaunchKernelGGL(kp, dim3(256), dim3(512), lds, stream, a);
+      UDM_CHECK_LAUNCH("udm_gemm_nt_bf16(big, persistent)");
+      return 0;
+    }
   }
   hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n * (a.splitk > 1 ? a.splitk : 1)), dim3(512), lds, stream, a);
   UDM_CHECK_LAUNCH("udm_gemm_nt_bf16(big)");
@@ -834,5 +886,10 @@ extern "C" int udm_cast_transpose_f32_bf16(const float* in, void* out, void* out
   dim3 grid((unsigned)((C + TT - 1) / TT), (unsigned)((R + TT - 1) / TT));
   hipLaunchKernelGGL(cast_transpose_kernel, grid, dim3(256), 0, stream, in, (bf16_t*)out, (bf16_t*)out_t, (int)R, (int)C, (long)ld_in, (long)ld_out, (long)ld_t);
   UDM_CHECK_LAUNCH("udm_cast_transpose_f32_bf16");
+  return 0;
+}
+
+extern "C" int udm_gemm_set_persist(int enable) {   // diagnostics / tests: 0 = one block per output tile everywhere
+  g_gemm_persist = enable ? 1 : 0;
   return 0;
 }

@@ -197,6 +197,10 @@ def colsum(x, out):
     return out
 
 
+def gemm_set_persist(enable: int):
+    _lib.call("udm_gemm_set_persist", int(enable))
+
+
 def gemm_set_tile(tile: int):
     """Diagnostics: force the GEMM tile family (-1 auto, 0 small kernel, 192/256/320)."""
     _lib.call("udm_gemm_set_tile", tile)
