@@ -231,27 +231,41 @@ class Diffusion:
                 if cfg_get(tr, "interleaved", False):
                     # model.py:483-522: every (modality, packed sample) block of more than 4 tokens is masked as a whole with probability
                     # 2 p (k + 1) / n  (k: index of the block inside its sample, n: blocks of that sample); one uniform per block, drawn after
-                    # the two per-row draws above (same call order as the reference).  Block boundaries are found on the host: a handful per row.
-                    mod_h, sid_h = batch["modality"].cpu(), batch["sample_ids"].cpu()
-                    blocks = []
-                    for b in range(batch_size):
-                        mrow, srow = mod_h[b].tolist(), sid_h[b].tolist()
-                        st = 0
-                        for i in range(1, seq_len + 1):
-                            if i == seq_len or mrow[i] != mrow[st] or srow[i] != srow[st]:
-                                if srow[st] >= 0 and i - st > 4:
-                                    blocks.append((b, st, i, srow[st]))
-                                st = i
-                    r = self._rand(len(blocks), 1, device=x.device).reshape(-1).tolist() if blocks else []
+                    # the two per-row draws above (same call order as the reference).
+                    # Everything stays on the device; the ONE host read is the number of candidate blocks (it sizes the uniform draw - the reference
+                    # reads every block boundary back).  Blocks are numbered in (row, position) order, the order of the reference's draws.
+                    mod, sid = batch["modality"], batch["sample_ids"]
+                    dev, N = x.device, batch_size * seq_len
+                    chg = torch.ones((batch_size, seq_len), dtype=torch.bool, device=dev)
+                    chg[:, 1:] = (mod[:, 1:] != mod[:, :-1]) | (sid[:, 1:] != sid[:, :-1])
+                    gid = chg.reshape(-1).cumsum(0) - 1                                          # block of every position
+                    one = torch.ones(N, dtype=torch.int64, device=dev)
+                    ar = torch.arange(N, device=dev)
+                    blen = torch.zeros(N, dtype=torch.int64, device=dev).scatter_add_(0, gid, one)
+                    bsid = torch.full((N,), -1, dtype=torch.int64, device=dev).scatter_(0, gid, sid.reshape(-1))
+                    brow = torch.zeros(N, dtype=torch.int64, device=dev).scatter_(0, gid, ar // seq_len)
+                    cand = (bsid >= 0) & (blen > 4)
+                    n_cand = int(cand.sum())
                     accum = torch.zeros_like(move_indices)
-                    ignore_batch_mask_for_metrics = torch.zeros((batch_size,), device=x.device, dtype=torch.bool)
-                    for i, (b, st, en, sidv) in enumerate(blocks):
-                        k = sum(1 for (b2, _, _, s2) in blocks[:i] if b2 == b and s2 == sidv)
-                        n = sum(1 for (b2, _, _, s2) in blocks if b2 == b and s2 == sidv)
-                        thr = mask_prob * (torch.tensor(k + 1) / torch.tensor(n)) * 2   # fp32, in the reference's order of operations
-                        if r[i] < float(thr):
-                            accum[b, st:en] = True
-                            ignore_batch_mask_for_metrics[b] = True
+                    ignore_batch_mask_for_metrics = torch.zeros((batch_size,), device=dev, dtype=torch.bool)
+                    if n_cand:
+                        # k = index of the block among the candidate blocks of its (row, sample id), n = their number: stable sort by that key
+                        key = torch.where(cand, brow * (seq_len + 1) + bsid, torch.full_like(brow, (batch_size + 1) * (seq_len + 1)))
+                        order = torch.argsort(key, stable=True)
+                        skey = key[order]
+                        newg = torch.ones(N, dtype=torch.bool, device=dev)
+                        newg[1:] = skey[1:] != skey[:-1]
+                        g_first = torch.cummax(torch.where(newg, ar, torch.zeros_like(ar)), 0).values
+                        g_id = newg.cumsum(0) - 1
+                        g_size = torch.zeros(N, dtype=torch.int64, device=dev).scatter_add_(0, g_id, one)
+                        k = torch.empty_like(ar).scatter_(0, order, ar - g_first)
+                        n = torch.empty_like(ar).scatter_(0, order, g_size[g_id])
+                        r = self._rand(n_cand, 1, device=dev).reshape(-1)
+                        r_blk = r[(cand.cumsum(0) - 1).clamp(min=0)]
+                        thr = mask_prob * ((k + 1) / n) * 2                                      # fp32, in the reference's order of operations
+                        hit = cand & (r_blk < thr)
+                        accum = hit[gid].reshape(batch_size, seq_len)
+                        ignore_batch_mask_for_metrics = torch.zeros(batch_size, dtype=torch.int64, device=dev).scatter_add_(0, brow, hit.long()) > 0
                     move_indices = move_indices | accum
                     xt = torch.where(move_indices, self.mask_index, x)
                     if allow_move_mask is not None:

@@ -407,9 +407,9 @@ class DIT(nn.Module, _HubMixin):
         # image index inside its packed sample: running count of image-run starts per (row, sample id)
         sid = sample_ids
         nsid = int(sid.max().item()) + 1 if sid.numel() else 1
-        onehot = start[:, :, None] & (sid[:, :, None] == torch.arange(max(nsid, 1), device=dev)[None, None])
-        cum = onehot.cumsum(1)                                                   # [B, L, nsid] starts with that id up to and including l
-        j_at = (cum.gather(2, sid.clamp(min=0)[:, :, None]).squeeze(2) - 1)      # at a run start: earlier runs with the same id
+        onehot = start[:, None, :] & (sid[:, None, :] == torch.arange(max(nsid, 1), device=dev)[None, :, None])
+        cum = onehot.cumsum(2)                                                   # [B, nsid, L] starts with that id up to and including l (scan over the contiguous dim)
+        j_at = (cum.gather(1, sid.clamp(min=0)[:, None, :]).squeeze(1) - 1)      # at a run start: earlier runs with the same id
         j_run = j_at.gather(1, run_start.clamp(min=0))
         count_idx = torch.where(valid_img, j_run, torch.full_like(j_run, -1))
         # text: positions restart at every run of one sample id
