@@ -248,33 +248,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// delta[b,h,q] = sum_d dO[b,q,h,d] * O[b,q,h,d]
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout, float* __restrict__ delta, long o_stride,
-                                                        long do_stride, int B, int H, int L, int D) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int lph = D / 8;  // lanes per head
-  const int d = H * D;
-  const long M = (long)B * L;
-  for (long row = (long)blockIdx.x * 4 + wave; row < M; row += (long)gridDim.x * 4) {
-    const int b = (int)(row / L), l = (int)(row % L);
-    for (int t = lane; t < d / 8; t += 64) {
-      uint4 uo = *reinterpret_cast<const uint4*>(o + row * o_stride + t * 8);
-      uint4 ud = *reinterpret_cast<const uint4*>(dout + row * do_stride + t * 8);
-      const uint32_t wo[4] = {uo.x, uo.y, uo.z, uo.w}, wd[4] = {ud.x, ud.y, ud.z, ud.w};
-      float s = 0.f;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        s += __uint_as_float(wo[k] << 16) * __uint_as_float(wd[k] << 16);
-        s += __uint_as_float(wo[k] & 0xffff0000u) * __uint_as_float(wd[k] & 0xffff0000u);
-      }
-      for (int off = 1; off < lph; off <<= 1) s += __shfl_xor(s, off, 64);
-      if ((lane & (lph - 1)) == 0) delta[((long)b * H + t / lph) * L + l] = s;
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
 // backward, dQ: block owns 128 queries, walks key tiles.  dQ^T = K^T dS^T (lane owns a query column).
 // ------------------------------------------------------------------------------------------------
 template <int D, bool HAS_SID, bool USE_TR>
@@ -303,7 +276,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
   if (HAS_SID) sid_q = q_ok ? a.sample_ids[rowbase + qi] : -1;
   const long sidx = ((long)b * a.H + h) * a.L + qi;
   float lse_q = q_ok ? a.lse[sidx] : INFINITY;
-  float delta_q = q_ok ? a.delta[sidx] : 0.f;
+  // delta = rowsum(dO * O) of this lane's query, from the dO fragments it holds anyway plus one read of the O row: the lane pair (hi = 0, 1) covers
+  // the D columns between them.  Stored for the dK/dV kernel, which runs after this one on the same stream (this replaced a separate pass over O, dO).
+  float delta_q = 0.f;
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    const bf16x8_t of = load_frag_global(a.o + (rowbase + qi) * a.o_stride + h * D + ks * 16 + hi * 8, q_ok);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) delta_q += (float)of[e] * (float)dof[ks][e];
+  }
+  delta_q += __shfl_xor(delta_q, 32, 64);
+  if (q_ok && hi == 0) const_cast<float*>(a.delta)[sidx] = delta_q;
   const float c = a.scale_log2;
   // (as in the forward kernel: the compiler's wait for these global loads must sit before the loop, not behind the inline-asm refills)
 #pragma unroll
@@ -666,10 +649,7 @@ extern "C" int udm_attention_bwd(const void* q, const void* k, const void* v, co
   a.scale_log2 = a.scale * 1.4426950408889634f;
   static const bool env_once = [] { if (const char* e = getenv("UDM_DKV_WS")) g_dkv_ws = atoi(e); return true; }();
   (void)env_once;
-  const long M = (long)B * L;
-  const int grid = (int)((M + 3) / 4 < 2048 ? (M + 3) / 4 : 2048);
-  hipLaunchKernelGGL(attn_delta_kernel, dim3(grid), dim3(256), 0, stream, a.o, a.dout, delta, (long)o_stride, (long)do_stride, (int)B, (int)H, (int)L, (int)D);
-  UDM_CHECK_LAUNCH("udm_attention_bwd(delta)");
+  // (delta is computed and stored by the dQ kernel, which launch_bwd runs first)
   ATTN_DISPATCH(launch_bwd, a, D, sample_ids != nullptr, g_use_tr, stream);
   UDM_CHECK_LAUNCH("udm_attention_bwd");
   return 0;
