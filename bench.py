@@ -258,7 +258,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     timer.enabled = False
-    loss = float(out.loss)
+    loss = float(out.loss.detach())
     if world > 1:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
