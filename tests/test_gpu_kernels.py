@@ -98,7 +98,9 @@ def test_gemm_persistent_blocks_every_epilogue(K, M, N, K_):
         dg = torch.zeros((M, N), dtype=torch.bfloat16, device=DEV)
         dbias = torch.zeros(N, dtype=torch.float32, device=DEV)
         K.gemm_nt(ga, gb, out=dg, N=N, epilogue=K.EPI_DGELU, aux=aux, bias=dbias)
-        return out, o32, aux, g, dg, dbias
+        c = torch.full((M, N), 0.25, dtype=torch.float32, device=DEV)
+        K.gemm_nt(ga, gb, out=c, beta=1.0)                     # fp32 accumulate into C (the epilogue reads C back)
+        return out, o32, aux, g, dg, c, dbias
 
     res_p = run_all()
     K.gemm_set_persist(0)
@@ -106,10 +108,11 @@ def test_gemm_persistent_blocks_every_epilogue(K, M, N, K_):
         res_1 = run_all()
     finally:
         K.gemm_set_persist(1)
-    for x, y, name in zip(res_p[:5], res_1[:5], ("plain", "bias f32", "aux", "gelu", "dgelu")):
+    for x, y, name in zip(res_p[:6], res_1[:6], ("plain", "bias f32", "aux", "gelu", "dgelu", "beta accumulate")):
         assert torch.equal(x, y), name
-    assert torch.allclose(res_p[5], res_1[5], rtol=1e-4, atol=1e-3)   # column sums are fp32 atomics: order differs
-    out, o32, aux, g, dg, dbias = res_p
+    assert torch.allclose(res_p[6], res_1[6], rtol=1e-4, atol=1e-3)   # column sums are fp32 atomics: order differs
+    out, o32, aux, g, dg, cacc, dbias = res_p
+    assert rel_err(cacc.cpu(), acc + 0.25) < 1e-5
     assert rel_err(out.float().cpu(), acc) < 4e-3
     assert rel_err(o32.cpu(), acc + bias) < 1e-5
     u = (acc + bias).bfloat16().float().requires_grad_()
