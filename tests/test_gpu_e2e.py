@@ -187,3 +187,28 @@ def test_fp8_attention_forward_training_step(heads):
     assert l1 != l0                                             # the fp8 kernel really ran
     bad = [(k, rel_err(g1[k], g0[k])) for k in g0 if rel_err(g1[k], g0[k]) > 0.25]
     assert not bad, bad[:6]
+
+
+@pytest.mark.parametrize("frac", [0.0, 1.0])
+def test_no_masked_rows_and_all_masked_rows(frac):
+    """Extremes of the corruption: a batch without a single [MASK] (the compacted vocabulary head has zero real rows: log p = 0 everywhere, loss 0,
+    all gradients exactly 0) and a fully masked batch (every row goes through the head); both must agree with the oracle."""
+    g = Golden("c_large")
+    diff = build_product(g, DEV)
+    b = O.update_batch(g.cfg, g.batch())
+    x0, mod = b["input_ids"], b["modality"]
+    xt = torch.where(torch.full_like(x0, frac, dtype=torch.float32) > 0.5, torch.full_like(x0, diff.mask_index), x0)
+    lp = diff.backbone.forward_logp(xt.to(DEV), x0.to(DEV), None, modality=mod.to(DEV), restrict_modality=True)
+    P, buf = g.params(), g.buffers()
+    logits = O.dit_forward(g.cfg, P, buf, xt, None, mod, None, False)
+    ref = O.subs_parameterization(g.cfg, logits, xt, mod).gather(-1, x0[..., None]).squeeze(-1)
+    if frac == 0.0:
+        assert torch.all(lp == 0) and torch.all(ref == 0)
+    else:
+        assert rel_err(lp.float().cpu(), ref) < 1e-2
+    lp.sum().backward()
+    torch.cuda.synchronize()
+    grads = [p.grad for p in diff.backbone.parameters() if p.grad is not None]
+    assert grads and all(torch.isfinite(x).all() for x in grads)
+    if frac == 0.0:
+        assert all(float(x.abs().max()) == 0.0 for x in grads)
