@@ -393,6 +393,12 @@ __global__ __launch_bounds__(512) void gemm_nt_stagger_kernel(GemmArgs p) {
   const bf16_t* src[LOADS];
   int dst[LOADS];
   constexpr int RB_A = BMX * 2, RB_B = BNX * 2, NG_A = RB_A / 64, NG_B = RB_B / 64;  // TN: row bytes / 64-byte granules per k-row
+  // TN granule rotation of k-row r (mod 4): the four k-rows of one transposing read must land in four different 64-byte bank groups of the
+  // 256-byte LDS line.  Rows of a multiple of 256 bytes all start at the same bank: rotate by r.  Rows of 384 bytes (192-wide tile) alternate
+  // between bank offsets 0 and 128, so r would collide whenever (granule + r) wraps past 6 (measured: bank conflicts on 23 % of the qkv
+  // wgrad's LDS cycles); rotating by r >> 1 gives {g, g + 128 B, g + 1, g + 1 + 128 B} - distinct for every granule, wrap included.
+#define ROT_A(r) ((NG_A % 4 == 0) ? (r) : ((r) >> 1))
+#define ROT_B(r) ((NG_B % 4 == 0) ? (r) : ((r) >> 1))
   if (!TN) {
 #pragma unroll
     for (int j = 0; j < A_PW; ++j) {
@@ -411,7 +417,7 @@ __global__ __launch_bounds__(512) void gemm_nt_stagger_kernel(GemmArgs p) {
     for (int j = 0; j < A_PW; ++j) {
       const int off = (wave * A_PW + j) * 1024 + lane * 16;
       const int row = off / RB_A, within = off % RB_A;
-      const int gran = (within / 64 + NG_A - (row & 3)) % NG_A;
+      const int gran = (within / 64 + NG_A - ROT_A(row & 3)) % NG_A;
       const long col = min((long)row0 + (gran * 64 + within % 64) / 2, p.lda - 8);
       src[j] = p.A + (long)row * p.lda + col;
       dst[j] = (wave * A_PW + j) * 1024;
@@ -420,7 +426,7 @@ __global__ __launch_bounds__(512) void gemm_nt_stagger_kernel(GemmArgs p) {
     for (int j = 0; j < B_PW; ++j) {
       const int off = (wave * B_PW + j) * 1024 + lane * 16;
       const int row = off / RB_B, within = off % RB_B;
-      const int gran = (within / 64 + NG_B - (row & 3)) % NG_B;
+      const int gran = (within / 64 + NG_B - ROT_B(row & 3)) % NG_B;
       const long col = min((long)col0 + (gran * 64 + within % 64) / 2, p.ldb - 8);
       src[A_PW + j] = p.B + (long)row * p.ldb + col;
       dst[A_PW + j] = A_BYTES + (wave * B_PW + j) * 1024;
@@ -431,9 +437,9 @@ __global__ __launch_bounds__(512) void gemm_nt_stagger_kernel(GemmArgs p) {
   const int p16 = lane & 15, g1 = (lane >> 4) & 1, rot = p16 >> 2;
   int a_fo[FM], b_fo[FN];
 #pragma unroll
-  for (int i = 0; i < FM; ++i) a_fo[i] = (((wm * WM + i * 32) / 32 + rot) % NG_A) * 64 + g1 * 32 + (p16 & 3) * 8;
+  for (int i = 0; i < FM; ++i) a_fo[i] = (((wm * WM + i * 32) / 32 + ROT_A(rot)) % NG_A) * 64 + g1 * 32 + (p16 & 3) * 8;
 #pragma unroll
-  for (int j = 0; j < FN; ++j) b_fo[j] = (((wn * WN + j * 32) / 32 + rot) % NG_B) * 64 + g1 * 32 + (p16 & 3) * 8;
+  for (int j = 0; j < FN; ++j) b_fo[j] = (((wn * WN + j * 32) / 32 + ROT_B(rot)) % NG_B) * 64 + g1 * 32 + (p16 & 3) * 8;
   const int sw = (l31 >> 1) & 7;
   f32x16_t acc[FM][FN];
 #pragma unroll
@@ -661,6 +667,8 @@ __global__ __launch_bounds__(512) void gemm_nt_stagger_kernel(GemmArgs p) {
   }  // output tiles of this block
 }
 
+#undef ROT_A
+#undef ROT_B
 int g_gemm_persist = 1;   // diagnostics (UDM_GEMM_PERSIST=0): 0 = one block per output tile everywhere
 
 template <int BMX, int EPI, bool OUT_F32, bool TN = false>
