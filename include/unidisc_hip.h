@@ -54,6 +54,10 @@ int udm_gemm_tn_bf16(const void* A, const void* B, void* C, int64_t M, int64_t N
  * udm_gemm_tn_bf16 when the workspace is too small.  C contiguous (ldc == N). */
 int udm_gemm_tn_splitk_bf16(const void* A, const void* B, void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, float beta,
                             float* ws, int64_t ws_elems, hipStream_t stream);
+/* NT form of the same idea with a bf16 result (head dgrad on the compacted [MASK] rows: few 320 x 256 tiles over K = V): fp32 partial tiles in ws
+ * (>= slices*M*N), reduce pass rounds to bf16; falls back to udm_gemm_nt_bf16 when splitting does not apply. */
+int udm_gemm_nt_splitk_bf16(const void* A, const void* B, void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, float* ws,
+                            int64_t ws_elems, hipStream_t stream);
 int udm_gemm_set_tile(int tile); /* diagnostics: force the tile family (-1 auto, 0 = 128x128 kernel, 192/256/320 = BMx256 kernel) */
 int udm_gemm_set_persist(int enable); /* diagnostics: 0 = one block per output tile (default 1: persistent blocks for multi-round NT shapes) */
 /* out[C,R] = in[R,C]ᵀ (bf16); optional colsum[c] += Σ_r in[r,c] (bias gradient).  Feeds the wgrad GEMMs. */

@@ -360,6 +360,10 @@ def gemm_tn(a, b, out, *, M=None, N=None, beta=0.0):
 gemm_tn_splitk = gemm_tn
 
 
+def gemm_nt_splitk(a, b, out=None, *, N=None):
+    return gemm_nt(a, b, out=out, N=N)
+
+
 def colsum(x, out):
     out += x.float().sum(0)
     return out

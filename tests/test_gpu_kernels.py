@@ -154,6 +154,18 @@ def test_gemm_tn_splitk_workspace(K, Kc, M, N):
     assert rel_err(out.cpu(), 2 * ref) < 2e-5
 
 
+@pytest.mark.parametrize("M,N,K_", [(5120, 2048, 48512), (5056, 2048, 4096), (704, 512, 8192), (100, 300, 640), (5120, 2048, 192)])
+def test_gemm_nt_splitk_bf16_output(K, M, N, K_):
+    """NT split-K with a bf16 result (the head dgrad on the compacted rows): ragged row counts, shapes where it must fall back, long K."""
+    a, b = bf(rnd(M, K_, seed=280, scale=0.5)), bf(rnd(N, K_, seed=281, scale=0.3))
+    ref = a.float() @ b.float().t()
+    out = K.gemm_nt_splitk(a.to(DEV), b.to(DEV))
+    assert out.dtype == torch.bfloat16 and rel_err(out.float().cpu(), ref) < 4e-3
+    buf = torch.zeros((M, N + 64), dtype=torch.bfloat16, device=DEV)          # row stride != N
+    K.gemm_nt_splitk(a.to(DEV), b.to(DEV), out=buf[:, :N])
+    assert rel_err(buf[:, :N].float().cpu(), ref) < 4e-3 and torch.all(buf[:, N:] == 0)
+
+
 @pytest.mark.parametrize("M,N", [(64, 128), (320, 512)])
 def test_gemm_gelu_epilogues_extreme_preactivations(K, M, N):
     """GELU / GELU' in the epilogues are written through the logistic function (exp2 + rcp): no inf * 0 for |x| up to 100."""

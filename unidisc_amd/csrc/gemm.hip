@@ -836,7 +836,52 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     reinterpret_cast<float4*>(out)[i] = acc;
   }
 }
+// the same sum for a bf16 result with a row stride (NT split-K below)
+__global__ __launch_bounds__(256) void splitk_reduce_bf16_kernel(const float* __restrict__ ws, bf16_t* __restrict__ out, long M, int N, long ldc, int S, long stride) {
+  const int n4 = N / 4;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < M * n4; i += (long)gridDim.x * 256) {
+    const long r = i / n4;
+    const int c = (int)(i % n4) * 4;
+    float4 acc = *reinterpret_cast<const float4*>(ws + r * N + c);
+    for (int s = 1; s < S; ++s) {
+      const float4 v = *reinterpret_cast<const float4*>(ws + s * stride + r * N + c);
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    *reinterpret_cast<uint2*>(out + r * ldc + c) = make_uint2(pack2bf(acc.x, acc.y), pack2bf(acc.z, acc.w));
+  }
+}
 }  // namespace
+
+// C[M,N] (bf16) = A[M,K] B[N,K]^T for FEW output tiles over a LONG contraction (the vocabulary-head dgrad on the compacted [MASK] rows:
+// ~5 k x 2048 outputs over K = 48 512): 320 x 256 tiles, the K range cut into slices so that tiles x slices fill the 256 CUs once, fp32 partial
+// tiles in `ws` (>= slices * M * N), a reduce pass that rounds to bf16.  Falls back to udm_gemm_nt_bf16 when splitting does not apply.
+extern "C" int udm_gemm_nt_splitk_bf16(const void* A, const void* B, void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc,
+                                       float* ws, int64_t ws_elems, hipStream_t stream) {
+  UDM_CHECK_ARG(A && B && C, "udm_gemm_nt_splitk_bf16: null operand");
+  UDM_CHECK_ARG(M > 0 && N > 0 && K > 0, "udm_gemm_nt_splitk_bf16: empty problem");
+  const long tiles = ((M + 319) / 320) * ((N + 255) / 256);
+  const long nkt = K / 64;
+  long skl = 256 / tiles;
+  if (skl > nkt / 8) skl = nkt / 8;
+  if (skl > 32) skl = 32;
+  const int sk = skl < 2 ? 1 : (int)skl;
+  if (sk == 1 || K % 64 != 0 || !ws || ws_elems < (int64_t)sk * M * N || N % 4 != 0 || ldc % 4 != 0 || M < 320 || N < 256)
+    return udm_gemm_nt_bf16(A, B, C, M, N, K, lda, ldb, ldc, 0, UDM_EPI_NONE, nullptr, nullptr, 0, 0.f, stream);
+  UDM_CHECK_ARG(lda % 8 == 0 && ldb % 8 == 0, "udm_gemm_nt_splitk_bf16: lda/ldb must be multiples of 8");
+  UDM_CHECK_ARG(((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0) && ((uintptr_t)C % 8 == 0) && ((uintptr_t)ws % 16 == 0), "udm_gemm_nt_splitk_bf16: operand alignment");
+  GemmArgs a;
+  a.A = (const bf16_t*)A; a.B = (const bf16_t*)B; a.C = ws; a.bias = nullptr; a.aux = nullptr;
+  a.lda = lda; a.ldb = ldb; a.ldc = N; a.ldaux = 0;
+  a.M = (int)M; a.N = (int)N; a.K = (int)K; a.beta = 0.f;
+  a.splitk = sk;
+  a.slice_stride = (long)M * N;
+  if (int rc = launch_big_t<320, UDM_EPI_NONE, true, false>(a, stream)) return rc;
+  const long n4 = (long)M * N / 4;
+  const int grid = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
+  hipLaunchKernelGGL(splitk_reduce_bf16_kernel, dim3(grid), dim3(256), 0, stream, (const float*)ws, (bf16_t*)C, (long)M, (int)N, (long)ldc, sk, (long)M * N);
+  UDM_CHECK_LAUNCH("udm_gemm_nt_splitk_bf16(reduce)");
+  return 0;
+}
 
 // C[M,N] (fp32) = beta*C + A[K,M]^T B[K,N] for FEW output tiles over a LONG contraction (the 2048 x 2048 out-proj wgrad, K = B*L): the K
 // range is cut into slices so that tiles x slices fill the 256 CUs, every slice writes its partial tile into `ws` (no atomics: a 4-way

@@ -736,7 +736,8 @@ class DIT(nn.Module, _HubMixin):
         else:
             dlogits = torch.zeros_like(logits)
             dlogits[:, :V].copy_(grad_out.reshape(M, V))
-        dhf = K.gemm_nt(dlogits, head.w16t, N=d, out=torch.empty((M, d), dtype=BF16, device=dev)[: dlogits.shape[0]])
+        # few output tiles (compacted rows x d) over K = V: split K so that all CUs work (falls back to the plain kernel otherwise)
+        dhf = K.gemm_nt_splitk(dlogits, head.w16t, N=d, out=torch.empty((M, d), dtype=BF16, device=dev)[: dlogits.shape[0]])
         self._wgrad(dlogits, S["hf"], head, G)
         if head_rows is not None:  # scatter the masked rows' gradient back; every other row of d(final norm output) is exactly zero
             rows_p, n_masked = head_rows

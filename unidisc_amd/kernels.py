@@ -104,6 +104,21 @@ def gemm_tn_splitk(a, b, out, *, M=None, N=None, beta=0.0):
     return out
 
 
+def gemm_nt_splitk(a, b, out=None, *, N=None):
+    """out[M,N] (bf16) = a[M,K] b[N,K]^T for few output tiles over a long contraction: K split across CUs through an fp32 workspace."""
+    _chk(a, BF16, "gemm_nt_splitk a"), _chk(b, BF16, "gemm_nt_splitk b")
+    M, Kd = a.shape
+    N = b.shape[0] if N is None else N
+    if out is None:
+        out = torch.empty((M, N), dtype=BF16, device=a.device)
+    tiles = ((M + 319) // 320) * ((N + 255) // 256)
+    sk = max(1, min(256 // tiles, (Kd // 64) // 8, 32))   # the rule of udm_gemm_nt_splitk_bf16 (sizes the workspace)
+    ws = _scratch(sk * M * N, a.device) if sk > 1 else None
+    _lib.call("udm_gemm_nt_splitk_bf16", _p(a), _p(b), _p(out), M, N, Kd, a.stride(0), b.stride(0), out.stride(0), _p(ws),
+              ws.numel() if ws is not None else 0, _s())
+    return out
+
+
 def ddpm_sample_rows(logits, V, Vt, mask_id, *, t=None, s=None, modality=None, restrict=False, u=None, seed=0, greedy=False, logits_u=None, w=None):
     """Sampled (or, greedy, arg-max) token per row of `logits` [rows, ld] bf16: one reverse-diffusion update of [MASK] rows.
     `logits_u` (same shape / stride) + `w` fp32 [rows]: classifier-free guidance, z = (1 + w) logits - w logits_u, mixed inside the kernel."""
