@@ -32,6 +32,7 @@ struct GemmArgs {
   float beta;
   int splitk;  // > 1: the K range is cut into `splitk` slices per tile and partial tiles are atomically added into an fp32 C
   long slice_stride;  // split-K with a workspace: slice s stores its partial tile (no atomics) at C + s * slice_stride; 0 = atomic form
+  int group_m;        // big-tile kernels: row tiles per group of the tile order (0 = GROUP_M); diagnostics knob UDM_GEMM_GROUP_M
 };
 
 template <int EPI, bool OUT_F32>
@@ -365,15 +366,16 @@ __global__ __launch_bounds__(512) void gemm_nt_stagger_kernel(GemmArgs p) {
   const int wm = wave / WGN, wn = wave % WGN;
   const int l31 = lane & 31, hi = lane >> 5;
   const int lrow = lane >> 3, lslot = lane & 7;
-  const int per_group = GROUP_M * p.tiles_n;
+  const int grp_rows = p.group_m > 0 ? p.group_m : GROUP_M;
+  const int per_group = grp_rows * p.tiles_n;
   int par = 0;           // PERSIST: stage that holds the first K tile of the current output tile
   bool primed = false;   // PERSIST: ... and it is already there (staged by the previous output tile's last K iteration)
   for (int wi = blockIdx.x;; wi += gridDim.x) {   // one pass unless PERSIST
   int pid = xcd_remap(wi, nwg * S);
   const int slice = pid % S;  // slices of one tile are neighbours in the remapped order: same XCD, shared operand panels
   pid /= S;
-  const int grp = pid / per_group, first_m = grp * GROUP_M;
-  const int gsz = min(p.tiles_m - first_m, GROUP_M);
+  const int grp = pid / per_group, first_m = grp * grp_rows;
+  const int gsz = min(p.tiles_m - first_m, grp_rows);
   const int tm = first_m + (pid % per_group) % gsz, tn = (pid % per_group) / gsz;
   const int row0 = tm * BMX, col0 = tn * BNX;
   bool has_next = false;
@@ -383,8 +385,8 @@ __global__ __launch_bounds__(512) void gemm_nt_stagger_kernel(GemmArgs p) {
     has_next = wn_i < nwg;
     if (has_next) {
       const int pid2 = xcd_remap(wn_i, nwg);
-      const int grp2 = pid2 / per_group, first2 = grp2 * GROUP_M;
-      const int gsz2 = min(p.tiles_m - first2, GROUP_M);
+      const int grp2 = pid2 / per_group, first2 = grp2 * grp_rows;
+      const int gsz2 = min(p.tiles_m - first2, grp_rows);
       const int tm2 = first2 + (pid2 % per_group) % gsz2, tn2 = (pid2 % per_group) / gsz2;
       next_da = (long)(tm2 - tm) * BMX * p.lda;
       next_db = (long)(tn2 - tn) * BNX * p.ldb;
@@ -676,6 +678,8 @@ int launch_big_t(const GemmArgs& a0, hipStream_t stream) {
   GemmArgs a = a0;
   a.tiles_m = (a.M + BMX - 1) / BMX;
   a.tiles_n = (a.N + 255) / 256;
+  static const int env_gm = [] { const char* e = getenv("UDM_GEMM_GROUP_M"); return e ? atoi(e) : 0; }();
+  a.group_m = env_gm;
   const size_t lds = (size_t)2 * (BMX + 256) * BK * 2;
   auto kern = gemm_nt_stagger_kernel<BMX, EPI, OUT_F32, TN>;
   static bool attr_set = false;
