@@ -24,6 +24,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_BF16_DENSE_TFLOPS = 2500.0  # MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA (AMD's 5 PF figure is 2:1 sparse)
+PEAK_HBM_TBS = 8.0               # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (about 6.3 TB/s achievable with a plain copy)
 
 WORKLOADS = {
     # BASELINE.json configs[2]: large_scale_train + large_scale_train_high_res, data.block_size=256
@@ -103,10 +104,53 @@ def synthetic_batch(workload, B, seed):
                 txt_attention_mask=torch.ones(B, w["txt_length"], dtype=torch.bool))
 
 
-class GemmTimer:
-    """HIP-event timing of every udm_gemm_nt_bf16 launch, on the stream it is launched on (torch's current stream)."""
+GEMM_ENTRY_POINTS = ("udm_gemm_nt_bf16", "udm_gemm_tn_bf16", "udm_gemm_nt_splitk_bf16", "udm_gemm_tn_splitk_bf16")   # (A, B, C, M, N, K, ...)
 
-    def __init__(self):
+
+def _work(name, a):
+    """Algorithmic work of one launch from the C-ABI arguments: ("flop" | "byte", amount) or None.  Bytes follow DESIGN.md §4 (per-element
+    figures of the HBM-bound kernels: what the op must read and write once), flops count what the MFMA pipe is asked to do."""
+    if name in GEMM_ENTRY_POINTS:
+        return "flop", 2.0 * a[3] * a[4] * a[5]
+    if name == "udm_attention_fwd":
+        return "flop", 4.0 * a[7] * a[8] * a[9] * a[9] * a[10]
+    if name == "udm_attention_bwd":          # dQ pass 6 (S, dP, dQ) + dK/dV pass 8 (S, dP, dV, dK): executed, recompute included
+        return "flop", 14.0 * a[12] * a[13] * a[14] * a[14] * a[15]
+    if name == "udm_norm_fwd":
+        return "byte", 6.0 * a[10] * a[11]
+    if name == "udm_norm_bwd":
+        return "byte", (14.0 if a[18] else 10.0) * a[14] * a[15]
+    if name == "udm_residual_fwd":
+        return "byte", 10.0 * a[9] * a[10]
+    if name == "udm_residual_norm_fwd":
+        return "byte", 12.0 * a[9] * a[10]
+    if name == "udm_residual_bwd":
+        return "byte", 8.0 * a[11] * a[12]
+    if name == "udm_qknorm_rope_fwd":
+        return "byte", 8.0 * a[10] * a[11]
+    if name == "udm_qknorm_rope_bwd":
+        return "byte", 12.0 * a[13] * a[14]
+    if name == "udm_cast_transpose_f32_bf16":
+        return "byte", 8.0 * a[3] * a[4]
+    if name == "udm_transpose_bf16":
+        return "byte", (4.0 if a[1] else 2.0) * a[2] * a[3]
+    if name == "udm_embedding_fwd":
+        return "byte", 8.0 * a[5] * a[6]
+    if name == "udm_embedding_bwd":
+        return "byte", 8.0 * a[5] * a[6]
+    if name in ("udm_subs_ce_fwd", "udm_subs_ce_bwd"):   # whole padded rows (the valid id range of a row is data dependent): an upper bound
+        return "byte", (2.0 if name.endswith("fwd") else 4.0) * a[7] * a[8]
+    if name in ("udm_cast_f32_bf16", "udm_cast_bf16_f32"):
+        return "byte", 6.0 * a[2]
+    return None
+
+
+class KernelTimer:
+    """HIP-event timing of C-ABI launches on the stream they are launched on (torch's current stream).  `names` = None times every entry
+    point (the post-pass that builds `roofline_table`); the timed region only brackets the GEMM family (`roofline`)."""
+
+    def __init__(self, names=GEMM_ENTRY_POINTS):
+        self.names = names
         self.records = []
         self.enabled = False
 
@@ -117,23 +161,50 @@ class GemmTimer:
         timer = self
 
         def call(name, *args):
-            if timer.enabled and name in ("udm_gemm_nt_bf16", "udm_gemm_tn_bf16"):
+            if timer.enabled and (timer.names is None or name in timer.names):
                 s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 s.record()
                 orig(name, *args)
                 e.record()
-                timer.records.append((s, e, 2.0 * args[3] * args[4] * args[5]))
+                timer.records.append((s, e, name, _work(name, args)))
             else:
                 orig(name, *args)
 
+        self._orig = orig
         _lib.call = call
+
+    def uninstall(self):
+        from unidisc_amd import _lib
+
+        _lib.call = self._orig
 
     def summary(self):
         if not self.records:
             return None
-        ms = sum(s.elapsed_time(e) for s, e, _ in self.records)
-        fl = sum(f for _, _, f in self.records)
+        ms = sum(s.elapsed_time(e) for s, e, _, _ in self.records)
+        fl = sum(w[1] for _, _, _, w in self.records if w and w[0] == "flop")
         return dict(launches=len(self.records), total_ms=ms, flops=fl)
+
+    def table(self, steps):
+        """Per entry point: launches and ms per step, achieved TFLOP/s against the dense bf16 MFMA peak or TB/s against the 8 TB/s HBM peak."""
+        agg = {}
+        for s, e, name, w in self.records:
+            r = agg.setdefault(name, dict(launches=0, ms=0.0, flop=0.0, byte=0.0))
+            r["launches"] += 1
+            r["ms"] += s.elapsed_time(e)
+            if w:
+                r[w[0]] += w[1]
+        rows = []
+        for name, r in sorted(agg.items(), key=lambda kv: -kv[1]["ms"]):
+            row = dict(entry_point=name, launches_per_step=r["launches"] / steps, ms_per_step=r["ms"] / steps)
+            if r["flop"]:
+                ach = r["flop"] / (r["ms"] * 1e-3) / 1e12
+                row.update(bound="mfma", achieved=ach, peak=PEAK_BF16_DENSE_TFLOPS, unit="TFLOP/s", frac=ach / PEAK_BF16_DENSE_TFLOPS)
+            elif r["byte"]:
+                ach = r["byte"] / (r["ms"] * 1e-3) / 1e12
+                row.update(bound="hbm", achieved=ach, peak=PEAK_HBM_TBS, unit="TB/s", frac=ach / PEAK_HBM_TBS)
+            rows.append(row)
+        return rows
 
 
 def cpu_baseline(workload, cfg, diff, seed):
@@ -183,6 +254,65 @@ def cpu_baseline(workload, cfg, diff, seed):
                         f"({threads} threads of {cores} available cores)"))
 
 
+def cpu_baseline_legs(seed):
+    """SURVEY §8(d) flavour of the CPU comparator, beside the workload's own leg: the oracle with the reference's bf16-autocast rounding points
+    emulated (`bf16=True`), on ALL host cores, for BASELINE configs[0] (config A: n=2, d=256, H=4, L=128, V=1001, B=32; fwd+loss and fwd+bwd)
+    and configs[1] (config B: UniDisc-S, n=12, d=768, L=128+256, V=40193, B=8; 2 steps fwd+bwd).  Bounded: a few seconds each."""
+    from oracle import unidisc_oracle as O
+    from oracle.cases import lumina_rope_2d
+    from unidisc_amd import Diffusion, make_config
+
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    legs = {}
+    shapes = {
+        "config_a": (dict(hidden_size=256, n_heads=4, cond_dim=128, n_blocks=2, txt_length=128, img_length=0, text_vocab_size=1001, vocab_size=1001,
+                          norm_type="layernorm", qk_norm=False, sandwich_normalization=False, modality_embed=False, rope_2d=False, time_conditioning=True,
+                          multimodal_batches=False, force_argmax_valid_indices=False), 32, 3),
+        "config_b": (dict(hidden_size=768, n_heads=12, cond_dim=128, n_blocks=12, txt_length=128, img_length=256, text_vocab_size=32001, vocab_size=40193,
+                          norm_type="rms", qk_norm=True, sandwich_normalization=True, modality_embed=True, rope_2d=False, time_conditioning=False,
+                          multimodal_batches=True, force_argmax_valid_indices=True, mask_entire_modality=0.1, softmin_snr=5, text_loss_weight=1.0,
+                          force_full_attention_mask_loss_only=True), 8, 2),
+    }
+    for name, (case, B, steps) in shapes.items():
+        kw = {k: case[k] for k in ("hidden_size", "n_heads", "cond_dim", "n_blocks", "txt_length", "img_length", "norm_type", "qk_norm", "sandwich_normalization",
+                                    "modality_embed", "rope_2d", "time_conditioning", "multimodal_batches", "force_argmax_valid_indices")}
+        pc = make_config(**kw, image_vocab_size=(case["vocab_size"] - case["text_vocab_size"]) or None)
+        pc.model.force_text_vocab_size = case["text_vocab_size"] - 1
+        torch.manual_seed(seed)
+        P = {k: v.detach().float().requires_grad_() for k, v in Diffusion(pc, None, "cpu").backbone.named_parameters()}   # parameter containers only (no compute)
+        ocfg = O.OracleConfig.from_case(case)
+        bufs = O.make_buffers(ocfg, lumina_rope_2d)
+        g = torch.Generator().manual_seed(seed)
+        Lt, Li, Vt = case["txt_length"], case["img_length"], case["text_vocab_size"]
+        if Li:
+            raw = dict(txt_input_ids=torch.randint(0, Vt - 1, (B, Lt), generator=g, dtype=torch.int32),
+                       img_input_ids=torch.randint(0, case["vocab_size"] - Vt, (B, Li), generator=g, dtype=torch.int32).to(torch.int16),
+                       txt_attention_mask=torch.ones(B, Lt, dtype=torch.bool))
+        else:
+            raw = dict(input_ids=torch.randint(0, Vt - 1, (B, Lt), generator=g), attention_mask=torch.ones(B, Lt, dtype=torch.bool))
+        batch = O.update_batch(ocfg, raw)
+        L = Lt + Li
+        with torch.no_grad():   # fwd + loss
+            O.compute_loss(ocfg, P, bufs, batch, torch.Generator().manual_seed(seed), bf16=True)
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                O.compute_loss(ocfg, P, bufs, batch, torch.Generator().manual_seed(seed), bf16=True)
+            t_fwd = (time.perf_counter() - t0) / steps
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            for p_ in P.values():
+                p_.grad = None
+            O.compute_loss(ocfg, P, bufs, batch, torch.Generator().manual_seed(seed), bf16=True).loss.backward()
+        t_fb = (time.perf_counter() - t0) / steps
+        legs[name] = dict(batch=B, seq_len=L, steps=steps, fwd_loss_tokens_per_s=B * L / t_fwd, fwd_bwd_tokens_per_s=B * L / t_fb, cores=cores,
+                          numerics="oracle with bf16-autocast rounding points emulated")
+    return legs
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -194,6 +324,7 @@ def main():
     ap.add_argument("--fp8-attention", action="store_true", help="attention forward through the fp8 kernel (config E option; changes numerics, not the headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--table-steps", type=int, default=2, help="extra untimed steps after the timed region with every launch event-timed (roofline_table); 0 = off")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -232,7 +363,7 @@ def main():
         ddp.broadcast_parameters(diff.backbone)
         sync = ddp.wrap(diff.backbone)
     batch = {k: v.to(device) for k, v in synthetic_batch(args.workload, B, seed).items()}
-    timer = GemmTimer()
+    timer = KernelTimer()
     if not args.no_kernel_timing:
         timer.install()
 
@@ -251,6 +382,8 @@ def main():
     for i in range(args.warmup):
         out = step(i)
     fence()
+    if sync is not None:
+        sync.measure_exposed = True
     timer.enabled = True
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -277,20 +410,39 @@ def main():
                    "dropout": args.dropout, "weights": "random init (zero_linear_init=false)",
                    "attention_forward": "fp8 e4m3" if args.fp8_attention else "bf16"},
         "tokens_per_s_per_gpu": value / world, "loss": loss, "flops_per_token": f_tok,
-        "step_mfu": (value / world) * f_tok / (PEAK_BF16_DENSE_TFLOPS * 1e12),
+        "step_mfu": (value / world) * f_tok / (PEAK_BF16_DENSE_TFLOPS * 1e12),   # dense head, no recompute credit
     }
     gs = timer.summary()
     if gs:
         ach = gs["flops"] / (gs["total_ms"] * 1e-3) / 1e12
-        traffic, traffic_src = pmc_traffic("gemm_nt_stagger_kernel") if args.workload == "unidisc-1.4b-l1280" else (None, None)
-        result["roofline"] = {"bound": "mfma", "kernel": "gemm_nt_stagger_kernel (udm_gemm_nt_bf16 / udm_gemm_tn_bf16)", "achieved": ach, "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s",
+        traffic, traffic_src = pmc_traffic("gemm_") if args.workload == "unidisc-1.4b-l1280" else (None, None)
+        result["roofline"] = {"bound": "mfma", "kernel": "GEMM family (udm_gemm_nt_bf16 / udm_gemm_tn_bf16 and their split-K forms)", "achieved": ach,
+                              "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s",
                               "frac": ach / PEAK_BF16_DENSE_TFLOPS, "traffic": traffic, "traffic_source": traffic_src, "launches": gs["launches"],
                               "avg_launch_ms": gs["total_ms"] / gs["launches"], "share_of_step_time": gs["total_ms"] * 1e-3 / dt}
     if sync is not None:
         result["allreduce_bytes_per_step"] = sync.bytes_on_wire // (args.steps + args.warmup)
+        # time the compute stream spent waiting for the comm stream at the end of backward (events around BucketedGradSync.finish)
+        result["exposed_comm_ms_per_step"] = sync.exposed_ms() / args.steps
+    if not args.no_kernel_timing and args.table_steps > 0:
+        # post-pass, OUTSIDE the timed region: the same step with EVERY launch bracketed by events -> one roofline row per C-ABI entry point
+        timer.uninstall()
+        full = KernelTimer(names=None)
+        full.install()
+        full.enabled = True
+        for i in range(args.table_steps):
+            step(args.warmup + args.steps + i)
+        fence()
+        full.enabled = False
+        full.uninstall()
+        result["roofline_table"] = full.table(args.table_steps)
+        ex = sum(w[1] for _, _, _, w in full.records if w and w[0] == "flop") / args.table_steps   # everything the matrix pipe executed in a step
+        result["executed_mfma_flops_per_step"] = ex
+        result["executed_mfma_utilization"] = ex / (dt / args.steps) / (PEAK_BF16_DENSE_TFLOPS * 1e12)
     if rank == 0 and world == 1 and not args.no_cpu_baseline and "packed" not in w:
         try:
             result["cpu_baseline"] = cpu_baseline(args.workload, cfg, diff, seed)
+            result["cpu_baseline"]["legs"] = cpu_baseline_legs(seed)
         except Exception as e:  # the GPU number stands on its own; say why the comparator is missing
             result["cpu_baseline"] = {"value": None, "unit": "tokens/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {type(e).__name__}: {e}"}
     if rank == 0:

@@ -60,6 +60,9 @@ int udm_gemm_nt_splitk_bf16(const void* A, const void* B, void* C, int64_t M, in
                             int64_t ws_elems, hipStream_t stream);
 int udm_gemm_set_tile(int tile); /* diagnostics: force the tile family (-1 auto, 0 = 128x128 kernel, 192/256/320 = BMx256 kernel) */
 int udm_gemm_set_persist(int enable); /* diagnostics: 0 = one block per output tile (default 1: persistent blocks for multi-round NT shapes) */
+/* data-parallel runs: cap the persistent NT grid at `cus` blocks (multiple of 8 in [8, 256]; 0 = all 256 CUs) so RCCL's channel kernels of the
+ * gradient all-reduce overlapped with backward (main.py:641-656) find free CUs; also env UDM_GEMM_CUS */
+int udm_gemm_set_cus(int cus);
 /* out[C,R] = in[R,C]ᵀ (bf16); optional colsum[c] += Σ_r in[r,c] (bias gradient).  Feeds the wgrad GEMMs. */
 int udm_transpose_bf16(const void* in, void* out, int64_t R, int64_t C, int64_t ld_in, int64_t ld_out, float* colsum, hipStream_t stream);
 /* fp32 master weights -> bf16 shadow (and Kᵀ-major shadow for dgrad): the per-forward autocast weight cast. */

@@ -4,7 +4,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from unidisc_amd import _lib, kernels as K
 lib = _lib.load()
-fn = lib.udm_gemm_nt_bf16_variant
+fn = _lib.load_experiments().udm_gemm_nt_bf16_variant
 fn.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 3 + [ctypes.c_int64] * 6 + [ctypes.c_void_p]
 
 def timeit(f, n=20, w=5):

@@ -5,7 +5,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from unidisc_amd import _lib, kernels as K
 lib = _lib.load()
-fn = lib.udm_gemm_nt_bf16_variant
+fn = _lib.load_experiments().udm_gemm_nt_bf16_variant
 fn.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 3 + [ctypes.c_int64] * 6 + [ctypes.c_void_p]
 fn.restype = ctypes.c_int
 VARS = [int(x) for x in sys.argv[1].split(",")] if len(sys.argv) > 1 else [30, 50]
@@ -22,7 +22,7 @@ def timeit(f, n=20, w=5):
 def run(v, a, b, out):
     m, k = a.shape; n = b.shape[0]
     rc = fn(v, a.data_ptr(), b.data_ptr(), out.data_ptr(), m, n, k, k, k, n, torch.cuda.current_stream().cuda_stream)
-    if rc: raise RuntimeError(lib.udm_last_error().decode())
+    if rc: raise RuntimeError(_lib.load_experiments().udm_last_error().decode())
 
 shapes = {"fc1_wgrad": (8192, 2048, 10240), "fc1_fwd": (10240, 8192, 2048), "out_fwd": (10240, 2048, 2048), "qkv_fwd": (10240, 6144, 2048), "k96": (512, 512, 96), "k224": (768, 512, 224)}
 for sname, (m, n, k) in shapes.items():

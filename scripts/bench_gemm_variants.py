@@ -14,7 +14,7 @@ NAMES = {0: "128x128 w2x2 s2", 1: "128x128 w2x2 s3", 2: "128x128 w2x2 s4", 3: "2
          6: "256x256 w2x4 s2", 7: "256x256 w4x4 s2", 8: "256x256 w4x2 s2", 9: "128x256 w2x4 s3", 10: "stg 256x256 w2x4 p1", 11: "stg 256x256 w2x4 p2",
          12: "stg 256x128 w4x2 p2", 13: "stg 128x256 w2x4 p2", 14: "stg 256x256 w4x2 p1", 15: "stg 128x128 w2x4 p2", 16: "stg 320x256 w2x4 p1", 17: "stg 256x320 w2x4 p1", 20: "320 p1 mf", 21: "320 p1 mf+prio", 22: "320 p2 mf", 23: "320 p2 mf+prio", 24: "320 p1 plain", 30: "quad 256x256 w2x2", 31: "quad + hints", 39: "stg256 dma", 40: "stg256 regstage", 41: "stg320 regstage", 42: "stg320 global_lds", 43: "stg320 buffer_lds"}
 lib = _lib.load()
-fn = lib.udm_gemm_nt_bf16_variant
+fn = _lib.load_experiments().udm_gemm_nt_bf16_variant
 fn.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 3 + [ctypes.c_int64] * 6 + [ctypes.c_void_p]
 fn.restype = ctypes.c_int
 
@@ -23,7 +23,7 @@ def variant(v, a, b, out):
     rc = fn(v, a.data_ptr(), b.data_ptr(), out.data_ptr(), a.shape[0], b.shape[0], a.shape[1], a.stride(0), b.stride(0), out.stride(0),
             torch.cuda.current_stream().cuda_stream)
     if rc:
-        raise RuntimeError(lib.udm_last_error().decode())
+        raise RuntimeError(_lib.load_experiments().udm_last_error().decode())
 
 
 def timeit(fn_, iters=8):

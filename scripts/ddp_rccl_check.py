@@ -1,0 +1,116 @@
+#!/usr/bin/env python3
+"""One rank, REAL RCCL: the data-parallel gradient path of `unidisc_amd.ddp` with backend "nccl" (= RCCL on ROCm) at world_size 1.
+
+    python scripts/ddp_rccl_check.py            (prints one JSON line; exit code 1 on a failed check)
+
+A one-GPU box cannot show scaling, but it can prove the path RUNS under RCCL: process-group init on the device, buckets reported from inside the HIP
+backward, bf16 compress on the comm stream, `all_reduce` through RCCL's own kernels (world 1 still launches them), decompress, the event hand-offs
+between the compute and comm streams, the accumulate-then-sync path and the persistent-GEMM CU reservation (`UDM_GEMM_CUS`).  At world 1 the
+reduction is the identity, so the synchronised gradients must equal bf16(local gradients) EXACTLY (the reference hook's compression, main.py:641-656).
+tests/test_gpu_ddp_rccl.py runs this script in a child process.
+"""
+import json
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29517")
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    from product_utils import product_config
+    from unidisc_amd import Diffusion, ddp
+
+    case = dict(hidden_size=768, n_heads=12, cond_dim=128, n_blocks=3, batch_size=4, txt_length=128, img_length=256, text_vocab_size=32001,
+                vocab_size=40193, norm_type="rms", qk_norm=True, sandwich_normalization=True, modality_embed=True, rope_2d=False,
+                time_conditioning=False, multimodal_batches=True, force_argmax_valid_indices=True, mask_entire_modality=0.1, softmin_snr=5,
+                text_loss_weight=1.0, img_loss_weight=None, force_full_attention_mask_loss_only=True)
+    torch.manual_seed(0)
+    diff = Diffusion(product_config(case), None, dev)
+    diff.backbone.train()
+    diff.rng_device = "cpu"
+    ddp.broadcast_parameters(diff.backbone)
+    gen = torch.Generator().manual_seed(5)
+    B = 4
+
+    def batch(seed):
+        g = torch.Generator().manual_seed(seed)
+        return dict(txt_input_ids=torch.randint(0, 32000, (B, 128), generator=g, dtype=torch.int32),
+                    img_input_ids=torch.randint(0, 8192, (B, 256), generator=g, dtype=torch.int32).to(torch.int16),
+                    txt_attention_mask=torch.ones(B, 128, dtype=torch.bool))
+
+    def grads(seed, zero=True):
+        if zero:
+            diff.backbone.zero_grad(set_to_none=True)
+        torch.manual_seed(seed)
+        out = diff.training_step(batch(seed), 1)
+        out.loss.backward()
+        torch.cuda.synchronize()
+        return {k: p.grad.detach().clone() for k, p in diff.backbone.named_parameters()}
+
+    def bf16(x):
+        return x.to(torch.bfloat16).float()
+
+    def worst(a, b):
+        return max(float((a[k] - b[k]).abs().max() / (b[k].abs().max() + 1e-30)) for k in a)
+
+    res, fails = {}, []
+    local = grads(1)
+    for min_bucket in (1, 4 * 1024 * 1024, 1 << 30):
+        if getattr(diff.backbone, "_grad_sync", None) is not None:
+            del diff.backbone._grad_sync
+        sync = ddp.wrap(diff.backbone, min_bucket_elems=min_bucket, force_single_rank=True)
+        sync.measure_exposed = True
+        synced = grads(1)
+        # the backward is not bit-reproducible run to run (fp32 atomics in column reductions), so two statements: the synchronised values ARE
+        # bf16-representable (they went through the wire format), and they equal bf16(local) up to that run-to-run noise
+        repr_ok = all(torch.equal(synced[k], bf16(synced[k])) for k in synced)
+        err = worst(synced, {k: bf16(v) for k, v in local.items()})
+        res[f"bucket{min_bucket}"] = dict(bf16_representable=repr_ok, worst_rel_vs_bf16_local=err, bytes_on_wire=sync.bytes_on_wire,
+                                         exposed_ms=sync.exposed_ms())
+        if not repr_ok or err > 1e-2 or sync.bytes_on_wire == 0:
+            fails.append(("sync", min_bucket, repr_ok, err))
+    # no_sync keeps gradients local (NOT bf16-rounded), then accumulate-then-sync reduces the accumulated sum
+    sync.enabled = False
+    g1 = grads(1)
+    if all(torch.equal(g1[k], bf16(g1[k])) for k in g1):
+        fails.append(("no_sync gradients went through the wire",))
+    other = grads(2)
+    grads(1)
+    sync.enabled = True
+    acc = grads(2, zero=False)
+    exp = {k: bf16(g1[k] + other[k]) for k in g1}
+    acc_err = worst(acc, exp)
+    acc_repr = all(torch.equal(acc[k], bf16(acc[k])) for k in acc)
+    res["accumulate_then_sync"] = dict(bf16_representable=acc_repr, worst_rel_vs_bf16_sum=acc_err)
+    if not acc_repr or acc_err > 1e-2:
+        fails.append(("accumulate", acc_repr, acc_err))
+    # persistent GEMM grid with CUs left free for RCCL's channels: same results
+    from unidisc_amd import kernels as K
+    K.gemm_set_cus(224)
+    red = grads(1)
+    K.gemm_set_cus(0)
+    cu_err = worst(red, {k: bf16(v) for k, v in local.items()})
+    res["gemm_cus_224"] = dict(worst_rel_vs_bf16_local=cu_err)
+    if cu_err > 1e-2:
+        fails.append(("gemm_cus", cu_err))
+    dist.barrier()
+    dist.destroy_process_group()
+    res["backend"] = "nccl (RCCL)"
+    res["ok"] = not fails
+    res["fails"] = [str(f) for f in fails]
+    print(json.dumps(res), flush=True)
+    sys.exit(1 if fails else 0)
+
+
+if __name__ == "__main__":
+    main()

@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from unidisc_amd import _lib, kernels as K
 v, m, n, k = (int(x) for x in sys.argv[1:5])
 lib = _lib.load()
-fn = lib.udm_gemm_nt_bf16_variant
+fn = _lib.load_experiments().udm_gemm_nt_bf16_variant
 fn.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 3 + [ctypes.c_int64] * 6 + [ctypes.c_void_p]
 g = torch.Generator(device="cuda").manual_seed(0)
 a = (torch.rand(m, k, device="cuda", generator=g) - 0.5).to(torch.bfloat16)

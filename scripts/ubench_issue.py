@@ -7,7 +7,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from unidisc_amd import _lib
 lib = _lib.load()
-fn = lib.udm_ubench_issue
+fn = _lib.load_experiments().udm_ubench_issue
 fn.argtypes = [ctypes.c_int] * 7 + [ctypes.c_void_p] * 4
 fn.restype = ctypes.c_int
 src = torch.zeros(256 * 4 * 65536 + (1 << 20), dtype=torch.uint8, device="cuda")
@@ -18,7 +18,7 @@ iters = 200
 
 def run(mode, blocks, stride, win, bstride, wstride):
     rc = fn(mode, blocks, iters, stride, win - 1, bstride, wstride, src.data_ptr(), out.data_ptr(), sink.data_ptr(), torch.cuda.current_stream().cuda_stream)
-    if rc: raise RuntimeError(lib.udm_last_error().decode())
+    if rc: raise RuntimeError(_lib.load_experiments().udm_last_error().decode())
     torch.cuda.synchronize()
     return [round(x / iters) for x in out.tolist()]
 

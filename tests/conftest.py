@@ -21,3 +21,14 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """Write the parity ledger (tests/ledger.py) of a GPU session."""
+    try:
+        import ledger
+    except Exception:
+        return
+    path = ledger.dump()
+    if path:
+        print(f"\nparity ledger: {len(ledger.ROWS)} rows -> {path}")

@@ -8,6 +8,7 @@ import torch
 
 import fake_kernels
 from golden_utils import CASE_NAMES, Golden, rel_err
+from oracle import unidisc_oracle as O
 from product_utils import build_product, product_config
 from unidisc_amd import Diffusion, load_backbone_checkpoint, read_state_dict, save_backbone_checkpoint
 
@@ -79,3 +80,41 @@ def test_save_round_trip_has_reference_schema_and_same_forward(tmp_path, monkeyp
     assert torch.equal(a, b)
     truth = g.t("fp32/logits")
     assert rel_err(b.float(), truth) <= 3 * rel_err(g.t("bf16/logits"), truth) + 5e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["b_small", "c_large", "e_adaln_sandwich"])
+def test_gpu_checkpoint_round_trip_matches_golden_logits(tmp_path, name):
+    """N2 through the real kernels (models/dit.py:1095 schema, model_setup.py:914-923 file layout): a reference-style file (bf16-free fp32 masters
+    behind the torch.compile + DDP prefixes) -> `load_backbone_checkpoint` into a module that has ALREADY run (stale bf16 shadows must be rebuilt)
+    -> GPU forward equals the golden logits of the imported reference; `save_backbone_checkpoint` of that module -> a fresh module -> bit-identical
+    forward."""
+    from ledger import check
+
+    g = Golden(name)
+    dev = "cuda"
+    xt = g.t("fp32/xt").to(dev)
+    sigma = O.loglinear_noise(g.t("fp32/t"))[0].to(dev)
+    modality = g.t("fp32/modality").to(dev) if g.has("fp32/modality") and g.case["multimodal_batches"] else None
+    torch.manual_seed(3)
+    diff = Diffusion(product_config(g.case), None, dev)   # random init
+    diff.backbone.train()
+    with torch.no_grad():
+        before = diff.backbone(xt, sigma, modality=modality)   # builds shadows of the random weights
+    ckpt = _reference_style_file(g, str(tmp_path / "ref"), prefix="module._orig_mod.")
+    missing, unexpected = load_backbone_checkpoint(diff.backbone, ckpt)
+    assert missing == [] and unexpected == []
+    with torch.no_grad():
+        after = diff.backbone(xt, sigma, modality=modality)
+    truth = g.t("fp32/logits")
+    assert not torch.equal(before, after)
+    check(f"checkpoint_logits[{name}]", "logits_relrms_vs_fp32_reference", rel_err(after.float().cpu(), truth), 1e-2)
+    f = save_backbone_checkpoint(diff.backbone, str(tmp_path / "out"))
+    saved, ref = read_state_dict(f), g.params()
+    assert set(saved) == set(ref) and all(torch.equal(saved[k], ref[k].float()) for k in ref)
+    other = Diffusion(product_config(g.case), None, dev)
+    load_backbone_checkpoint(other.backbone, f)
+    other.backbone.train()
+    with torch.no_grad():
+        again = other.backbone(xt, sigma, modality=modality)
+    assert torch.equal(again, after)

@@ -19,12 +19,13 @@ def _free_port():
     return p
 
 
-def _grads(diff, golden, seed):
+def _grads(diff, golden, seed, zero=True):
     torch.manual_seed(seed)
     batch = golden.batch()
     g = torch.Generator().manual_seed(1000 + seed)
     batch["txt_input_ids"] = torch.randint(0, golden.case["text_vocab_size"] - 1, batch["txt_input_ids"].shape, generator=g, dtype=torch.int32)
-    diff.backbone.zero_grad(set_to_none=True)
+    if zero:
+        diff.backbone.zero_grad(set_to_none=True)
     out = diff.training_step(batch, 1)
     out.loss.backward()
     return {k: p.grad.clone() for k, p in diff.backbone.named_parameters()}
@@ -69,7 +70,29 @@ def _worker(rank, world, port, min_bucket, q):
         sync.enabled = False                                   # no_sync micro-step: gradients stay local
         unsynced = _grads(diff, golden, seed=rank)
         local_ok = all(torch.equal(unsynced[k], local[k]) for k in local)
-        q.put((rank, ok, same, local_ok, worst, sync.bytes_on_wire))
+        # gradient accumulation (DDP no_sync recipe): micro-step 1 local, micro-step 2 synchronised -> every rank must end with
+        # sum_ranks bf16(bf16(g1 + g2) / world), i.e. the ACCUMULATED gradients are what is reduced, and all ranks agree bit for bit
+        other = _grads(diff, golden, seed=10 + rank)            # second micro-batch, gradients kept local (sync still disabled)
+        sync.enabled = False
+        _grads(diff, golden, seed=rank)                          # micro-step 1 (p.grad = local)
+        sync.enabled = True
+        acc = _grads(diff, golden, seed=10 + rank, zero=False)   # micro-step 2: p.grad = reduce(local + other)
+        summed = {k: local[k] + other[k] for k in local}
+        gathered = [None] * world
+        dist.all_gather_object(gathered, summed)
+        acc_ok, acc_worst = True, 0.0
+        for k in local:
+            exp = sum((g[k].to(torch.bfloat16).float() / world).to(torch.bfloat16).float() for g in gathered).to(torch.bfloat16).float()
+            err = (acc[k] - exp).abs().max().item()
+            acc_worst = max(acc_worst, err / (exp.abs().max().item() + 1e-12))
+            acc_ok = acc_ok and err <= 2e-2 * exp.abs().max().item() + 1e-6
+        flat = torch.cat([acc[k].flatten() for k in sorted(acc)])
+        ref = flat.clone()
+        dist.broadcast(ref, src=0)
+        acc_same = torch.equal(flat, ref)
+        after = _grads(diff, golden, seed=rank)                  # and the next plain step takes the overlapped in-backward path again
+        again_ok = all(torch.equal(after[k], synced[k]) for k in synced)
+        q.put((rank, ok, same, local_ok, worst, sync.bytes_on_wire, acc_ok, acc_same, acc_worst, again_ok))
     finally:
         dist.destroy_process_group()
 
@@ -86,8 +109,11 @@ def test_bucketed_allreduce_world2(min_bucket):
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    for rank, ok, same, local_ok, worst, nbytes in res:
+    for rank, ok, same, local_ok, worst, nbytes, acc_ok, acc_same, acc_worst, again_ok in res:
         assert ok, (rank, worst)
         assert same, rank
         assert local_ok, rank
         assert nbytes > 0
+        assert acc_ok, (rank, acc_worst)      # accumulate-then-sync reduces the accumulated gradients
+        assert acc_same, rank                 # ... identically on every rank
+        assert again_ok, rank

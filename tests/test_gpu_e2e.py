@@ -1,22 +1,25 @@
 """End-to-end parity on a real MI355X (pytest -m gpu): the HIP path vs the golden vectors of the imported
 reference and vs the CPU oracle on the same seeded inputs.
 
-Tolerances: the reference's own bf16 run differs from its fp32 run by ~1e-3 on the loss and
-~3e-3 rel-RMS on logits, so the bar is an error budget against fp32 truth,
-    err(ours, truth) <= 2 * err(reference_bf16, truth) + eps,
-with eps = 2e-3 (logits rel-RMS, loss rel) — i.e. within north_star's 1e-3-class bf16 tolerance of the
-reference's own noise floor.  Mask indices (xt, move_indices, token_mask) must be bit-exact.
+Tolerances: every comparison is recorded in the parity ledger (tests/ledger.py -> profiles/r02_parity_ledger.json) together with the
+reference's own bf16-vs-fp32 deviation (~1e-3 on the loss, ~3e-3 rel-RMS on logits), and asserted against a STATED bound that is
+<= 3x the error achieved there: loss 1e-3 relative (north_star's figure), logits / NLL / gradients as rel-RMS against the reference's fp32 run.
+Mask indices (xt, move_indices, token_mask) must be bit-exact.
 """
 import pytest
 import torch
 
 from golden_utils import CASE_NAMES, Golden, rel_err
+from ledger import check, record
 from oracle import unidisc_oracle as O
 from oracle.cases import lumina_rope_2d
 from product_utils import build_product, product_config
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
+# Stated bounds (<= 3x the errors recorded in profiles/r02_parity_ledger.json; d = 64 goldens, so per-parameter gradients of 64-element vectors are
+# the noisiest quantity): relative error of the loss, rel-RMS of logits / per-token NLL / per-parameter gradients against the reference's fp32 run.
+LOSS_BOUND, LOGITS_BOUND, NLL_BOUND, GRAD_BOUND = 1e-3, 1e-2, 1e-2, 6e-2
 
 
 @pytest.mark.parametrize("name", CASE_NAMES)
@@ -31,7 +34,8 @@ def test_logits_match_golden(name):
     truth, ref16 = g.t("fp32/logits"), g.t("bf16/logits")
     assert logits.dtype == torch.bfloat16 and logits.shape == truth.shape
     e, budget = rel_err(logits.float().cpu(), truth), rel_err(ref16, truth)
-    assert e <= 2 * budget + 2e-3, (e, budget)
+    record(f"golden_logits[{name}]", "ref_bf16_vs_fp32_logits_relrms", budget, note="the reference's own bf16 run against its fp32 run")
+    check(f"golden_logits[{name}]", "logits_relrms_vs_fp32_reference", e, LOGITS_BOUND)
 
 
 @pytest.mark.parametrize("name", CASE_NAMES)
@@ -47,26 +51,28 @@ def test_training_step_matches_golden(name):
     assert torch.equal(out.token_mask.cpu(), g.t("fp32/token_mask"))
     assert torch.equal(diff._last["t"].cpu(), g.t("fp32/t"))
     l32, l16 = float(g.t("fp32/loss")), float(g.t("bf16/loss"))
-    assert abs(float(out.loss) - l32) <= 2 * abs(l16 - l32) + 2e-3 * abs(l32), (float(out.loss), l32, l16)
+    T = f"golden_step[{name}]"
+    record(T, "ref_bf16_vs_fp32_loss_rel", abs(l16 - l32) / abs(l32), note="the reference's own bf16 run against its fp32 run")
+    check(T, "loss_rel_vs_fp32_reference", abs(float(out.loss.detach()) - l32) / abs(l32), LOSS_BOUND)
     nll_truth, nll_ref = g.t("fp32/nlls"), g.t("bf16/nlls")
     e, budget = rel_err(out.nlls.cpu(), nll_truth), rel_err(nll_ref, nll_truth)
-    assert e <= 2 * budget + 2e-3, (e, budget)
+    record(T, "ref_bf16_vs_fp32_nll_relrms", budget)
+    check(T, "nll_relrms_vs_fp32_reference", e, NLL_BOUND)
     assert torch.all(out.nlls.cpu()[~g.t("fp32/move_indices")] == 0)  # unmasked tokens: nll exactly 0
     for k in ("txt_loss", "img_loss"):
         if g.has("fp32/" + k):
-            v32, v16 = float(g.t("fp32/" + k)), float(g.t("bf16/" + k))
-            assert abs(float(getattr(out, k)) - v32) <= 2 * abs(v16 - v32) + 3e-3 * abs(v32) + 1e-6, k
+            v32 = float(g.t("fp32/" + k))
+            check(T, f"{k}_rel_vs_fp32_reference", abs(float(getattr(out, k)) - v32) / max(abs(v32), 1e-6), 3 * LOSS_BOUND)
     out.loss.backward()
     torch.cuda.synchronize()
     gref, gb16 = g.grads("fp32"), g.grads("bf16")
     named = dict(diff.backbone.named_parameters())
     assert set(gref) == {k for k, p in named.items() if p.grad is not None}
-    worst = []
-    for k, gr in gref.items():
-        e, budget = rel_err(named[k].grad.cpu(), gr), rel_err(gb16[k], gr)
-        worst.append((e - (2 * budget + 2e-2), k, e, budget))
-    worst.sort(reverse=True)
-    assert worst[0][0] <= 0, worst[:5]
+    errs = sorted(((rel_err(named[k].grad.cpu(), gr), k) for k, gr in gref.items()), reverse=True)
+    floors = sorted((rel_err(gb16[k], gr) for k, gr in gref.items()), reverse=True)
+    record(T, "ref_bf16_vs_fp32_grad_relrms_worst_param", floors[0])
+    check(T, "grad_relrms_worst_param", errs[0][0], GRAD_BOUND, note=errs[0][1])
+    check(T, "grad_relrms_median_param", errs[len(errs) // 2][0], GRAD_BOUND / 2)
 
 
 def test_matches_oracle_at_unidisc_s_width():
@@ -100,16 +106,14 @@ def test_matches_oracle_at_unidisc_s_width():
     torch.manual_seed(123)
     out = diff.training_step(batch, 1)
     assert torch.equal(diff._last["xt"].cpu(), oout.aux["xt"])
-    assert abs(float(out.loss) - float(oout.loss)) <= 4e-3 * abs(float(oout.loss)), (float(out.loss), float(oout.loss))
-    assert rel_err(out.nlls.cpu(), oout.nlls) < 1e-2
+    T = "oracle_step[unidisc_s_width_2blocks]"
+    check(T, "loss_rel_vs_fp32_oracle", abs(float(out.loss.detach()) - float(oout.loss.detach())) / abs(float(oout.loss.detach())), LOSS_BOUND)
+    check(T, "nll_relrms_vs_fp32_oracle", rel_err(out.nlls.cpu(), oout.nlls), NLL_BOUND)
     out.loss.backward()
     torch.cuda.synchronize()
-    bad = []
-    for k, p in diff.backbone.named_parameters():
-        e = rel_err(p.grad.cpu(), P[k].grad)
-        if e > 6e-2:
-            bad.append((k, e))
-    assert not bad, bad[:8]
+    errs = sorted(((rel_err(p.grad.cpu(), P[k].grad), k) for k, p in diff.backbone.named_parameters()), reverse=True)
+    check(T, "grad_relrms_worst_param", errs[0][0], GRAD_BOUND, note=errs[0][1])
+    check(T, "grad_relrms_median_param", errs[len(errs) // 2][0], GRAD_BOUND / 2)
 
 
 def test_dropout_training_runs_and_is_finite():
@@ -182,11 +186,12 @@ def test_fp8_attention_forward_training_step(heads):
         res.append((diff._last["xt"].cpu(), float(out.loss), out.nlls.detach().cpu(), {k: p.grad.cpu() for k, p in diff.backbone.named_parameters() if p.grad is not None}))
     (x0, l0, n0, g0), (x1, l1, n1, g1) = res
     assert torch.equal(x0, x1)
-    assert abs(l1 - l0) <= 2e-2 * abs(l0), (l0, l1)
-    assert rel_err(n1, n0) < 5e-2
+    T = f"fp8_attention_step[heads={heads}]"
+    check(T, "loss_rel_vs_bf16_path", abs(l1 - l0) / abs(l0), 2e-2)
+    check(T, "nll_relrms_vs_bf16_path", rel_err(n1, n0), 5e-2)
     assert l1 != l0                                             # the fp8 kernel really ran
-    bad = [(k, rel_err(g1[k], g0[k])) for k in g0 if rel_err(g1[k], g0[k]) > 0.25]
-    assert not bad, bad[:6]
+    errs = sorted(((rel_err(g1[k], g0[k]), k) for k in g0), reverse=True)
+    check(T, "grad_relrms_worst_param_vs_bf16_path", errs[0][0], 0.25, note=errs[0][1])
 
 
 @pytest.mark.parametrize("frac", [0.0, 1.0])

@@ -26,6 +26,7 @@ PROTOTYPES = {
     "udm_gemm_tn_splitk_bf16": [_P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _F, _P, _I64, _P],
     "udm_gemm_set_tile": [_I],
     "udm_gemm_set_persist": [_I],
+    "udm_gemm_set_cus": [_I],
     "udm_transpose_bf16": [_P, _P, _I64, _I64, _I64, _I64, _P, _P],
     "udm_cast_transpose_f32_bf16": [_P, _P, _P, _I64, _I64, _I64, _I64, _I64, _P],
     "udm_cast_f32_bf16": [_P, _P, _I64, _F, _P],
@@ -100,6 +101,19 @@ def load():
     lib.udm_abi_version.restype = c_int
     lib.udm_abi_version.argtypes = []
     _lib = lib
+    return lib
+
+
+def load_experiments():
+    """``libunidisc_exp.so``: GEMM variant / micro-benchmark experiments used by scripts/ only (``make -C unidisc_amd/csrc exp``); never
+    loaded by the product."""
+    path = os.path.join(_HERE, "libunidisc_exp.so")
+    if not os.path.exists(path):
+        out = subprocess.run(["make", "-C", CSRC, "-j4", "exp"], capture_output=True, text=True)
+        if out.returncode != 0:
+            raise RuntimeError("building libunidisc_exp.so failed:\n" + out.stderr[-3000:])
+    lib = ctypes.CDLL(path)
+    lib.udm_last_error.restype = ctypes.c_char_p
     return lib
 
 

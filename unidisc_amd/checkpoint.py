@@ -60,8 +60,8 @@ def load_backbone_checkpoint(backbone: torch.nn.Module, path: str, strict: bool 
     own = backbone.state_dict()
     cast = {k: (v.to(own[k].dtype) if k in own and v.is_floating_point() else v) for k, v in sd.items()}
     res = backbone.load_state_dict(cast, strict=strict)
-    if hasattr(backbone, "refresh_weight_shadows") and getattr(backbone, "_lins", None) is not None:
-        backbone._shadow_versions = None  # force a re-cast
+    if hasattr(backbone, "invalidate_shadows"):
+        backbone.invalidate_shadows()  # force a re-cast
     return list(res.missing_keys), list(res.unexpected_keys)
 
 

@@ -672,6 +672,10 @@ __global__ __launch_bounds__(512) void gemm_nt_stagger_kernel(GemmArgs p) {
 #undef ROT_A
 #undef ROT_B
 int g_gemm_persist = 1;   // diagnostics (UDM_GEMM_PERSIST=0): 0 = one block per output tile everywhere
+// Data-parallel runs: the persistent blocks of a multi-round NT GEMM occupy every CU for the whole launch, and RCCL's channel kernels (the
+// gradient all-reduce overlapped with backward) then only get CUs between launches.  UDM_GEMM_CUS = n (or udm_gemm_set_cus) caps the
+// persistent grid at n blocks (a multiple of 8: one block per CU, XCD round-robin), leaving 256 - n CUs to the collective.  0 = all 256.
+int g_gemm_cus = 0;
 
 template <int BMX, int EPI, bool OUT_F32, bool TN = false>
 int launch_big_t(const GemmArgs& a0, hipStream_t stream) {
@@ -689,7 +693,11 @@ int launch_big_t(const GemmArgs& a0, hipStream_t stream) {
   }
   if constexpr (!TN && BMX >= 256) {
     // more than one round of whole tiles: 256 persistent blocks walk them (see PERSIST above)
-    static const bool env_once = [] { if (const char* e = getenv("UDM_GEMM_PERSIST")) g_gemm_persist = atoi(e); return true; }();
+    static const bool env_once = [] {
+      if (const char* e = getenv("UDM_GEMM_PERSIST")) g_gemm_persist = atoi(e);
+      if (const char* e = getenv("UDM_GEMM_CUS")) { const int n = atoi(e); if (n >= 8 && n <= 256) g_gemm_cus = n / 8 * 8; }
+      return true;
+    }();
     (void)env_once;
     if (g_gemm_persist && a.splitk <= 1 && a.tiles_m * a.tiles_n > 256 && a.M % BMX == 0 && a.N % 256 == 0 && a.K / BK >= 2) {
       auto kp = gemm_nt_stagger_kernel<BMX, EPI, OUT_F32, false, 1, true>;
@@ -698,7 +706,7 @@ int launch_big_t(const GemmArgs& a0, hipStream_t stream) {
         (void)hipFuncSetAttribute((const void*)kp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_p = true;
       }
-      hipLaunchKernelGGL(kp, dim3(256), dim3(512), lds, stream, a);
+      hipLaunchKernelGGL(kp, dim3(g_gemm_cus ? g_gemm_cus : 256), dim3(512), lds, stream, a);
       UDM_CHECK_LAUNCH("udm_gemm_nt_bf16(big, persistent)");
       return 0;
     }
@@ -943,6 +951,12 @@ extern "C" int udm_cast_transpose_f32_bf16(const float* in, void* out, void* out
   dim3 grid((unsigned)((C + TT - 1) / TT), (unsigned)((R + TT - 1) / TT));
   hipLaunchKernelGGL(cast_transpose_kernel, grid, dim3(256), 0, stream, in, (bf16_t*)out, (bf16_t*)out_t, (int)R, (int)C, (long)ld_in, (long)ld_out, (long)ld_t);
   UDM_CHECK_LAUNCH("udm_cast_transpose_f32_bf16");
+  return 0;
+}
+
+extern "C" int udm_gemm_set_cus(int cus) {   // 0 = all CUs; otherwise the persistent NT grid (a multiple of 8 in [8, 256])
+  UDM_CHECK_ARG(cus == 0 || (cus >= 8 && cus <= 256 && cus % 8 == 0), "udm_gemm_set_cus: 0 or a multiple of 8 in [8, 256]");
+  g_gemm_cus = cus;
   return 0;
 }
 

@@ -9,11 +9,19 @@ bucket (~100 MB bf16 per DiT block at 1.4 B: large messages, because xGMI rings 
 compressed, all-reduced and decompressed in place on a dedicated comm stream while the compute stream keeps
 running the remaining layers.  The compute stream waits for the comm stream once, at the end of backward.
 
+Gradient accumulation (DDP ``no_sync``, model.py:1412): backward passes run with ``sync.enabled = False`` keep
+their gradients local (autograd sums them into ``p.grad``).  The first backward with ``enabled = True`` after such
+passes must reduce the ACCUMULATED gradients, which only exist once autograd has added this pass's gradients to
+``p.grad`` — so that pass does not reduce inside the backward; it queues an end-of-backward callback that
+compresses, all-reduces and decompresses ``p.grad`` bucket by bucket (``allreduce_accumulated``).  Without
+accumulation every pass takes the overlapped in-backward path.
+
 One process per GPU; ``torch.distributed`` backend "nccl" is RCCL on ROCm.  On CPU tensors (gloo, used by the
 world_size-2 tests of this file) the same code path runs with torch casts instead of the HIP cast kernels.
 """
 from __future__ import annotations
 
+import os
 from typing import List, Optional, Tuple
 
 import torch
@@ -23,26 +31,34 @@ from . import kernels as K
 
 
 class BucketedGradSync:
-    def __init__(self, module, process_group=None, min_bucket_elems: int = 32 * 1024 * 1024, wire_dtype=torch.bfloat16):
+    def __init__(self, module, process_group=None, min_bucket_elems: int = 32 * 1024 * 1024, wire_dtype=torch.bfloat16, force_single_rank=None):
         if not dist.is_initialized():
             raise RuntimeError("BucketedGradSync needs an initialised torch.distributed process group")
         self.module, self.pg = module, process_group
         self.world = dist.get_world_size(process_group)
         self.min_bucket = int(min_bucket_elems)
         self.wire_dtype = wire_dtype
+        # world_size 1 has nothing to reduce and is skipped, unless forced (tests / the 1-GPU RCCL rehearsal run the whole path on one rank)
+        self.force_single_rank = bool(int(os.environ.get("UDM_DDP_FORCE", "0"))) if force_single_rank is None else bool(force_single_rank)
         self.comm_stream: Optional[torch.cuda.Stream] = None
         self._pending: Optional[Tuple[torch.Tensor, int, int]] = None
-        self._work: List = []
         self._bufs = {}
-        self.enabled = True  # set False for gradient-accumulation micro-steps (DDP no_sync, model.py:1412)
+        self.enabled = True            # set False for gradient-accumulation micro-steps (DDP no_sync, model.py:1412)
+        self._unsynced_passes = 0      # backward passes since the last reduction whose gradients stayed local
         self.bytes_on_wire = 0
+        self.measure_exposed = False   # bench: time the compute stream spends waiting for the comm stream at the end of backward
+        self._exposed: List[Tuple[torch.cuda.Event, torch.cuda.Event]] = []
         module.grad_ready_callback = self._on_ready
         module.grad_sync_finish = self.finish
 
+    @property
+    def active(self):
+        return self.world > 1 or self.force_single_rank
+
     # ---- called from inside backward, on the compute stream's thread
     def _on_ready(self, flat: torch.Tensor, lo: int, hi: int):
-        if not self.enabled or self.world == 1:
-            return
+        if not self.active or not self.enabled or self._unsynced_passes:
+            return   # local pass, or accumulated gradients: reduced after autograd has summed them (finish)
         if self._pending is not None and self._pending[0] is flat and self._pending[2] == lo:
             lo = self._pending[1]
         elif self._pending is not None:
@@ -52,42 +68,116 @@ class BucketedGradSync:
             self._launch(flat, lo, hi)
             self._pending = None
 
-    def _wire_buffer(self, n: int, device) -> torch.Tensor:
-        key = (n, device)
+    def _wire_buffer(self, key, n: int, device) -> torch.Tensor:
+        """Persistent bf16 wire buffer of one bucket position (the flat layout is the same every step, so a bucket keeps its buffer; several
+        buckets are in flight at once, so they cannot share one)."""
+        key = (key, n, device)
         buf = self._bufs.get(key)
         if buf is None:
             buf = torch.empty(n, dtype=self.wire_dtype, device=device)
             self._bufs[key] = buf
         return buf
 
-    def _launch(self, flat: torch.Tensor, lo: int, hi: int):
-        seg = flat[lo:hi]
-        n = hi - lo
+    def _reduce_segment(self, seg: torch.Tensor, key):
+        """bf16-compress `seg` (fp32, contiguous), all-reduce, decompress in place.  GPU: on the comm stream, after what the current stream queued."""
+        n = seg.numel()
         self.bytes_on_wire += n * 2
-        if flat.is_cuda:
+        if seg.is_cuda:
             if self.comm_stream is None:
-                self.comm_stream = torch.cuda.Stream(device=flat.device)
+                self.comm_stream = torch.cuda.Stream(device=seg.device)
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())
-            wire = torch.empty(n, dtype=self.wire_dtype, device=flat.device)  # per-bucket: several buckets are in flight at once
-            wire.record_stream(self.comm_stream)
+            wire = self._wire_buffer(key, n, seg.device)   # reuse is stream-ordered: all users run on the comm stream
             with torch.cuda.stream(self.comm_stream):
                 self.comm_stream.wait_event(ev)
                 K.cast_f32_bf16(seg, wire, scale=1.0 / self.world)   # bf16 first, then divide in bf16 (reference hook order)
                 dist.all_reduce(wire, op=dist.ReduceOp.SUM, group=self.pg)
                 K.cast_bf16_f32(wire, seg, scale=1.0)
+            seg.record_stream(self.comm_stream)
         else:  # gloo / CPU tensors (tests)
             wire = (seg.to(self.wire_dtype).float() * (1.0 / self.world)).to(self.wire_dtype)
             dist.all_reduce(wire, op=dist.ReduceOp.SUM, group=self.pg)
             seg.copy_(wire.float())
 
+    def _launch(self, flat: torch.Tensor, lo: int, hi: int):
+        self._reduce_segment(flat[lo:hi], ("flat", lo))
+
+    def _join(self):
+        if self.comm_stream is not None:
+            cur = torch.cuda.current_stream()
+            if self.measure_exposed:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(cur)
+                cur.wait_stream(self.comm_stream)
+                e1.record(cur)
+                self._exposed.append((e0, e1))
+            else:
+                cur.wait_stream(self.comm_stream)
+
     def finish(self):
-        """End of backward: flush the last partial bucket and make the compute stream wait for all reductions."""
+        """End of the engine's backward: flush the last partial bucket and make the compute stream wait for all reductions; after
+        accumulation micro-steps, reduce the accumulated ``p.grad`` once autograd has finished this pass."""
+        if not self.active:
+            return
+        if not self.enabled:
+            self._unsynced_passes += 1
+            return
+        if self._unsynced_passes:
+            torch.autograd.Variable._execution_engine.queue_callback(self.allreduce_accumulated)
+            return
         if self._pending is not None:
             self._launch(*self._pending)
             self._pending = None
-        if self.comm_stream is not None:
+        self._join()
+
+    def allreduce_accumulated(self):
+        """Reduce what is in ``p.grad`` now (sum of this rank's micro-step gradients) across ranks, bucket by bucket in backward-completion
+        order.  Runs by itself at the end of the first ``enabled`` backward after ``enabled = False`` passes; callable directly as well."""
+        params = [p for p in self.module._ordered_params() if p.grad is not None]
+        bucket, size = [], 0
+        for i, p in enumerate(params):
+            bucket.append(p)
+            size += p.grad.numel()
+            if size >= self.min_bucket or i + 1 == len(params):
+                self._reduce_params(bucket)
+                bucket, size = [], 0
+        self._unsynced_passes = 0
+        self._join()
+
+    def _reduce_params(self, bucket):
+        grads = [p.grad for p in bucket]
+        key = ("acc", id(bucket[0]))
+        first = grads[0]
+        contiguous = all(g.is_contiguous() and g.dtype == torch.float32 for g in grads)
+        if contiguous and len(grads) > 1:   # views of one flat buffer laid out back to back (the engine's layout, 64-element aligned): reduce in place
+            end = first.data_ptr()
+            for g in grads:
+                gap = g.data_ptr() - end
+                contiguous = contiguous and 0 <= gap < 64 * 4 and g.untyped_storage().data_ptr() == first.untyped_storage().data_ptr()
+                end = g.data_ptr() + g.numel() * 4
+            if contiguous:
+                n = (end - first.data_ptr()) // 4
+                seg = torch.as_strided(first, (n,), (1,), first.storage_offset())
+                self._reduce_segment(seg, key)
+                return
+        if len(grads) == 1 and first.is_contiguous() and first.dtype == torch.float32:
+            self._reduce_segment(first.view(-1), key)
+            return
+        cat = torch.cat([g.reshape(-1).float() for g in grads])
+        self._reduce_segment(cat, key)
+        if cat.is_cuda:
             torch.cuda.current_stream().wait_stream(self.comm_stream)
+        off = 0
+        for g in grads:
+            g.copy_(cat[off:off + g.numel()].view_as(g))
+            off += g.numel()
+
+    def exposed_ms(self, reset=True) -> float:
+        """Sum over recorded backward passes of the time the compute stream waited for the comm stream (needs ``measure_exposed`` and a device sync)."""
+        total = sum(a.elapsed_time(b) for a, b in self._exposed)
+        if reset:
+            self._exposed = []
+        return total
 
 
 def wrap(module, **kw) -> BucketedGradSync:
@@ -100,6 +190,10 @@ def wrap(module, **kw) -> BucketedGradSync:
 
 
 def broadcast_parameters(module, src: int = 0, process_group=None):
-    """Make every rank start from rank `src`'s weights (what torch DDP does at construction)."""
-    for p in module.parameters():
-        dist.broadcast(p.data, src=src, group=process_group)
+    """Make every rank start from rank `src`'s weights (what torch DDP does at construction).  The bf16 weight shadows of the engine are
+    invalidated: a collective writes the parameter storage without bumping tensor versions."""
+    with torch.no_grad():
+        for p in module.parameters():
+            dist.broadcast(p, src=src, group=process_group)
+    if hasattr(module, "invalidate_shadows"):
+        module.invalidate_shadows()

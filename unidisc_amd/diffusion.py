@@ -55,6 +55,13 @@ class Diffusion:
         self.dtype = torch.float32 if ("fp32" in prec or "no" in prec) else (torch.bfloat16 if "bf16" in prec else torch.float16)
         if self.dtype != torch.bfloat16:
             raise NotImplementedError(f"unidisc_amd: trainer.precision={prec}; only bf16 (the reference's training precision) is implemented in HIP")
+        # trainer options that change the loss / the batch and are not built: refuse them instead of training silently with another objective
+        for flag, why in (("ar_llm_loss", "the extra auto-regressive LLM loss term (model.py:1076-1136)"),
+                          ("force_remove_img_tokens", "dropping image tokens from the batch (model.py:316-319, :1054)"),
+                          ("add_label", "the class-label token written by update_batch (model.py:321-334)"),
+                          ("low_precision_loss", "the bf16 loss reduction (this path reduces in fp32)")):
+            if cfg_get(tr, flag, False):
+                raise NotImplementedError(f"unidisc_amd: trainer.{flag} — {why} — is not on the denoising hot path (SURVEY.md §8)")
         self.image_model = bool(cfg_get(m, "image_model", False))
         self.unified_model = bool(cfg_get(m, "unified_model", False))
         self.antithetic_sampling = cfg_get(tr, "antithetic_sampling", True)
@@ -290,8 +297,6 @@ class Diffusion:
         for flag in ("joint_ar_nar_prob", "first_token_dropout"):
             if cfg_get(tr, flag, None) is not None:
                 raise NotImplementedError(f"unidisc_amd: trainer.{flag} is not on the denoising hot path")
-        if cfg_get(tr, "add_label", False):
-            move_indices[:, 0] = False
         if allow_move_mask is not None:
             move_indices = move_indices & allow_move_mask
         if cfg_get(tr, "discrete_diffusion_mode", "absorbing") != "absorbing":

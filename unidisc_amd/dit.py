@@ -167,6 +167,12 @@ class DIT(nn.Module, _HubMixin):
         self.vocab_size, self.text_vocab_size, self.mask_index = vocab_size, text_vocab_size, mask_index
         self.time_conditioning = bool(cfg_get(config, "time_conditioning", False) or cfg_get(m, "force_time_conditioning", False))
         self.use_gradient_checkpointing = cfg_get(tr, "use_gradient_checkpointing", False)
+        if self.use_gradient_checkpointing:
+            # models/dit.py:1486-1490 recomputes every block in the backward to fit 48 GB parts.  The engine keeps a block's activations
+            # (0.92 GB per block at 1.4 B, B = 8: 22 GB of 288 GB) and never recomputes: results are identical, the flag only trades memory.
+            import warnings
+            warnings.warn("unidisc_amd.DIT: trainer.use_gradient_checkpointing=true is accepted but activations are KEPT, not recomputed "
+                          "(identical results; ~0.92 GB per block per 10k tokens at d=2048 stay resident)", stacklevel=2)
         self.sandwich_normalization = cfg_get(m, "sandwich_normalization", False)
         self.static_img_sl, self.static_txt_sl = static_img_sl, static_txt_sl
         for flag, why in (("img_cond", "cross-attention image conditioning"), ("cond_label", "class-label conditioning"),
@@ -328,6 +334,18 @@ class DIT(nn.Module, _HubMixin):
                         lin.refresh()
             self._shadow_versions = versions
 
+    def invalidate_shadows(self):
+        """Force the next forward to rebuild the bf16 weight shadows.  Needed after any write to the master weights that does not bump tensor
+        versions (collectives, ``p.data`` writes, kernels called through ctypes, optimizer state reloads)."""
+        self._shadow_versions = None
+
+    @staticmethod
+    def _dropout_rank():
+        """Data-parallel ranks seeded identically must still draw different dropout masks (torch's CUDA generator differs per process in the
+        reference because every rank seeds with seed + rank, main.py:1058-1068; here the rank is mixed in explicitly)."""
+        import torch.distributed as dist
+        return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
     def _await_cast(self, key):
         ev = self._cast_events.pop(str(key), None)
         if ev is not None:
@@ -450,9 +468,10 @@ class DIT(nn.Module, _HubMixin):
         train = self.training
         self.refresh_weight_shadows()
         lin = self._lins
-        self._fwd_count += 1
-        seed0 = (torch.initial_seed() * 1000003 + self._fwd_count * 4096) & ((1 << 62) - 1)
         p_drop = self.dropout if train else 0.0
+        if train and save:   # only training forwards advance the dropout stream (eval / sampler passes draw no dropout masks)
+            self._fwd_count += 1
+        seed0 = ((torch.initial_seed() * 1000003 + self._fwd_count * 4096) ^ (self._dropout_rank() * 0x9E3779B97F4A7C15)) & ((1 << 62) - 1)
 
         ids = ids.contiguous().view(-1).to(torch.int64)
         modality = inp["modality"]
@@ -622,28 +641,30 @@ class DIT(nn.Module, _HubMixin):
         is_mask = ids == self.mask_index
         if not ids.is_cuda:  # CPU orchestration tests
             return dict(order=torch.argsort((~is_mask).to(torch.int8), stable=True), count=int(is_mask.sum()), event=None)
-        main = torch.cuda.current_stream()
-        if getattr(self, "_side_stream", None) is None:
-            self._side_stream = torch.cuda.Stream()
-            self._count_host = torch.zeros(1, dtype=torch.int64).pin_memory()
-        side = self._side_stream
+        dev = ids.device
+        main = torch.cuda.current_stream(dev)
+        side = self._side_streams.get(dev) if getattr(self, "_side_streams", None) else None
+        if side is None:   # one side stream per device the module has run on
+            self._side_streams = dict(getattr(self, "_side_streams", None) or {})
+            side = self._side_streams[dev] = torch.cuda.Stream(device=dev)
+        count_host = torch.empty(1, dtype=torch.int64).pin_memory()   # per call: forwards on two streams / threads must not share the counter
         side.wait_stream(main)
         with torch.cuda.stream(side):
             order = torch.argsort((~is_mask).to(torch.int8), stable=True)
-            self._count_host.copy_(is_mask.sum().view(1), non_blocking=True)
+            count_host.copy_(is_mask.sum().view(1), non_blocking=True)
             event = torch.cuda.Event()
             event.record(side)
         is_mask.record_stream(side)
         order.record_stream(main)
-        return dict(order=order, count=None, event=event)
+        return dict(order=order, count=None, event=event, count_host=count_host, side=side)
 
     def _masked_rows(self, plan, M, always=False):
         """(row indices: the [MASK] rows, then as many unmasked rows as pad the list to a multiple of 64; number of masked rows), or
         None when compaction would not shrink the head.  Unmasked rows have zero loss and zero gradient, so padding with them is exact."""
         if plan["event"] is not None:
             plan["event"].synchronize()
-            n = int(self._count_host[0])
-            torch.cuda.current_stream().wait_stream(self._side_stream)
+            n = int(plan["count_host"][0])
+            torch.cuda.current_stream().wait_stream(plan["side"])
         else:
             n = plan["count"]
         n_pad = _ceil(max(n, 1), 64)

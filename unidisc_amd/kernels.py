@@ -216,6 +216,11 @@ def gemm_set_persist(enable: int):
     _lib.call("udm_gemm_set_persist", int(enable))
 
 
+def gemm_set_cus(cus: int):
+    """Cap the persistent NT GEMM grid at `cus` blocks (multiple of 8; 0 = all 256 CUs): leaves CUs to RCCL's kernels in data-parallel runs."""
+    _lib.call("udm_gemm_set_cus", int(cus))
+
+
 def gemm_set_tile(tile: int):
     """Diagnostics: force the GEMM tile family (-1 auto, 0 small kernel, 192/256/320)."""
     _lib.call("udm_gemm_set_tile", tile)

@@ -139,6 +139,7 @@ class FusedAdamW:
         return dict(step=self.step_count, lr=self.lr, betas=self.betas, eps=self.eps, weight_decay=self.weight_decay, max_grad_norm=self.max_grad_norm,
                     exp_avg=[self.state[id(p)][0] for p in self.params], exp_avg_sq=[self.state[id(p)][1] for p in self.params],
                     ema_decay=self.ema_decay, ema_num_updates=self.ema_num_updates,
+                    dropout_fwd_count=int(getattr(self.backbone, "_fwd_count", 0)),   # position of the engine's dropout stream (resume must not replay masks)
                     ema=[self.ema[id(p)] for p in self.params] if self.ema is not None else None)
 
     def load_state_dict(self, sd):
@@ -150,3 +151,9 @@ class FusedAdamW:
             self.ema_num_updates = sd.get("ema_num_updates", self.ema_num_updates)
             for p, e in zip(self.params, sd["ema"]):
                 self.ema[id(p)].copy_(e)
+        if "dropout_fwd_count" in sd and hasattr(self.backbone, "_fwd_count"):
+            self.backbone._fwd_count = int(sd["dropout_fwd_count"])
+        # a resume usually reloads the master weights as well (writes the version counters do not see): rebuild the bf16 shadows on the next forward
+        if hasattr(self.backbone, "invalidate_shadows"):
+            self.backbone.invalidate_shadows()
+            self.backbone.recast_every_forward = True
