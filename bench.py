@@ -256,8 +256,8 @@ def cpu_baseline(workload, cfg, diff, seed):
 
 def cpu_baseline_legs(seed):
     """SURVEY §8(d) flavour of the CPU comparator, beside the workload's own leg: the oracle with the reference's bf16-autocast rounding points
-    emulated (`bf16=True`), on ALL host cores, for BASELINE configs[0] (config A: n=2, d=256, H=4, L=128, V=1001, B=32; fwd+loss and fwd+bwd)
-    and configs[1] (config B: UniDisc-S, n=12, d=768, L=128+256, V=40193, B=8; 2 steps fwd+bwd).  Bounded: a few seconds each."""
+    emulated (`bf16=True`), on min(cores, 32) threads, for BASELINE configs[0] (config A: n=2, d=256, H=4, L=128, V=1001, B=32; fwd+loss and fwd+bwd)
+    and configs[1] (config B: UniDisc-S, n=12, d=768, L=128+256, V=40193, B=8; 1 step fwd+bwd).  Bounded: a few seconds each."""
     from oracle import unidisc_oracle as O
     from oracle.cases import lumina_rope_2d
     from unidisc_amd import Diffusion, make_config
@@ -266,7 +266,10 @@ def cpu_baseline_legs(seed):
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    # torch's CPU thread pool is counter-productive far below the core count of a 256-core host at these sizes (measured on the GPU box: config A
+    # forward 41 k tokens/s on 8 threads here vs 0.18 k tokens/s on 256 threads there), so the legs use min(cores, 32) threads and say so
+    threads = min(cores, 32)
+    torch.set_num_threads(threads)
     legs = {}
     shapes = {
         "config_a": (dict(hidden_size=256, n_heads=4, cond_dim=128, n_blocks=2, txt_length=128, img_length=0, text_vocab_size=1001, vocab_size=1001,
@@ -275,7 +278,7 @@ def cpu_baseline_legs(seed):
         "config_b": (dict(hidden_size=768, n_heads=12, cond_dim=128, n_blocks=12, txt_length=128, img_length=256, text_vocab_size=32001, vocab_size=40193,
                           norm_type="rms", qk_norm=True, sandwich_normalization=True, modality_embed=True, rope_2d=False, time_conditioning=False,
                           multimodal_batches=True, force_argmax_valid_indices=True, mask_entire_modality=0.1, softmin_snr=5, text_loss_weight=1.0,
-                          force_full_attention_mask_loss_only=True), 8, 2),
+                          force_full_attention_mask_loss_only=True), 8, 1),
     }
     for name, (case, B, steps) in shapes.items():
         kw = {k: case[k] for k in ("hidden_size", "n_heads", "cond_dim", "n_blocks", "txt_length", "img_length", "norm_type", "qk_norm", "sandwich_normalization",
@@ -308,7 +311,7 @@ def cpu_baseline_legs(seed):
                 p_.grad = None
             O.compute_loss(ocfg, P, bufs, batch, torch.Generator().manual_seed(seed), bf16=True).loss.backward()
         t_fb = (time.perf_counter() - t0) / steps
-        legs[name] = dict(batch=B, seq_len=L, steps=steps, fwd_loss_tokens_per_s=B * L / t_fwd, fwd_bwd_tokens_per_s=B * L / t_fb, cores=cores,
+        legs[name] = dict(batch=B, seq_len=L, steps=steps, fwd_loss_tokens_per_s=B * L / t_fwd, fwd_bwd_tokens_per_s=B * L / t_fb, cores=threads, cores_available=cores,
                           numerics="oracle with bf16-autocast rounding points emulated")
     return legs
 

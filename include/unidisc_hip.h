@@ -59,6 +59,7 @@ int udm_gemm_tn_splitk_bf16(const void* A, const void* B, void* C, int64_t M, in
 int udm_gemm_nt_splitk_bf16(const void* A, const void* B, void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, float* ws,
                             int64_t ws_elems, hipStream_t stream);
 int udm_gemm_set_tile(int tile); /* diagnostics: force the tile family (-1 auto, 0 = 128x128 kernel, 192/256/320 = BMx256 kernel) */
+int udm_gemm_set_quad(int mode); /* diagnostics: one-wave-per-SIMD GEMM kernels: 0 = off, 1 = auto (default; env UDM_GEMM_QUAD), 2 = wherever the shape fits */
 int udm_gemm_set_persist(int enable); /* diagnostics: 0 = one block per output tile (default 1: persistent blocks for multi-round NT shapes) */
 /* data-parallel runs: cap the persistent NT grid at `cus` blocks (multiple of 8 in [8, 256]; 0 = all 256 CUs) so RCCL's channel kernels of the
  * gradient all-reduce overlapped with backward (main.py:641-656) find free CUs; also env UDM_GEMM_CUS */

@@ -154,6 +154,80 @@ def test_gemm_tn_splitk_workspace(K, Kc, M, N):
     assert rel_err(out.cpu(), 2 * ref) < 2e-5
 
 
+@pytest.mark.parametrize("M,N,K_", [(512, 512, 128), (512, 256, 192), (768, 512, 448), (384, 256, 256), (1024, 768, 1024), (640, 512, 320), (2560, 2048, 2048)])
+def test_gemm_nt_quad_one_wave_per_simd_every_epilogue(K, M, N, K_):
+    """The one-wave-per-SIMD NT kernel (gemm_quad.hip) forced on every shape it fits (192-, 256- and 320-row tiles - the last with its fifth accumulator row in arch VGPRs -, K-tile counts 2 / 3 / 4 / 5 / 7 / 16 / 32):
+    every epilogue against fp32, and bit-identical to the 8-wave kernel (same MFMA k order per output element)."""
+    a, b, bias = bf(rnd(M, K_, seed=380, scale=0.5)), bf(rnd(N, K_, seed=381, scale=0.3)), rnd(N, seed=382)
+    acc = a.float() @ b.float().t()
+    ga, gb, gbias = a.to(DEV), b.to(DEV), bias.to(DEV)
+
+    def run_all():
+        out = K.gemm_nt(ga, gb, N=N)
+        o32 = K.gemm_nt(ga, gb, out_dtype=torch.float32)
+        ob = K.gemm_nt(ga, gb, epilogue=K.EPI_BIAS, bias=gbias)
+        aux = torch.zeros((M, N), dtype=torch.bfloat16, device=DEV)
+        g = torch.zeros((M, N), dtype=torch.bfloat16, device=DEV)
+        K.gemm_nt(ga, gb, out=g, N=N, epilogue=K.EPI_BIAS_GELU, bias=gbias, aux=aux)
+        dg = torch.zeros((M, N), dtype=torch.bfloat16, device=DEV)
+        dbias = torch.zeros(N, dtype=torch.float32, device=DEV)
+        K.gemm_nt(ga, gb, out=dg, N=N, epilogue=K.EPI_DGELU, aux=aux, bias=dbias)
+        return out, o32, ob, aux, g, dg, dbias
+
+    try:
+        K.gemm_set_quad(2)
+        res_q = run_all()
+        K.gemm_set_quad(0)
+        res_8 = run_all()
+    finally:
+        K.gemm_set_quad(1)
+    for x, y, name in zip(res_q[:6], res_8[:6], ("plain", "f32", "bias", "aux", "gelu", "dgelu")):
+        assert torch.equal(x, y), name
+    assert torch.allclose(res_q[6], res_8[6], rtol=1e-4, atol=1e-3)   # column sums are fp32 atomics: order differs
+    out, o32, ob, aux, g, dg, dbias = res_q
+    assert rel_err(out.float().cpu(), acc) < 4e-3 and rel_err(o32.cpu(), acc) < 1e-5
+    assert rel_err(ob.float().cpu(), acc + bias) < 4e-3
+    u = (acc + bias).bfloat16().float().requires_grad_()
+    y = torch.nn.functional.gelu(u, approximate="tanh")
+    (gp,) = torch.autograd.grad(y.sum(), u)
+    assert rel_err(g.float().cpu(), y.detach()) < 6e-3 and rel_err(aux.float().cpu(), gp) < 6e-3
+    assert rel_err(dg.float().cpu(), acc * gp) < 8e-3
+    assert torch.allclose(dbias.cpu(), dg.float().cpu().sum(0), atol=2e-2, rtol=2e-3)
+
+
+@pytest.mark.parametrize("Kc,M,N", [(128, 256, 256), (192, 512, 512), (256, 512, 256), (448, 256, 512), (1024, 768, 512), (320, 384, 256), (640, 192, 512),
+                                    (10240, 2048, 2048), (2560, 8192, 2048)])
+def test_gemm_tn_quad_one_wave_per_simd(K, Kc, M, N):
+    """The one-wave-per-SIMD K-major kernel (gemm_quad.hip), forced on every shape it fits: K-tile counts 2 / 3 / 4 / 7 / 16 / 160 (prologue, the
+    unrolled steady-state pair, the run-time tail), 192- and 256-row tiles, beta = 0 / 1, padded strides; against fp32 and against the 8-wave kernel."""
+    lda, ldb = M + 8, N + 16
+    a, b = torch.zeros(Kc, lda, dtype=torch.bfloat16), torch.zeros(Kc, ldb, dtype=torch.bfloat16)
+    a[:, :M], b[:, :N] = bf(rnd(Kc, M, seed=190, scale=0.5)), bf(rnd(Kc, N, seed=191, scale=0.5))
+    ref = a[:, :M].float().t() @ b[:, :N].float()
+    c0 = rnd(M, N, seed=192)
+    ad, bd = a.to(DEV), b.to(DEV)
+    try:
+        K.gemm_set_quad(2)
+        out = c0.clone().to(DEV)
+        K.gemm_tn(ad, bd, out, M=M, N=N, beta=0.0)
+        assert rel_err(out.cpu(), ref) < 1e-5
+        K.gemm_tn(ad, bd, out, M=M, N=N, beta=1.0)
+        assert rel_err(out.cpu(), 2 * ref) < 2e-5
+        quad = torch.empty(M, N, device=DEV)
+        K.gemm_tn(ad, bd, quad, M=M, N=N, beta=0.0)
+        K.gemm_set_quad(0)
+        old = torch.empty(M, N, device=DEV)
+        K.gemm_tn(ad, bd, old, M=M, N=N, beta=0.0)
+        assert rel_err(quad.cpu(), old.cpu()) < 1e-6      # same products, fp32 accumulation in a different order
+        if M % 256 == 0:                                   # workspace split-K through the quad tiles
+            K.gemm_set_quad(2)
+            sk = c0.clone().to(DEV)
+            K.gemm_tn_splitk(ad[:, :M].contiguous(), bd[:, :N].contiguous(), sk, beta=1.0)
+            assert rel_err(sk.cpu(), c0 + ref) < 2e-5
+    finally:
+        K.gemm_set_quad(1)
+
+
 @pytest.mark.parametrize("M,N,K_", [(5120, 2048, 48512), (5056, 2048, 4096), (704, 512, 8192), (100, 300, 640), (5120, 2048, 192)])
 def test_gemm_nt_splitk_bf16_output(K, M, N, K_):
     """NT split-K with a bf16 result (the head dgrad on the compacted rows): ragged row counts, shapes where it must fall back, long K."""

@@ -26,6 +26,7 @@ PROTOTYPES = {
     "udm_gemm_tn_splitk_bf16": [_P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _F, _P, _I64, _P],
     "udm_gemm_set_tile": [_I],
     "udm_gemm_set_persist": [_I],
+    "udm_gemm_set_quad": [_I],
     "udm_gemm_set_cus": [_I],
     "udm_transpose_bf16": [_P, _P, _I64, _I64, _I64, _I64, _P, _P],
     "udm_cast_transpose_f32_bf16": [_P, _P, _P, _I64, _I64, _I64, _I64, _I64, _P],

@@ -11,6 +11,7 @@
 // through LDS so the epilogue (bias / GELU / GELU' / accumulate) runs on coalesced 16-byte rows.
 // Tile order is XCD-aware (8 private L2s) with a grouped-M sweep.
 #include "common.h"
+#include "gemm_quad.h"
 #include "../../include/unidisc_hip.h"
 
 namespace {
@@ -780,6 +781,21 @@ extern "C" int udm_gemm_nt_bf16(const void* A, const void* B, void* C, int64_t M
   if (epilogue == UDM_EPI_BIAS_GELU) UDM_CHECK_ARG(aux && !out_f32, "udm_gemm_nt_bf16: EPI_BIAS_GELU needs aux and bf16 output");
   if (epilogue == UDM_EPI_DGELU) UDM_CHECK_ARG(aux, "udm_gemm_nt_bf16: EPI_DGELU needs aux (the saved GELU derivative)");
   UDM_CHECK_ARG(epilogue >= 0 && epilogue <= 3, "udm_gemm_nt_bf16: unknown epilogue %d", epilogue);
+  {  // whole tiles: the one-wave-per-SIMD kernel (gemm_quad.hip) where its tile count fills rounds of the chip at least as well
+    int fm = 0;
+    if (g_force_tile < 0 && (beta == 0.f) && udm_quad_nt_ok(M, N, K, &fm)) {
+      const long qt = (M / (64 * fm)) * (N / 256);
+      const int t8 = choose_tile(M, N, K, lda, ldb);
+      const long t8n = t8 ? ((M + t8 - 1) / t8) * ((N + 255) / 256) : 0;
+      const double q_cost = (double)((qt + 255) / 256) * 64 * fm, o_cost = t8 ? (double)((t8n + 255) / 256) * t8 : 1e30;
+      if (udm_quad_mode() == 2 || (qt >= 128 && q_cost <= o_cost)) {
+        QuadArgs q{};
+        q.A = a.A; q.B = a.B; q.C = C; q.bias = bias; q.aux = (bf16_t*)aux; q.lda = lda; q.ldb = ldb; q.ldc = ldc; q.ldaux = ldaux;
+        q.M = a.M; q.N = a.N; q.K = a.K; q.beta = 0.f; q.splitk = 1;
+        if (ldc % 4 == 0 && (epilogue < UDM_EPI_BIAS_GELU || ldaux % 4 == 0)) return udm_quad_launch_nt(q, fm, epilogue, out_f32, stream);
+      }
+    }
+  }
   switch (choose_tile(M, N, K, lda, ldb)) {
     case 192: return launch_big<192>(a, epilogue, out_f32, stream);
     case 256: return launch_big<256>(a, epilogue, out_f32, stream);
@@ -812,10 +828,18 @@ extern "C" int udm_gemm_tn_bf16(const void* A, const void* B, void* C, int64_t M
   a.A = (const bf16_t*)A; a.B = (const bf16_t*)B; a.C = C; a.bias = nullptr; a.aux = nullptr;
   a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ldaux = 0;
   a.M = (int)M; a.N = (int)N; a.K = (int)K; a.beta = beta;
-  int tile = choose_tile(M, N, K, lda, ldb);
-  if (tile == 0) tile = M <= 192 ? 192 : 256;  // the K-major path has no small-tile kernel; the large one handles any M, N by clamping
   a.splitk = 1;
   a.slice_stride = 0;
+  {  // whole tiles that fill the chip: the one-wave-per-SIMD kernel (gemm_quad.hip)
+    int fm = 0;
+    if (g_force_tile < 0 && udm_quad_tn_ok(M, N, K, &fm) && ((M / (64 * fm)) * (N / 256) >= 128 || udm_quad_mode() == 2)) {
+      QuadArgs q{};
+      q.A = a.A; q.B = a.B; q.C = C; q.lda = lda; q.ldb = ldb; q.ldc = ldc; q.M = a.M; q.N = a.N; q.K = a.K; q.beta = beta; q.splitk = 1;
+      return udm_quad_launch_tn(q, fm, stream);
+    }
+  }
+  int tile = choose_tile(M, N, K, lda, ldb);
+  if (tile == 0) tile = M <= 192 ? 192 : 256;  // the K-major path has no small-tile kernel; the large one handles any M, N by clamping
   if (beta == 1.0f) {  // accumulate form: few output tiles over a long K (e.g. the 2048x2048 out-proj wgrad, K = B*L) -> split K, atomically add
     const long tiles = ((M + tile - 1) / tile) * ((N + 255) / 256);
     const long nkt = K / 64;
@@ -920,7 +944,13 @@ extern "C" int udm_gemm_tn_splitk_bf16(const void* A, const void* B, void* C, in
   a.M = (int)M; a.N = (int)N; a.K = (int)K; a.beta = 0.f;
   a.splitk = sk;
   a.slice_stride = (long)M * N;
-  if (int rc = launch_big_t<256, UDM_EPI_NONE, true, true>(a, stream)) return rc;
+  int fm = 0;
+  if (g_force_tile < 0 && M % 256 == 0 && udm_quad_tn_ok(M, N, K, &fm)) {   // same slices, 256 x 256 one-wave-per-SIMD tiles
+    QuadArgs q{};
+    q.A = a.A; q.B = a.B; q.C = ws; q.lda = lda; q.ldb = ldb; q.ldc = N; q.M = a.M; q.N = a.N; q.K = a.K; q.beta = 0.f; q.splitk = sk;
+    q.slice_stride = (long)M * N;
+    if (int rc = udm_quad_launch_tn(q, 4, stream)) return rc;
+  } else if (int rc = launch_big_t<256, UDM_EPI_NONE, true, true>(a, stream)) return rc;
   const long n4 = (long)M * N / 4;
   const int grid = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid), dim3(256), 0, stream, (const float*)ws, (float*)C, n4, sk, (long)M * N, beta);
@@ -957,6 +987,12 @@ extern "C" int udm_cast_transpose_f32_bf16(const float* in, void* out, void* out
 extern "C" int udm_gemm_set_cus(int cus) {   // 0 = all CUs; otherwise the persistent NT grid (a multiple of 8 in [8, 256])
   UDM_CHECK_ARG(cus == 0 || (cus >= 8 && cus <= 256 && cus % 8 == 0), "udm_gemm_set_cus: 0 or a multiple of 8 in [8, 256]");
   g_gemm_cus = cus;
+  return 0;
+}
+
+extern "C" int udm_gemm_set_quad(int mode) {   // diagnostics / tests: 0 = 8-wave kernels only, 1 = auto (default), 2 = quad wherever the shape fits
+  UDM_CHECK_ARG(mode >= 0 && mode <= 2, "udm_gemm_set_quad: mode must be 0, 1 or 2");
+  g_quad_mode = mode;
   return 0;
 }
 

@@ -1,0 +1,27 @@
+// Internal interface between gemm.hip (dispatch, C ABI) and gemm_quad.hip (one-wave-per-SIMD kernels).  Not part of the C ABI.
+#pragma once
+#include "common.h"
+
+struct QuadArgs {
+  const bf16_t* A;
+  const bf16_t* B;
+  void* C;
+  const float* bias;   // EPI_BIAS / EPI_BIAS_GELU: fp32 [N] input; EPI_DGELU: fp32 [N] OUTPUT receiving the column sums (or null)
+  bf16_t* aux;
+  long lda, ldb, ldc, ldaux;
+  int M, N, K;
+  int tiles_m, tiles_n;
+  float beta;
+  int splitk;          // > 1 (fp32 output only): K cut into slices, slice s stores its partial tile at C + s * slice_stride
+  long slice_stride;
+  int group_m;
+};
+
+extern int g_quad_mode;
+int udm_quad_mode();   // 0 off, 1 auto (shapes that fill the chip), 2 force wherever the shape fits
+// TN (wgrad) form: does a quad tile fit (whole tiles, K % 64 == 0)?  *fm receives the tile height / 64 (3, 4 or 5).
+bool udm_quad_tn_ok(long M, long N, long K, int* fm);
+int udm_quad_launch_tn(const QuadArgs& a, int fm, hipStream_t stream);
+// NT (forward / dgrad) form
+bool udm_quad_nt_ok(long M, long N, long K, int* fm);
+int udm_quad_launch_nt(const QuadArgs& a, int fm, int epilogue, int out_f32, hipStream_t stream);

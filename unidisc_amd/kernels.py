@@ -216,6 +216,11 @@ def gemm_set_persist(enable: int):
     _lib.call("udm_gemm_set_persist", int(enable))
 
 
+def gemm_set_quad(mode: int):
+    """Diagnostics: one-wave-per-SIMD GEMM kernels (gemm_quad.hip): 0 = off, 1 = auto, 2 = wherever the shape fits."""
+    _lib.call("udm_gemm_set_quad", int(mode))
+
+
 def gemm_set_cus(cus: int):
     """Cap the persistent NT GEMM grid at `cus` blocks (multiple of 8; 0 = all 256 CUs): leaves CUs to RCCL's kernels in data-parallel runs."""
     _lib.call("udm_gemm_set_cus", int(cus))
