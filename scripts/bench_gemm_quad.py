@@ -58,3 +58,19 @@ if which in ("nt", "all"):
             "quad": (lambda: K.gemm_set_quad(2), lambda: K.gemm_nt(a, b, out)),
             "torch": (lambda: None, lambda: torch.matmul(a, b.t())),
         })
+
+if which in ("epi", "all"):
+    for name, N, Kd, epi in [("fc1 fwd +bias+GELU", 8192, 2048, "gelu"), ("fc2 dgrad *GELU'", 8192, 2048, "dgelu"), ("fc2 fwd +bias", 2048, 8192, "bias")]:
+        a = (torch.randn(Mtok, Kd, device=dev, generator=g) * 0.5).bfloat16()
+        b = (torch.randn(N, Kd, device=dev, generator=g) * 0.05).bfloat16()
+        bias = torch.randn(N, device=dev, generator=g)
+        out = torch.empty(Mtok, N, device=dev, dtype=torch.bfloat16)
+        aux = (torch.rand(Mtok, N, device=dev, generator=g)).bfloat16()
+        dbias = torch.zeros(N, device=dev)
+        if epi == "gelu":
+            fn = lambda: K.gemm_nt(a, b, out, epilogue=K.EPI_BIAS_GELU, bias=bias, aux=aux)
+        elif epi == "dgelu":
+            fn = lambda: K.gemm_nt(a, b, out, epilogue=K.EPI_DGELU, aux=aux, bias=dbias)
+        else:
+            fn = lambda: K.gemm_nt(a, b, out, epilogue=K.EPI_BIAS, bias=bias)
+        ab(f"NT {name} {Mtok}x{N}x{Kd}", 2.0 * Mtok * N * Kd, {"8-wave": (lambda: K.gemm_set_quad(0), fn), "quad": (lambda: K.gemm_set_quad(2), fn)})

@@ -788,11 +788,15 @@ extern "C" int udm_gemm_nt_bf16(const void* A, const void* B, void* C, int64_t M
       const int t8 = choose_tile(M, N, K, lda, ldb);
       const long t8n = t8 ? ((M + t8 - 1) / t8) * ((N + 255) / 256) : 0;
       const double q_cost = (double)((qt + 255) / 256) * 64 * fm, o_cost = t8 ? (double)((t8n + 255) / 256) * t8 : 1e30;
-      if (udm_quad_mode() == 2 || (qt >= 128 && q_cost <= o_cost)) {
+      // measured (scripts/bench_gemm_quad.py, 1.4 B shapes, random operands): the quad kernel wins 1-3 % on single-round shapes with a plain or
+      // bias epilogue and loses 3 % where the GELU / GELU' epilogue runs (one wave per SIMD has nothing to overlap its VALU with);
+      // multi-round shapes stay with the persistent 8-wave blocks
+      if (udm_quad_mode() == 2 || (qt >= 128 && qt <= 256 && q_cost <= o_cost && epilogue <= UDM_EPI_BIAS)) {
         QuadArgs q{};
         q.A = a.A; q.B = a.B; q.C = C; q.bias = bias; q.aux = (bf16_t*)aux; q.lda = lda; q.ldb = ldb; q.ldc = ldc; q.ldaux = ldaux;
         q.M = a.M; q.N = a.N; q.K = a.K; q.beta = 0.f; q.splitk = 1;
-        if (ldc % 4 == 0 && (epilogue < UDM_EPI_BIAS_GELU || ldaux % 4 == 0)) return udm_quad_launch_nt(q, fm, epilogue, out_f32, stream);
+        if (ldc % 4 == 0 && (epilogue < UDM_EPI_BIAS_GELU || ldaux % 4 == 0) && !(out_f32 && epilogue != UDM_EPI_NONE))
+          return udm_quad_launch_nt(q, fm, epilogue, out_f32, stream);
       }
     }
   }

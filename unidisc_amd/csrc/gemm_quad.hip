@@ -42,7 +42,9 @@ __device__ __forceinline__ const char* uniform_ptr(const char* ptr) {   // pin a
   return reinterpret_cast<const char*>(((uint64_t)hi32 << 32) | lo);
 }
 
-template <int FM, bool TN, int EPI, bool OUT_F32, int DMA_GAP>
+// ABL (timing-only ablations, WRONG results; env UDM_QUAD_ABL): bit 0 = no refills after the prologue, bit 1 = the boundary does not wait for the refills,
+// bit 2 = no L2 touch-ahead
+template <int FM, bool TN, int EPI, bool OUT_F32, int DMA_GAP, int ABL = 0>
 __global__ __launch_bounds__(256, 1) void gemm_quad_kernel(QuadArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int FN = 4, BM = 64 * FM, BN = 256;
@@ -113,6 +115,7 @@ __global__ __launch_bounds__(256, 1) void gemm_quad_kernel(QuadArgs p) {
   const char* bp = uniform_ptr(reinterpret_cast<const char*>(TN ? p.B + col0 : p.B + (long)col0 * p.ldb) + kt0 * kstep_b);
   const uint32_t dsta = lds0 + A0 + wave * A_PW * 1024, dstb = lds0 + B0 + wave * B_PW * 1024;
   auto dma_piece = [&](int ahead, int stage, int j) {   // the tile `ahead` K tiles after the current one into `stage`; j < A_PW: A piece j, else B piece j - A_PW
+    if ((ABL & 1) && ahead == 2) return;
     if (j < A_PW) dma16(ap + ahead * kstep_a, offa[j], dsta + stage * A_BYTES + j * 1024);
     else dma16(bp + ahead * kstep_b, offb[j - A_PW], dstb + stage * B_BYTES + (j - A_PW) * 1024);
   };
@@ -219,7 +222,8 @@ __global__ __launch_bounds__(256, 1) void gemm_quad_kernel(QuadArgs p) {
           // boundary: every fragment of this stage is in registers (lgkmcnt) and this wave's pieces of the next tile have landed (vmcnt);
           // after the barrier every wave's have, and the stage just read may be refilled
           __builtin_amdgcn_sched_barrier(0);
-          asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+          if (ABL & 2) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         }
         __builtin_amdgcn_sched_barrier(0);
         const int i = m / FN, j = m % FN;
@@ -350,10 +354,15 @@ int launch_quad_t(const QuadArgs& a0, hipStream_t stream) {
   const size_t lds = (size_t)2 * (BM + 256) * BK * 2;
   constexpr int GAP = 2;
   auto kern = gemm_quad_kernel<FM, TN, EPI, OUT_F32, GAP>;
-  static bool attr_set = false;
-  if (!attr_set) {
+  if constexpr (EPI == UDM_EPI_NONE && FM >= 4) {   // timing-only ablations of the plain kernels (scripts/bench_gemm_quad.py)
+    static const int abl = [] { const char* e = getenv("UDM_QUAD_ABL"); return e ? atoi(e) : 0; }();
+    if (abl == 1) kern = gemm_quad_kernel<FM, TN, EPI, OUT_F32, GAP, 1>;
+    if (abl == 2) kern = gemm_quad_kernel<FM, TN, EPI, OUT_F32, GAP, 2>;
+  }
+  static const void* attr_set = nullptr;
+  if (attr_set != (const void*)kern) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
+    attr_set = (const void*)kern;
   }
   hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n * (a.splitk > 1 ? a.splitk : 1)), dim3(256), lds, stream, a);
   UDM_CHECK_LAUNCH("udm_gemm (quad)");
