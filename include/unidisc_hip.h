@@ -95,7 +95,13 @@ int udm_residual_norm_fwd(const float* x_in, const void* branch, float* x_out, c
                           uint64_t seed, const float* w_next, void* h_out, float* rstd_next, float* mean_next, hipStream_t stream);
 int udm_residual_bwd(const float* dx, const void* branch, void* dbranch, const float* w_b, const float* rstd_b, const float* mean_b, const void* gate,
                      int64_t mod_stride, const int64_t* modality, float* dw_b, float* dgate, int64_t M, int64_t d, int64_t L, int norm_type, float p_drop,
-                     uint64_t seed, float* ws, int64_t ws_elems, hipStream_t stream); /* ws: optional fp32 scratch (>= 1024*d) for a two-phase dw_b reduction */
+                     uint64_t seed, float* ws, int64_t ws_elems, hipStream_t stream);
+/* udm_norm_bwd (unmodulated) immediately followed by udm_residual_bwd (no gate) on the dx it has just updated, as ONE pass per row
+ * (d = 2048 / 4096): the pairs norm2 -> attention branch, norm1 -> previous block's MLP branch, final norm -> last MLP branch of the block
+ * backward (models/dit.py:77-100 RMSNorm / :383-403 LayerNorm backward feeding :229-253, :993-994).  ws: >= min(M, 1536) * 2 * d floats. */
+int udm_norm_residual_bwd(const void* dy, const float* x, const float* rstd, const float* mean, const float* w, float* dx, float* dw, int accumulate,
+                          const void* branch, void* dbranch, const float* w_b, const float* rstd_b, const float* mean_b, float* dw_b, int64_t M, int64_t d,
+                          int norm_type, float p_drop, uint64_t seed, float* ws, int64_t ws_elems, hipStream_t stream); /* ws: optional fp32 scratch (>= 1024*d) for a two-phase dw_b reduction */
 
 /* ---- QK LayerNorm (models/dit.py:569-572, 680-682) + rotary (models/standalone_rotary.py:14-31, call dit.py:723-726)
  * qkv bf16 [M,3d] -> qkr bf16 [M,2d] (normalised, rotated q | k).  cos/sin fp32 [L,D/2] or per-sample [M,D/2]. */

@@ -150,6 +150,12 @@ def residual_fwd(x_in, branch, L, *, w_b=None, norm_type=NORM_RMS, mod=None, gat
 
 
 @torch.enable_grad()
+def norm_residual_bwd(dy, x, rstd, mean, w, norm_type, L, dx, dw, branch, *, accumulate=True, w_b=None, rstd_b=None, mean_b=None, dw_b=None, p_drop=0.0, seed=0):
+    norm_bwd(dy, x, rstd, mean, w, norm_type, L, dx, dw, accumulate=accumulate)
+    return residual_bwd(dx, branch, L, w_b=w_b, rstd=rstd_b, mean=mean_b, norm_type=norm_type, dw_b=dw_b, p_drop=p_drop, seed=seed)
+
+
+@torch.enable_grad()
 def residual_bwd(dx, branch, L, *, w_b=None, rstd=None, mean=None, norm_type=NORM_RMS, mod=None, dmod=None, gate_idx=None, modality=None, dw_b=None,
                  p_drop=0.0, seed=0):
     br = branch.float().clone().requires_grad_()

@@ -19,7 +19,7 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 # Stated bounds (<= 3x the errors recorded in profiles/r02_parity_ledger.json; d = 64 goldens, so per-parameter gradients of 64-element vectors are
 # the noisiest quantity): relative error of the loss, rel-RMS of logits / per-token NLL / per-parameter gradients against the reference's fp32 run.
-LOSS_BOUND, LOGITS_BOUND, NLL_BOUND, GRAD_BOUND = 1e-3, 1e-2, 1e-2, 6e-2
+LOSS_BOUND, LOGITS_BOUND, NLL_BOUND, GRAD_BOUND = 1e-3, 1e-2, 4.5e-3, 6e-2
 
 
 @pytest.mark.parametrize("name", CASE_NAMES)

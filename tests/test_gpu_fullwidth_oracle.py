@@ -34,17 +34,20 @@ _PLUMB = dict(hidden_size=256, n_heads=4, cond_dim=128, txt_length=128, img_leng
               qk_norm=False, sandwich_normalization=False, modality_embed=False, rope_2d=False, time_conditioning=True, multimodal_batches=False,
               force_argmax_valid_indices=False)
 
-# name -> (case, batch size, asserted bounds).  Bounds: loss relative error vs {fp32, bf16} oracle; per-token NLL rel-RMS; worst / median
-# per-parameter gradient rel-RMS vs the fp32 oracle.  Numbers are <= 3x the errors recorded in profiles/r02_parity_ledger.json.
+# name -> (case, batch size, asserted bounds).  Bounds: loss relative error vs the fp32 oracle; per-token NLL rel-RMS; worst / median
+# per-parameter gradient rel-RMS vs the fp32 oracle.  Numbers are <= 3x the errors recorded in profiles/r02_parity_ledger.json, except the loss:
+# achieved 5e-7 .. 4e-6 (a mean over thousands of tokens), asserted at 5e-5 - twenty times inside north_star's 1e-3.  The worst gradient is
+# always a 768- / 2048-element qk-norm vector deep in the stack (bf16 noise of every layer above it); the reference's own bf16 run (oracle with
+# its rounding points emulated) is recorded next to it as the floor.
 FULLWIDTH = {
     # BASELINE configs[2] at its exact per-GPU shape M = 8 x 1280 = 10 240 rows (the bench's GEMM tiles), one block
-    "config_c_1block_b8": (dict(_LARGE, n_blocks=1), 8, dict(loss=1e-3, nll=1.2e-2, grad_max=6e-2, grad_med=3e-2)),
+    "config_c_1block_b8": (dict(_LARGE, n_blocks=1), 8, dict(loss=5e-5, nll=1e-3, grad_max=3.2e-2, grad_med=2e-2)),
     # the same width, two blocks composed (block -> block fused residual+norm), B = 2
-    "config_c_2blocks_b2": (dict(_LARGE, n_blocks=2), 2, dict(loss=1e-3, nll=1.2e-2, grad_max=6e-2, grad_med=3e-2)),
+    "config_c_2blocks_b2": (dict(_LARGE, n_blocks=2), 2, dict(loss=5e-5, nll=1e-3, grad_max=1.1e-1, grad_med=2.2e-2)),
     # BASELINE configs[1]: UniDisc-S, all 12 blocks, L = 128 + 256
-    "unidisc_s_12blocks_b4": (dict(_SMALL, n_blocks=12), 4, dict(loss=1e-3, nll=1.2e-2, grad_max=6e-2, grad_med=3e-2)),
+    "unidisc_s_12blocks_b4": (dict(_SMALL, n_blocks=12), 4, dict(loss=5e-5, nll=1.2e-3, grad_max=2e-1, grad_med=3e-2)),
     # BASELINE configs[0]: 2-layer d = 256 text-only adaLN DiT, L = 128, vocabulary 1k (+ [MASK])
-    "config_a_plumbing_b8": (dict(_PLUMB, n_blocks=2), 8, dict(loss=1e-3, nll=1.2e-2, grad_max=6e-2, grad_med=3e-2)),
+    "config_a_plumbing_b8": (dict(_PLUMB, n_blocks=2), 8, dict(loss=5e-5, nll=1e-3, grad_max=2.5e-2, grad_med=2e-2)),
 }
 
 
@@ -88,8 +91,9 @@ def test_training_step_matches_oracle_at_full_width(name):
     ob = O.update_batch(ocfg, {k: v.clone() for k, v in batch.items()})
     o32 = O.compute_loss(ocfg, P, bufs, ob, torch.Generator().manual_seed(123))
     o32.loss.backward()
-    with torch.no_grad():
-        o16 = O.compute_loss(ocfg, {k: v.detach() for k, v in P.items()}, bufs, ob, torch.Generator().manual_seed(123), bf16=True)
+    P16 = {k: v.detach().clone().requires_grad_() for k, v in P.items()}
+    o16 = O.compute_loss(ocfg, P16, bufs, ob, torch.Generator().manual_seed(123), bf16=True)   # the reference's own bf16 numerics: the noise floor
+    o16.loss.backward()
 
     torch.manual_seed(123)
     out = diff.training_step({k: v.clone() for k, v in batch.items()}, 1)
@@ -100,13 +104,13 @@ def test_training_step_matches_oracle_at_full_width(name):
     assert torch.equal(diff._last["t"].cpu(), o32.aux["t"])
     assert 0 < int(o32.aux["move_indices"].sum()) < o32.aux["move_indices"].numel()
 
-    l, l32, l16 = float(out.loss.detach()), float(o32.loss.detach()), float(o16.loss)
+    l, l32, l16 = float(out.loss.detach()), float(o32.loss.detach()), float(o16.loss.detach())
     floor = abs(l16 - l32) / abs(l32)
     record(name, "ref_bf16_vs_fp32_loss_rel", floor, note="the reference's own bf16-vs-fp32 noise floor (oracle bf16 emulation: bf16 log-softmax)")
     check(name, "loss_rel_vs_fp32_oracle", abs(l - l32) / abs(l32), bound["loss"])
     # the HIP path keeps the log-sum-exp in fp32, so it sits next to the fp32 truth; its distance to the bf16 emulation is that emulation's own error
     check(name, "loss_rel_vs_bf16_oracle", abs(l - l16) / abs(l16), floor + bound["loss"])
-    record(name, "ref_bf16_vs_fp32_nll_relrms", _rel(o16.nlls, o32.nlls))
+    record(name, "ref_bf16_vs_fp32_nll_relrms", _rel(o16.nlls.detach(), o32.nlls))
     check(name, "nll_relrms_vs_fp32_oracle", _rel(out.nlls.cpu(), o32.nlls), bound["nll"])
     assert torch.all(out.nlls.cpu()[~o32.aux["move_indices"]] == 0)   # unmasked tokens: nll exactly 0
     for k in ("txt_loss", "img_loss"):
@@ -123,6 +127,9 @@ def test_training_step_matches_oracle_at_full_width(name):
             continue
         errs.append((_rel(p.grad.cpu(), P[k].grad), k))
     errs.sort(reverse=True)
+    floors = sorted(((_rel(P16[k].grad, P[k].grad), k) for k in P if P[k].grad is not None), reverse=True)
+    record(name, "ref_bf16_vs_fp32_grad_relrms_worst_param", floors[0][0], note=floors[0][1])
+    record(name, "ref_bf16_vs_fp32_grad_relrms_median_param", floors[len(floors) // 2][0])
     check(name, "grad_relrms_worst_param", errs[0][0], bound["grad_max"], note=errs[0][1])
     check(name, "grad_relrms_median_param", errs[len(errs) // 2][0], bound["grad_med"])
     allg = torch.cat([p.grad.reshape(-1).cpu() for k, p in diff.backbone.named_parameters() if P[k].grad is not None])

@@ -418,6 +418,36 @@ def test_residual_with_fused_next_norm_equals_separate_kernels(K, d, variant):
         assert torch.equal(mn1, mn2) and torch.equal(m1, m2)
 
 
+@pytest.mark.parametrize("d", [2048, 4096])
+@pytest.mark.parametrize("nt,sandwich,p,acc", [(0, True, 0.0, True), (0, True, 0.1, True), (1, True, 0.0, True), (0, False, 0.1, True), (0, True, 0.0, False), (1, False, 0.0, False)])
+def test_norm_residual_bwd_fused_equals_the_two_kernels(K, d, nt, sandwich, p, acc):
+    """The fused norm-backward + residual-branch-backward pass (one kernel per row pair of the block backward at d = 2048 / 4096) against the
+    two kernels it replaces run back to back, and - through them - against the fp32 references those are tested with: dx, d branch, both
+    weight gradients; rms / LayerNorm, with and without the sandwich norm, dropout mask regenerated from the same (seed, index)."""
+    M, L = 1000, 250     # not a multiple of the grid: the row loop's tail
+    x, dx0 = rnd(M, d, seed=400), rnd(M, d, seed=401)
+    w, wb = 1 + 0.1 * rnd(d, seed=402), 1 + 0.1 * rnd(d, seed=403)
+    dy, br = bf(rnd(M, d, seed=404)), bf(rnd(M, d, seed=405, scale=0.7))
+    xg, wg, wbg, dyg, brg = x.to(DEV), w.to(DEV), wb.to(DEV), dy.to(DEV), br.to(DEV)
+    _, rstd, mean = K.norm_fwd(xg, wg, nt, L)
+    rb = mb = None
+    if sandwich:
+        _, rb, mb = K.residual_fwd(xg, brg, L, w_b=wbg, norm_type=nt)
+    dxa, dwa, dwba = dx0.clone().to(DEV), torch.zeros(d, device=DEV), torch.zeros(d, device=DEV)
+    K.norm_bwd(dyg, xg, rstd, mean, wg, nt, L, dxa, dwa, accumulate=acc)
+    da = K.residual_bwd(dxa, brg, L, w_b=wbg if sandwich else None, rstd=rb, mean=mb, norm_type=nt, dw_b=dwba if sandwich else None, p_drop=p, seed=77)
+    dxb, dwb_, dwbb = dx0.clone().to(DEV), torch.zeros(d, device=DEV), torch.zeros(d, device=DEV)
+    db = K.norm_residual_bwd(dyg, xg, rstd, mean, wg, nt, L, dxb, dwb_, brg, accumulate=acc, w_b=wbg if sandwich else None, rstd_b=rb, mean_b=mb,
+                             dw_b=dwbb if sandwich else None, p_drop=p, seed=77)
+    torch.cuda.synchronize()
+    assert rel_err(dxb.cpu(), dxa.cpu()) < 1e-6
+    assert rel_err(db.float().cpu(), da.float().cpu()) < 1e-3          # bf16 outputs: a few last-bit flips from the different summation order
+    assert torch.equal((db == 0).cpu(), (da == 0).cpu())                # the same dropout mask
+    assert rel_err(dwb_.cpu(), dwa.cpu()) < 1e-5
+    if sandwich:
+        assert rel_err(dwbb.cpu(), dwba.cpu()) < 1e-5
+
+
 def test_residual_dropout_mask_consistent(K):
     M, d, L, p = 64, 256, 32, 0.25
     x_in, br, dx = torch.zeros(M, d), bf(torch.ones(M, d)), torch.ones(M, d)

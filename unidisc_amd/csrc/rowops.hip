@@ -1027,6 +1027,163 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict_
   if (sub == 0 && col < ncols) atomicAdd(out + col, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Fused backward of  h = norm(x; w)  FOLLOWED BY the backward of the residual branch that produced x:
+//     dx   (+)= d norm / dx (dy)                                (udm_norm_bwd, unmodulated)
+//     dbr   =  d [x = x_in + dropout(sandwich_norm(branch; w_b))] / d branch  evaluated at the UPDATED dx   (udm_residual_bwd, no gate)
+// The two kernels always run back to back in the block's backward (norm2 -> attention branch, norm1 -> the previous block's MLP branch,
+// final norm -> the last block's MLP branch) and the second re-reads the fp32 dx the first has just written: fused, a row moves
+// 12 B read + 6 B written per element instead of 14 + 8.  Block per row (d = 2048 / 4096): a thread holds 8 NCB columns of every operand,
+// the next row's four operands are requested before the current row's two block-wide reductions.
+// Column sums (dw of the norm, dw_b of the sandwich norm) go through ONE workspace [gridDim.x][2][d] and one reduction launch.
+// ---------------------------------------------------------------------------------------------
+struct NormResidBwdArgs {
+  const bf16_t* dy; const float* x; const float* rstd; const float* mean; const float* w;   // the norm whose input is x
+  float* dx; float* dw; int accumulate;
+  const bf16_t* branch; bf16_t* dbranch; const float* w_b; const float* rstd_b; const float* mean_b; float* dw_b;   // the residual branch
+  float* ws;
+  int M, d, norm_type;
+  float p_drop;
+  uint64_t seed;
+};
+
+template <int NCB>
+__global__ __launch_bounds__(256) void norm_residual_bwd_kernel(NormResidBwdArgs a) {
+  __shared__ float sm[8];
+  const int tid = threadIdx.x;
+  float dwn[NCB][8], dwb[NCB][8];
+#pragma unroll
+  for (int i = 0; i < NCB; ++i)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { dwn[i][k] = 0.f; dwb[i][k] = 0.f; }
+  const float keep_scale = 1.f / (1.f - a.p_drop);
+  float dy_n[NCB][8], x_n[NCB][8], dx_n[NCB][8], br_n[NCB][8];
+  auto fetch = [&](long row) {
+#pragma unroll
+    for (int i = 0; i < NCB; ++i) {
+      const int c = (i * 256 + tid) * 8;
+      if (row < a.M) {
+        load8_bf16(a.dy + row * a.d + c, dy_n[i]);
+        load8_f32(a.x + row * a.d + c, x_n[i]);
+        if (a.accumulate) load8_f32(a.dx + row * a.d + c, dx_n[i]);
+        load8_bf16(a.branch + row * a.d + c, br_n[i]);
+      }
+    }
+  };
+  fetch(blockIdx.x);
+  float w8[NCB][8], wb8[NCB][8];
+#pragma unroll
+  for (int i = 0; i < NCB; ++i) {
+    const int c = (i * 256 + tid) * 8;
+    load8_f32(a.w + c, w8[i]);
+    if (a.w_b) load8_f32(a.w_b + c, wb8[i]);
+  }
+  for (long row = blockIdx.x; row < a.M; row += gridDim.x) {
+    const float rs = a.rstd[row];
+    const float mu = a.norm_type ? a.mean[row] : 0.f;
+    const float rsb = a.w_b ? a.rstd_b[row] : 1.f;
+    const float mub = (a.w_b && a.norm_type) ? a.mean_b[row] : 0.f;
+    float xh[NCB][8], g[NCB][8], dxo[NCB][8], br[NCB][8];
+    float red[2] = {0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < NCB; ++i)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        xh[i][k] = (x_n[i][k] - mu) * rs;
+        const float dyv = dy_n[i][k];
+        dwn[i][k] += dyv * xh[i][k];
+        g[i][k] = dyv * w8[i][k];
+        red[0] += g[i][k];
+        red[1] += g[i][k] * xh[i][k];
+        dxo[i][k] = a.accumulate ? dx_n[i][k] : 0.f;
+        br[i][k] = br_n[i][k];
+      }
+    fetch(row + gridDim.x);
+    block_sum4<2>(red, sm);
+    const float s_gx = red[1] / a.d, s_g = a.norm_type ? red[0] / a.d : 0.f;
+    float nh[NCB][8], g2[NCB][8];
+    float red2[2] = {0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < NCB; ++i) {
+      const int c = (i * 256 + tid) * 8;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) dxo[i][k] += rs * (g[i][k] - s_g - xh[i][k] * s_gx);
+      store8_f32(a.dx + row * a.d + c, dxo[i]);
+      float dn[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) dn[k] = dxo[i][k];
+      if (a.p_drop > 0.f) {
+        bool keep[8];
+        dropout_keep8(a.seed, (uint64_t)row * a.d + c, a.p_drop, keep);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) dn[k] *= keep[k] ? keep_scale : 0.f;
+      }
+      if (a.w_b) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          nh[i][k] = (br[i][k] - mub) * rsb;
+          const float nr = (a.norm_type == 0) ? rbf(nh[i][k]) : nh[i][k];
+          dwb[i][k] += dn[k] * nr;
+          g2[i][k] = dn[k] * wb8[i][k];
+          red2[0] += g2[i][k];
+          red2[1] += g2[i][k] * nh[i][k];
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) g2[i][k] = dn[k];
+      }
+    }
+    float s2_gx = 0.f, s2_g = 0.f;
+    if (a.w_b) {
+      block_sum4<2>(red2, sm);
+      s2_gx = red2[1] / a.d;
+      s2_g = a.norm_type ? red2[0] / a.d : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < NCB; ++i) {
+      const int c = (i * 256 + tid) * 8;
+      float o[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) o[k] = a.w_b ? rsb * (g2[i][k] - s2_g - nh[i][k] * s2_gx) : g2[i][k];
+      store8_bf16(a.dbranch + row * a.d + c, o);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NCB; ++i) {
+    const int c = (i * 256 + tid) * 8;
+    store8_f32(a.ws + ((long)blockIdx.x * 2) * a.d + c, dwn[i]);
+    if (a.w_b) store8_f32(a.ws + ((long)blockIdx.x * 2 + 1) * a.d + c, dwb[i]);
+  }
+}
+
+// out0[c] += sum_r ws[r][0][c], out1[c] += sum_r ws[r][1][c]  (ws is [nrows][2][d]; out1 may be null)
+__global__ __launch_bounds__(256) void colreduce2_kernel(const float* __restrict__ ws, float* __restrict__ out0, float* __restrict__ out1, int nrows, int d) {
+  __shared__ float red[4][64];
+  const int which = blockIdx.z;
+  if (which == 1 && !out1) return;
+  const int col = blockIdx.x * 64 + (threadIdx.x & 63), sub = threadIdx.x >> 6;
+  const int per = (nrows + gridDim.y - 1) / gridDim.y;
+  const int r0 = blockIdx.y * per, r1 = min(nrows, r0 + per);
+  const float* base = ws + (long)which * d;
+  const long rstride = 2L * d;
+  float s = 0.f;
+  if (col < d) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int r = r0 + sub;
+    for (; r + 12 < r1; r += 16) {
+      s0 += base[(long)r * rstride + col];
+      s1 += base[(long)(r + 4) * rstride + col];
+      s2 += base[(long)(r + 8) * rstride + col];
+      s3 += base[(long)(r + 12) * rstride + col];
+    }
+    for (; r < r1; r += 4) s0 += base[(long)r * rstride + col];
+    s = (s0 + s1) + (s2 + s3);
+  }
+  red[sub][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (sub == 0 && col < d) atomicAdd((which ? out1 : out0) + col, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
 // item t = i * 256 + tid -> (part, head, j): 8 columns at c_lo and 8 at c_lo + D/2 (see the wave-per-row kernels above)
 template <int NIB>
 __global__ __launch_bounds__(256) void qknorm_rope_fwd_brow_kernel(QkArgs a) {
@@ -1372,6 +1529,25 @@ extern "C" int udm_residual_bwd(const float* dx, const void* branch, void* dbran
     hipLaunchKernelGGL(colreduce_kernel, dim3((unsigned)((d + 63) / 64), 16), dim3(256), 0, stream, (const float*)ws, dw_b, grid, (int)d);
     UDM_CHECK_LAUNCH("udm_residual_bwd(colreduce)");
   }
+  return 0;
+}
+
+extern "C" int udm_norm_residual_bwd(const void* dy, const float* x, const float* rstd, const float* mean, const float* w, float* dx, float* dw, int accumulate,
+                                     const void* branch, void* dbranch, const float* w_b, const float* rstd_b, const float* mean_b, float* dw_b, int64_t M,
+                                     int64_t d, int norm_type, float p_drop, uint64_t seed, float* ws, int64_t ws_elems, hipStream_t stream) {
+  UDM_CHECK_ARG(dy && x && rstd && w && dx && dw && branch && dbranch && ws, "udm_norm_residual_bwd: null pointer");
+  UDM_CHECK_ARG(M > 0 && (d == 2048 || d == 4096), "udm_norm_residual_bwd: the fused form is built for d = 2048 / 4096 (got %ld); use udm_norm_bwd + udm_residual_bwd", (long)d);
+  UDM_CHECK_ARG(norm_type == 0 || mean, "udm_norm_residual_bwd: LayerNorm needs the saved mean");
+  UDM_CHECK_ARG(!w_b || (rstd_b && dw_b && (norm_type == 0 || mean_b)), "udm_norm_residual_bwd: sandwich norm needs rstd_b, dw_b (and mean_b for LayerNorm)");
+  const int grid = (int)(M < 1536 ? M : 1536);
+  UDM_CHECK_ARG(ws_elems >= (int64_t)grid * 2 * d, "udm_norm_residual_bwd: workspace too small (need %ld floats)", (long)grid * 2 * d);
+  NormResidBwdArgs a{(const bf16_t*)dy, x, rstd, mean, w, dx, dw, accumulate, (const bf16_t*)branch, (bf16_t*)dbranch, w_b, rstd_b, mean_b, dw_b, ws,
+                     (int)M, (int)d, norm_type, p_drop, seed};
+  if (d == 2048) hipLaunchKernelGGL((norm_residual_bwd_kernel<1>), dim3(grid), dim3(256), 0, stream, a);
+  else hipLaunchKernelGGL((norm_residual_bwd_kernel<2>), dim3(grid), dim3(256), 0, stream, a);
+  UDM_CHECK_LAUNCH("udm_norm_residual_bwd");
+  hipLaunchKernelGGL(colreduce2_kernel, dim3((unsigned)((d + 63) / 64), 16, 2), dim3(256), 0, stream, (const float*)ws, dw, w_b ? dw_b : nullptr, grid, (int)d);
+  UDM_CHECK_LAUNCH("udm_norm_residual_bwd(colreduce)");
   return 0;
 }
 

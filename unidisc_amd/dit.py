@@ -776,11 +776,29 @@ class DIT(nn.Module, _HubMixin):
         fl = self.output_layer
         fmod = S["fmod"]
         dx = torch.empty((M, d), dtype=F32, device=dev)
-        K.norm_bwd(dhf, S["x_final"], S["rstdf"], S["meanf"], fl.norm_final.weight.detach(), nt, L, dx, G[id(fl.norm_final.weight)], accumulate=False,
-                   mod=fmod, dmod=dmodf, mod_idx=(0, 1), modality=mod_flat, any_img=any_img)
+        # Without adaLN every pre-norm backward is immediately followed by the backward of the residual branch that produced the norm's input, on
+        # the dx it has just updated: the pair runs as ONE fused pass (K.norm_residual_bwd).  `pend` carries the norm half to the branch that
+        # consumes it - the final norm and each block's norm1 pair with the MLP branch of the block below them in the schedule, so a block's
+        # gradient range is reported (and its activations dropped) only after that fused pass.
+        pend = None
         if tc:
+            K.norm_bwd(dhf, S["x_final"], S["rstdf"], S["meanf"], fl.norm_final.weight.detach(), nt, L, dx, G[id(fl.norm_final.weight)], accumulate=False,
+                       mod=fmod, dmod=dmodf, mod_idx=(0, 1), modality=mod_flat, any_img=any_img)
             self._ada_backward(dmodf, lin["head.ada"], S["c"], dc, G)
-        self._notify(flat, list(fl.parameters()))
+            self._notify(flat, list(fl.parameters()))
+        else:
+            pend = dict(dy=dhf, x=S["x_final"], rstd=S["rstdf"], mean=S["meanf"], w=fl.norm_final.weight.detach(), dw=G[id(fl.norm_final.weight)], accumulate=False,
+                        done=lambda: self._notify(flat, list(fl.parameters())))
+
+        def branch_bwd(pend, branch, **kw):
+            """residual-branch backward, fused with the pending norm backward when there is one"""
+            if pend is None:
+                return K.residual_bwd(dx, branch, L, **kw)
+            out = K.norm_residual_bwd(pend["dy"], pend["x"], pend["rstd"], pend["mean"], pend["w"], nt, L, dx, pend["dw"], branch, accumulate=pend["accumulate"],
+                                      w_b=kw.get("w_b"), rstd_b=kw.get("rstd"), mean_b=kw.get("mean"), dw_b=kw.get("dw_b"), p_drop=kw.get("p_drop", 0.0),
+                                      seed=kw.get("seed", 0))
+            pend["done"]()
+            return out
 
         for i in reversed(range(self.n_blocks)):
             blk, R = self.blocks[i], S["blocks"][i]
@@ -789,23 +807,37 @@ class DIT(nn.Module, _HubMixin):
             dmod = torch.zeros((Bp, 6 * d), dtype=F32, device=dev) if tc else None
             f1, f2 = lin[f"{i}.fc1"], lin[f"{i}.fc2"]
             # MLP branch
-            du2 = K.residual_bwd(dx, R["u2"], L, w_b=blk.post_ff_norm.weight.detach() if sw else None, rstd=R["rstd_m"], mean=R["mean_m"], norm_type=nt,
-                                 mod=mod, dmod=dmod, gate_idx=5 if tc else None, modality=mod_flat if tc else None,
+            if tc:
+                du2 = K.residual_bwd(dx, R["u2"], L, w_b=blk.post_ff_norm.weight.detach() if sw else None, rstd=R["rstd_m"], mean=R["mean_m"], norm_type=nt,
+                                     mod=mod, dmod=dmod, gate_idx=5, modality=mod_flat, dw_b=G[id(blk.post_ff_norm.weight)] if sw else None,
+                                     p_drop=p_drop, seed=seed0 + 4 * i + 2)
+            else:
+                du2 = branch_bwd(pend, R["u2"], w_b=blk.post_ff_norm.weight.detach() if sw else None, rstd=R["rstd_m"], mean=R["mean_m"], norm_type=nt,
                                  dw_b=G[id(blk.post_ff_norm.weight)] if sw else None, p_drop=p_drop, seed=seed0 + 4 * i + 2)
+                pend = None
             # dgrad through mlp.2 with the GELU' multiply and the mlp.0 bias gradient (column sums of du1) fused into the epilogue
             du1 = K.gemm_nt(du2, f2.w16t, N=4 * d, epilogue=K.EPI_DGELU, aux=R["u1"], bias=G[id(f1.bias)])
             self._wgrad(du2, R["g"], f2, G)
             dh2 = K.gemm_nt(du1, f1.w16t, N=d)
             self._wgrad(du1, R["h2"], f1, G, bias_done=True)
             del du1, du2
-            K.norm_bwd(dh2, R["x_mid"], R["rstd2"], R["mean2"], blk.norm2.weight.detach(), nt, L, dx, G[id(blk.norm2.weight)], accumulate=True,
-                       mod=mod, dmod=dmod, mod_idx=(3, 4), modality=mod_flat, any_img=any_img)
-            # attention branch
-            if sw:
-                da = K.residual_bwd(dx, R["a_out"], L, w_b=blk.pre_residual_norm.weight.detach(), rstd=R["rstd_a"], mean=R["mean_a"], norm_type=nt,
-                                    dw_b=G[id(blk.pre_residual_norm.weight)])
+            # norm2 backward + attention branch
+            if tc:
+                K.norm_bwd(dh2, R["x_mid"], R["rstd2"], R["mean2"], blk.norm2.weight.detach(), nt, L, dx, G[id(blk.norm2.weight)], accumulate=True,
+                           mod=mod, dmod=dmod, mod_idx=(3, 4), modality=mod_flat, any_img=any_img)
+                if sw:
+                    da = K.residual_bwd(dx, R["a_out"], L, w_b=blk.pre_residual_norm.weight.detach(), rstd=R["rstd_a"], mean=R["mean_a"], norm_type=nt,
+                                        dw_b=G[id(blk.pre_residual_norm.weight)])
+                else:
+                    da = K.residual_bwd(dx, R["a_out"], L, mod=mod, dmod=dmod, gate_idx=2, p_drop=p_drop, seed=seed0 + 4 * i + 1)
             else:
-                da = K.residual_bwd(dx, R["a_out"], L, mod=mod, dmod=dmod, gate_idx=2 if tc else None, p_drop=p_drop, seed=seed0 + 4 * i + 1)
+                p2 = dict(dy=dh2, x=R["x_mid"], rstd=R["rstd2"], mean=R["mean2"], w=blk.norm2.weight.detach(), dw=G[id(blk.norm2.weight)], accumulate=True,
+                          done=lambda: None)
+                if sw:
+                    da = branch_bwd(p2, R["a_out"], w_b=blk.pre_residual_norm.weight.detach(), rstd=R["rstd_a"], mean=R["mean_a"], norm_type=nt,
+                                    dw_b=G[id(blk.pre_residual_norm.weight)])
+                else:
+                    da = branch_bwd(p2, R["a_out"], p_drop=p_drop, seed=seed0 + 4 * i + 1)
             lo, lq = lin[f"{i}.out"], lin[f"{i}.qkv"]
             do = K.gemm_nt(da, lo.w16t, N=d)
             self._wgrad(da, R["o"], lo, G)
@@ -819,12 +851,20 @@ class DIT(nn.Module, _HubMixin):
                               dbk=G[id(at.k_norm.bias)] if qn else None)
             dh1 = K.gemm_nt(dqkv, lq.w16t, N=d)
             self._wgrad(dqkv, R["h1"], lq, G)
-            K.norm_bwd(dh1, R["x_in"], R["rstd1"], R["mean1"], blk.norm1.weight.detach(), nt, L, dx, G[id(blk.norm1.weight)], accumulate=True,
-                       mod=mod, dmod=dmod, mod_idx=(0, 1), modality=mod_flat, any_img=any_img)
             if tc:
+                K.norm_bwd(dh1, R["x_in"], R["rstd1"], R["mean1"], blk.norm1.weight.detach(), nt, L, dx, G[id(blk.norm1.weight)], accumulate=True,
+                           mod=mod, dmod=dmod, mod_idx=(0, 1), modality=mod_flat, any_img=any_img)
                 self._ada_backward(dmod, lin[f"{i}.ada"], S["c"], dc, G)
-            S["blocks"][i] = None  # free this block's activations
-            self._notify(flat, list(blk.parameters()))
+                S["blocks"][i] = None  # free this block's activations
+                self._notify(flat, list(blk.parameters()))
+            else:   # norm1 pairs with the MLP branch of block i - 1: keep what it needs alive, report this block's range after that pass
+                def done(i=i, blk=blk):
+                    S["blocks"][i] = None
+                    self._notify(flat, list(blk.parameters()))
+                pend = dict(dy=dh1, x=R["x_in"], rstd=R["rstd1"], mean=R["mean1"], w=blk.norm1.weight.detach(), dw=G[id(blk.norm1.weight)], accumulate=True, done=done)
+        if pend is not None:   # block 0's norm1 (or the final norm of a model without blocks): nothing below it to pair with
+            K.norm_bwd(pend["dy"], pend["x"], pend["rstd"], pend["mean"], pend["w"], nt, L, dx, pend["dw"], accumulate=pend["accumulate"])
+            pend["done"]()
 
         # ---- embeddings
         if S.get("cnt_rows") is not None and S["cnt_rows"].numel():

@@ -326,6 +326,20 @@ def residual_bwd(dx, branch, L, *, w_b=None, rstd=None, mean=None, norm_type=NOR
     return dbranch
 
 
+def norm_residual_bwd(dy, x, rstd, mean, w, norm_type, L, dx, dw, branch, *, accumulate=True, w_b=None, rstd_b=None, mean_b=None, dw_b=None, p_drop=0.0, seed=0):
+    """Unmodulated norm backward (dx (+)= ..., dw += ...) followed by the residual-branch backward on the updated dx (returns d branch, bf16; dw_b += ...).
+    One fused pass per row at d = 2048 / 4096, the two kernels otherwise."""
+    M, d = x.shape
+    if d in (2048, 4096) and x.is_cuda:
+        dbranch = torch.empty((M, d), dtype=BF16, device=x.device)
+        ws = _scratch(min(M, 1536) * 2 * d, x.device)
+        _lib.call("udm_norm_residual_bwd", _p(dy), _p(x), _p(rstd), _p(mean), _p(w), _p(dx), _p(dw), 1 if accumulate else 0, _p(branch), _p(dbranch), _p(w_b),
+                  _p(rstd_b), _p(mean_b), _p(dw_b), M, d, norm_type, float(p_drop), int(seed), _p(ws), ws.numel(), _s())
+        return dbranch
+    norm_bwd(dy, x, rstd, mean, w, norm_type, L, dx, dw, accumulate=accumulate)
+    return residual_bwd(dx, branch, L, w_b=w_b, rstd=rstd_b, mean=mean_b, norm_type=norm_type, dw_b=dw_b, p_drop=p_drop, seed=seed)
+
+
 # ------------------------------------------------------------------------------------------------ attention
 def qknorm_rope_fwd(qkv, cos, sin, L, D, *, gq=None, bq=None, gk=None, bk=None):
     M, d3 = qkv.shape
