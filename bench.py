@@ -120,6 +120,8 @@ def _work(name, a):
         return "byte", 6.0 * a[10] * a[11]
     if name == "udm_norm_bwd":
         return "byte", (14.0 if a[18] else 10.0) * a[14] * a[15]
+    if name == "udm_norm_residual_bwd":   # dy 2 + x 4 + dx 4 (when accumulating) + branch 2 read, dx 4 + d branch 2 written
+        return "byte", (18.0 if a[7] else 14.0) * a[15] * a[16]
     if name == "udm_residual_fwd":
         return "byte", 10.0 * a[9] * a[10]
     if name == "udm_residual_norm_fwd":
@@ -132,6 +134,8 @@ def _work(name, a):
         return "byte", 12.0 * a[13] * a[14]
     if name == "udm_cast_transpose_f32_bf16":
         return "byte", 8.0 * a[3] * a[4]
+    if name == "udm_cast_transpose_multi_f32_bf16":   # 64 x 64 tiles of fp32 read once, bf16 written twice (edge tiles counted whole)
+        return "byte", 8.0 * 4096 * a[2]
     if name == "udm_transpose_bf16":
         return "byte", (4.0 if a[1] else 2.0) * a[2] * a[3]
     if name == "udm_embedding_fwd":

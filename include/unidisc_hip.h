@@ -69,6 +69,10 @@ int udm_transpose_bf16(const void* in, void* out, int64_t R, int64_t C, int64_t 
 /* fp32 master weights -> bf16 shadow (and Kᵀ-major shadow for dgrad): the per-forward autocast weight cast. */
 int udm_cast_transpose_f32_bf16(const float* in, void* out, void* out_t, int64_t R, int64_t C, int64_t ld_in, int64_t ld_out, int64_t ld_t,
                                 hipStream_t stream);
+/* the same for MANY matrices in one launch.  jobs: device array of njobs 64-byte records, sorted by tile0:
+ *   { const float* in; bf16* out (or null); bf16* out_t (or null); int64 ld_in, ld_out, ld_t; int32 R, C; int32 tile0, tiles_c }
+ * with tiles_c = ceil(C / 64), tile0 = number of 64 x 64 tiles of all earlier records; total_tiles = sum of ceil(R/64) * tiles_c. */
+int udm_cast_transpose_multi_f32_bf16(const void* jobs, int64_t njobs, int64_t total_tiles, hipStream_t stream);
 int udm_cast_f32_bf16(const float* x, void* y, int64_t n, float scale, hipStream_t stream); /* DDP bf16 compress hook, main.py:645 */
 int udm_cast_bf16_f32(const void* x, float* y, int64_t n, float scale, hipStream_t stream); /* ... and decompress */
 
@@ -98,10 +102,11 @@ int udm_residual_bwd(const float* dx, const void* branch, void* dbranch, const f
                      uint64_t seed, float* ws, int64_t ws_elems, hipStream_t stream);
 /* udm_norm_bwd (unmodulated) immediately followed by udm_residual_bwd (no gate) on the dx it has just updated, as ONE pass per row
  * (d = 2048 / 4096): the pairs norm2 -> attention branch, norm1 -> previous block's MLP branch, final norm -> last MLP branch of the block
- * backward (models/dit.py:77-100 RMSNorm / :383-403 LayerNorm backward feeding :229-253, :993-994).  ws: >= min(M, 1536) * 2 * d floats. */
+ * backward (models/dit.py:77-100 RMSNorm / :383-403 LayerNorm backward feeding :229-253, :993-994).  dbias (nullable): += column sums of the
+ * bf16 d branch, i.e. the bias gradient of the Linear that produced the branch (mlp.2, :919).  ws: >= min(M, 1536) * 3 * d floats. */
 int udm_norm_residual_bwd(const void* dy, const float* x, const float* rstd, const float* mean, const float* w, float* dx, float* dw, int accumulate,
-                          const void* branch, void* dbranch, const float* w_b, const float* rstd_b, const float* mean_b, float* dw_b, int64_t M, int64_t d,
-                          int norm_type, float p_drop, uint64_t seed, float* ws, int64_t ws_elems, hipStream_t stream); /* ws: optional fp32 scratch (>= 1024*d) for a two-phase dw_b reduction */
+                          const void* branch, void* dbranch, const float* w_b, const float* rstd_b, const float* mean_b, float* dw_b, float* dbias,
+                          int64_t M, int64_t d, int norm_type, float p_drop, uint64_t seed, float* ws, int64_t ws_elems, hipStream_t stream); /* ws: optional fp32 scratch (>= 1024*d) for a two-phase dw_b reduction */
 
 /* ---- QK LayerNorm (models/dit.py:569-572, 680-682) + rotary (models/standalone_rotary.py:14-31, call dit.py:723-726)
  * qkv bf16 [M,3d] -> qkr bf16 [M,2d] (normalised, rotated q | k).  cos/sin fp32 [L,D/2] or per-sample [M,D/2]. */

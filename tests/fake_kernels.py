@@ -67,6 +67,15 @@ def cast_transpose(w, out, out_t):
         out_t[:C, :R] = w.t().bfloat16()
 
 
+def cast_transpose_jobs(items, device):
+    return list(items), len(items), 0
+
+
+def cast_transpose_multi(jobs):
+    for w, out, out_t in jobs[0]:
+        cast_transpose(w, out, out_t)
+
+
 def cast_f32_bf16(x, y, scale=1.0):
     y.copy_((x.bfloat16().float() * scale).bfloat16())
     return y
@@ -150,9 +159,13 @@ def residual_fwd(x_in, branch, L, *, w_b=None, norm_type=NORM_RMS, mod=None, gat
 
 
 @torch.enable_grad()
-def norm_residual_bwd(dy, x, rstd, mean, w, norm_type, L, dx, dw, branch, *, accumulate=True, w_b=None, rstd_b=None, mean_b=None, dw_b=None, p_drop=0.0, seed=0):
+def norm_residual_bwd(dy, x, rstd, mean, w, norm_type, L, dx, dw, branch, *, accumulate=True, w_b=None, rstd_b=None, mean_b=None, dw_b=None, p_drop=0.0, seed=0,
+                      dbias=None):
     norm_bwd(dy, x, rstd, mean, w, norm_type, L, dx, dw, accumulate=accumulate)
-    return residual_bwd(dx, branch, L, w_b=w_b, rstd=rstd_b, mean=mean_b, norm_type=norm_type, dw_b=dw_b, p_drop=p_drop, seed=seed)
+    out = residual_bwd(dx, branch, L, w_b=w_b, rstd=rstd_b, mean=mean_b, norm_type=norm_type, dw_b=dw_b, p_drop=p_drop, seed=seed)
+    if dbias is not None:
+        colsum(out, dbias)
+    return out
 
 
 @torch.enable_grad()

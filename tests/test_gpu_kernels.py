@@ -320,6 +320,32 @@ def test_cast_transpose(K, R_, C):
     assert torch.equal(ot.cpu()[:, :R_], w.t().bfloat16()) and torch.all(ot.cpu()[:, R_:] == 0)
 
 
+def test_cast_transpose_multi_one_launch(K):
+    """Every weight of a forward cast in one launch (job table + bisection per block): bit-identical to the single-matrix kernel, incl. ragged
+    shapes, a padded shadow (head: rows beyond R stay zero) and jobs with only one of the two outputs."""
+    shapes = [(2048, 2048), (200, 136), (8192, 2048), (1001, 72), (64, 64), (130, 520)]
+    items, refs = [], []
+    for i, (R_, C) in enumerate(shapes):
+        w = rnd(R_, C, seed=600 + i).to(DEV)
+        Rp = (R_ + 127) // 128 * 128 if i == 3 else R_
+        out = torch.zeros(Rp, C, dtype=torch.bfloat16, device=DEV) if i != 4 else None
+        out_t = torch.zeros(C, Rp, dtype=torch.bfloat16, device=DEV) if i != 5 else None
+        items.append((w, out, out_t))
+        o1 = torch.zeros(Rp, C, dtype=torch.bfloat16, device=DEV)
+        t1 = torch.zeros(C, Rp, dtype=torch.bfloat16, device=DEV)
+        K.cast_transpose(w, o1, t1)
+        refs.append((o1, t1))
+    jobs = K.cast_transpose_jobs(items, torch.device(DEV))
+    K.cast_transpose_multi(jobs)
+    torch.cuda.synchronize()
+    for (w, out, out_t), (o1, t1) in zip(items, refs):
+        if out is not None:
+            assert torch.equal(out, o1)
+        if out_t is not None:
+            assert torch.equal(out_t, t1)
+        assert torch.equal(o1[: w.shape[0]], w.bfloat16())
+
+
 def test_cast_roundtrip(K):
     x = rnd(4099, seed=11)
     y = torch.empty(4099, dtype=torch.bfloat16, device=DEV)
@@ -437,9 +463,11 @@ def test_norm_residual_bwd_fused_equals_the_two_kernels(K, d, nt, sandwich, p, a
     K.norm_bwd(dyg, xg, rstd, mean, wg, nt, L, dxa, dwa, accumulate=acc)
     da = K.residual_bwd(dxa, brg, L, w_b=wbg if sandwich else None, rstd=rb, mean=mb, norm_type=nt, dw_b=dwba if sandwich else None, p_drop=p, seed=77)
     dxb, dwb_, dwbb = dx0.clone().to(DEV), torch.zeros(d, device=DEV), torch.zeros(d, device=DEV)
+    dbias = torch.zeros(d, device=DEV)
     db = K.norm_residual_bwd(dyg, xg, rstd, mean, wg, nt, L, dxb, dwb_, brg, accumulate=acc, w_b=wbg if sandwich else None, rstd_b=rb, mean_b=mb,
-                             dw_b=dwbb if sandwich else None, p_drop=p, seed=77)
+                             dw_b=dwbb if sandwich else None, p_drop=p, seed=77, dbias=dbias)
     torch.cuda.synchronize()
+    assert torch.allclose(dbias.cpu(), db.float().cpu().sum(0), rtol=1e-4, atol=1e-3 * float(db.float().abs().max()) * M ** 0.5)   # fused bias gradient
     assert rel_err(dxb.cpu(), dxa.cpu()) < 1e-6
     assert rel_err(db.float().cpu(), da.float().cpu()) < 1e-3          # bf16 outputs: a few last-bit flips from the different summation order
     assert torch.equal((db == 0).cpu(), (da == 0).cpu())                # the same dropout mask

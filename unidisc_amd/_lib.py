@@ -30,6 +30,7 @@ PROTOTYPES = {
     "udm_gemm_set_cus": [_I],
     "udm_transpose_bf16": [_P, _P, _I64, _I64, _I64, _I64, _P, _P],
     "udm_cast_transpose_f32_bf16": [_P, _P, _P, _I64, _I64, _I64, _I64, _I64, _P],
+    "udm_cast_transpose_multi_f32_bf16": [_P, _I64, _I64, _P],
     "udm_cast_f32_bf16": [_P, _P, _I64, _F, _P],
     "udm_cast_bf16_f32": [_P, _P, _I64, _F, _P],
     "udm_norm_fwd": [_P, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _I64, _I64, _I64, _I, _F, _P],
@@ -37,7 +38,7 @@ PROTOTYPES = {
     "udm_residual_fwd": [_P, _P, _P, _P, _P, _P, _P, _I64, _P, _I64, _I64, _I64, _I, _F, _F, _U64, _P],
     "udm_residual_norm_fwd": [_P, _P, _P, _P, _P, _P, _P, _I64, _P, _I64, _I64, _I64, _I, _F, _F, _U64, _P, _P, _P, _P, _P],
     "udm_residual_bwd": [_P, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _P, _I64, _I64, _I64, _I, _F, _U64, _P, _I64, _P],
-    "udm_norm_residual_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I64, _I64, _I, _F, _U64, _P, _I64, _P],
+    "udm_norm_residual_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I, _F, _U64, _P, _I64, _P],
     "udm_qknorm_rope_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I64, _I64, _I64, _I64, _F, _P],
     "udm_qknorm_rope_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _P, _I64, _P],
     "udm_attention_doc_ranges": [_P, _I64, _I64, _P, _P],

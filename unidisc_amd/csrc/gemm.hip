@@ -255,10 +255,8 @@ __global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __res
 
 // fp32 [R,C] -> bf16 [R,C] (ld_out) and/or bf16 transposed [C,R] (ld_t): the per-step weight shadow that
 // autocast makes in the reference (cast of fp32 master weights), plus the K-major copy used by dgrad.
-__global__ __launch_bounds__(256) void cast_transpose_kernel(const float* __restrict__ in, bf16_t* __restrict__ out, bf16_t* __restrict__ out_t,
-                                                            int R, int C, long ld_in, long ld_out, long ld_t) {
-  __shared__ __attribute__((aligned(16))) bf16_t tile[TT][TT + TPAD];
-  const int r0 = blockIdx.y * TT, c0 = blockIdx.x * TT;
+__device__ __forceinline__ void cast_transpose_tile(const float* __restrict__ in, bf16_t* __restrict__ out, bf16_t* __restrict__ out_t, int R, int C, long ld_in,
+                                                    long ld_out, long ld_t, int r0, int c0, bf16_t (*tile)[TT + TPAD]) {
   const int tid = threadIdx.x;
   const int cs = (tid & 15) * 4;
 #pragma unroll
@@ -291,7 +289,7 @@ __global__ __launch_bounds__(256) void cast_transpose_kernel(const float* __rest
 #pragma unroll
     for (int k = 0; k < 4; ++k) tile[cs + k][r] = b[k];
   }
-  if (!out_t) return;
+  if (!out_t) return;   // (block-uniform)
   __syncthreads();
 #pragma unroll
   for (int pass = 0; pass < 2; ++pass) {
@@ -306,6 +304,33 @@ __global__ __launch_bounds__(256) void cast_transpose_kernel(const float* __rest
         if (r0 + rs + k < R) op[k] = tile[c][rs + k];
     }
   }
+}
+
+__global__ __launch_bounds__(256) void cast_transpose_kernel(const float* __restrict__ in, bf16_t* __restrict__ out, bf16_t* __restrict__ out_t,
+                                                            int R, int C, long ld_in, long ld_out, long ld_t) {
+  __shared__ __attribute__((aligned(16))) bf16_t tile[TT][TT + TPAD];
+  cast_transpose_tile(in, out, out_t, R, C, ld_in, ld_out, ld_t, blockIdx.y * TT, blockIdx.x * TT, tile);
+}
+
+// All weight casts of a forward in ONE launch (the reference's autocast casts every Linear weight once per forward, models/dit.py:1096-1109 under
+// torch.autocast): 97 back-to-back launches of the single-matrix kernel spend a third of their time ramping up and draining (34 MB matrices
+// run at 4.1 TB/s against 6.0 for 134 MB ones).  `jobs` is a device table sorted by first tile; a block finds its matrix by bisection.
+struct CastJob {
+  const float* in; bf16_t* out; bf16_t* out_t;
+  long ld_in, ld_out, ld_t;
+  int R, C, tile0, tiles_c;
+};
+__global__ __launch_bounds__(256) void cast_transpose_multi_kernel(const CastJob* __restrict__ jobs, int njobs) {
+  __shared__ __attribute__((aligned(16))) bf16_t tile[TT][TT + TPAD];
+  const int t = blockIdx.x;
+  int lo = 0, hi = njobs - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (jobs[mid].tile0 <= t) lo = mid; else hi = mid - 1;
+  }
+  const CastJob j = jobs[lo];
+  const int lt = t - j.tile0;
+  cast_transpose_tile(j.in, j.out, j.out_t, j.R, j.C, j.ld_in, j.ld_out, j.ld_t, (lt / j.tiles_c) * TT, (lt % j.tiles_c) * TT, tile);
 }
 
 
@@ -985,6 +1010,13 @@ extern "C" int udm_cast_transpose_f32_bf16(const float* in, void* out, void* out
   dim3 grid((unsigned)((C + TT - 1) / TT), (unsigned)((R + TT - 1) / TT));
   hipLaunchKernelGGL(cast_transpose_kernel, grid, dim3(256), 0, stream, in, (bf16_t*)out, (bf16_t*)out_t, (int)R, (int)C, (long)ld_in, (long)ld_out, (long)ld_t);
   UDM_CHECK_LAUNCH("udm_cast_transpose_f32_bf16");
+  return 0;
+}
+
+extern "C" int udm_cast_transpose_multi_f32_bf16(const void* jobs, int64_t njobs, int64_t total_tiles, hipStream_t stream) {
+  UDM_CHECK_ARG(jobs && njobs > 0 && total_tiles > 0 && total_tiles < (1LL << 31), "udm_cast_transpose_multi_f32_bf16: bad job table");
+  hipLaunchKernelGGL(cast_transpose_multi_kernel, dim3((unsigned)total_tiles), dim3(256), 0, stream, (const CastJob*)jobs, (int)njobs);
+  UDM_CHECK_LAUNCH("udm_cast_transpose_multi_f32_bf16");
   return 0;
 }
 

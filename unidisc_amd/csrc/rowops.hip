@@ -1041,6 +1041,7 @@ struct NormResidBwdArgs {
   const bf16_t* dy; const float* x; const float* rstd; const float* mean; const float* w;   // the norm whose input is x
   float* dx; float* dw; int accumulate;
   const bf16_t* branch; bf16_t* dbranch; const float* w_b; const float* rstd_b; const float* mean_b; float* dw_b;   // the residual branch
+  float* dbias;   // optional [d]: += column sums of the (bf16-rounded) d branch = bias gradient of the Linear that produced the branch
   float* ws;
   int M, d, norm_type;
   float p_drop;
@@ -1051,11 +1052,11 @@ template <int NCB>
 __global__ __launch_bounds__(256) void norm_residual_bwd_kernel(NormResidBwdArgs a) {
   __shared__ float sm[8];
   const int tid = threadIdx.x;
-  float dwn[NCB][8], dwb[NCB][8];
+  float dwn[NCB][8], dwb[NCB][8], dbs[NCB][8];
 #pragma unroll
   for (int i = 0; i < NCB; ++i)
 #pragma unroll
-    for (int k = 0; k < 8; ++k) { dwn[i][k] = 0.f; dwb[i][k] = 0.f; }
+    for (int k = 0; k < 8; ++k) { dwn[i][k] = 0.f; dwb[i][k] = 0.f; dbs[i][k] = 0.f; }
   const float keep_scale = 1.f / (1.f - a.p_drop);
   float dy_n[NCB][8], x_n[NCB][8], dx_n[NCB][8], br_n[NCB][8];
   auto fetch = [&](long row) {
@@ -1146,26 +1147,33 @@ __global__ __launch_bounds__(256) void norm_residual_bwd_kernel(NormResidBwdArgs
 #pragma unroll
       for (int k = 0; k < 8; ++k) o[k] = a.w_b ? rsb * (g2[i][k] - s2_g - nh[i][k] * s2_gx) : g2[i][k];
       store8_bf16(a.dbranch + row * a.d + c, o);
+      if (a.dbias) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) dbs[i][k] += rbf(o[k]);
+      }
     }
   }
 #pragma unroll
   for (int i = 0; i < NCB; ++i) {
     const int c = (i * 256 + tid) * 8;
-    store8_f32(a.ws + ((long)blockIdx.x * 2) * a.d + c, dwn[i]);
-    if (a.w_b) store8_f32(a.ws + ((long)blockIdx.x * 2 + 1) * a.d + c, dwb[i]);
+    store8_f32(a.ws + ((long)blockIdx.x * 3) * a.d + c, dwn[i]);
+    if (a.w_b) store8_f32(a.ws + ((long)blockIdx.x * 3 + 1) * a.d + c, dwb[i]);
+    if (a.dbias) store8_f32(a.ws + ((long)blockIdx.x * 3 + 2) * a.d + c, dbs[i]);
   }
 }
 
-// out0[c] += sum_r ws[r][0][c], out1[c] += sum_r ws[r][1][c]  (ws is [nrows][2][d]; out1 may be null)
-__global__ __launch_bounds__(256) void colreduce2_kernel(const float* __restrict__ ws, float* __restrict__ out0, float* __restrict__ out1, int nrows, int d) {
+// out_j[c] += sum_r ws[r][j][c], j = blockIdx.z in 0..2  (ws is [nrows][3][d]; out1 / out2 may be null)
+__global__ __launch_bounds__(256) void colreduce3_kernel(const float* __restrict__ ws, float* __restrict__ out0, float* __restrict__ out1, float* __restrict__ out2,
+                                                         int nrows, int d) {
   __shared__ float red[4][64];
   const int which = blockIdx.z;
-  if (which == 1 && !out1) return;
+  float* const outp = which == 0 ? out0 : (which == 1 ? out1 : out2);
+  if (!outp) return;
   const int col = blockIdx.x * 64 + (threadIdx.x & 63), sub = threadIdx.x >> 6;
   const int per = (nrows + gridDim.y - 1) / gridDim.y;
   const int r0 = blockIdx.y * per, r1 = min(nrows, r0 + per);
   const float* base = ws + (long)which * d;
-  const long rstride = 2L * d;
+  const long rstride = 3L * d;
   float s = 0.f;
   if (col < d) {
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
@@ -1181,7 +1189,7 @@ __global__ __launch_bounds__(256) void colreduce2_kernel(const float* __restrict
   }
   red[sub][threadIdx.x & 63] = s;
   __syncthreads();
-  if (sub == 0 && col < d) atomicAdd((which ? out1 : out0) + col, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+  if (sub == 0 && col < d) atomicAdd(outp + col, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
 // item t = i * 256 + tid -> (part, head, j): 8 columns at c_lo and 8 at c_lo + D/2 (see the wave-per-row kernels above)
@@ -1533,20 +1541,20 @@ extern "C" int udm_residual_bwd(const float* dx, const void* branch, void* dbran
 }
 
 extern "C" int udm_norm_residual_bwd(const void* dy, const float* x, const float* rstd, const float* mean, const float* w, float* dx, float* dw, int accumulate,
-                                     const void* branch, void* dbranch, const float* w_b, const float* rstd_b, const float* mean_b, float* dw_b, int64_t M,
-                                     int64_t d, int norm_type, float p_drop, uint64_t seed, float* ws, int64_t ws_elems, hipStream_t stream) {
+                                     const void* branch, void* dbranch, const float* w_b, const float* rstd_b, const float* mean_b, float* dw_b, float* dbias,
+                                     int64_t M, int64_t d, int norm_type, float p_drop, uint64_t seed, float* ws, int64_t ws_elems, hipStream_t stream) {
   UDM_CHECK_ARG(dy && x && rstd && w && dx && dw && branch && dbranch && ws, "udm_norm_residual_bwd: null pointer");
   UDM_CHECK_ARG(M > 0 && (d == 2048 || d == 4096), "udm_norm_residual_bwd: the fused form is built for d = 2048 / 4096 (got %ld); use udm_norm_bwd + udm_residual_bwd", (long)d);
   UDM_CHECK_ARG(norm_type == 0 || mean, "udm_norm_residual_bwd: LayerNorm needs the saved mean");
   UDM_CHECK_ARG(!w_b || (rstd_b && dw_b && (norm_type == 0 || mean_b)), "udm_norm_residual_bwd: sandwich norm needs rstd_b, dw_b (and mean_b for LayerNorm)");
   const int grid = (int)(M < 1536 ? M : 1536);
-  UDM_CHECK_ARG(ws_elems >= (int64_t)grid * 2 * d, "udm_norm_residual_bwd: workspace too small (need %ld floats)", (long)grid * 2 * d);
-  NormResidBwdArgs a{(const bf16_t*)dy, x, rstd, mean, w, dx, dw, accumulate, (const bf16_t*)branch, (bf16_t*)dbranch, w_b, rstd_b, mean_b, dw_b, ws,
+  UDM_CHECK_ARG(ws_elems >= (int64_t)grid * 3 * d, "udm_norm_residual_bwd: workspace too small (need %ld floats)", (long)grid * 3 * d);
+  NormResidBwdArgs a{(const bf16_t*)dy, x, rstd, mean, w, dx, dw, accumulate, (const bf16_t*)branch, (bf16_t*)dbranch, w_b, rstd_b, mean_b, dw_b, dbias, ws,
                      (int)M, (int)d, norm_type, p_drop, seed};
   if (d == 2048) hipLaunchKernelGGL((norm_residual_bwd_kernel<1>), dim3(grid), dim3(256), 0, stream, a);
   else hipLaunchKernelGGL((norm_residual_bwd_kernel<2>), dim3(grid), dim3(256), 0, stream, a);
   UDM_CHECK_LAUNCH("udm_norm_residual_bwd");
-  hipLaunchKernelGGL(colreduce2_kernel, dim3((unsigned)((d + 63) / 64), 16, 2), dim3(256), 0, stream, (const float*)ws, dw, w_b ? dw_b : nullptr, grid, (int)d);
+  hipLaunchKernelGGL(colreduce3_kernel, dim3((unsigned)((d + 63) / 64), 16, 3), dim3(256), 0, stream, (const float*)ws, dw, w_b ? dw_b : nullptr, dbias, grid, (int)d);
   UDM_CHECK_LAUNCH("udm_norm_residual_bwd(colreduce)");
   return 0;
 }

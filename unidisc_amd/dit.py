@@ -146,11 +146,14 @@ class _Lin:
         self.outp = _ceil(self.out, out_pad)
         self.w16 = self.w16t = None
 
-    def refresh(self):
+    def alloc(self):
         dev = self.weight.device
         if self.w16 is None or self.w16.device != dev:
             self.w16 = torch.zeros((self.outp, self.inp), dtype=BF16, device=dev)
             self.w16t = torch.zeros((self.inp, self.outp), dtype=BF16, device=dev)
+
+    def refresh(self):
+        self.alloc()
         K.cast_transpose(self.weight.detach(), self.w16, self.w16t)
 
 
@@ -329,9 +332,16 @@ class DIT(nn.Module, _HubMixin):
                         ev.record(side)
                         self._cast_events[k] = ev
             else:
-                for k in order:
-                    for lin in groups[k]:
-                        lin.refresh()
+                # every weight of the forward in ONE launch (97 at 1.4 B): the job table lives on the device and is rebuilt only when a
+                # master weight or a shadow moved
+                lins = [lin for k in order for lin in groups[k]]
+                for lin in lins:
+                    lin.alloc()
+                key = tuple((l.weight.data_ptr(), l.w16.data_ptr(), l.w16t.data_ptr()) for l in lins)
+                if getattr(self, "_cast_jobs_key", None) != key:
+                    self._cast_jobs = K.cast_transpose_jobs([(l.weight.detach(), l.w16, l.w16t) for l in lins], dev)
+                    self._cast_jobs_key = key
+                K.cast_transpose_multi(self._cast_jobs)
             self._shadow_versions = versions
 
     def invalidate_shadows(self):
@@ -791,12 +801,16 @@ class DIT(nn.Module, _HubMixin):
                         done=lambda: self._notify(flat, list(fl.parameters())))
 
         def branch_bwd(pend, branch, **kw):
-            """residual-branch backward, fused with the pending norm backward when there is one"""
+            """residual-branch backward, fused with the pending norm backward when there is one (dbias: += column sums of the result)"""
             if pend is None:
-                return K.residual_bwd(dx, branch, L, **kw)
+                dbias = kw.pop("dbias", None)
+                out = K.residual_bwd(dx, branch, L, **kw)
+                if dbias is not None:
+                    K.colsum(out, dbias)
+                return out
             out = K.norm_residual_bwd(pend["dy"], pend["x"], pend["rstd"], pend["mean"], pend["w"], nt, L, dx, pend["dw"], branch, accumulate=pend["accumulate"],
                                       w_b=kw.get("w_b"), rstd_b=kw.get("rstd"), mean_b=kw.get("mean"), dw_b=kw.get("dw_b"), p_drop=kw.get("p_drop", 0.0),
-                                      seed=kw.get("seed", 0))
+                                      seed=kw.get("seed", 0), dbias=kw.get("dbias"))
             pend["done"]()
             return out
 
@@ -812,12 +826,13 @@ class DIT(nn.Module, _HubMixin):
                                      mod=mod, dmod=dmod, gate_idx=5, modality=mod_flat, dw_b=G[id(blk.post_ff_norm.weight)] if sw else None,
                                      p_drop=p_drop, seed=seed0 + 4 * i + 2)
             else:
+                # (the mlp.2 bias gradient = column sums of du2 comes out of the same pass)
                 du2 = branch_bwd(pend, R["u2"], w_b=blk.post_ff_norm.weight.detach() if sw else None, rstd=R["rstd_m"], mean=R["mean_m"], norm_type=nt,
-                                 dw_b=G[id(blk.post_ff_norm.weight)] if sw else None, p_drop=p_drop, seed=seed0 + 4 * i + 2)
+                                 dw_b=G[id(blk.post_ff_norm.weight)] if sw else None, p_drop=p_drop, seed=seed0 + 4 * i + 2, dbias=G[id(f2.bias)])
                 pend = None
             # dgrad through mlp.2 with the GELU' multiply and the mlp.0 bias gradient (column sums of du1) fused into the epilogue
             du1 = K.gemm_nt(du2, f2.w16t, N=4 * d, epilogue=K.EPI_DGELU, aux=R["u1"], bias=G[id(f1.bias)])
-            self._wgrad(du2, R["g"], f2, G)
+            self._wgrad(du2, R["g"], f2, G, bias_done=not tc)
             dh2 = K.gemm_nt(du1, f1.w16t, N=d)
             self._wgrad(du1, R["h2"], f1, G, bias_done=True)
             del du1, du2

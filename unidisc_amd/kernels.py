@@ -250,6 +250,28 @@ def cast_transpose(w, out, out_t):
               out_t.stride(0) if out_t is not None else 0, _s())
 
 
+def cast_transpose_jobs(items, device):
+    """Device job table for `cast_transpose_multi`: items = [(w fp32 [R, C], out bf16 [>=R, C] or None, out_t bf16 [C, >=R] or None), ...]."""
+    import struct
+
+    buf, tile0 = bytearray(), 0
+    for w, out, out_t in items:
+        _chk(w, F32, "cast_transpose_jobs")
+        R, C = w.shape
+        tiles_c = (C + 63) // 64
+        buf += struct.pack("<QQQqqqiiii", _p(w), _p(out) or 0, _p(out_t) or 0, w.stride(0), out.stride(0) if out is not None else 0,
+                           out_t.stride(0) if out_t is not None else 0, R, C, tile0, tiles_c)
+        tile0 += ((R + 63) // 64) * tiles_c
+    table = torch.frombuffer(bytes(buf), dtype=torch.uint8).to(device)
+    return table, len(items), tile0
+
+
+def cast_transpose_multi(jobs):
+    """fp32 -> bf16 (and transposed bf16) for every matrix of a job table (see `cast_transpose_jobs`) in one launch."""
+    table, n, tiles = jobs
+    _lib.call("udm_cast_transpose_multi_f32_bf16", _p(table), n, tiles, _s())
+
+
 def cast_f32_bf16(x, y, scale=1.0):
     _lib.call("udm_cast_f32_bf16", _p(x), _p(y), x.numel(), float(scale), _s())
     return y
@@ -326,18 +348,22 @@ def residual_bwd(dx, branch, L, *, w_b=None, rstd=None, mean=None, norm_type=NOR
     return dbranch
 
 
-def norm_residual_bwd(dy, x, rstd, mean, w, norm_type, L, dx, dw, branch, *, accumulate=True, w_b=None, rstd_b=None, mean_b=None, dw_b=None, p_drop=0.0, seed=0):
-    """Unmodulated norm backward (dx (+)= ..., dw += ...) followed by the residual-branch backward on the updated dx (returns d branch, bf16; dw_b += ...).
-    One fused pass per row at d = 2048 / 4096, the two kernels otherwise."""
+def norm_residual_bwd(dy, x, rstd, mean, w, norm_type, L, dx, dw, branch, *, accumulate=True, w_b=None, rstd_b=None, mean_b=None, dw_b=None, p_drop=0.0, seed=0,
+                      dbias=None):
+    """Unmodulated norm backward (dx (+)= ..., dw += ...) followed by the residual-branch backward on the updated dx (returns d branch, bf16; dw_b += ...;
+    dbias += column sums of d branch when given).  One fused pass per row at d = 2048 / 4096, the separate kernels otherwise."""
     M, d = x.shape
     if d in (2048, 4096) and x.is_cuda:
         dbranch = torch.empty((M, d), dtype=BF16, device=x.device)
-        ws = _scratch(min(M, 1536) * 2 * d, x.device)
+        ws = _scratch(min(M, 1536) * 3 * d, x.device)
         _lib.call("udm_norm_residual_bwd", _p(dy), _p(x), _p(rstd), _p(mean), _p(w), _p(dx), _p(dw), 1 if accumulate else 0, _p(branch), _p(dbranch), _p(w_b),
-                  _p(rstd_b), _p(mean_b), _p(dw_b), M, d, norm_type, float(p_drop), int(seed), _p(ws), ws.numel(), _s())
+                  _p(rstd_b), _p(mean_b), _p(dw_b), _p(dbias), M, d, norm_type, float(p_drop), int(seed), _p(ws), ws.numel(), _s())
         return dbranch
     norm_bwd(dy, x, rstd, mean, w, norm_type, L, dx, dw, accumulate=accumulate)
-    return residual_bwd(dx, branch, L, w_b=w_b, rstd=rstd_b, mean=mean_b, norm_type=norm_type, dw_b=dw_b, p_drop=p_drop, seed=seed)
+    out = residual_bwd(dx, branch, L, w_b=w_b, rstd=rstd_b, mean=mean_b, norm_type=norm_type, dw_b=dw_b, p_drop=p_drop, seed=seed)
+    if dbias is not None:
+        colsum(out, dbias)
+    return out
 
 
 # ------------------------------------------------------------------------------------------------ attention
