@@ -699,6 +699,18 @@ def maskgit_update(cfg: OracleConfig, P, buffers, x, t, schedule, step, pred, gu
     return torch.where(conf >= thr, pred, x), 1
 
 
+def nucleus_filter(p, top_p=0.9, temperature=1.0):
+    """model_eval.py:2642-2685 `nucleus_sampling_batch` up to its multinomial draw: the distribution it samples from, in the ORIGINAL id order.
+    Reference quirks kept: the "temperature" divides PROBABILITIES (so the kept set is the largest ids whose cumulative probability stays
+    <= top_p * temperature), the most likely id is always kept, the kept probabilities are renormalised."""
+    sp, si = torch.sort(p / temperature, descending=True, dim=-1)
+    keep = sp.cumsum(-1) <= top_p
+    keep[..., 0] = True
+    fp = sp * keep.float()
+    fp = fp / fp.sum(-1, keepdim=True)
+    return torch.zeros_like(p).scatter_(-1, si, fp)
+
+
 def sample_maskgit(cfg: OracleConfig, P, buffers, x_init, timesteps, dt, preds, gumbels, r_temp, x0=None, x0_unmask=None, modality=None, batch=None,
                    noise_removal=True, bf16=False):
     """The `maskgit` path of model_eval.py:2274-2447: arccos schedule from the initial x, one update per step, final arg-max of the log-probs."""

@@ -172,6 +172,37 @@ def test_guided_sampler_host_logic_replays_reference_run(monkeypatch):
     assert not torch.equal(x, y)
 
 
+def test_guided_sampler_split_cfg_batches_is_the_same_sampler(monkeypatch):
+    """config.eval.split_cfg_batches (model_eval.py:1770-1784): two backbone passes instead of one over [x ; x_uncond]; rows of a batch never
+    interact, so every token of the replayed run is the same."""
+    from unidisc_amd import dit as dit_mod, diffusion as diff_mod
+
+    monkeypatch.setattr(dit_mod, "K", fake_kernels)
+    monkeypatch.setattr(diff_mod, "K", fake_kernels)
+    g, s, diff = _cfg_product("cpu")
+    steps = int(s["steps"])
+    noise = [s[f"step{i}/u"] for i in range(steps)]
+    x0, x0_unmask = s["x0"], s["x0_unmask"].bool()
+    kw = dict(num_steps=steps, eps=float(s["eps"]), x0=x0, x0_unmask=x0_unmask, batch_size=x0.shape[0], modality=s["modality"], noise=noise, return_nfe=True)
+    x1, nfe1 = diff.sample(**kw)
+    diff.config.eval.split_cfg_batches = True
+    x2, nfe2 = diff.sample(**kw)
+    assert torch.equal(x1, x2) and nfe1 == nfe2
+
+
+@pytest.mark.gpu
+def test_guided_sampler_split_cfg_batches_on_gpu():
+    g, s, diff = _cfg_product(DEV)
+    steps = int(s["steps"])
+    noise = [s[f"step{i}/u"].to(DEV) for i in range(steps)]
+    x0, x0_unmask = s["x0"].to(DEV), s["x0_unmask"].bool().to(DEV)
+    kw = dict(num_steps=steps, eps=float(s["eps"]), x0=x0, x0_unmask=x0_unmask, batch_size=x0.shape[0], modality=s["modality"].to(DEV), noise=noise)
+    x1 = diff.sample(**kw)
+    diff.config.eval.split_cfg_batches = True
+    x2 = diff.sample(**kw)
+    assert (x1 == x2).float().mean().item() >= 0.99      # same kernels per row; a different GEMM tile family may flip a near-tie draw
+
+
 @pytest.mark.gpu
 def test_guided_sample_rows_kernel_matches_oracle_on_reference_logits():
     """Token-exact: both logits halves of the reference's CFG run (rounded to bf16), its weights and uniforms through udm_ddpm_sample_rows_cfg;
@@ -260,7 +291,68 @@ def test_maskgit_host_logic_replays_reference_run(name, monkeypatch):
     if "x0" in s:
         assert torch.equal(x[s["x0_unmask"].bool()], s["x0"][s["x0_unmask"].bool()])
     with pytest.raises(NotImplementedError):
-        diff.sample(num_steps=2, batch_size=2, predictor="maskgit_nucleus")
+        diff.sample(num_steps=2, batch_size=2, predictor="ddpm_tweedie")
+
+
+def _nucleus_golden():
+    z = np.load(os.path.join(GOLDEN_DIR, "maskgit_nucleus_c_large.npz"))
+    return {k: torch.from_numpy(np.asarray(z[k])) for k in z.files}
+
+
+def test_nucleus_filter_oracle_matches_reference_draw_support():
+    """The oracle's restatement of `nucleus_sampling_batch` on the reference's own p_x0: every token the reference drew lies in the kept set, the kept
+    set is the top of the distribution with cumulative p / temperature <= top_p (+ the arg-max), and the filtered distribution is normalised."""
+    s = _nucleus_golden()
+    top_p, temp = float(s["top_p"]), float(s["temperature"])
+    seen = 0
+    for i in range(int(s["steps"])):
+        if f"step{i}/p_x0" not in s:
+            continue
+        p, pred, x = s[f"step{i}/p_x0"].float(), s[f"step{i}/pred"], s[f"step{i}/x"]
+        fp = O.nucleus_filter(p, top_p, temp)
+        assert torch.allclose(fp.sum(-1), torch.ones_like(fp.sum(-1)), atol=1e-5)
+        masked = x == int(Golden("c_large").cfg.mask_index)
+        assert bool((fp.gather(-1, pred[..., None]).squeeze(-1)[masked] > 0).all())          # the reference's draws come from the kept set
+        kept = fp > 0
+        assert bool(kept.gather(-1, p.argmax(-1, keepdim=True)).all())                          # the arg-max always stays
+        worst_kept = torch.where(kept, p, torch.full_like(p, 2.0)).min(-1).values
+        best_dropped = torch.where(kept, torch.zeros_like(p), p).max(-1).values
+        assert bool((worst_kept >= best_dropped).all())                                         # a prefix of the sorted order
+        # at least the rows whose top-1 probability alone is below the budget keep a cumulative mass of no more than top_p * temperature
+        cm = torch.where(kept, p, torch.zeros_like(p)).sum(-1)
+        ok = (cm <= top_p * temp + 1e-5) | (kept.sum(-1) == 1)
+        assert bool(ok.all())
+        seen += 1
+    assert seen >= 3
+
+
+def test_maskgit_nucleus_host_logic_replays_reference_run(monkeypatch):
+    """CPU: the maskgit_nucleus loop (batch size 1: the reference's early exit is a tensor truth test) with kernel doubles, fed the reference's nucleus
+    draws and Gumbel noise, reveals the reference's tokens; free-running draws stay inside the kept set."""
+    from unidisc_amd import dit as dit_mod, diffusion as diff_mod
+    from unidisc_amd.config import Cfg
+
+    monkeypatch.setattr(dit_mod, "K", fake_kernels)
+    monkeypatch.setattr(diff_mod, "K", fake_kernels)
+    g, s = Golden("c_large"), _nucleus_golden()
+    diff = build_product(g, device="cpu")
+    diff.backbone.eval()
+    steps = int(s["steps"])
+    diff.config.eval = Cfg(maskgit_r_temp=float(s["r_temp"]), top_p=float(s["top_p"]), temperature=float(s["temperature"]))
+    replay = [(s[f"step{i}/pred"], s[f"step{i}/gumbel"].float()) if f"step{i}/pred" in s else (None, None) for i in range(steps)]
+    x0, x0_unmask = s["x0"], s["x0_unmask"].bool()
+    x, nfe = diff.sample(num_steps=steps, eps=float(s["eps"]), x0=x0, x0_unmask=x0_unmask, batch_size=1, modality=s["modality"], predictor="maskgit_nucleus",
+                         replay=replay, return_nfe=True)
+    assert (x == s["x_final"]).float().mean().item() >= 0.9 and nfe == int(s["nfe"]) + 1 and not (x == diff.mask_index).any()
+    assert torch.equal(x[x0_unmask], x0[x0_unmask])
+    # free draw of one step: tokens come from the nucleus of the step's own distribution
+    xs, t = s["step1/x"], s["timesteps"][1] * torch.ones(1, 1)
+    logits, rows, n = diff.backbone.forward_masked_logits(xs, None, modality=s["modality"])
+    rm = diff._row_modality(rows[:n], 1, xs.shape[1], s["modality"])
+    tok = diff._nucleus_draw(logits[:n], None, None, rm, float(s["top_p"]), float(s["temperature"]), seed=5)
+    lp = O.subs_parameterization(g.cfg, logits[:n, : g.cfg.vocab_size].float()[None], torch.full((1, n), g.cfg.mask_index), rm[None], None).float()[0]
+    fp = O.nucleus_filter(lp.exp(), float(s["top_p"]), float(s["temperature"]))
+    assert bool((fp.gather(-1, tok[:, None]) > 0).all())
 
 
 @pytest.mark.gpu
@@ -330,6 +422,29 @@ def test_maskgit_loop_on_gpu(name):
     a = diff.sample(num_steps=int(s["steps"]), batch_size=B, modality=modality, predictor="maskgit", seed=3)
     b = diff.sample(num_steps=int(s["steps"]), batch_size=B, modality=modality, predictor="maskgit", seed=3)
     c = diff.sample(num_steps=int(s["steps"]), batch_size=B, modality=modality, predictor="maskgit", seed=4)
+    assert torch.equal(a, b) and not torch.equal(a, c) and not (a == diff.mask_index).any()
+
+
+@pytest.mark.gpu
+def test_maskgit_nucleus_loop_on_gpu():
+    from unidisc_amd.config import Cfg
+
+    g, s = Golden("c_large"), _nucleus_golden()
+    diff = build_product(g, device=DEV)
+    diff.backbone.eval()
+    steps = int(s["steps"])
+    diff.config.eval = Cfg(maskgit_r_temp=float(s["r_temp"]), top_p=float(s["top_p"]), temperature=float(s["temperature"]))
+    replay = [(s[f"step{i}/pred"].to(DEV), s[f"step{i}/gumbel"].float().to(DEV)) if f"step{i}/pred" in s else (None, None) for i in range(steps)]
+    x0, x0_unmask, mod = s["x0"].to(DEV), s["x0_unmask"].bool().to(DEV), s["modality"].to(DEV)
+    x, nfe = diff.sample(num_steps=steps, eps=float(s["eps"]), x0=x0, x0_unmask=x0_unmask, batch_size=1, modality=mod, predictor="maskgit_nucleus",
+                         replay=replay, return_nfe=True)
+    assert (x.cpu() == s["x_final"]).float().mean().item() >= 0.9 and nfe == int(s["nfe"]) + 1 and not (x == diff.mask_index).any()
+    # free-running on a batch (the generalisation `all(num_unmask <= 0)` of the reference's batch-1 early exit): complete, reproducible per seed
+    B = 4
+    mod4 = mod.expand(B, -1).contiguous()
+    a = diff.sample(num_steps=steps, batch_size=B, modality=mod4, predictor="maskgit_nucleus", seed=3)
+    b = diff.sample(num_steps=steps, batch_size=B, modality=mod4, predictor="maskgit_nucleus", seed=3)
+    c = diff.sample(num_steps=steps, batch_size=B, modality=mod4, predictor="maskgit_nucleus", seed=4)
     assert torch.equal(a, b) and not torch.equal(a, c) and not (a == diff.mask_index).any()
 
 

@@ -365,7 +365,7 @@ class Diffusion:
         return self._subs_parameterization(logits, xt=x, batch=batch, **kwargs)
 
     # ---- sampler inner loop: the `ddpm_cache` predictor (config.sampling.predictor default) with classifier-free guidance
-    # (config.eval.cfg); no attention caching, no split_cfg_batches
+    # (config.eval.cfg, one pass over [x ; x_uncond] or two with config.eval.split_cfg_batches); no attention caching
     def _sample_prior(self, *batch_dims):  # model_eval.py:1734-1735
         return self.mask_index * torch.ones(*batch_dims, dtype=torch.int64, device=self.device)
 
@@ -410,14 +410,22 @@ class Diffusion:
         B, L = x.shape
         x_uncond = x.clone()
         x_uncond[x0_unmask] = self.mask_index
-        cat2 = (lambda v: None if v is None else torch.cat([v, v], 0))
-        logits, rows, n2 = self.backbone.forward_masked_logits(torch.cat([x, x_uncond], 0), cat2(sigma), modality=cat2(modality), sample_ids=cat2(sample_ids),
-                                                               plan_ids=torch.cat([x, x], 0))
-        n = n2 // 2   # the stable partition lists the [MASK] rows of the first half, then the same positions of the second half
+        if cfg_get(ev, "split_cfg_batches", False):
+            # model_eval.py:1770-1784: two backbone passes of batch B instead of one of 2 B (half the activation memory); the head runs on the
+            # SAME [MASK] positions of both (plan_ids = x), so the two logits blocks line up row for row
+            logits, rows, n = self.backbone.forward_masked_logits(x, sigma, modality=modality, sample_ids=sample_ids, plan_ids=x)
+            logits_u, _, n_u = self.backbone.forward_masked_logits(x_uncond, sigma, modality=modality, sample_ids=sample_ids, plan_ids=x)
+            assert n_u == n
+        else:
+            cat2 = (lambda v: None if v is None else torch.cat([v, v], 0))
+            both, rows, n2 = self.backbone.forward_masked_logits(torch.cat([x, x_uncond], 0), cat2(sigma), modality=cat2(modality), sample_ids=cat2(sample_ids),
+                                                                 plan_ids=torch.cat([x, x], 0))
+            n = n2 // 2   # the stable partition lists the [MASK] rows of the first half, then the same positions of the second half
+            logits, logits_u = both, both[n:]
         b_of = torch.div(rows[:n], L, rounding_mode="floor")
         w_b = w.to(torch.float32).reshape(-1)
         w_rows = (w_b.index_select(0, b_of) if w_b.numel() == B else w_b.expand(B).index_select(0, b_of)).contiguous()
-        return logits[:n], rows[:n], n, logits[n:2 * n], w_rows
+        return logits[:n], rows[:n], n, logits_u[:n], w_rows
 
     @torch.no_grad()
     def _ddpm_caching_update(self, x, t, dt, p_x0=None, x0=None, x0_unmask=None, modality=None, sample_ids=None, u=None, seed=None, **kwargs):
@@ -480,8 +488,41 @@ class Diffusion:
         return torch.stack(out, dim=0)
 
     @torch.no_grad()
+    def _nucleus_draw(self, logits, logits_u, w_rows, row_modality, top_p, temperature, seed):
+        """Token per [MASK] row from the nucleus-filtered SUBS distribution (`nucleus_sampling_batch`, model_eval.py:2642-2685, quirks included: the
+        temperature divides probabilities, the top id always stays).  Sort / cumsum / multinomial over [rows, V] are device tensor ops in row
+        chunks (an evaluation-time sampler variant: no fused kernel)."""
+        V, Vt = self.vocab_size, self.text_vocab_size
+        out = torch.empty(logits.shape[0], dtype=torch.int64, device=logits.device)
+        gen = torch.Generator(device=logits.device).manual_seed(int(seed) + 2)
+        ids = torch.arange(V, device=logits.device)
+        for lo in range(0, logits.shape[0], 2048):
+            z = logits[lo:lo + 2048, :V].float()
+            if logits_u is not None:
+                wv = w_rows[lo:lo + 2048, None]
+                z = (1 + wv) * z - wv * logits_u[lo:lo + 2048, :V].float()
+            bad = (ids == self.mask_index)[None].expand_as(z)
+            if row_modality is not None:
+                is_img = row_modality[lo:lo + 2048, None] == 1
+                bad = bad | torch.where(is_img, ids[None] < Vt, ids[None] >= Vt)
+            p = torch.softmax(z.masked_fill(bad, float("-inf")), dim=-1)
+            sp, si = torch.sort(p / temperature, descending=True, dim=-1)
+            keep = sp.cumsum(-1) <= top_p
+            keep[:, 0] = True
+            fp = sp * keep
+            out[lo:lo + 2048] = si.gather(-1, torch.multinomial(fp / fp.sum(-1, keepdim=True), 1, generator=gen)).squeeze(-1)
+        return out
+
+    @torch.no_grad()
+    def _maskgit_nucleus_update(self, x, t, dt, **kwargs):
+        """`_maskgit_nucleus_update` (model_eval.py:3118-3167): the maskgit step with the token drawn from the nucleus-filtered distribution
+        (config.eval.top_p / temperature); the confidence stays log p(token) under the UNfiltered distribution."""
+        ev = cfg_get(self.config, "eval", None)
+        return self._maskgit_update(x, t, dt, nucleus=(float(cfg_get(ev, "top_p", 0.95)), float(cfg_get(ev, "temperature", 0.9))), **kwargs)
+
+    @torch.no_grad()
     def _maskgit_update(self, x, t, dt, schedule=None, step=None, x0=None, x0_unmask=None, modality=None, sample_ids=None, pred=None, gumbel=None, seed=None,
-                        **kwargs):
+                        nucleus=None, **kwargs):
         """One `maskgit` step on the [MASK] rows only: token ~ p (or the replayed `pred`) and its log-probability from the fused row kernel
         (`udm_categorical_sample_rows`), confidence = log p + r_temp * gumbel * t, each sample keeps its num_unmask most confident predictions
         (threshold = k-th largest, as the reference).  `gumbel` [B, L]: explicit noise (replay); otherwise drawn on the device."""
@@ -501,6 +542,9 @@ class Diffusion:
         logits_u, w_rows = (cache[3], cache[4]) if len(cache) == 5 else (None, None)
         rows_n = rows[:n]
         given = pred.reshape(-1).index_select(0, rows_n).contiguous() if pred is not None else None
+        if given is None and nucleus is not None and n > 0:
+            given = self._nucleus_draw(logits[:n], logits_u, w_rows, self._row_modality(rows_n, B, L, modality), nucleus[0], nucleus[1],
+                                       int(seed if seed is not None else torch.initial_seed()))
         tok, logp = K.categorical_sample_rows(logits[:n], self.vocab_size, self.text_vocab_size, self.mask_index,
                                               modality=self._row_modality(rows_n, B, L, modality), restrict=self._restrict(), given=given,
                                               seed=int(seed if seed is not None else torch.initial_seed()), logits_u=logits_u, w=w_rows)
@@ -580,18 +624,21 @@ class Diffusion:
         cache, nfe = None, 0
         if predictor is None:
             predictor = cfg_get(sampling, "predictor", "ddpm_cache") if sampling is not None else "ddpm_cache"
-        if predictor not in ("ddpm_cache", "maskgit", "first_hitting"):
-            raise NotImplementedError(f"unidisc_amd.Diffusion.sample: predictor {predictor!r} is not built (ddpm_cache, maskgit, first_hitting)")
+        if predictor not in ("ddpm_cache", "maskgit", "maskgit_nucleus", "first_hitting"):
+            raise NotImplementedError(f"unidisc_amd.Diffusion.sample: predictor {predictor!r} is not built (ddpm_cache, maskgit, maskgit_nucleus, first_hitting)")
         schedule = None
-        if predictor in ("maskgit", "first_hitting"):   # model_eval.py:2274-2290
-            schedule = self.adap_sche(x, num_steps, self.mask_index, "arccos" if predictor == "maskgit" else "linear")
+        if predictor in ("maskgit", "maskgit_nucleus", "first_hitting"):   # model_eval.py:2274-2290
+            schedule = self.adap_sche(x, num_steps, self.mask_index, "linear" if predictor == "first_hitting" else "arccos")
         for i in range(num_steps):
             t = timesteps[i] * torch.ones(B, 1, device=self.device)
-            if predictor == "maskgit":   # replay: list of (pred [B, L] or None, gumbel [B, L] or None) per step
+            if predictor in ("maskgit", "maskgit_nucleus"):   # replay: list of (pred [B, L] or None, gumbel [B, L] or None) per step
                 pr, gm = replay[i] if replay is not None else (None, None)
-                x, n = self._maskgit_update(x, t, dt, schedule=schedule, step=i, x0=x0, x0_unmask=x0_unmask, modality=modality, sample_ids=sample_ids,
-                                            pred=pr, gumbel=gm, seed=base_seed + 7919 * i)
+                upd = self._maskgit_update if predictor == "maskgit" else self._maskgit_nucleus_update
+                x, n = upd(x, t, dt, schedule=schedule, step=i, x0=x0, x0_unmask=x0_unmask, modality=modality, sample_ids=sample_ids,
+                           pred=pr, gumbel=gm, seed=base_seed + 7919 * i)
                 nfe += n
+                if x0 is not None:
+                    x = torch.where(x0_unmask, x0, x)
                 continue
             if predictor == "first_hitting":   # replay: list of (u [B, L, V] or None, pos_u [B, L] or None) per step
                 uu, pu = replay[i] if replay is not None else (None, None)
