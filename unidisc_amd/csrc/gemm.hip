@@ -494,26 +494,6 @@ __global__ __launch_bounds__(512) void gemm_nt_stagger_kernel(GemmArgs p) {
     const char* Bs = As + A_BYTES;
     char* nxt = smem + ((kt + 1 + par) & 1) * STAGE_BYTES;
     const bool more = kt + 1 < nk;
-    if (EPI == UDM_EPI_DGELU && !OUT_F32 && kt == nk - 2) {
-      // The GELU' epilogue multiplies by the saved derivative tile (BMX x 256 bf16 of `aux`): 160 KiB that every block of a round would
-      // otherwise request from HBM at the same moment, right before it needs them.  Touch its 128-byte lines one K tile early (4 bytes per
-      // line through the LDS-DMA path into a scratch area behind the stages: no registers, counted by this tile's vmcnt(0)), so the
-      // epilogue's loads hit the L2.  Whole tiles only.
-      if ((row0 + BMX <= p.M) && (col0 + BNX <= p.N)) {
-        constexpr int NINS = BMX * 4 / 64;   // 64 lines per wave instruction, 4 lines per 512-byte tile row
-        char* scratch = smem + 2 * STAGE_BYTES + wave * 256;
-#pragma unroll
-        for (int j = 0; j < (NINS + NWAVES - 1) / NWAVES; ++j) {
-          const int ii = wave + NWAVES * j;
-          if (ii < NINS) {
-            const int line = ii * 64 + lane;
-            const bf16_t* g = p.aux + (long)(row0 + (line >> 2)) * p.ldaux + col0 + (line & 3) * 64;
-            const uint32_t dst = (uint32_t)(size_t)(UDM_LDS const char*)scratch;
-            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(g), "s"(dst) : "memory", "m0");
-          }
-        }
-      }
-    }
 #pragma unroll
     for (int ph = 0; ph < NPH; ++ph) {
       bf16x8_t a[KKPP][FM], b[KKPP][FN];
@@ -730,7 +710,7 @@ int launch_big_t(const GemmArgs& a0, hipStream_t stream) {
   a.tiles_n = (a.N + 255) / 256;
   static const int env_gm = [] { const char* e = getenv("UDM_GEMM_GROUP_M"); return e ? atoi(e) : 0; }();
   a.group_m = env_gm;
-  const size_t lds = (size_t)2 * (BMX + 256) * BK * 2 + (EPI == UDM_EPI_DGELU ? 8 * 256 : 0);   // (+ the GELU' epilogue's touch-ahead scratch)
+  const size_t lds = (size_t)2 * (BMX + 256) * BK * 2;
   auto kern = gemm_nt_stagger_kernel<BMX, EPI, OUT_F32, TN>;
   static bool attr_set = false;
   if (!attr_set) {
