@@ -318,19 +318,38 @@ class DIT(nn.Module, _HubMixin):
             order = [k for k in ["pre"] + [str(i) for i in range(len(self.blocks))] + ["head"] if k in groups]
             dev = self.vocab_embed.embedding.device
             if self.overlap_weight_cast and dev.type == "cuda" and not force:
-                # The casts are HBM-bound and the GEMMs they feed are not: run them on a side stream, in the order the forward consumes them,
-                # under the compute of the layers before; the compute stream waits for a block's shadows right before that block (_await_cast).
+                # Opt-in (UDM_OVERLAP_CAST=1): the casts are HBM-bound and the GEMMs they feed are not, so all but the first blocks' shadows are
+                # refreshed on a side stream under the forward of the blocks before them: a few multi-matrix launches (first two blocks /
+                # next quarter / the rest + head); the compute stream waits for a group right before its first block (_await_cast).
                 if getattr(self, "_cast_stream", None) is None:
                     self._cast_stream = torch.cuda.Stream(device=dev)
                 side, main = self._cast_stream, torch.cuda.current_stream(dev)
+                nb = len(self.blocks)
+                cuts = [0, min(2, nb), min(max(nb // 3, 2), nb), nb]
+                bounds = sorted(set(cuts))
+                parts = []
+                for lo_b, hi_b in zip(bounds[:-1], bounds[1:]):
+                    keys = [str(i) for i in range(lo_b, hi_b)]
+                    if lo_b == 0:
+                        keys = ["pre"] + keys
+                    if hi_b == nb:
+                        keys = keys + ["head"]
+                    parts.append([k for k in keys if k in groups])
+                for lins_k in parts:
+                    for k in lins_k:
+                        for lin in groups[k]:
+                            lin.alloc()
+                key = tuple((l.weight.data_ptr(), l.w16.data_ptr(), l.w16t.data_ptr()) for k in order for l in groups[k])
+                if getattr(self, "_cast_parts_key", None) != key:
+                    self._cast_parts = [K.cast_transpose_jobs([(l.weight.detach(), l.w16, l.w16t) for k in ks for l in groups[k]], dev) for ks in parts]
+                    self._cast_parts_key = key
                 side.wait_stream(main)   # everything enqueued so far (the previous backward reads the Wᵀ shadows) comes first
                 with torch.cuda.stream(side):
-                    for k in order:
-                        for lin in groups[k]:
-                            lin.refresh()
+                    for ks, jobs in zip(parts, self._cast_parts):
+                        K.cast_transpose_multi(jobs)
                         ev = torch.cuda.Event()
                         ev.record(side)
-                        self._cast_events[k] = ev
+                        self._cast_events[ks[0]] = ev
             else:
                 # every weight of the forward in ONE launch (97 at 1.4 B): the job table lives on the device and is rebuilt only when a
                 # master weight or a shadow moved
