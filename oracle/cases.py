@@ -84,3 +84,13 @@ INTERLEAVED_CASES = {
                 [(0, 0, 16), (0, 1, 256), (0, 0, 8), (0, 1, 256), (0, 0, 12), (-1, -1, 12)]],
     ),
 }
+
+
+# Modality attention dropout (model.flex_attention_{txt,img}_masking_prob; fixture made by oracle/make_golden_attn_dropout.py): the 1.4 B flavour with
+# eight samples so the per-sample draws cover all four combinations, whole-modality masking on (its `& ~should_mask_*` interaction is part of the rule).
+ATTN_DROPOUT_CASES = {
+    "g_attn_dropout": _case(
+        rope_2d=True, linear_factor=2.0, mask_entire_modality=0.6, softmin_snr=5, text_loss_weight=1.0, img_loss_weight=0.5, force_full_attention_mask=True,
+        batch_size=8, step_seed=29, data_seed=103, flex_attention_txt_masking_prob=0.5, flex_attention_img_masking_prob=0.5,
+    ),
+}

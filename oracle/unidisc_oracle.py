@@ -60,6 +60,8 @@ class OracleConfig:
     set_max_txt_loss_ratio: Optional[float] = None
     antithetic_sampling: bool = True
     sampling_eps: float = 1e-3
+    flex_attention_txt_masking_prob: Optional[float] = None   # model.flex_attention_{txt,img}_masking_prob: modality attention dropout (model.py:863-878)
+    flex_attention_img_masking_prob: Optional[float] = None
     interleaved: bool = False          # trainer.interleaved + data.require_sample_ids + interleaved_training_flex_attention
     extra: dict = field(default_factory=dict)
 
@@ -177,12 +179,25 @@ def bias_dropout_add_scale(x, scale, residual, modality):
     return residual + out
 
 
-def attention_core(q, k, v, sample_ids=None):
+def modality_dropout_mask(txt_drop, img_drop, txt_length, L):
+    """model_utils.py:721-731 `_attn_mask`: allowed[b, q, kv] for the modality attention dropout of model.py:863-878."""
+    q = torch.arange(L)[None, :, None]
+    kv = torch.arange(L)[None, None, :]
+    td, idr = txt_drop.reshape(-1, 1, 1).bool(), img_drop.reshape(-1, 1, 1).bool()
+    txt_case = ~td | (((q < txt_length) & (kv < txt_length)) | (q >= txt_length))
+    img_case = ~idr | (((q >= txt_length) & (kv >= txt_length)) | (q < txt_length))
+    return txt_case & img_case
+
+
+def attention_core(q, k, v, sample_ids=None, allow_mask=None):
     """softmax(q kᵀ/√D) v, bidirectional (dit.py:826-829 SDPA ≡ :843 FA2); optional document mask
-    ``sid[q]==sid[kv] & sid[q]!=-1`` (model_utils.py:740-771).  q,k,v: [B, L, H, D] → [B, L, H*D]."""
+    ``sid[q]==sid[kv] & sid[q]!=-1`` (model_utils.py:740-771) or a dense allowed[b, q, kv] mask (FlexAttention block_mask, dit.py:784-812).
+    q,k,v: [B, L, H, D] → [B, L, H*D]."""
     B, L, H, D = q.shape
     q, k, v = (t.transpose(1, 2) for t in (q, k, v))
     s = (q @ k.transpose(-1, -2)) / math.sqrt(D)
+    if allow_mask is not None:
+        s = s.masked_fill(~allow_mask[:, None], float("-inf"))
     if sample_ids is not None:
         sid = sample_ids.clone()
         allpad = (sid == -1).all(-1)
@@ -292,7 +307,7 @@ def make_buffers(cfg: OracleConfig, lumina_fn=None):
     return out
 
 
-def dit_block(cfg, P, pre, x, cos, sin, c, modality, sample_ids, bf16):
+def dit_block(cfg, P, pre, x, cos, sin, c, modality, sample_ids, bf16, allow_mask=None):
     """models/dit.py:948-1033 ``DDiTBlock.forward`` + :616-887 ``Attention.forward`` (SDPA branch)."""
     B, L, d = x.shape
     H, D = cfg.n_heads, cfg.head_dim
@@ -314,7 +329,7 @@ def dit_block(cfg, P, pre, x, cos, sin, c, modality, sample_ids, bf16):
     qk = torch.stack([q, k], 2).reshape(B, L, 2 * H, D)  # "b s (three h d)" → q heads then k heads
     qk = _r(apply_rotary(qk, cos, sin), bf16)  # dit.py:723-726
     q, k = qk[:, :, :H], qk[:, :, H:]
-    a = _r(attention_core(q, k, v.reshape(B, L, H, D), sample_ids), bf16)
+    a = _r(attention_core(q, k, v.reshape(B, L, H, D), sample_ids, allow_mask), bf16)
     a = linear(a, P[pre + "attention.attn_out.weight"], None, bf16)
     if cfg.sandwich_normalization:  # dit.py:993-994 (gate_msa unused, :983)
         x = x_skip + (rms_norm_lowp_input(a, P[pre + "pre_residual_norm.weight"], bf16=bf16) if cfg.norm_type == "rms"
@@ -335,7 +350,7 @@ def dit_block(cfg, P, pre, x, cos, sin, c, modality, sample_ids, bf16):
 
 
 def dit_forward(cfg: OracleConfig, P: Dict[str, torch.Tensor], buffers, indices, sigma=None, modality=None,
-                sample_ids=None, bf16=False, return_hidden=False):
+                sample_ids=None, bf16=False, return_hidden=False, allow_mask=None):
     """models/dit.py:1324-1500 ``DIT.forward`` → logits [B, L, V]."""
     B, L = indices.shape
     x = P["vocab_embed.embedding"][indices]  # :1375
@@ -355,7 +370,7 @@ def dit_forward(cfg: OracleConfig, P: Dict[str, torch.Tensor], buffers, indices,
     else:
         cos, sin = select_rotary(cfg, buffers, modality, L)
     for i in range(cfg.n_blocks):
-        x = dit_block(cfg, P, f"blocks.{i}.", x, cos, sin, c, modality, sample_ids, bf16)
+        x = dit_block(cfg, P, f"blocks.{i}.", x, cos, sin, c, modality, sample_ids, bf16, allow_mask)
     norm = get_norm(cfg)
     h = norm(x, P["output_layer.norm_final.weight"])  # :1083-1092
     if cfg.time_conditioning:
@@ -557,11 +572,21 @@ def compute_loss(cfg: OracleConfig, P, buffers, batch, generator=None, bf16=Fals
     move_chance = 1 - torch.exp(-sigma[:, None])
     xt, ignore, smt, smi, move = q_xt(cfg, x0, move_chance, batch, training, generator)
     modality = batch["modality"] if cfg.multimodal_batches else None
-    logits = dit_forward(cfg, P, buffers, xt, sigma, modality, batch["sample_ids"] if cfg.interleaved else None, bf16)
+    allow_mask = None
+    if (cfg.flex_attention_txt_masking_prob is not None or cfg.flex_attention_img_masking_prob is not None) and training:   # model.py:863-875
+        B = x0.shape[0]
+        txt_drop = torch.rand(B, generator=generator) < cfg.flex_attention_txt_masking_prob
+        img_drop = torch.rand(B, generator=generator) < cfg.flex_attention_img_masking_prob
+        if smt is not None:   # a modality that is masked out entirely must not be left seeing only itself
+            txt_drop = txt_drop & ~smt.squeeze(-1)
+            img_drop = img_drop & ~smi.squeeze(-1)
+        allow_mask = modality_dropout_mask(txt_drop, img_drop, cfg.txt_length, x0.shape[1])
+        ignore = (txt_drop | img_drop).unsqueeze(-1) if ignore is None else (ignore | (txt_drop | img_drop).unsqueeze(-1))
+    logits = dit_forward(cfg, P, buffers, xt, sigma, modality, batch["sample_ids"] if cfg.interleaved else None, bf16, allow_mask=allow_mask)
     lp = subs_parameterization(cfg, logits, xt, modality, batch, bf16).float()
     log_p = torch.gather(lp, -1, x0[:, :, None]).squeeze(-1)
     out = reduce_loss(cfg, log_p, sigma, dsigma, am, modality_mask, ignore)
-    out.aux = dict(t=t, sigma=sigma, dsigma=dsigma, xt=xt, move_indices=move, logits=logits, log_probs=lp,
+    out.aux = dict(t=t, sigma=sigma, dsigma=dsigma, xt=xt, move_indices=move, logits=logits, log_probs=lp, allow_mask=allow_mask,
                    ignore_batch_mask=ignore, should_mask_txt=smt, should_mask_img=smi, log_p=log_p)
     return out
 

@@ -4,7 +4,7 @@ import os
 import numpy as np
 import torch
 
-from oracle.cases import CASES, INTERLEAVED_CASES, lumina_rope_2d
+from oracle.cases import ATTN_DROPOUT_CASES, CASES, INTERLEAVED_CASES, lumina_rope_2d
 from oracle import unidisc_oracle as O
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -14,7 +14,7 @@ CASE_NAMES = sorted(CASES)
 class Golden:
     def __init__(self, name):
         self.name = name
-        self.case = CASES[name] if name in CASES else INTERLEAVED_CASES[name]
+        self.case = CASES[name] if name in CASES else (INTERLEAVED_CASES[name] if name in INTERLEAVED_CASES else ATTN_DROPOUT_CASES[name])
         self.z = np.load(os.path.join(GOLDEN_DIR, f"{name}.npz"))
         self.cfg = O.OracleConfig.from_case(self.case)
 

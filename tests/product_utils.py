@@ -16,6 +16,9 @@ def product_config(case):
         kw[k] = case.get(k)
     cfg = make_config(**kw)
     cfg.model.force_text_vocab_size = case["text_vocab_size"] - 1  # tokenizer-less: len(tokenizer) stand-in (model_setup.py:90-92)
+    for k in ("flex_attention_txt_masking_prob", "flex_attention_img_masking_prob"):   # modality attention dropout
+        if case.get(k) is not None:
+            setattr(cfg.model, k, case[k])
     if case.get("interleaved"):  # configs of the interleaved checkpoints: packed samples, document mask from sample ids
         cfg.trainer.interleaved = True
         cfg.trainer.interleaved_training_flex_attention = True

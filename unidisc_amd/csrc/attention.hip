@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
         for (int r = 0; r < 16; ++r) {
           const int kl = f * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
           bool ok = kv0 + kl < a.L;
-          if (HAS_SID) ok = ok && (!id_test || ((sidk[kl] == sid_q) && (sid_q >= 0)));
+          if (HAS_SID) ok = ok && (!id_test || attn_pair_ok(sid_q, sidk[kl]));
           if (!ok) sT[f][r] = -INFINITY;
         }
     }
@@ -349,7 +349,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
         for (int r = 0; r < 16; ++r) {
           const int kl = f * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
           bool ok = (kv0 + kl < a.L) && q_ok;
-          if (HAS_SID) ok = ok && (!id_test || ((sidk[kl] == sid_q) && (sid_q >= 0)));
+          if (HAS_SID) ok = ok && (!id_test || attn_pair_ok(sid_q, sidk[kl]));
           const float pv = ok ? __builtin_amdgcn_exp2f(sT[r] * c - lse_q) : 0.f;
           ds[f][r] = pv * (dpT[r] - delta_q);
         }
@@ -494,7 +494,7 @@ __global__ __launch_bounds__(256, WAVES) void attn_bwd_dkv_kernel(AttnArgs a) {
           for (int e = 0; e < 4; ++e) {
             const int r = rg * 4 + e;
             bool ok = k_ok && (q0 + ql0 + e < a.L);
-            if (decltype(IDT)::value) ok = ok && (sidq[ql0 + e] == sid_k) && (sid_k >= 0);
+            if (decltype(IDT)::value) ok = ok && attn_pair_ok(sidq[ql0 + e], sid_k);
             p[r] = ok ? __builtin_amdgcn_exp2f(s[r] * c - lv[e]) : 0.f;
             ds[r] = p[r] * (dp[r] - dv[e]);
           }

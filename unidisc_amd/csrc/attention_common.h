@@ -76,6 +76,19 @@ struct AttnArgs {
   float scale;          // 1 / sqrt(D)
 };
 
+// Attention mask codes.  `sample_ids` holds one int64 per position:  bits 0-31 = sample id (signed; < 0 = padding), bits 32-39 = the KEY classes this
+// position belongs to, bits 40-47 = the key classes this position may see as a QUERY.  A query sees a key iff both sample ids are equal and >= 0 and
+// (query mask & key class) != 0.  Raw sample ids (document masks of packed batches) have zero high bits, which reads as "every class": the plain
+// document mask.  Modality attention dropout (model.py:863-878, model_utils.py:721-731: text queries see text keys only / image queries see image
+// keys only, per sample) sets key class 1 = text, 2 = image and the query mask accordingly - an asymmetric mask the id equality alone cannot express.
+__device__ __forceinline__ bool attn_pair_ok(long code_q, long code_k) {
+  const int iq = (int)code_q, ik = (int)code_k;
+  unsigned qm = (unsigned)(code_q >> 40) & 0xffu, kb = (unsigned)(code_k >> 32) & 0xffu;
+  qm = qm ? qm : 0xffu;
+  kb = kb ? kb : 0xffu;
+  return iq == ik && iq >= 0 && (qm & kb) != 0;
+}
+
 constexpr int DOC_STRIDE = 8;   // ints per tile in doc_ranges: {lo, hi, idmin, idmax, exact, 0, 0, 0}
 // Document masks (packed samples): a 128-row block only has to walk the 64-row tiles of the other side that can hold one of its sample ids.
 // `doc_ranges` (udm_attention_doc_ranges) gives, per 64-row tile, {lo, hi, idmin, idmax, exact}: the [lo, hi) span of positions whose id lies inside the

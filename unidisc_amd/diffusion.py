@@ -22,7 +22,7 @@ import torch
 import torch.nn.functional as F
 
 from . import kernels as K
-from .dit import DIT, cfg_get
+from .dit import DIT, ModalityMask, cfg_get
 from .noise_schedule import get_noise
 
 
@@ -683,14 +683,27 @@ class Diffusion:
         xt, ignore_batch_mask_for_metrics, joint_ar_nar_mask, should_mask_txt, should_mask_img, move_indices = self.q_xt(
             x0, move_chance, return_ignore_batch_mask_for_metrics=True, batch=batch)
         m = cfg_get(cfg, "model")
-        if (cfg_get(m, "flex_attention_img_masking_prob", None) is not None or cfg_get(m, "flex_attention_txt_masking_prob", None) is not None) and self.backbone.training:
-            raise NotImplementedError("unidisc_amd: modality attention dropout (flex_attention_*_masking_prob) is not implemented")
+        p_txt, p_img = cfg_get(m, "flex_attention_txt_masking_prob", None), cfg_get(m, "flex_attention_img_masking_prob", None)
+        if (p_img is not None or p_txt is not None) and self.backbone.training:
+            # modality attention dropout (model.py:863-878): per sample, text queries are restricted to text keys and / or image queries to image keys
+            if p_img is None or p_txt is None:
+                raise ValueError("unidisc_amd: set both model.flex_attention_txt_masking_prob and flex_attention_img_masking_prob (the reference compares both)")
+            assert xt.shape[1] == cfg_get(m, "img_length") + cfg_get(m, "txt_length")
+            txt_drop = self._rand(xt.shape[0], device=xt.device) < p_txt
+            img_drop = self._rand(xt.shape[0], device=xt.device) < p_img
+            if should_mask_txt is not None:   # a modality that is masked out entirely must not be left seeing only itself
+                txt_drop = txt_drop & ~should_mask_txt.squeeze(-1)
+                img_drop = img_drop & ~should_mask_img.squeeze(-1)
+            kwargs["block_mask"] = ModalityMask(txt_drop, img_drop, cfg_get(m, "txt_length"))
+            drop_any = (txt_drop | img_drop).unsqueeze(-1)
+            ignore_batch_mask_for_metrics = drop_any if ignore_batch_mask_for_metrics is None else (ignore_batch_mask_for_metrics | drop_any)
         if cfg_get(tr, "interleaved_training_flex_attention", False):
             kwargs["sample_ids"] = batch["sample_ids"]  # the document mask is derived from sample_ids inside the attention kernel
 
         # fused backbone + SUBS + gather: log p_theta(x0 | xt) per token, fp32 (model.py:908-925, :967)
         log_p_theta = self.backbone.forward_logp(xt, x0, self._process_sigma(unet_conditioning), modality=kwargs.get("modality"),
-                                                 sample_ids=kwargs.get("sample_ids"), restrict_modality=self._restrict())
+                                                 sample_ids=kwargs.get("sample_ids"), restrict_modality=self._restrict(),
+                                                 block_mask=kwargs.get("block_mask"))
         self._last = dict(t=t, sigma=sigma, dsigma=dsigma, xt=xt, move_indices=move_indices, log_p_theta=log_p_theta)
 
         if cfg_get(tr, "no_ce_weighting", False):

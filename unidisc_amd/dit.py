@@ -137,6 +137,15 @@ class DDitFinalLayer(nn.Module):  # models/dit.py:1063-1092
             self.adaLN_modulation.bias.data.zero_()
 
 
+class ModalityMask:
+    """What the reference's `get_block_mask(txt_batch_attn_dropout, img_batch_attn_dropout, txt_length, ...)` (model_utils.py:721-737) describes: in
+    samples with txt_drop[b] text queries attend to text keys only, with img_drop[b] image queries to image keys only (positions < txt_length are
+    text).  Passed as `block_mask=` where the reference passes its FlexAttention BlockMask."""
+
+    def __init__(self, txt_drop, img_drop, txt_length):
+        self.txt_drop, self.img_drop, self.txt_length = txt_drop.reshape(-1).bool(), img_drop.reshape(-1).bool(), int(txt_length)
+
+
 class _Lin:
     """bf16 shadows of one nn.Linear weight: w16 [out(p), in] for forward, w16t [in, out(p)] for dgrad."""
 
@@ -386,14 +395,17 @@ class DIT(nn.Module, _HubMixin):
         """→ logits [B, L, V] (bf16).  Signature of the reference's DIT.forward (models/dit.py:1324-1338)."""
         self._check_unsupported(label, x_cond, attention_mask, continuous_mode, x_img_emb, start_pos, block_mask, update_cache_slice, sample_ids)
         params = self._ordered_params()
-        inputs = dict(indices=indices, sigma=sigma, modality=modality, sample_ids=sample_ids, x0=None, save=self._needs_grad(params))
+        inputs = dict(indices=indices, sigma=sigma, modality=modality, sample_ids=sample_ids, x0=None, save=self._needs_grad(params),
+                      block_mask=block_mask if isinstance(block_mask, ModalityMask) else None)
         return _DitFn.apply(self, "logits", inputs, *params)
 
-    def forward_logp(self, xt, x0, sigma=None, modality=None, sample_ids=None, restrict_modality=False):
+    def forward_logp(self, xt, x0, sigma=None, modality=None, sample_ids=None, restrict_modality=False, block_mask=None):
         """Fused training path: log p_theta(x0 | xt) per token [B, L] fp32 under the SUBS parameterisation
-        (== gather(_subs_parameterization(logits, xt), x0), model.py:621-658 + :967) without materialising log-probs."""
+        (== gather(_subs_parameterization(logits, xt), x0), model.py:621-658 + :967) without materialising log-probs.
+        block_mask: a `ModalityMask` (modality attention dropout) or None."""
         params = self._ordered_params()
-        inputs = dict(indices=xt, sigma=sigma, modality=modality, sample_ids=sample_ids, x0=x0, restrict=restrict_modality, save=self._needs_grad(params))
+        inputs = dict(indices=xt, sigma=sigma, modality=modality, sample_ids=sample_ids, x0=x0, restrict=restrict_modality, save=self._needs_grad(params),
+                      block_mask=block_mask)
         return _DitFn.apply(self, "logp", inputs, *params)
 
     @torch.no_grad()
@@ -417,9 +429,9 @@ class DIT(nn.Module, _HubMixin):
                 raise NotImplementedError(f"unidisc_amd.DIT.forward: argument `{name}` is outside the denoising hot path")
         if continuous_mode:
             raise NotImplementedError("unidisc_amd.DIT.forward: continuous_mode is outside the denoising hot path")
-        if block_mask is not None and sample_ids is None:
-            raise NotImplementedError("unidisc_amd.DIT.forward: FlexAttention block_mask without sample_ids (modality attention dropout) is not implemented; "
-                                      "document masks are derived from sample_ids")
+        if block_mask is not None and block_mask is not True and sample_ids is None and not isinstance(block_mask, ModalityMask):
+            raise NotImplementedError("unidisc_amd.DIT.forward: pass a unidisc_amd.ModalityMask (modality attention dropout) as block_mask; "
+                                      "FlexAttention BlockMask objects are not used here (document masks are derived from sample_ids)")
 
     # -------------------------------------------------------------------------------------------- engine: forward
     def _rotary_interleaved(self, modality, sample_ids):
@@ -517,8 +529,14 @@ class DIT(nn.Module, _HubMixin):
             del pos
         else:
             emb_mod = mod_flat
+        doc_ranges = K.attention_doc_ranges(sid) if sid is not None else None   # once per step, shared by every block's forward and backward
+        bm = inp.get("block_mask")
+        if isinstance(bm, ModalityMask) and sid is None:
+            # modality attention dropout (model.py:863-878): an asymmetric per-sample mask, carried to the attention kernels as mask codes in
+            # the sample-id slot (class bits: no tile skipping, every tile takes the per-element test)
+            sid = K.modality_mask_codes(bm.txt_drop.to(dev), bm.img_drop.to(dev), bm.txt_length, L)
         S = dict(B=B, L=L, ids=ids, modality=mod_flat, emb_mod=emb_mod, sid=sid, p_drop=p_drop, seed0=seed0, blocks=[])
-        S["doc_ranges"] = K.attention_doc_ranges(sid) if sid is not None else None   # once per step, shared by every block's forward and backward
+        S["doc_ranges"] = doc_ranges
         # SUBS: only [MASK] rows have a non-zero log-probability (model.py:621-658), so in "logp" mode the vocabulary head (GEMM fwd,
         # dgrad, wgrad and the cross-entropy) runs on the masked rows only.  Their number is data dependent: it is counted on a side
         # stream NOW and only read back right before the head, when the host has already queued every block of this forward -- the

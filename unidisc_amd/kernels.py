@@ -387,6 +387,20 @@ def qknorm_rope_bwd(dqkr, qkv, dqkv, cos, sin, L, D, *, gq=None, gk=None, stats=
               _p(dbk), M, d, L, D, _p(ws), ws.numel() if ws is not None else 0, _s())
 
 
+def modality_mask_codes(txt_drop, img_drop, txt_length, L):
+    """Attention mask codes [B, L] int64 (csrc/attention_common.h) of the reference's modality attention dropout (`_attn_mask`, model_utils.py:721-731):
+    in samples with `txt_drop` text queries see text keys only, with `img_drop` image queries see image keys only; positions < txt_length are text.
+    Sample id 0 everywhere (one document per row); key class 1 = text, 2 = image; query mask = the classes a position may attend to."""
+    B = txt_drop.shape[0]
+    dev = txt_drop.device
+    is_img = (torch.arange(L, device=dev) >= int(txt_length))[None].expand(B, L)
+    kbit = torch.where(is_img, 2, 1).to(torch.int64)
+    qm_txt = torch.where(txt_drop.reshape(B, 1).bool(), 1, 3)
+    qm_img = torch.where(img_drop.reshape(B, 1).bool(), 2, 3)
+    qmask = torch.where(is_img, qm_img, qm_txt).to(torch.int64)
+    return ((kbit << 32) | (qmask << 40)).contiguous()
+
+
 def attention_doc_ranges(sample_ids):
     """int32 [B, ceil(L/64), 8] = {lo, hi, idmin, idmax, exact, 0, 0, 0} per 64-row tile: the span of positions that can share a sample id with it
     (tile skipping for packed samples), the tile's id interval (idmin = -1 if it holds padding; idmin == idmax: one document, no per-element id
