@@ -620,10 +620,10 @@ def cfg_weight(cfg_scale, t, cfg_min_timestep=None, cfg_max_timestep=None, force
     return w if isinstance(w, torch.Tensor) else torch.tensor(w)
 
 
-def ddpm_forward(cfg: OracleConfig, P, buffers, x, sigma_t, modality=None, batch=None, bf16=False, x0_unmask=None, w=None):
+def ddpm_forward(cfg: OracleConfig, P, buffers, x, sigma_t, modality=None, batch=None, bf16=False, x0_unmask=None, w=None, allow_mask=None):
     """model_eval.py:1761-1834: p_x0 = exp(SUBS log-probs).  With a guidance weight `w` (> 0 somewhere) and conditioning positions
     `x0_unmask`: logits = (1 + w) logits(x) - w logits(x with the conditioning masked), SUBS WITHOUT the carry-over (xt=None, :1813)."""
-    logits = dit_forward(cfg, P, buffers, x, sigma_t, modality, None, bf16)
+    logits = dit_forward(cfg, P, buffers, x, sigma_t, modality, None, bf16, allow_mask=allow_mask)
     if w is not None and x0_unmask is not None and x0_unmask.sum() > 0 and (w > 0).any():
         x_uncond = x.clone()
         x_uncond[x0_unmask] = cfg.mask_index
@@ -634,7 +634,8 @@ def ddpm_forward(cfg: OracleConfig, P, buffers, x, sigma_t, modality=None, batch
     return subs_parameterization(cfg, logits, x, modality, batch, bf16).float().exp(), logits
 
 
-def ddpm_caching_update(cfg: OracleConfig, P, buffers, x, t, dt, u, p_x0=None, modality=None, batch=None, bf16=False, x0_unmask=None, cfg_scale=None):
+def ddpm_caching_update(cfg: OracleConfig, P, buffers, x, t, dt, u, p_x0=None, modality=None, batch=None, bf16=False, x0_unmask=None, cfg_scale=None,
+                        allow_mask=None):
     """model_eval.py:2073-2106.  t: [B] or [B,1]; u: uniforms [B, L, V] (what torch.rand_like drew).  Returns (p_x0, x_next, nfe)."""
     if t.ndim > 1:
         t = t.squeeze(-1)
@@ -643,7 +644,7 @@ def ddpm_caching_update(cfg: OracleConfig, P, buffers, x, t, dt, u, p_x0=None, m
     nfe = 0
     if p_x0 is None:
         w = cfg_weight(cfg_scale, t) if (cfg_scale is not None and x0_unmask is not None and x0_unmask.sum() > 0) else None
-        p_x0, _ = ddpm_forward(cfg, P, buffers, x, sigma_t, modality, batch, bf16, x0_unmask=x0_unmask, w=w)
+        p_x0, _ = ddpm_forward(cfg, P, buffers, x, sigma_t, modality, batch, bf16, x0_unmask=x0_unmask, w=w, allow_mask=allow_mask)
         nfe = 1
     q_xs = p_x0 * (move_t - move_s)
     q_xs[:, :, cfg.mask_index] = move_s[:, :, 0]
