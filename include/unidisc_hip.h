@@ -139,6 +139,8 @@ int udm_attention_quantize_fp8(const void* q, const void* k, const void* v, void
 int udm_attention_fwd_fp8(const void* q8, const void* k8, const void* v8t, const float* scales, void* o, float* lse, const int64_t* sample_ids,
                           const int32_t* doc_ranges, int64_t B, int64_t H, int64_t L, int64_t D, int64_t o_stride, hipStream_t stream);
 int udm_attention_set_tr_read(int enable); /* diagnostics: 0 = gather Vᵀ fragments with scalar LDS reads */
+int udm_attention_w64_timeline(uint64_t* buf); /* diagnostics: device buffer of 512 cycle stamps (2 blocks x 4 waves x 64 tags) written by the next forward launches; null = off */
+int udm_attention_set_w64(int enable);     /* diagnostics / A-B runs: 0 = the 8-wave forward kernel also at head dim 128 without a document mask (default 1; env UDM_ATTN_W64) */
 
 /* ---- embeddings: EmbeddingLayer models/dit.py:1036-1043 (+modality embedding :1402-1411) ------------- */
 int udm_embedding_fwd(const int64_t* ids, const float* E, const int64_t* modality, const float* Em, float* x, int64_t M, int64_t d, int64_t V,

@@ -1,0 +1,49 @@
+"""A/B of the two forward attention kernels at head dim 128 (no document mask): bit-identity of O / LSE and wall time per call."""
+import json, os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from unidisc_amd import kernels as K
+
+
+def timeit(fn, n=30, w=5):
+    for _ in range(w): fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+
+
+def run(B, H, L, D=128, spike=False, bench=True):
+    g = torch.Generator(device="cuda").manual_seed(L)
+    q, k, v = ((torch.randn(B * L, H * D, device="cuda", generator=g)).to(torch.bfloat16) for _ in range(3))
+    if spike and L > 200:   # force the lazy-rescale branch late in the sequence
+        k[L - 100] *= 12
+        q[7] = (k[L - 100].float() / 4).to(torch.bfloat16)
+    K.set_attention_w64(False)
+    o0, l0 = K.attention_fwd_generic(q, k, v, B, L, H, D)
+    K.set_attention_w64(True)
+    o1, l1 = K.attention_fwd_generic(q, k, v, B, L, H, D)
+    torch.cuda.synchronize()
+    rec = dict(B=B, H=H, L=L, spike=spike, o_equal=bool(torch.equal(o0, o1)), lse_equal=bool(torch.equal(l0, l1)),
+               o_maxdiff=float((o0.float() - o1.float()).abs().max()), lse_maxdiff=float((l0 - l1).abs().max()), finite=bool(torch.isfinite(o1.float()).all()))
+    if bench:
+        fl = 4 * B * H * L * L * D
+        K.set_attention_w64(False)
+        t0 = timeit(lambda: K.attention_fwd_generic(q, k, v, B, L, H, D))
+        K.set_attention_w64(True)
+        t1 = timeit(lambda: K.attention_fwd_generic(q, k, v, B, L, H, D))
+        rec.update(old_us=round(t0 * 1e3, 1), new_us=round(t1 * 1e3, 1), old_tf=round(fl / t0 / 1e9), new_tf=round(fl / t1 / 1e9))
+    print(json.dumps(rec), flush=True)
+
+
+if __name__ == "__main__":
+    if os.environ.get("UDM_ATTN_W64_ABL"):   # timing-only ablations (wrong results): just the headline shape
+        run(8, 16, 1280)
+        sys.exit(0)
+    for (B, H, L) in [(1, 1, 64), (1, 1, 2), (2, 3, 100), (1, 2, 257), (3, 5, 640), (2, 2, 1000), (1, 1, 191), (2, 1, 129)]:
+        run(B, H, L, bench=False)
+        run(B, H, L, spike=True, bench=False)
+    for (B, H, L) in [(8, 16, 1280), (8, 16, 1024), (8, 16, 2048), (2, 16, 4608), (8, 16, 1536)]:
+        run(B, H, L)

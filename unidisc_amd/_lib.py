@@ -47,6 +47,8 @@ PROTOTYPES = {
     "udm_attention_quantize_fp8": [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _P],
     "udm_attention_fwd_fp8": [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _P],
     "udm_attention_set_tr_read": [_I],
+    "udm_attention_set_w64": [_I],
+    "udm_attention_w64_timeline": [_P],
     "udm_assemble_joint_tokens": [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _P, _P, _P, _P],
     "udm_categorical_sample_rows": [_P, _P, _P, _I64, _P, _P, _I64, _U64, _P, _P, _P, _I64, _I64, _I64, _I64, _I, _P],
     "udm_ddpm_sample_rows_cfg": [_P, _P, _P, _I64, _P, _P, _P, _P, _I64, _U64, _P, _I64, _I64, _I64, _I64, _I, _I, _P],

@@ -74,6 +74,7 @@ struct AttnArgs {
   int B, H, L;
   float scale_log2;     // log2(e) / sqrt(D)
   float scale;          // 1 / sqrt(D)
+  unsigned long long* timeline;   // diagnostics (attention_w64.hip): cycle stamps of a few blocks, or null
 };
 
 // Attention mask codes.  `sample_ids` holds one int64 per position:  bits 0-31 = sample id (signed; < 0 = padding), bits 32-39 = the KEY classes this
@@ -203,3 +204,5 @@ __device__ __forceinline__ void wait_all_vmem() { asm volatile("s_waitcnt vmcnt(
 
 // dK/dV kernel for head dim 128 without a document mask (attention_dkv_ws.hip); grid = ceil(L / 128) * B * H blocks of 512 threads
 void udm_launch_attn_bwd_dkv_ws(const void* args, hipStream_t stream);
+// forward kernel for head dim 128 without a document mask, one wave per SIMD / 64 queries per wave (attention_w64.hip); false = switched off (UDM_ATTN_W64=0)
+bool udm_launch_attn_fwd_w64(const void* args, hipStream_t stream);

@@ -482,6 +482,11 @@ def set_tr_read(enable: bool):
     _lib.load().udm_attention_set_tr_read(1 if enable else 0)
 
 
+def set_attention_w64(enable: bool):
+    """A/B switch: the one-wave-per-SIMD forward kernel (head dim 128, no document mask) on / off."""
+    _lib.load().udm_attention_set_w64(1 if enable else 0)
+
+
 # ------------------------------------------------------------------------------------------------ embedding / CE / adaLN helpers
 def embedding_fwd(ids, E, modality=None, Em=None):
     M = ids.numel()
