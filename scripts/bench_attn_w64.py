@@ -5,6 +5,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from unidisc_amd import kernels as K
 
 
+MODE = int(os.environ.get("MODE", "1"))   # 1 = one wave per SIMD (attention_w64.hip), 2 = wave-specialised (attention_ws64.hip)
+
+
 def timeit(fn, n=30, w=5):
     for _ in range(w): fn()
     torch.cuda.synchronize()
@@ -23,7 +26,7 @@ def run(B, H, L, D=128, spike=False, bench=True):
         q[7] = (k[L - 100].float() / 4).to(torch.bfloat16)
     K.set_attention_w64(False)
     o0, l0 = K.attention_fwd_generic(q, k, v, B, L, H, D)
-    K.set_attention_w64(True)
+    K.set_attention_w64(MODE)
     o1, l1 = K.attention_fwd_generic(q, k, v, B, L, H, D)
     torch.cuda.synchronize()
     rec = dict(B=B, H=H, L=L, spike=spike, o_equal=bool(torch.equal(o0, o1)), lse_equal=bool(torch.equal(l0, l1)),
@@ -32,7 +35,7 @@ def run(B, H, L, D=128, spike=False, bench=True):
         fl = 4 * B * H * L * L * D
         K.set_attention_w64(False)
         t0 = timeit(lambda: K.attention_fwd_generic(q, k, v, B, L, H, D))
-        K.set_attention_w64(True)
+        K.set_attention_w64(MODE)
         t1 = timeit(lambda: K.attention_fwd_generic(q, k, v, B, L, H, D))
         rec.update(old_us=round(t0 * 1e3, 1), new_us=round(t1 * 1e3, 1), old_tf=round(fl / t0 / 1e9), new_tf=round(fl / t1 / 1e9))
     print(json.dumps(rec), flush=True)
@@ -42,7 +45,7 @@ if __name__ == "__main__":
     if os.environ.get("UDM_ATTN_W64_ABL"):   # timing-only ablations (wrong results): just the headline shape
         run(8, 16, 1280)
         sys.exit(0)
-    for (B, H, L) in [(1, 1, 64), (1, 1, 2), (2, 3, 100), (1, 2, 257), (3, 5, 640), (2, 2, 1000), (1, 1, 191), (2, 1, 129)]:
+    for (B, H, L) in [(1, 1, 64), (1, 1, 2), (2, 3, 100), (1, 2, 257), (3, 5, 640), (2, 2, 1000), (1, 1, 191), (2, 1, 129), (1, 1, 128), (2, 3, 256), (1, 2, 384), (3, 1, 1152)]:
         run(B, H, L, bench=False)
         run(B, H, L, spike=True, bench=False)
     for (B, H, L) in [(8, 16, 1280), (8, 16, 1024), (8, 16, 2048), (2, 16, 4608), (8, 16, 1536)]:
