@@ -570,7 +570,10 @@ void launch_bwd(const AttnArgs& a, hipStream_t s) {
   auto kk = attn_bwd_dkv_kernel<D, SID, TR, 3, W>;
   static bool once = false;
   if (!once) { set_lds(kq, lds_q); set_lds(kk, lds_k); once = true; }
-  hipLaunchKernelGGL(kq, gq, dim3(256), lds_q, s, a);
+  static const int dq_w64 = [] { const char* e = getenv("UDM_ATTN_DQ_W64"); return e ? atoi(e) : 1; }();
+  if (D == 128 && !SID && TR && dq_w64 && udm_attn_w64_mode() && a.L % 128 == 0 && a.k_stride == a.v_stride && a.out_stride % 8 == 0)
+    udm_launch_attn_bwd_dq_w64(&a, s, udm_attn_w64_timeline());
+  else hipLaunchKernelGGL(kq, gq, dim3(256), lds_q, s, a);
   if (D == 128 && !SID && TR && g_dkv_ws) udm_launch_attn_bwd_dkv_ws(&a, s);
   else if (D == 128 && SID && TR && g_dkv_ws && a.doc_ranges) {
     // packed documents: key blocks that lie inside one document and whose query span is exactly that document go to the wave-specialised

@@ -439,6 +439,12 @@ extern "C" int udm_attention_set_w64(int enable) {
   return 0;
 }
 
+int udm_attn_w64_mode() {
+  if (w64::g_enabled < 0) { const char* e = getenv("UDM_ATTN_W64"); w64::g_enabled = e ? atoi(e) : 1; }
+  return w64::g_enabled;
+}
+unsigned long long* udm_attn_w64_timeline() { return w64::g_timeline; }
+
 // forward at head dim 128 without a document mask (called from attention.hip's dispatch); returns false when the kernel is switched off
 bool udm_launch_attn_fwd_w64(const void* args, hipStream_t stream) {
   using namespace w64;
