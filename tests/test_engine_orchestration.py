@@ -66,24 +66,33 @@ def test_logits_path_and_state_dict(fake_k):
     assert torch.allclose(lp.float()[finite], ref[finite], atol=0.1, rtol=0.05)
 
 
-@pytest.mark.parametrize("name", ["b_small", "d_adaln_mm"])
+@pytest.mark.parametrize("name", ["b_small", "c_large", "d_adaln_mm"])
 def test_masked_row_head_compaction_is_exact(name, fake_k):
-    """The vocabulary head restricted to the [MASK] rows must give the same loss and the same gradients as the full-row head."""
+    """The vocabulary head restricted to the [MASK] rows - and, without adaLN, the last block's out-proj / MLP / final norm restricted to them too -
+    must give the same loss and the same gradients as the full-row run."""
     g = Golden(name)
     res = []
-    for compact in (False, True):
+    for compact, last in ((False, False), (True, False), (True, True)):
         diff = build_product(g, device="cpu")
         diff.rng_device = "cpu"
         diff.backbone.compact_head = compact
+        diff.backbone.compact_last_block = last
+        seen = []
+        orig = type(diff.backbone)._engine_backward
+        diff.backbone._engine_backward = lambda S, grad, mode, orig=orig, bb=diff.backbone: (seen.append((S["hf"].shape[0], bool(S.get("stream_compact")))), orig(bb, S, grad, mode))[1]
         torch.manual_seed(g.case["step_seed"])
-        out = diff.training_step(g.batch(), 1)
+        batch = {k: torch.cat([v] * 4) for k, v in g.batch().items()}   # 512 rows: the padded [MASK] row list is shorter than the batch
+        out = diff.training_step(batch, 1)
         out.loss.backward()
+        M = 4 * g.case["batch_size"] * (g.case["txt_length"] + g.case["img_length"])
+        assert seen and (seen[0][0] < M) == compact and seen[0][1] == (last and not g.case["time_conditioning"]), (seen, M)
         res.append((out.loss.detach().clone(), out.nlls.detach().clone(), {k: p.grad.clone() for k, p in diff.backbone.named_parameters() if p.grad is not None}))
-    (l0, n0, g0), (l1, n1, g1) = res
-    assert torch.allclose(l0, l1, rtol=1e-6, atol=1e-7) and torch.allclose(n0, n1, rtol=1e-6, atol=1e-7)
-    assert set(g0) == set(g1)
-    for k in g0:
-        assert torch.allclose(g0[k], g1[k], rtol=1e-5, atol=1e-7), k
+    (l0, n0, g0) = res[0]
+    for (l1, n1, g1) in res[1:]:
+        assert torch.allclose(l0, l1, rtol=1e-6, atol=1e-7) and torch.allclose(n0, n1, rtol=1e-6, atol=1e-7)
+        assert set(g0) == set(g1)
+        for k in g0:
+            assert torch.allclose(g0[k], g1[k], rtol=1e-5, atol=1e-7), k
 
 
 def test_val_and_test_prefixes_update_attached_metrics(fake_k):

@@ -257,6 +257,9 @@ class DIT(nn.Module, _HubMixin):
         self._lins: Optional[Dict[str, _Lin]] = None
         self._fwd_count = 0
         self.compact_head = True          # "logp" mode: run the vocabulary head on the [MASK] rows only (exact: other rows have log p = 0)
+        # ... and with it everything of the LAST block behind its attention (out-proj, residual adds, MLP, final norm): only the head reads that
+        # block's output, so its unmasked rows feed nothing and receive a zero gradient (exact; no adaLN: the row kernels would need the row -> sample map)
+        self.compact_last_block = os.environ.get("UDM_COMPACT_LAST", "1") != "0"
         self.grad_ready_callback = None   # fn(flat_grads, lo, hi): elements [lo, hi) of this backward's flat fp32 gradient buffer are final
         self.grad_sync_finish = None      # fn(): called at the end of backward (e.g. make the compute stream wait for the all-reduces)
         self.recast_every_forward = True  # mirror autocast: fp32 master -> bf16 shadow on every training forward
@@ -599,6 +602,18 @@ class DIT(nn.Module, _HubMixin):
                 o, lse = K.attention_fwd_fp8(qkr, qkv, B, L, H, D, sid, S["doc_ranges"])
             else:
                 o, lse = K.attention_fwd(qkr, qkv, B, L, H, D, sid, S["doc_ranges"])
+            rows_c = None
+            if i + 1 == self.n_blocks and head_plan is not None and mode == "logp" and self.compact_last_block and not tc:
+                head_rows_c = self._masked_rows(head_plan, M)   # (the count was queued at the top of this forward: the host does not wait for the device here)
+                if head_rows_c is not None:
+                    rows_c = head_rows_c[0]
+            x_full, o_full = x, o
+            if rows_c is not None:   # from here on this block works on the [MASK] rows (+ padding) only
+                o = o.index_select(0, rows_c)
+                x = x.index_select(0, rows_c)
+                Mb = rows_c.numel()
+            else:
+                Mb = M
             a_out = K.gemm_nt(o, lin[f"{i}.out"].w16, N=d)
             # Without adaLN the next pre-norm is unmodulated and is fused into the residual add (x_out is normalised while in registers)
             fuse_w2 = None if tc else blk.norm2.weight.detach()
@@ -612,7 +627,7 @@ class DIT(nn.Module, _HubMixin):
             else:
                 h2, rstd2, mean2 = K.norm_fwd(x_mid, blk.norm2.weight.detach(), nt, L, mod=mod, mod_idx=(3, 4), modality=mod_flat, any_img=any_img)
             f1, f2 = lin[f"{i}.fc1"], lin[f"{i}.fc2"]
-            u1 = torch.empty((M, 4 * d), dtype=BF16, device=dev)
+            u1 = torch.empty((Mb, 4 * d), dtype=BF16, device=dev)
             g = K.gemm_nt(h2, f1.w16, N=4 * d, epilogue=K.EPI_BIAS_GELU, bias=f1.bias.detach(), aux=u1)
             u2 = K.gemm_nt(g, f2.w16, N=d, epilogue=K.EPI_BIAS, bias=f2.bias.detach())
             nxt_w = None
@@ -623,8 +638,9 @@ class DIT(nn.Module, _HubMixin):
             x_out, rstd_m, mean_m = res[:3]
             pre = res[3] if nxt_w is not None else None
             if save:
-                R.update(x_in=x, h1=h1, rstd1=rstd1, mean1=mean1, qkv=qkv, qkr=qkr, qstats=qstats, o=o, lse=lse, a_out=a_out, rstd_a=rstd_a, mean_a=mean_a,
-                         x_mid=x_mid, h2=h2, rstd2=rstd2, mean2=mean2, u1=u1, g=g, u2=u2, rstd_m=rstd_m, mean_m=mean_m)
+                R.update(x_in=x_full, h1=h1, rstd1=rstd1, mean1=mean1, qkv=qkv, qkr=qkr, qstats=qstats, o=o_full, lse=lse, a_out=a_out, rstd_a=rstd_a, mean_a=mean_a,
+                         x_mid=x_mid, h2=h2, rstd2=rstd2, mean2=mean2, u1=u1, g=g, u2=u2, rstd_m=rstd_m, mean_m=mean_m, rows_c=rows_c,
+                         o_c=o if rows_c is not None else None)
                 S["blocks"].append(R)
             x = x_out
 
@@ -662,11 +678,12 @@ class DIT(nn.Module, _HubMixin):
             ce_mod = mod_flat
         ids_h = ids
         head_rows = self._masked_rows(head_plan, M) if head_plan is not None else None
+        stream_compact = head_rows is not None and hf.shape[0] != M   # the last block already runs on the compacted rows (same list, same order)
         if head_rows is not None:  # compact operands: masked rows first, padded (with an unmasked row: zero loss, zero gradient) to a multiple of 64
             rows_p, n_masked = head_rows
             # fixed-capacity buffers (views of M-row allocations): a different size every step would make the caching allocator go back
             # to hipMalloc until its pool covers every size seen (measured: occasional 120+ ms steps)
-            hf_h = torch.index_select(hf, 0, rows_p, out=torch.empty_like(hf)[: rows_p.numel()])
+            hf_h = hf if stream_compact else torch.index_select(hf, 0, rows_p, out=torch.empty_like(hf)[: rows_p.numel()])
             x0, ids_h = x0.index_select(0, rows_p), ids.index_select(0, rows_p)
             ce_mod = ce_mod.index_select(0, rows_p) if ce_mod is not None else None
         else:
@@ -680,7 +697,7 @@ class DIT(nn.Module, _HubMixin):
             log_p = full
         if save:
             S.update(x_final=x, hf=hf_h, rstdf=rstdf, meanf=meanf, fmod=fmod, logits=logits, head_rows=head_rows, ids_h=ids_h,
-                     x0=x0, ce_mod=ce_mod, restrict=restrict, lse_ce=lse_ce)
+                     x0=x0, ce_mod=ce_mod, restrict=restrict, lse_ce=lse_ce, stream_compact=stream_compact)
         return log_p.view(B, L), S
 
     def _plan_masked_rows(self, ids):
@@ -708,12 +725,15 @@ class DIT(nn.Module, _HubMixin):
     def _masked_rows(self, plan, M, always=False):
         """(row indices: the [MASK] rows, then as many unmasked rows as pad the list to a multiple of 64; number of masked rows), or
         None when compaction would not shrink the head.  Unmasked rows have zero loss and zero gradient, so padding with them is exact."""
-        if plan["event"] is not None:
+        if plan.get("n") is not None:
+            n = plan["n"]
+        elif plan["event"] is not None:
             plan["event"].synchronize()
             n = int(plan["count_host"][0])
             torch.cuda.current_stream().wait_stream(plan["side"])
         else:
             n = plan["count"]
+        plan["n"] = n
         n_pad = _ceil(max(n, 1), 64)
         if n_pad >= M:
             return (plan["order"], n) if always else None   # always: every row, [MASK] rows first
@@ -807,7 +827,8 @@ class DIT(nn.Module, _HubMixin):
         # few output tiles (compacted rows x d) over K = V: split K so that all CUs work (falls back to the plain kernel otherwise)
         dhf = K.gemm_nt_splitk(dlogits, head.w16t, N=d, out=torch.empty((M, d), dtype=BF16, device=dev)[: dlogits.shape[0]])
         self._wgrad(dlogits, S["hf"], head, G)
-        if head_rows is not None:  # scatter the masked rows' gradient back; every other row of d(final norm output) is exactly zero
+        stream_compact = bool(S.get("stream_compact"))
+        if head_rows is not None and not stream_compact:  # scatter the masked rows' gradient back; every other row of d(final norm output) is exactly zero
             rows_p, n_masked = head_rows
             full = torch.zeros((M, d), dtype=dhf.dtype, device=dev)
             full.index_copy_(0, rows_p[:n_masked], dhf[:n_masked])
@@ -822,7 +843,8 @@ class DIT(nn.Module, _HubMixin):
             dmodf = torch.zeros((Bp, 2 * d), dtype=F32, device=dev)
         fl = self.output_layer
         fmod = S["fmod"]
-        dx = torch.empty((M, d), dtype=F32, device=dev)
+        # (compacted last block: its residual-stream gradient lives on the compacted rows until the block's attention is reached)
+        dx = torch.empty((dhf.shape[0] if stream_compact else M, d), dtype=F32, device=dev)
         # Without adaLN every pre-norm backward is immediately followed by the backward of the residual branch that produced the norm's input, on
         # the dx it has just updated: the pair runs as ONE fused pass (K.norm_residual_bwd).  `pend` carries the norm half to the branch that
         # consumes it - the final norm and each block's norm1 pair with the MLP branch of the block below them in the schedule, so a block's
@@ -892,7 +914,14 @@ class DIT(nn.Module, _HubMixin):
                     da = branch_bwd(p2, R["a_out"], p_drop=p_drop, seed=seed0 + 4 * i + 1)
             lo, lq = lin[f"{i}.out"], lin[f"{i}.qkv"]
             do = K.gemm_nt(da, lo.w16t, N=d)
-            self._wgrad(da, R["o"], lo, G)
+            if R.get("rows_c") is not None:
+                # back to all rows: the rows left out have a zero gradient in both the attention output and the residual stream
+                self._wgrad(da, R["o_c"], lo, G)
+                rows_c = R["rows_c"]
+                do = torch.zeros((M, d), dtype=do.dtype, device=dev).index_copy_(0, rows_c, do)
+                dx = torch.zeros((M, d), dtype=F32, device=dev).index_copy_(0, rows_c, dx)
+            else:
+                self._wgrad(da, R["o"], lo, G)
             dqkr = torch.empty((M, 2 * d), dtype=BF16, device=dev)
             dqkv = torch.empty((M, 3 * d), dtype=BF16, device=dev)
             K.attention_bwd(R["qkr"], R["qkv"], R["o"], do, R["lse"], dqkr, dqkv, B, L, H, D, S["sid"], S["doc_ranges"])
