@@ -234,6 +234,15 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
   }
   const float ltot = lsum + __shfl_xor(lsum, 32, 64);
   const float inv = ltot > 0.f ? 1.f / ltot : 0.f;
+  if (q_ok && hi == 0) a.lse[((long)b * a.H + h) * a.L + qi] = ltot > 0.f ? __builtin_fmaf(m, c, log2f(ltot)) : INFINITY;
+  if constexpr (D == 128) {
+    if (a.out_stride % 8 == 0) {   // block-uniform: whole-row stores through the (now idle) K / V stages
+      __syncthreads();
+      const int q0 = tile_x * BQ + wave * 32;
+      store_rows_via_lds_d128(smem + wave * 8192, oT, inv, a.out + (rowbase + q0) * a.out_stride + h * D, a.out_stride, a.L - q0, lane);
+      return;
+    }
+  }
   if (q_ok) {
     bf16_t* op = a.out + (rowbase + qi) * a.out_stride + h * D;
 #pragma unroll
@@ -243,7 +252,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
         const int d0 = i * 32 + 8 * rg + 4 * hi;
         *reinterpret_cast<uint2*>(op + d0) = make_uint2(pack2bf(oT[i][rg * 4] * inv, oT[i][rg * 4 + 1] * inv), pack2bf(oT[i][rg * 4 + 2] * inv, oT[i][rg * 4 + 3] * inv));
       }
-    if (hi == 0) a.lse[((long)b * a.H + h) * a.L + qi] = ltot > 0.f ? m * c + log2f(ltot) : INFINITY;
   }
 }
 
@@ -366,6 +374,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
         bf16x8_t kt = lds_frag_T<D, USE_TR>(Ks, cc * 16, i * 32, lane);
         dqT[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kt, dsb, dqT[i], 0, 0, 0);
       }
+    }
+  }
+  if constexpr (D == 128) {
+    if (a.out_stride % 8 == 0) {   // block-uniform: whole-row stores through the (now idle) K / V stages
+      __syncthreads();
+      const int q0 = tile_x * BQ + wave * 32;
+      store_rows_via_lds_d128(smem + wave * 8192, dqT, a.scale, a.out + (rowbase + q0) * a.out_stride + h * D, a.out_stride, a.L - q0, lane);
+      return;
     }
   }
   if (q_ok) {
@@ -547,7 +563,7 @@ void launch_fwd(const AttnArgs& a, hipStream_t s) {
   auto kern = attn_fwd_kernel<D, SID, TR>;
   static bool once = false;
   if (!once) { set_lds(kern, lds); once = true; }
-  if (D == 128 && !SID && TR && a.out_stride % 8 == 0 && a.k_stride == a.v_stride && a.L % 128 == 0 && udm_launch_attn_fwd_w64(&a, s)) return;
+  if (D == 128 && !SID && TR && a.out_stride % 8 == 0 && a.L % 128 == 0 && udm_launch_attn_fwd_w64(&a, s)) return;
   if (D == 128 && !SID && TR) {   // UDM_ATTN_ABL=1|2: timing-only ablations of the forward kernel (scripts/bench_attn.py)
     static const int abl = [] { const char* e = getenv("UDM_ATTN_ABL"); return e ? atoi(e) : 0; }();
     if (abl == 1) { auto k1 = attn_fwd_kernel<128, false, true, 1>; set_lds(k1, lds); hipLaunchKernelGGL(k1, grid, dim3(256), lds, s, a); return; }
@@ -571,7 +587,7 @@ void launch_bwd(const AttnArgs& a, hipStream_t s) {
   static bool once = false;
   if (!once) { set_lds(kq, lds_q); set_lds(kk, lds_k); once = true; }
   static const int dq_w64 = [] { const char* e = getenv("UDM_ATTN_DQ_W64"); return e ? atoi(e) : 1; }();
-  if (D == 128 && !SID && TR && dq_w64 && udm_attn_w64_mode() && a.L % 128 == 0 && a.k_stride == a.v_stride && a.out_stride % 8 == 0)
+  if (D == 128 && !SID && TR && dq_w64 && udm_attn_w64_mode() && a.L % 128 == 0 && a.out_stride % 8 == 0)
     udm_launch_attn_bwd_dq_w64(&a, s, udm_attn_w64_timeline());
   else hipLaunchKernelGGL(kq, gq, dim3(256), lds_q, s, a);
   if (D == 128 && !SID && TR && g_dkv_ws) udm_launch_attn_bwd_dkv_ws(&a, s);

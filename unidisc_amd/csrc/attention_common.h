@@ -200,6 +200,32 @@ __device__ __forceinline__ void dma4_asm(const void* gptr, const char* lds) {
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(gptr), "s"(dst) : "memory", "m0");
 }
 __device__ __forceinline__ void wait_all_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// Epilogue of the transposed-accumulator kernels at head dim 128: a wave holds X^T for 32 rows (lane & 31 = row, registers walk the 128
+// columns: acc[i][r] = column i*32 + 8*(r>>2) + 4*hi + (r&3)).  Per-lane stores of that layout are 8-byte pieces at a row stride (32 - 64 cache
+// lines touched per store instruction; the store tail is issue-bound).  Instead: scale, pack to bf16, stage through 8 KiB of LDS owned by the wave
+// (16-byte slots XOR-swizzled with the row: conflict-free for the 8-byte writes and the 16-byte reads) and store whole 256-byte rows, four rows
+// per instruction.  `rows_valid` rows are stored (ragged last block).  The caller makes sure nobody still reads that LDS (barrier).
+// (rows 16..31 are staged `half_stride` bytes behind rows 0..15: 4096 = one contiguous 8 KiB region)
+__device__ __forceinline__ void store_rows_via_lds_d128(char* wave_lds, const f32x16_t (&acc)[4], float scale, bf16_t* out_row0, long stride, int rows_valid, int lane,
+                                                        int half_stride = 4096) {
+  const int row = lane & 31, hi = lane >> 5;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+      const int slot = i * 4 + rg;
+      *reinterpret_cast<uint2*>(wave_lds + (row >> 4) * half_stride + (row & 15) * 256 + ((slot ^ (row & 15)) << 4) + hi * 8) =
+          make_uint2(pack2bf(acc[i][rg * 4] * scale, acc[i][rg * 4 + 1] * scale), pack2bf(acc[i][rg * 4 + 2] * scale, acc[i][rg * 4 + 3] * scale));
+    }
+  // (the wave reads back only what it wrote: the compiler orders this wave's LDS writes before its reads, no barrier needed)
+#pragma unroll
+  for (int p = 0; p < 8; ++p) {
+    const int r = p * 4 + (lane >> 4), slot = lane & 15;
+    const uint4 v = *reinterpret_cast<const uint4*>(wave_lds + (r >> 4) * half_stride + (r & 15) * 256 + ((slot ^ (r & 15)) << 4));
+    if (r < rows_valid) *reinterpret_cast<uint4*>(out_row0 + (long)r * stride + slot * 8) = v;
+  }
+}
 }  // namespace
 
 // dK/dV kernel for head dim 128 without a document mask (attention_dkv_ws.hip); grid = ceil(L / 128) * B * H blocks of 512 threads

@@ -316,7 +316,13 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_ws_kernel(AttnArgs a) {
     if (j <= nsub) { UDM_WS_Z(4); ++j; }
     if (j <= nsub) { UDM_WS_Z(5); ++j; }
 #undef UDM_WS_Z
-    if (k_ok) {
+    if (a.out2_stride % 8 == 0 && a.out3_stride % 8 == 0) {
+      // whole-row stores through this key group's two exchange slots (free: the last P / dS hand-over has been consumed by this very wave)
+      const int k0 = ki - l31;   // first key of this wave's 32
+      char* stg = smem + XC_OFF + (wave & 3) * 4096;
+      store_rows_via_lds_d128(stg, dkT, a.scale, a.out2 + (rowbase + k0) * a.out2_stride + h * D, a.out2_stride, a.L - k0, lane, 4 * 4096);
+      store_rows_via_lds_d128(stg, dvT, 1.0f, a.out3 + (rowbase + k0) * a.out3_stride + h * D, a.out3_stride, a.L - k0, lane, 4 * 4096);
+    } else if (k_ok) {
       bf16_t* kp = a.out2 + (rowbase + ki) * a.out2_stride + h * D;
       bf16_t* vp = a.out3 + (rowbase + ki) * a.out3_stride + h * D;
 #pragma unroll

@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_w64_kernel(AttnArgs a) {
   const long rowbase = (long)b * a.L;
   const float c = a.scale_log2;
   const int L = a.L;
-  const long kvs = a.k_stride;                 // == v_stride (dispatch condition)
+  const long ks_ = a.k_stride, vs_ = a.v_stride;   // row strides of K and V (the engine reads K from the roped [M, 2d] buffer, V from qkv [M, 3d])
   const int q0w = tile_x * BQW + wave * 64;    // first query of this wave
   const int nkv = L / BKV;                     // even, >= 2 (dispatch condition)
   const uint32_t lds0 = (uint32_t)(size_t)(UDM_LDS char*)smem;
@@ -121,17 +121,18 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_w64_kernel(AttnArgs a) {
   };
   stamp(0);
 
-  const bf16_t* kbase = a.k + rowbase * kvs + h * D;
-  const bf16_t* vbase = a.v + rowbase * kvs + h * D;
-  DmaPlan<D, BKV> plan;   // one set of per-lane piece offsets serves K and V (same row stride)
-  plan.init(kvs, wave, lane);
-  const long tile_step = (long)BKV * kvs;
+  const bf16_t* kbase = a.k + rowbase * ks_ + h * D;
+  const bf16_t* vbase = a.v + rowbase * vs_ + h * D;
+  DmaPlan<D, BKV> plank, planv;
+  plank.init(ks_, wave, lane);
+  planv.init(vs_, wave, lane);
+  const long ktile_step = (long)BKV * ks_, vtile_step = (long)BKV * vs_;
   auto refill = [&](int T) {   // K and V tile T into stage T % 3, this wave's four pieces of each
     const uint32_t dst = lds0 + (T % NST) * TB + wave * 4096;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) dma_piece(plan.off[j], kbase + T * tile_step, dst + j * 1024);
+    for (int j = 0; j < 4; ++j) dma_piece(plank.off[j], kbase + T * ktile_step, dst + j * 1024);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) dma_piece(plan.off[j], vbase + T * tile_step, dst + V_OFF + j * 1024);
+    for (int j = 0; j < 4; ++j) dma_piece(planv.off[j], vbase + T * vtile_step, dst + V_OFF + j * 1024);
   };
   refill(0);
   refill(1);
@@ -272,15 +273,15 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_w64_kernel(AttnArgs a) {
     uint32_t kb = lds0 + st + kl, vb = lds0 + st + V_OFF + kl, kbn = lds0 + stn + kl, vbn = lds0 + stn + V_OFF + kl;
     uint32_t b1 = lds0 + st + t1, b2 = lds0 + st + t2;
     asm volatile("" : "+v"(kb), "+v"(vb), "+v"(kbn), "+v"(vbn), "+v"(b1), "+v"(b2));   // per-tile values: keeps XOR-ed addresses out of loop-invariant registers
-    const bf16_t* ksrc = kbase + min(T + 2, nkv - 1) * tile_step;   // tile T+2 -> the stage tile T-1 left (past the end: a harmless re-fetch)
-    const bf16_t* vsrc = vbase + min(T + 2, nkv - 1) * tile_step;
+    const bf16_t* ksrc = kbase + min(T + 2, nkv - 1) * ktile_step;   // tile T+2 -> the stage tile T-1 left (past the end: a harmless re-fetch)
+    const bf16_t* vsrc = vbase + min(T + 2, nkv - 1) * vtile_step;
     const uint32_t dst = lds0 + ((T + 2) % NST) * TB + wave * 4096;
     // even half (rows 0..31 of tile T): scores of the odd half under its softmax backward, then its dQ update (with the refill of tile T+2: it
     // has the whole odd half to land)
     phase_x(std::true_type{}, SA, PA, SB, PB, kb, vb, 1);
     phase_y(b1, b2, 0, [&](int mi) {
-      if (mi >= 1 && mi < 5) dma_piece(plan.off[mi - 1], ksrc, dst + (mi - 1) * 1024);
-      if (mi >= 5 && mi < 9) dma_piece(plan.off[mi - 5], vsrc, dst + V_OFF + (mi - 5) * 1024);
+      if (mi >= 1 && mi < 5) dma_piece(plank.off[mi - 1], ksrc, dst + (mi - 1) * 1024);
+      if (mi >= 5 && mi < 9) dma_piece(planv.off[mi - 5], vsrc, dst + V_OFF + (mi - 5) * 1024);
       if (!LAST) {   // first fragments of the next X: tile T+1, rows 0..31
         if (mi == 12) kfr[0] = rowfrag(kbn, 0, 0);
         if (mi == 13) vfr[0] = rowfrag(vbn, 0, 0);
@@ -334,7 +335,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_w64_kernel(AttnArgs a) {
 }  // namespace dq64
 }  // namespace
 
-// dQ at head dim 128, no document mask, L % 128 == 0, k_stride == v_stride, dq_stride % 8 == 0 (called from attention.hip's launch_bwd)
+// dQ at head dim 128, no document mask, L % 128 == 0, dq_stride % 8 == 0 (called from attention.hip's launch_bwd)
 void udm_launch_attn_bwd_dq_w64(const void* args, hipStream_t stream, unsigned long long* timeline) {
   using namespace dq64;
   AttnArgs a = *reinterpret_cast<const AttnArgs*>(args);

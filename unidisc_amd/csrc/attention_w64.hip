@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w64_kernel(AttnArgs a) {
   const long rowbase = (long)b * a.L;
   const float c = a.scale_log2;
   const int L = a.L;
-  const long kvs = a.k_stride;                 // == v_stride (dispatch condition)
+  const long ks_ = a.k_stride, vs_ = a.v_stride;   // row strides of K and V (the engine reads K from the roped [M, 2d] buffer, V from qkv [M, 3d])
   const int q0w = tile_x * BQW + wave * 64;    // first query of this wave
 
   {
@@ -152,14 +152,15 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w64_kernel(AttnArgs a) {
     });
   }
 
-  const bf16_t* kbase = a.k + rowbase * kvs + h * D;
-  const bf16_t* vbase = a.v + rowbase * kvs + h * D;
+  const bf16_t* kbase = a.k + rowbase * ks_ + h * D;
+  const bf16_t* vbase = a.v + rowbase * vs_ + h * D;
   using Stg = DmaStager<D, BKV>;
-  DmaPlan<D, BKV> plan;   // one set of per-lane piece offsets serves K and V (same row stride)
-  plan.init(kvs, wave, lane);
+  DmaPlan<D, BKV> plank, planv;
+  plank.init(ks_, wave, lane);
+  planv.init(vs_, wave, lane);
   const int nkv = (L + BKV - 1) / BKV;
   const uint32_t lds0 = (uint32_t)(size_t)(UDM_LDS char*)smem;
-  const long tile_step = (long)BKV * kvs;   // elements per 64-row tile
+  const long ktile_step = (long)BKV * ks_, vtile_step = (long)BKV * vs_;   // elements per 64-row tile
   // ABL & 4: cycle stamps (s_memtime) of blocks 0 and 300, [block][wave][64 tags], written by lane 0
   auto stamp = [&](int tag) {
     if (ABL & 4) {
@@ -178,8 +179,8 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w64_kernel(AttnArgs a) {
   auto refill_all = [&](int which, int t) {   // any tile, also the ragged last one (rows clamped to L - 1)
     const bf16_t* base = which ? vbase : kbase;
     char* dst = smem + (which ? v_stage(t) : k_stage(t));
-    if ((t + 1) * BKV <= L) plan.issue_full(base + t * tile_step, dst, wave);
-    else Stg::issue(base, kvs, t * BKV, L, dst, wave, lane);
+    if ((t + 1) * BKV <= L) (which ? planv : plank).issue_full(base + t * (which ? vtile_step : ktile_step), dst, wave);
+    else Stg::issue(base, which ? vs_ : ks_, t * BKV, L, dst, wave, lane);
   };
 
   refill_all(0, 0);
@@ -311,8 +312,8 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w64_kernel(AttnArgs a) {
     asm volatile("" : "+v"(kb), "+v"(kb2), "+v"(vb1), "+v"(vb2));   // per-tile values: keeps the XOR-ed fragment addresses out of loop-invariant registers
     // V(t+1) -> the stage V(t-1) left, K(t+3) -> the stage K(t) left.  Past the last tile the steady body re-fetches the last tile into a
     // stage nobody reads any more: same instruction stream (and the same counted waits) for every tile of the block.
-    const bf16_t* vsrc = vbase + min(t + 1, nkv - 1) * tile_step;
-    const bf16_t* ksrc = kbase + min(t + 3, nkv - 1) * tile_step;
+    const bf16_t* vsrc = vbase + min(t + 1, nkv - 1) * vtile_step;
+    const bf16_t* ksrc = kbase + min(t + 3, nkv - 1) * ktile_step;
     const uint32_t vdst = lds0 + v_stage(t + 1) + wave * 4096, kdst = lds0 + k_stage(t + 3) + wave * 4096;
     psum[0] = 0.f;
     psum[1] = 0.f;
@@ -334,8 +335,8 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w64_kernel(AttnArgs a) {
         sb();
         if (!(ABL & 8) && q == 1 && j + AHEAD < 16) kfr[(j + AHEAD) % NFR] = kread(kb, j + AHEAD);
         // refills, early in the tile: V(t+1) at gaps 1, 3, 5, 7 and K(t+3) at gaps 9, 11, 13, 15
-        if (!(ABL & 2) && (mi & 1) && mi < 8) dma_piece(plan.off[mi >> 1], vsrc, vdst + (mi >> 1) * 1024);
-        if (!(ABL & 2) && (mi & 1) && mi >= 8 && mi < 16) dma_piece(plan.off[(mi - 8) >> 1], ksrc, kdst + ((mi - 8) >> 1) * 1024);
+        if (!(ABL & 2) && (mi & 1) && mi < 8) dma_piece(planv.off[mi >> 1], vsrc, vdst + (mi >> 1) * 1024);
+        if (!(ABL & 2) && (mi & 1) && mi >= 8 && mi < 16) dma_piece(plank.off[(mi - 8) >> 1], ksrc, kdst + ((mi - 8) >> 1) * 1024);
         // first V(t) fragments for phase B
         if constexpr (mi >= 32 - AHEAD) { if (!(ABL & 8)) vfr[mi - (32 - AHEAD)] = vread(vb1, vb2, mi - (32 - AHEAD)); }
         sb();
@@ -440,7 +441,7 @@ extern "C" int udm_attention_set_w64(int enable) {
 }
 
 int udm_attn_w64_mode() {
-  if (w64::g_enabled < 0) { const char* e = getenv("UDM_ATTN_W64"); w64::g_enabled = e ? atoi(e) : 1; }
+  if (w64::g_enabled < 0) { const char* e = getenv("UDM_ATTN_W64"); w64::g_enabled = e ? atoi(e) : 0; }
   return w64::g_enabled;
 }
 unsigned long long* udm_attn_w64_timeline() { return w64::g_timeline; }
@@ -448,7 +449,7 @@ unsigned long long* udm_attn_w64_timeline() { return w64::g_timeline; }
 // forward at head dim 128 without a document mask (called from attention.hip's dispatch); returns false when the kernel is switched off
 bool udm_launch_attn_fwd_w64(const void* args, hipStream_t stream) {
   using namespace w64;
-  if (g_enabled < 0) { const char* e = getenv("UDM_ATTN_W64"); g_enabled = e ? atoi(e) : 1; }
+  if (g_enabled < 0) { const char* e = getenv("UDM_ATTN_W64"); g_enabled = e ? atoi(e) : 0; }
   if (!g_enabled) return false;
   if (g_enabled == 2) {
     AttnArgs a2 = *reinterpret_cast<const AttnArgs*>(args);

@@ -251,19 +251,20 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_ws64_kernel(AttnArgs a) {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // barrier nkv
   } else {
     // =================================================================================================== PV wave
-    const long kvs = a.k_stride;   // == v_stride (dispatch condition)
-    const bf16_t* kbase = a.k + rowbase * kvs + h * D;
-    const bf16_t* vbase = a.v + rowbase * kvs + h * D;
-    const long tile_step = (long)BKV * kvs;
-    DmaPlan<D, BKV> plan;
-    plan.init(kvs, pair, lane);
-    auto refill = [&](const bf16_t* src, uint32_t dst) {
+    const long ks_ = a.k_stride, vs_ = a.v_stride;
+    const bf16_t* kbase = a.k + rowbase * ks_ + h * D;
+    const bf16_t* vbase = a.v + rowbase * vs_ + h * D;
+    const long ktile_step = (long)BKV * ks_, vtile_step = (long)BKV * vs_;
+    DmaPlan<D, BKV> plank, planv;
+    plank.init(ks_, pair, lane);
+    planv.init(vs_, pair, lane);
+    auto refill = [&](const DmaPlan<D, BKV>& plan, const bf16_t* src, uint32_t dst) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) dma_piece(plan.off[j], src, dst + j * 1024);
     };
-    refill(kbase, lds0 + 0 * TB + pair * 4096);
-    refill(kbase + tile_step, lds0 + 1 * TB + pair * 4096);
-    refill(kbase + min(2, nkv - 1) * tile_step, lds0 + 2 * TB + pair * 4096);
+    refill(plank, kbase, lds0 + 0 * TB + pair * 4096);
+    refill(plank, kbase + ktile_step, lds0 + 1 * TB + pair * 4096);
+    refill(plank, kbase + min(2, nkv - 1) * ktile_step, lds0 + 2 * TB + pair * 4096);
     f32x16_t oT[2][DB];
 #pragma unroll
     for (int q = 0; q < 2; ++q)
@@ -295,8 +296,8 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_ws64_kernel(AttnArgs a) {
       sb();
       stamp(4 + 3 * t);
       if (t < nkv) {
-        refill(vbase + t * tile_step, lds0 + V_OFF + (t & 1) * TB + pair * 4096);                                   // V(t)   -> the stage V(t-2) left
-        refill(kbase + min(t + 3, nkv - 1) * tile_step, lds0 + ((t + 3) % NKST) * TB + pair * 4096);               // K(t+3) -> the stage K(t) left
+        refill(planv, vbase + t * vtile_step, lds0 + V_OFF + (t & 1) * TB + pair * 4096);                                   // V(t)   -> the stage V(t-2) left
+        refill(plank, kbase + min(t + 3, nkv - 1) * ktile_step, lds0 + ((t + 3) % NKST) * TB + pair * 4096);               // K(t+3) -> the stage K(t) left
       }
       stamp(5 + 3 * t);
       if (t >= 1) {
@@ -363,7 +364,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_ws64_kernel(AttnArgs a) {
 }  // namespace ws64
 }  // namespace
 
-// forward at head dim 128, no document mask, L % 128 == 0, k_stride == v_stride, o_stride % 8 == 0 (called from attention_w64.hip's launcher)
+// forward at head dim 128, no document mask, L % 128 == 0, o_stride % 8 == 0 (called from attention_w64.hip's launcher)
 void udm_launch_attn_fwd_ws64(const void* args, hipStream_t stream) {
   using namespace ws64;
   const AttnArgs& a = *reinterpret_cast<const AttnArgs*>(args);
