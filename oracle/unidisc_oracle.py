@@ -681,6 +681,63 @@ def sample_ddpm_cache(cfg: OracleConfig, P, buffers, x_init, timesteps, dt, us, 
     return x, xs, x_last, nfe
 
 
+def sample_ddpm_cache_attention_caching(cfg: OracleConfig, P, buffers, x_init, timesteps, dt, us, ratio, modality=None, batch=None, noise_removal=True, bf16=False):
+    """`eval.attention_caching` on the `ddpm_cache` path (model_eval.py:2296-2366, :2425-2440), three kinds of step by i mod ratio:
+    0: a full joint update (text slice written back first when the state is sliced);  1: a full update under the block mask of
+    get_block_mask(img_batch_attn_dropout = all) - image queries see image keys only (the step that writes the reference's per-layer cache;
+    nothing ever reads that cache back, models/dit.py:797-803 vs :812);  else: the update runs on the TEXT slice alone (x, modality and the
+    p_x0 cache sliced to static_txt_sl; text queries see text keys only because nothing else is in the sequence).
+    us[i]: the uniforms of step i, [B, L, V] or [B, Lt, V].  Returns (x_final, xs (x_next of every step, in that step's view), x_last, nfe, modes)."""
+    x = x_init.clone()
+    B, Lt = x.shape[0], cfg.txt_length
+    sl = slice(0, Lt)
+    p_cache, nfe, xs, modes = None, 0, [], []
+    sliced, full = False, {}
+    cur_mod = modality
+    for i in range(len(timesteps) - 1):
+        t = timesteps[i] * torch.ones(B, 1)
+        allow = None
+        if i % ratio == 0:
+            if sliced:   # model_eval.py:2312-2323: the saved full tensors take the current text slice back
+                def back(key, new):
+                    if full[key] is not None:
+                        full[key][:, sl] = new
+                    return full[key]
+                x, p_cache, cur_mod = back("x", x), back("p", p_cache), back("m", cur_mod)
+                full, sliced = {}, False
+            mode = "full"
+        elif (i - 1) % ratio == 0:
+            allow = modality_dropout_mask(torch.zeros(B, dtype=torch.bool), torch.ones(B, dtype=torch.bool), Lt, x.shape[1])
+            mode = "build"
+        else:
+            if not sliced:   # :2345-2362
+                cl = lambda v: None if v is None else v.clone()
+                full = dict(x=cl(x), m=cl(cur_mod), p=cl(p_cache))
+                x, cur_mod = x[:, sl], (None if cur_mod is None else cur_mod[:, sl])
+                p_cache = None if p_cache is None else p_cache[:, sl]
+                sliced = True
+            mode = "text"
+        modes.append(mode)
+        p_cache, x_next, n = ddpm_caching_update(cfg, P, buffers, x, t, dt, us[i], p_x0=p_cache, modality=cur_mod, batch=batch, bf16=bf16, allow_mask=allow)
+        nfe += n
+        if not torch.allclose(x_next, x) or cfg.time_conditioning:
+            p_cache = None
+        x = x_next
+        xs.append(x.clone())
+    if sliced:   # :2425-2440
+        full["x"][:, sl] = x
+        x = full["x"]
+        if full["m"] is not None:
+            full["m"][:, sl] = cur_mod
+            cur_mod = full["m"]
+    x_last = x
+    if noise_removal:
+        t = timesteps[-1] * torch.ones(B)
+        logits = dit_forward(cfg, P, buffers, x, loglinear_noise(t)[0], cur_mod, None, bf16)
+        x = subs_parameterization(cfg, logits, x, cur_mod, batch, bf16).float().argmax(dim=-1)
+    return x, xs, x_last, nfe, modes
+
+
 # ------------------------------------------------------------------------------------------------
 # sampler inner loop (SURVEY §8f N1): `maskgit` predictor
 # ------------------------------------------------------------------------------------------------

@@ -16,7 +16,7 @@ DEV = "cuda"
 
 def load_sampler(name):
     z = np.load(os.path.join(GOLDEN_DIR, f"sampler_{name}.npz"))
-    return {k: torch.from_numpy(np.asarray(z[k])) for k in z.files}
+    return {k: torch.from_numpy(np.asarray(z[k])) for k in z.files if z[k].dtype.kind != "U"}   # (string entries: read them from the npz directly)
 
 
 def _oracle_tokens_from_logits(cfg, logits_bf16, x, t, dt, u, modality, batch):
@@ -259,7 +259,7 @@ def test_guided_sampler_loop_on_gpu():
 # ------------------------------------------------------------------------------------------------ `maskgit` predictor
 def _maskgit_golden(name):
     z = np.load(os.path.join(GOLDEN_DIR, f"maskgit_{name}.npz"))
-    return {k: torch.from_numpy(np.asarray(z[k])) for k in z.files}
+    return {k: torch.from_numpy(np.asarray(z[k])) for k in z.files if z[k].dtype.kind != "U"}   # (string entries: read them from the npz directly)
 
 
 def _maskgit_run(diff, s, device):
@@ -296,7 +296,7 @@ def test_maskgit_host_logic_replays_reference_run(name, monkeypatch):
 
 def _nucleus_golden():
     z = np.load(os.path.join(GOLDEN_DIR, "maskgit_nucleus_c_large.npz"))
-    return {k: torch.from_numpy(np.asarray(z[k])) for k in z.files}
+    return {k: torch.from_numpy(np.asarray(z[k])) for k in z.files if z[k].dtype.kind != "U"}   # (string entries: read them from the npz directly)
 
 
 def test_nucleus_filter_oracle_matches_reference_draw_support():
@@ -525,3 +525,83 @@ def test_categorical_rows_kernel_token_exact_on_reference_uniforms(name):
         tok, _ = K.categorical_sample_rows(lg.to(DEV), V, Vt, mask, modality=rm, restrict=cfg.force_argmax_valid_indices,
                                            u=u.reshape(B * L, V)[rows].contiguous().to(DEV))
         assert torch.equal(tok.cpu(), want.reshape(-1)[rows]), f"step {i}"
+
+
+# ------------------------------------------------------------------------------------------------ eval.attention_caching (model_eval.py:2296-2366)
+def _caching_product(device):
+    g, s = Golden("c_large"), load_sampler("c_large_attn_caching")
+    diff = build_product(g, device=device)
+    diff.backbone.eval()
+    from unidisc_amd.config import Cfg
+    diff.config.eval = Cfg(cfg=None, attention_caching=True, attention_caching_txt_to_img_ratio=int(s["ratio"]))
+    z = np.load(os.path.join(GOLDEN_DIR, "sampler_c_large_attn_caching.npz"))
+    modes = [str(z[f"step{i}/mode"]) for i in range(int(s["steps"]))]
+    return g, s, diff, modes
+
+
+def test_attention_caching_sampler_host_logic_replays_reference_run(monkeypatch):
+    """CPU: the three kinds of step (full / image queries on image keys only / text slice alone) with kernel doubles, fed the reference's uniforms"""
+    from unidisc_amd import dit as dit_mod, diffusion as diff_mod
+
+    monkeypatch.setattr(dit_mod, "K", fake_kernels)
+    monkeypatch.setattr(diff_mod, "K", fake_kernels)
+    g, s, diff, modes = _caching_product("cpu")
+    steps = int(s["steps"])
+    B, L = s["x_init"].shape
+    seen = []
+    orig = diff._ddpm_caching_update
+
+    def spy(x, t, dt, **kw):
+        out = orig(x, t, dt, **kw)
+        seen.append((tuple(x.shape), out[1].clone()))
+        return out
+
+    diff._ddpm_caching_update = spy
+    x, nfe = diff.sample(num_steps=steps, eps=float(s["eps"]), batch_size=B, modality=s["modality"], noise=[s[f"step{i}/u"] for i in range(steps)], return_nfe=True)
+    assert diff.sample_step_modes == modes and {"full", "build", "text"} <= set(modes)
+    for i in range(steps):   # every step ran in the reference's view (full sequence or the text slice) and mostly drew the reference's tokens
+        assert seen[i][0] == tuple(s[f"step{i}/x"].shape), i
+    agree = (x == s["x_final"]).float().mean().item()
+    assert agree >= 0.9, agree
+    assert nfe == int(s["nfe"]) + 1 and not (x == diff.mask_index).any()
+    assert x.shape == (B, L)
+
+
+def test_attention_caching_cache_moves_between_views():
+    """the logits cache of the [MASK] rows follows the reference's p_x0 slicing: to the text slice and back"""
+    from unidisc_amd.diffusion import Diffusion
+    L, Lt, B = 6, 2, 2
+    rows = torch.tensor([0, 3, 7, 8, 11])          # b0: l = 0, 3; b1: l = 1, 2, 5
+    logits = torch.arange(5, dtype=torch.float32)[:, None].repeat(1, 4)
+    cache = (torch.cat([logits, torch.zeros(3, 4)]), torch.cat([rows, torch.tensor([1, 2, 4])]), 5)   # padded to 8 rows like the product's
+    tl, tr, tn = Diffusion._cache_to_text(cache, L, Lt)
+    assert tn == 2 and tr.tolist() == [0, 3] and tl[:, 0].tolist() == [0.0, 2.0]      # (b0, l0) -> 0, (b1, l1) -> 1 * Lt + 1
+    new_text = (torch.full((1, 4), 9.0), torch.tensor([3]), 1)                          # the text slice was re-evaluated: one [MASK] left at (b1, l1)
+    fl, fr, fn = Diffusion._cache_to_full(cache, new_text, L, Lt)
+    assert fn == 4 and fr.tolist() == [3, 8, 11, 7] and fl[:, 0].tolist() == [1.0, 3.0, 4.0, 9.0]
+    assert Diffusion._cache_to_full(None, new_text, L, Lt) is None and Diffusion._cache_to_full(cache, None, L, Lt) is None
+    assert Diffusion._cache_to_text(None, L, Lt) is None
+
+
+@pytest.mark.gpu
+def test_attention_caching_sampler_loop_on_gpu():
+    g, s, diff, modes = _caching_product(DEV)
+    steps = int(s["steps"])
+    B, L = s["x_init"].shape
+    x, nfe = diff.sample(num_steps=steps, eps=float(s["eps"]), batch_size=B, modality=s["modality"].to(DEV), noise=[s[f"step{i}/u"].to(DEV) for i in range(steps)],
+                         return_nfe=True)
+    assert diff.sample_step_modes == modes
+    x = x.cpu()
+    assert (x == s["x_final"]).float().mean().item() >= 0.9
+    assert not (x == diff.mask_index).any() and nfe == int(s["nfe"]) + 1
+    a = diff.sample(num_steps=steps, batch_size=B, modality=s["modality"].to(DEV), seed=5)
+    b = diff.sample(num_steps=steps, batch_size=B, modality=s["modality"].to(DEV), seed=5)
+    assert torch.equal(a, b) and not (a == diff.mask_index).any()
+    # the kernels' view of the cache-building step: image queries masked from text keys changes the image rows' logits, not the text rows' inputs
+    from unidisc_amd.dit import ModalityMask
+    xq = s["step1/x"].to(DEV)
+    sig = diff._process_sigma(diff.noise(s["timesteps"][1].to(DEV) * torch.ones(B, device=DEV))[0])
+    bm = ModalityMask(torch.zeros(B, dtype=torch.bool, device=DEV), torch.ones(B, dtype=torch.bool, device=DEV), g.case["txt_length"])
+    lg_m, rows_m, n_m = diff.backbone.forward_masked_logits(xq, sig, modality=s["modality"].to(DEV), block_mask=bm)
+    lg, rows, n = diff.backbone.forward_masked_logits(xq, sig, modality=s["modality"].to(DEV))
+    assert n == n_m and torch.equal(rows, rows_m) and not torch.equal(lg[:n], lg_m[:n])

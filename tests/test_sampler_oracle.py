@@ -19,7 +19,7 @@ SAMPLER_CASES = ["c_large", "b_small"]
 
 def load_sampler(name):
     z = np.load(os.path.join(GOLDEN_DIR, f"sampler_{name}.npz"))
-    return {k: torch.from_numpy(np.asarray(z[k])) for k in z.files}
+    return {k: torch.from_numpy(np.asarray(z[k])) for k in z.files if z[k].dtype.kind != "U"}   # (string entries: read them from the npz directly)
 
 
 @pytest.mark.parametrize("name", SAMPLER_CASES)
@@ -139,3 +139,32 @@ def test_oracle_first_hitting_matches_reference_tokens(name):
     for i in range(steps):
         assert torch.equal(xs[i], s[f"step{i}/x_next"]), f"step {i}"
     assert torch.equal(x_final, s["x_final"]) and nfe == int(s["nfe"])
+
+
+def test_oracle_sampler_with_attention_caching_matches_reference_tokens():
+    """eval.attention_caching (full / cache-building / text-only steps, model_eval.py:2296-2366) replayed from the uniforms of a reference run."""
+    g = Golden("c_large")
+    s = load_sampler("c_large_attn_caching")
+    cfg, P, buffers, batch = oracle_setup(g)
+    steps, ratio = int(s["steps"]), int(s["ratio"])
+    us = [s[f"step{i}/u"] for i in range(steps)]
+    x_final, xs, x_last, nfe, modes = O.sample_ddpm_cache_attention_caching(cfg, P, buffers, s["x_init"], s["timesteps"], float(s["dt"]), us, ratio,
+                                                                            modality=s["modality"], batch=batch)
+    z = np.load(os.path.join(GOLDEN_DIR, "sampler_c_large_attn_caching.npz"))
+    assert modes == [str(z[f"step{i}/mode"]) for i in range(steps)]
+    assert {"full", "build", "text"} <= set(modes)
+    for i in range(steps):
+        assert xs[i].shape == s[f"step{i}/x_next"].shape and torch.equal(xs[i], s[f"step{i}/x_next"]), f"step {i}"
+    assert torch.equal(x_last, s["x_before_noise_removal"]) and torch.equal(x_final, s["x_final"])
+    assert nfe == int(s["nfe"])
+    # the three kinds of forward agree with the reference's probabilities to fp32 accuracy (step 1 = image queries masked from text keys,
+    # step 2 = the text slice alone)
+    B, Lt = s["x_init"].shape[0], cfg.txt_length
+    sig = lambda i: O.loglinear_noise(s["timesteps"][i] * torch.ones(B))[0]
+    allow = O.modality_dropout_mask(torch.zeros(B, dtype=torch.bool), torch.ones(B, dtype=torch.bool), Lt, s["x_init"].shape[1])
+    p1, _ = O.ddpm_forward(cfg, P, buffers, s["step1/x"], sig(1), s["modality"], batch, allow_mask=allow)
+    assert torch.allclose(p1, s["step1/p_x0"], atol=2e-6, rtol=1e-4)
+    p1_nomask, _ = O.ddpm_forward(cfg, P, buffers, s["step1/x"], sig(1), s["modality"], batch)
+    assert not torch.allclose(p1_nomask, s["step1/p_x0"], atol=1e-4, rtol=1e-3)   # the mask matters
+    p2, _ = O.ddpm_forward(cfg, P, buffers, s["step2/x"], sig(2), s["modality"][:, :Lt], batch)
+    assert torch.allclose(p2, s["step2/p_x0"], atol=2e-6, rtol=1e-4)

@@ -274,12 +274,15 @@ class DIT(nn.Module, _HubMixin):
         except Exception:
             return lumina_rope_2d(D, h, w, linear_factor=linear_factor, ntk_factor=1.0)
 
-    # reference API surface that callers touch; inference caches are out of scope
+    # Reference API surface that callers touch.  `eval.attention_caching` (model_eval.py:2296-2366): the reference allocates a per-layer
+    # K / V buffer here and WRITES it in the cache-building / text-only steps (models/dit.py:797-803), but no forward ever reads it back (:812 attends
+    # to the keys of the current input only) - so the sampler's three kinds of step need no state in the backbone: `Diffusion.sample` passes the
+    # image-queries-see-image-keys mask / the text slice itself.  The two calls are accepted and remembered for callers that probe them.
     def reset_kv_cache(self, *a, **k):
-        raise NotImplementedError("unidisc_amd.DIT: KV cache is an inference feature outside the denoising hot path")
+        self.use_flex_attention_cache = False
 
-    def set_flex_attention_cache(self, *a, **k):
-        raise NotImplementedError("unidisc_amd.DIT: modality KV cache is an inference feature outside the denoising hot path")
+    def set_flex_attention_cache(self, batch_size=None, seq_len=None, device=None, dtype=None):
+        self.use_flex_attention_cache = True
 
     # -------------------------------------------------------------------------------------------- parameters / shadows
     IMG_BLOCKS = ((256, 1), (1024, 2), (2304, 3), (4096, 4))   # (tokens of an image block, Lumina linear factor), models/dit.py:1210
@@ -412,12 +415,13 @@ class DIT(nn.Module, _HubMixin):
         return _DitFn.apply(self, "logp", inputs, *params)
 
     @torch.no_grad()
-    def forward_masked_logits(self, xt, sigma=None, modality=None, sample_ids=None, plan_ids=None):
+    def forward_masked_logits(self, xt, sigma=None, modality=None, sample_ids=None, plan_ids=None, block_mask=None):
         """Sampler path: (logits [R, Vp] bf16 of the [MASK] positions of `xt` first, then padding rows; their flat row indices [R];
         the number of [MASK] rows).  Unmasked positions keep their token under SUBS (model.py:646-656), so they need no logits.
         `plan_ids` (same shape as xt): take the row selection from the [MASK] positions of this tensor instead of xt's (guided sampling runs
         [x ; x_uncond] as one batch and needs the SAME positions from both halves)."""
-        inputs = dict(indices=xt, sigma=sigma, modality=modality, sample_ids=sample_ids, x0=None, save=False, plan_ids=plan_ids)
+        inputs = dict(indices=xt, sigma=sigma, modality=modality, sample_ids=sample_ids, x0=None, save=False, plan_ids=plan_ids,
+                      block_mask=block_mask if isinstance(block_mask, ModalityMask) else None)
         out, _ = self._engine_forward(inputs, "rows", save=False)
         return out
 
