@@ -95,6 +95,29 @@ def test_masked_row_head_compaction_is_exact(name, fake_k):
             assert torch.allclose(g0[k], g1[k], rtol=1e-5, atol=1e-7), k
 
 
+@pytest.mark.parametrize("name", ["b_small", "c_large", "d_adaln_mm"])
+@pytest.mark.parametrize("compact", [False, True])
+def test_chunked_head_and_cross_entropy_is_exact(name, compact, fake_k):
+    """model.head_chunk_rows: head + SUBS cross-entropy over row chunks (logits recomputed per chunk in the backward, wgrad accumulated) gives
+    the loss and the gradients of the one-piece head."""
+    g = Golden(name)
+    res = []
+    for chunk in (0, 64):
+        diff = build_product(g, device="cpu")
+        diff.rng_device = "cpu"
+        diff.backbone.compact_head = compact
+        diff.backbone.head_chunk_rows = chunk
+        torch.manual_seed(g.case["step_seed"])
+        batch = {k: torch.cat([v] * 4) for k, v in g.batch().items()}   # 512 rows: several chunks also when the head is compacted
+        out = diff.training_step(batch, 1)
+        out.loss.backward()
+        res.append((out.loss.detach().clone(), out.nlls.detach().clone(), {k: p.grad.clone() for k, p in diff.backbone.named_parameters() if p.grad is not None}))
+    (l0, n0, g0), (l1, n1, g1) = res
+    assert torch.allclose(l0, l1, rtol=1e-6, atol=1e-7) and torch.allclose(n0, n1, rtol=1e-6, atol=1e-7)
+    for k in g0:
+        assert torch.allclose(g0[k], g1[k], rtol=1e-5, atol=1e-7), k
+
+
 def test_val_and_test_prefixes_update_attached_metrics(fake_k):
     """model.py:1163-1171: prefix 'val' / 'test' feed (nlls, token_mask) - and the per-modality pairs - to the metric collections on the trainer."""
     class Mean:

@@ -217,3 +217,24 @@ def test_no_masked_rows_and_all_masked_rows(frac):
     assert grads and all(torch.isfinite(x).all() for x in grads)
     if frac == 0.0:
         assert all(float(x.abs().max()) == 0.0 for x in grads)
+
+
+@pytest.mark.gpu
+def test_chunked_head_and_cross_entropy_on_gpu():
+    """model.head_chunk_rows on the device: same loss (bit-equal log-probabilities per row: the chunks run the same kernels on the same rows) and
+    the same gradients up to the summation order of the head's weight gradient across chunks."""
+    g = Golden("c_large")
+    res = []
+    for chunk in (0, 64):
+        diff = build_product(g, device=DEV)
+        diff.rng_device = "cpu"
+        diff.backbone.head_chunk_rows = chunk
+        torch.manual_seed(g.case["step_seed"])
+        batch = {k: torch.cat([v] * 4).to(DEV) for k, v in g.batch().items()}
+        out = diff.training_step(batch, 1)
+        out.loss.backward()
+        res.append((float(out.loss), out.nlls.detach().cpu(), {k: p.grad.cpu() for k, p in diff.backbone.named_parameters() if p.grad is not None}))
+    (l0, n0, g0), (l1, n1, g1) = res
+    assert l0 == l1 and torch.equal(n0, n1)
+    for k in g0:
+        assert rel_err(g1[k], g0[k]) < 2e-3, (k, rel_err(g1[k], g0[k]))

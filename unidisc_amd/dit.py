@@ -217,6 +217,10 @@ class DIT(nn.Module, _HubMixin):
         # BASELINE config E: attention FORWARD through the fp8 (e4m3) MFMA kernel (no reference counterpart).  The backward stays
         # bf16 and reuses the forward's log-sum-exp, so gradients carry the forward's quantisation noise (tolerances in tests/test_gpu_e2e.py).
         self.fp8_attention = bool(cfg_get(m, "fp8_attention", False))
+        # model.head_chunk_rows (extension key, 0 = off): fused vocabulary head + SUBS cross-entropy that never materialises [rows, V] logits - the head
+        # runs on chunks of this many rows (forward: logits chunk -> log p, dropped; backward: the chunk's logits are recomputed, d logits formed in
+        # place and consumed by the dgrad / wgrad).  Trades one extra head GEMM per step for rows * V * 2 bytes of peak memory (SURVEY K11 + K12).
+        self.head_chunk_rows = int(cfg_get(m, "head_chunk_rows", 0) or 0)
         self.require_sample_ids = bool(cfg_get(data, "require_sample_ids", False))
         assert (self.txt_length + self.img_length == self.total_length) or self.multimodal_batches
         D = self.head_dim
@@ -692,16 +696,33 @@ class DIT(nn.Module, _HubMixin):
             ce_mod = ce_mod.index_select(0, rows_p) if ce_mod is not None else None
         else:
             hf_h = hf
-        logits = torch.empty((M, Vp), dtype=BF16, device=dev)[: hf_h.shape[0]]
-        K.gemm_nt(hf_h, head.w16, out=logits, N=V, epilogue=K.EPI_BIAS, bias=head.bias.detach())
-        log_p, lse_ce = K.subs_ce_fwd(logits, x0, ids_h, ce_mod, V, self.text_vocab_size, self.mask_index, restrict)
+        Mh = hf_h.shape[0]
+        chunk = _ceil(self.head_chunk_rows, 64) if self.head_chunk_rows > 0 else 0
+        if chunk and chunk < Mh:   # fused head + cross-entropy over row chunks: only one chunk of logits exists at a time, none is kept
+            logits = None
+            buf = torch.empty((chunk, Vp), dtype=BF16, device=dev)
+            lps, lses = [], []
+            for r0 in range(0, Mh, chunk):
+                r1 = min(Mh, r0 + chunk)
+                lg = buf[: r1 - r0]
+                K.gemm_nt(hf_h[r0:r1], head.w16, out=lg, N=V, epilogue=K.EPI_BIAS, bias=head.bias.detach())
+                lp_c, lse_c = K.subs_ce_fwd(lg, x0[r0:r1], ids_h[r0:r1], ce_mod[r0:r1] if ce_mod is not None else None, V, self.text_vocab_size, self.mask_index, restrict)
+                lps.append(lp_c)
+                lses.append(lse_c)
+            log_p, lse_ce = torch.cat(lps), torch.cat(lses)
+            del buf
+        else:
+            chunk = 0
+            logits = torch.empty((M, Vp), dtype=BF16, device=dev)[:Mh]
+            K.gemm_nt(hf_h, head.w16, out=logits, N=V, epilogue=K.EPI_BIAS, bias=head.bias.detach())
+            log_p, lse_ce = K.subs_ce_fwd(logits, x0, ids_h, ce_mod, V, self.text_vocab_size, self.mask_index, restrict)
         if head_rows is not None:
             full = torch.zeros(M, dtype=log_p.dtype, device=dev)
             full.index_copy_(0, rows_p[:n_masked], log_p[:n_masked])
             log_p = full
         if save:
             S.update(x_final=x, hf=hf_h, rstdf=rstdf, meanf=meanf, fmod=fmod, logits=logits, head_rows=head_rows, ids_h=ids_h,
-                     x0=x0, ce_mod=ce_mod, restrict=restrict, lse_ce=lse_ce, stream_compact=stream_compact)
+                     x0=x0, ce_mod=ce_mod, restrict=restrict, lse_ce=lse_ce, stream_compact=stream_compact, head_chunk=chunk)
         return log_p.view(B, L), S
 
     def _plan_masked_rows(self, ids):
@@ -780,7 +801,7 @@ class DIT(nn.Module, _HubMixin):
         hi = max(self._grad_ranges[id(p)][1] for p in group)
         cb(flat, lo, hi)
 
-    def _wgrad(self, dY, X, lin: _Lin, G, n_rows=None, bias_done=False):
+    def _wgrad(self, dY, X, lin: _Lin, G, n_rows=None, bias_done=False, beta=0.0):
         """dW[out,in] = dY[M,out]^T X[M,in] (fp32), db = colsum(dY).  dY/X bf16 [M, *]."""
         Mrows = dY.shape[0]
         outp = dY.shape[1]
@@ -792,15 +813,18 @@ class DIT(nn.Module, _HubMixin):
             if db is not None:
                 K.colsum(dY, db)
             if few_tiles:  # e.g. the 2048 x 2048 out-proj weight: 64 tiles over K = B*L -> split K through a workspace
-                K.gemm_tn_splitk(dY, X, G[id(lin.weight)], M=lin.out, N=lin.inp)
+                K.gemm_tn_splitk(dY, X, G[id(lin.weight)], M=lin.out, N=lin.inp, beta=beta)
             else:
-                K.gemm_tn(dY, X, G[id(lin.weight)], M=lin.out, N=lin.inp)
+                K.gemm_tn(dY, X, G[id(lin.weight)], M=lin.out, N=lin.inp, beta=beta)
         else:  # short contraction (e.g. adaLN over the padded batch): explicit transposes + NT kernel
             dYt = K.transpose(dY, colsum=db)
             Xt = K.transpose(X)
-            K.gemm_nt(dYt, Xt, out=G[id(lin.weight)], M=lin.out, N=lin.inp, K=Mrows)
+            K.gemm_nt(dYt, Xt, out=G[id(lin.weight)], M=lin.out, N=lin.inp, K=Mrows, beta=beta)
         if db is not None and outp != lin.out:
-            G[id(lin.bias)].copy_(db[: lin.out])
+            if beta != 0.0:
+                G[id(lin.bias)].add_(db[: lin.out])
+            else:
+                G[id(lin.bias)].copy_(db[: lin.out])
 
     def _engine_backward(self, S, grad_out, mode):
         params = self._ordered_params()
@@ -819,18 +843,37 @@ class DIT(nn.Module, _HubMixin):
 
         # ---- head: d logits -> dhf, dW_head, db_head
         head_rows = S.get("head_rows")
+        chunk = S.get("head_chunk", 0) if mode == "logp" else 0
         if mode == "logp":
             g = grad_out.contiguous().view(-1).to(F32)
             if head_rows is not None:
                 g = g.index_select(0, head_rows[0])
-            K.subs_ce_bwd(logits, S["x0"], S["ids_h"], S["ce_mod"], S["lse_ce"], g, V, self.text_vocab_size, self.mask_index, S["restrict"])
-            dlogits = logits
+        if chunk:   # fused head + cross-entropy: per row chunk recompute the logits, form d logits in place, consume them (dgrad, wgrad accumulated)
+            hf_h = S["hf"]
+            Mh, Vp = hf_h.shape[0], head.outp
+            dhf = torch.empty((M, d), dtype=BF16, device=dev)[:Mh]
+            buf = torch.empty((chunk, Vp), dtype=BF16, device=dev)
+            cm = S["ce_mod"]
+            for r0 in range(0, Mh, chunk):
+                r1 = min(Mh, r0 + chunk)
+                lg = buf[: r1 - r0]
+                K.gemm_nt(hf_h[r0:r1], head.w16, out=lg, N=V, epilogue=K.EPI_BIAS, bias=head.bias.detach())
+                K.subs_ce_bwd(lg, S["x0"][r0:r1], S["ids_h"][r0:r1], cm[r0:r1] if cm is not None else None, S["lse_ce"][r0:r1], g[r0:r1], V, self.text_vocab_size,
+                              self.mask_index, S["restrict"])
+                K.gemm_nt_splitk(lg, head.w16t, N=d, out=dhf[r0:r1])
+                self._wgrad(lg, hf_h[r0:r1], head, G, beta=0.0 if r0 == 0 else 1.0)
+            del buf
+            dlogits = None
         else:
-            dlogits = torch.zeros_like(logits)
-            dlogits[:, :V].copy_(grad_out.reshape(M, V))
-        # few output tiles (compacted rows x d) over K = V: split K so that all CUs work (falls back to the plain kernel otherwise)
-        dhf = K.gemm_nt_splitk(dlogits, head.w16t, N=d, out=torch.empty((M, d), dtype=BF16, device=dev)[: dlogits.shape[0]])
-        self._wgrad(dlogits, S["hf"], head, G)
+            if mode == "logp":
+                K.subs_ce_bwd(logits, S["x0"], S["ids_h"], S["ce_mod"], S["lse_ce"], g, V, self.text_vocab_size, self.mask_index, S["restrict"])
+                dlogits = logits
+            else:
+                dlogits = torch.zeros_like(logits)
+                dlogits[:, :V].copy_(grad_out.reshape(M, V))
+            # few output tiles (compacted rows x d) over K = V: split K so that all CUs work (falls back to the plain kernel otherwise)
+            dhf = K.gemm_nt_splitk(dlogits, head.w16t, N=d, out=torch.empty((M, d), dtype=BF16, device=dev)[: dlogits.shape[0]])
+            self._wgrad(dlogits, S["hf"], head, G)
         stream_compact = bool(S.get("stream_compact"))
         if head_rows is not None and not stream_compact:  # scatter the masked rows' gradient back; every other row of d(final norm output) is exactly zero
             rows_p, n_masked = head_rows
