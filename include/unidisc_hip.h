@@ -47,6 +47,10 @@ int udm_abi_version(void);
 int udm_gemm_nt_bf16(const void* A, const void* B, void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int out_f32,
                      int epilogue, const float* bias, void* aux, int64_t ldaux, float beta, hipStream_t stream);
 /* wgrad form read straight from row-major activations: C[M,N] (fp32) = beta*C + A[K,M]ᵀ · B[K,N]  (K % 64 == 0). */
+/* dgrad without a transposed weight shadow: C[M,N] bf16 = A[M,K] B[K,N] (A = dY with K = out features contiguous, B = the forward's bf16 W [out, in]);
+ * replaces the dX = dY W half of nn.Linear's backward (models/dit.py:642,877,917-919).  Whole tiles only: udm_gemm_nn_ok(M, N, K) != 0. */
+int udm_gemm_nn_bf16(const void* A, const void* B, void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, hipStream_t stream);
+int udm_gemm_nn_ok(int64_t M, int64_t N, int64_t K);
 int udm_gemm_tn_bf16(const void* A, const void* B, void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, float beta,
                      hipStream_t stream);
 /* the same wgrad for FEW output tiles over a LONG contraction (2048 x 2048 out-proj weight, K = B*L): K is split so that tiles x slices fill

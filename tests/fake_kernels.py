@@ -376,6 +376,19 @@ def subs_logprobs(logits, xt, modality, V, Vt, mask_id, restrict, out_dtype=BF16
     return out.to(out_dtype)
 
 
+def gemm_nn_ok(M, N, K):
+    return N % 256 == 0 and K % 64 == 0 and K >= 128 and any(M % t == 0 for t in (192, 256, 320))
+
+
+def gemm_nn(a, b, out=None, *, N=None):
+    N = b.shape[1] if N is None else N
+    r = (a.float() @ b[:, :N].float()).to(torch.bfloat16)
+    if out is None:
+        return r
+    out[:, :N] = r
+    return out
+
+
 def gemm_tn(a, b, out, *, M=None, N=None, beta=0.0):
     M = a.shape[1] if M is None else M
     N = b.shape[1] if N is None else N

@@ -228,6 +228,31 @@ def test_gemm_tn_quad_one_wave_per_simd(K, Kc, M, N):
         K.gemm_set_quad(1)
 
 
+@pytest.mark.parametrize("M,N,K_", [(192, 256, 128), (256, 512, 192), (320, 256, 256), (640, 512, 448), (768, 256, 1024), (10240, 2048, 2048), (1280, 2048, 6144), (2560, 2048, 8192)])
+def test_gemm_nn_dgrad_from_forward_shadow(K, M, N, K_):
+    """NN form (gemm_quad.hip MODE 2): dX = dY W with W in its forward layout [out = K, in = N] - the NT kernel's A side next to the TN kernel's B
+    side.  K-tile counts 2 / 3 / 4 / 7 / 16 / 32 / 96 / 128, every tile height, padded strides; against fp32, and bit-equal to the NT kernel fed
+    the explicitly transposed weight (same products, same k order)."""
+    assert K.gemm_nn_ok(M, N, K_)
+    assert not K.gemm_nn_ok(M + 8, N, K_) and not K.gemm_nn_ok(M, N + 128, K_) and not K.gemm_nn_ok(M, N, K_ + 32)
+    lda, ldb, ldc = K_ + 8, N + 16, N + 8
+    a, w = torch.zeros(M, lda, dtype=torch.bfloat16), torch.zeros(K_, ldb, dtype=torch.bfloat16)
+    a[:, :K_], w[:, :N] = bf(rnd(M, K_, seed=290, scale=0.5)), bf(rnd(K_, N, seed=291, scale=0.5))
+    ref = a[:, :K_].float() @ w[:, :N].float()
+    ad, wd = a.to(DEV), w.to(DEV)
+    out = torch.zeros(M, ldc, dtype=torch.bfloat16, device=DEV)
+    K.gemm_nn(ad[:, :K_], wd[:, :N], out=out[:, :N])
+    assert rel_err(out[:, :N].float().cpu(), ref) < 3e-3
+    assert torch.all(out[:, N:] == 0)
+    try:
+        K.gemm_set_quad(2)
+        wt = w[:, :N].t().contiguous().to(DEV)   # [N, K]: the transposed shadow the NT dgrad reads
+        nt = K.gemm_nt(ad[:, :K_], wt, N=N)
+        assert torch.equal(nt, out[:, :N])
+    finally:
+        K.gemm_set_quad(1)
+
+
 @pytest.mark.parametrize("M,N,K_", [(5120, 2048, 48512), (5056, 2048, 4096), (704, 512, 8192), (100, 300, 640), (5120, 2048, 192)])
 def test_gemm_nt_splitk_bf16_output(K, M, N, K_):
     """NT split-K with a bf16 result (the head dgrad on the compacted rows): ragged row counts, shapes where it must fall back, long K."""

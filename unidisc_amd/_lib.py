@@ -22,6 +22,8 @@ _P, _I64, _I, _F, _U64 = c_void_p, c_int64, c_int, c_float, c_uint64
 PROTOTYPES = {
     "udm_gemm_nt_bf16": [_P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _I, _I, _P, _P, _I64, _F, _P],
     "udm_gemm_tn_bf16": [_P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _F, _P],
+    "udm_gemm_nn_bf16": [_P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _P],
+    "udm_gemm_nn_ok": [_I64, _I64, _I64],
     "udm_gemm_nt_splitk_bf16": [_P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _P, _I64, _P],
     "udm_gemm_tn_splitk_bf16": [_P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _F, _P, _I64, _P],
     "udm_gemm_set_tile": [_I],

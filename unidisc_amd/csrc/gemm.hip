@@ -1020,6 +1020,24 @@ extern "C" int udm_cast_transpose_multi_f32_bf16(const void* jobs, int64_t njobs
   return 0;
 }
 
+// C[M, N] bf16 = A[M, K] B[K, N] (A row-major with K contiguous, B row-major with N contiguous): the dgrad dX = dY W read from the forward's own
+// bf16 shadow of W [out, in], so that no transposed shadow has to be produced by the per-step weight cast.  Whole tiles only (udm_gemm_nn_ok).
+extern "C" int udm_gemm_nn_ok(int64_t M, int64_t N, int64_t K) {
+  int fm = 0;
+  return (M > 0 && udm_quad_nn_ok(M, N, K, &fm)) ? 1 : 0;
+}
+extern "C" int udm_gemm_nn_bf16(const void* A, const void* B, void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, hipStream_t stream) {
+  UDM_CHECK_ARG(A && B && C, "udm_gemm_nn_bf16: null pointer");
+  int fm = 0;
+  UDM_CHECK_ARG(M > 0 && udm_quad_nn_ok(M, N, K, &fm), "udm_gemm_nn_bf16: shape %ld x %ld x %ld is not whole tiles (M %% 192/256/320, N %% 256, K %% 64; see udm_gemm_nn_ok)",
+                (long)M, (long)N, (long)K);
+  UDM_CHECK_ARG(lda >= K && ldb >= N && ldc >= N && lda % 8 == 0 && ldb % 8 == 0 && ldc % 4 == 0, "udm_gemm_nn_bf16: bad leading dimensions");
+  QuadArgs q{};
+  q.A = (const bf16_t*)A; q.B = (const bf16_t*)B; q.C = C; q.lda = lda; q.ldb = ldb; q.ldc = ldc;
+  q.M = (int)M; q.N = (int)N; q.K = (int)K; q.beta = 0.f; q.splitk = 1;
+  return udm_quad_launch_nn(q, fm, stream);
+}
+
 extern "C" int udm_gemm_set_cus(int cus) {   // 0 = all CUs; otherwise the persistent NT grid (a multiple of 8 in [8, 256])
   UDM_CHECK_ARG(cus == 0 || (cus >= 8 && cus <= 256 && cus % 8 == 0), "udm_gemm_set_cus: 0 or a multiple of 8 in [8, 256]");
   g_gemm_cus = cus;

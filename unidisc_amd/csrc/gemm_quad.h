@@ -25,3 +25,6 @@ int udm_quad_launch_tn(const QuadArgs& a, int fm, hipStream_t stream);
 // NT (forward / dgrad) form
 bool udm_quad_nt_ok(long M, long N, long K, int* fm);
 int udm_quad_launch_nt(const QuadArgs& a, int fm, int epilogue, int out_f32, hipStream_t stream);
+// NN (dgrad from the forward's W shadow) form: C[M, N] bf16 = A[M, K] B[K, N], plain epilogue
+bool udm_quad_nn_ok(long M, long N, long K, int* fm);
+int udm_quad_launch_nn(const QuadArgs& a, int fm, hipStream_t stream);

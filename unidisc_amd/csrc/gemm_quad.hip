@@ -44,15 +44,19 @@ __device__ __forceinline__ const char* uniform_ptr(const char* ptr) {   // pin a
 
 // ABL (timing-only ablations, WRONG results; env UDM_QUAD_ABL): bit 0 = no refills after the prologue, bit 1 = the boundary does not wait for the refills,
 // bit 2 = no L2 touch-ahead
-template <int FM, bool TN, int EPI, bool OUT_F32, int DMA_GAP, int ABL = 0>
+// MODE: 0 = NT (C = A B^T: both operands K-contiguous), 1 = TN (C = A^T B: both operands K-major, rows = contraction index: the wgrad form),
+// 2 = NN (C = A B: A K-contiguous, B K-major - the dgrad form dX = dY W read from the forward's own W shadow, so no W^T shadow has to be cast).
+// Every operand is staged and gathered by its own layout (TA / TB): NN is the NT kernel's A side next to the TN kernel's B side.
+template <int FM, int MODE, int EPI, bool OUT_F32, int DMA_GAP, int ABL = 0>
 __global__ __launch_bounds__(256, 1) void gemm_quad_kernel(QuadArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr bool TA = MODE == 1, TB = MODE >= 1;
   constexpr int FN = 4, BM = 64 * FM, BN = 256;
   constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
   constexpr int A_PW = A_BYTES / 1024 / 4, B_PW = B_BYTES / 1024 / 4, LOADS = A_PW + B_PW;   // 1 KiB pieces per wave per K tile
-  constexpr int RB_A = TN ? BM * 2 : 128, RB_B = TN ? BN * 2 : 128;                           // LDS row bytes
+  constexpr int RB_A = TA ? BM * 2 : 128, RB_B = TB ? BN * 2 : 128;                           // LDS row bytes
   constexpr int NMF = FM * FN;                                                                 // MFMAs per k-step
-  constexpr int NRD = TN ? 2 * (FM + FN) : (FM + FN);                                          // fragment reads per k-step
+  constexpr int NRD_A = TA ? 2 * FM : FM, NRD_B = TB ? 2 * FN : FN, NRD = NRD_A + NRD_B;       // fragment reads per k-step
   // LDS map: [A stage 0][A stage 1][B stage 0][B stage 1]
   constexpr int A0 = 0, B0 = 2 * A_BYTES;
   static_assert(2 * (A_BYTES + B_BYTES) <= 160 * 1024, "tile does not fit the LDS");
@@ -77,42 +81,41 @@ __global__ __launch_bounds__(256, 1) void gemm_quad_kernel(QuadArgs p) {
 
   // ---- LDS-DMA sources: per piece a 32-bit lane offset from the operand's tile base; the base advances by one K tile per iteration ----
   uint32_t offa[A_PW], offb[B_PW];
-  if (!TN) {
+  {
     const int lrow = lane >> 3, lslot = lane & 7;
 #pragma unroll
     for (int j = 0; j < A_PW; ++j) {
-      const int r = (wave * A_PW + j) * 8 + lrow;
-      offa[j] = (uint32_t)(((long)r * p.lda + ((lslot ^ ((r >> 1) & 7)) << 3)) * 2);
+      if (!TA) {
+        const int r = (wave * A_PW + j) * 8 + lrow;
+        offa[j] = (uint32_t)(((long)r * p.lda + ((lslot ^ ((r >> 1) & 7)) << 3)) * 2);
+      } else {
+        const int off = (wave * A_PW + j) * 1024 + lane * 16;
+        const int row = off / RB_A, within = off % RB_A;
+        const int xr = (FM % 2 == 0) ? (row & 3) : ((row & 3) >> 1);
+        const int col = (((within >> 6) ^ xr) << 5) + ((within & 63) >> 1);
+        offa[j] = (uint32_t)(((long)row * p.lda + col) * 2);
+      }
     }
 #pragma unroll
     for (int j = 0; j < B_PW; ++j) {
-      const int r = (wave * B_PW + j) * 8 + lrow;
-      offb[j] = (uint32_t)(((long)r * p.ldb + ((lslot ^ ((r >> 1) & 7)) << 3)) * 2);
-    }
-  } else {
-#pragma unroll
-    for (int j = 0; j < A_PW; ++j) {
-      const int off = (wave * A_PW + j) * 1024 + lane * 16;
-      const int row = off / RB_A, within = off % RB_A;
-      const int xr = (FM % 2 == 0) ? (row & 3) : ((row & 3) >> 1);
-      const int col = (((within >> 6) ^ xr) << 5) + ((within & 63) >> 1);
-      offa[j] = (uint32_t)(((long)row * p.lda + col) * 2);
-    }
-#pragma unroll
-    for (int j = 0; j < B_PW; ++j) {
-      const int off = (wave * B_PW + j) * 1024 + lane * 16;
-      const int row = off / RB_B, within = off % RB_B;
-      const int col = (((within >> 6) ^ (row & 3)) << 5) + ((within & 63) >> 1);
-      offb[j] = (uint32_t)(((long)row * p.ldb + col) * 2);
+      if (!TB) {
+        const int r = (wave * B_PW + j) * 8 + lrow;
+        offb[j] = (uint32_t)(((long)r * p.ldb + ((lslot ^ ((r >> 1) & 7)) << 3)) * 2);
+      } else {
+        const int off = (wave * B_PW + j) * 1024 + lane * 16;
+        const int row = off / RB_B, within = off % RB_B;
+        const int col = (((within >> 6) ^ (row & 3)) << 5) + ((within & 63) >> 1);
+        offb[j] = (uint32_t)(((long)row * p.ldb + col) * 2);
+      }
     }
   }
   const int nk_all = p.K / BK;
   const int kt0 = (int)((long)nk_all * slice / S), kt1 = (int)((long)nk_all * (slice + 1) / S);
   const int nk = kt1 - kt0;
-  const long kstep_a = TN ? (long)BK * p.lda * 2 : BK * 2, kstep_b = TN ? (long)BK * p.ldb * 2 : BK * 2;   // bytes per K tile
+  const long kstep_a = TA ? (long)BK * p.lda * 2 : BK * 2, kstep_b = TB ? (long)BK * p.ldb * 2 : BK * 2;   // bytes per K tile
   // running tile bases (wave-uniform, SGPR pairs): ap / bp = the K tile being COMPUTED; refills read one or two tiles ahead of it
-  const char* ap = uniform_ptr(reinterpret_cast<const char*>(TN ? p.A + row0 : p.A + (long)row0 * p.lda) + kt0 * kstep_a);
-  const char* bp = uniform_ptr(reinterpret_cast<const char*>(TN ? p.B + col0 : p.B + (long)col0 * p.ldb) + kt0 * kstep_b);
+  const char* ap = uniform_ptr(reinterpret_cast<const char*>(TA ? p.A + row0 : p.A + (long)row0 * p.lda) + kt0 * kstep_a);
+  const char* bp = uniform_ptr(reinterpret_cast<const char*>(TB ? p.B + col0 : p.B + (long)col0 * p.ldb) + kt0 * kstep_b);
   const uint32_t dsta = lds0 + A0 + wave * A_PW * 1024, dstb = lds0 + B0 + wave * B_PW * 1024;
   auto dma_piece = [&](int ahead, int stage, int j) {   // the tile `ahead` K tiles after the current one into `stage`; j < A_PW: A piece j, else B piece j - A_PW
     if ((ABL & 1) && ahead == 2) return;
@@ -121,17 +124,20 @@ __global__ __launch_bounds__(256, 1) void gemm_quad_kernel(QuadArgs p) {
   };
 
   // ---- fragment addresses ----
-  bf16x8_t fa[2][FM], fb[2][FN];                      // NT: whole fragments (one ds_read_b128 each)
-  s16x4_t ha[2][FM][2], hb[2][FN][2];                  // TN: fragment halves (k +0..3 / +4..7), one transposing read each
-  uint32_t fa_addr[TN ? FM : 1], fb_addr[TN ? FN : 1];
-  const int p16 = lane & 15, g1 = (lane >> 4) & 1, rot = p16 >> 2;   // TN gather: lane supplies k-row rot (+4), 4 columns of its 16-lane group
-  if (!TN) {
+  bf16x8_t fa[2][FM], fb[2][FN];                      // K-contiguous operand: whole fragments (one ds_read_b128 each)
+  s16x4_t ha[2][FM][2], hb[2][FN][2];                  // K-major operand: fragment halves (k +0..3 / +4..7), one transposing read each
+  uint32_t fa_addr[TA ? FM : 1], fb_addr[TB ? FN : 1];
+  const int p16 = lane & 15, g1 = (lane >> 4) & 1, rot = p16 >> 2;   // K-major gather: lane supplies k-row rot (+4), 4 columns of its 16-lane group
+  if (!TA) {
     fa_addr[0] = lds0 + A0 + (wm * 32 * FM + l31) * 128;
-    fb_addr[0] = lds0 + B0 + (wn * 128 + l31) * 128;
   } else {
     const int xra = (FM % 2 == 0) ? rot : (rot >> 1);
 #pragma unroll
     for (int i = 0; i < FM; ++i) fa_addr[i] = lds0 + A0 + (hi * 8 + rot) * RB_A + (((wm * FM + i) ^ xra) << 6) + g1 * 32 + (p16 & 3) * 8;
+  }
+  if (!TB) {
+    fb_addr[0] = lds0 + B0 + (wn * 128 + l31) * 128;
+  } else {
 #pragma unroll
     for (int j = 0; j < FN; ++j) fb_addr[j] = lds0 + B0 + (hi * 8 + rot) * RB_B + (((wn * FN + j) ^ rot) << 6) + g1 * 32 + (p16 & 3) * 8;
   }
@@ -139,22 +145,22 @@ __global__ __launch_bounds__(256, 1) void gemm_quad_kernel(QuadArgs p) {
   // read n of k-step kk (stage st) into register buffer buf, in the order the MFMAs need them: the FN B fragments (every MFMA row uses all
   // of them), then the A fragments row by row.  NT: one ds_read_b128 per fragment.  TN: two transposing reads per fragment (k-rows +0..3, +4..7).
   auto read_one = [&](int st, int kk, int buf, int n) {
-    if (!TN) {
-      const uint32_t so = (uint32_t)(((kk * 2 + hi) ^ sw) << 4);
-      if (n < FN) fb[buf][n] = *reinterpret_cast<UDM_LDS const bf16x8_t*>((size_t)(fb_addr[0] + st * B_BYTES + n * 4096 + so));
-      else fa[buf][n - FN] = *reinterpret_cast<UDM_LDS const bf16x8_t*>((size_t)(fa_addr[0] + st * A_BYTES + (n - FN) * 4096 + so));
+    const uint32_t so = (uint32_t)(((kk * 2 + hi) ^ sw) << 4);
+    if (n < NRD_B) {   // the B fragments first
+      if (!TB) fb[buf][n] = *reinterpret_cast<UDM_LDS const bf16x8_t*>((size_t)(fb_addr[0] + st * B_BYTES + n * 4096 + so));
+      else hb[buf][n >> 1][n & 1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((UDM_LDS s16x4_t*)(size_t)(fb_addr[TB ? (n >> 1) : 0] + st * B_BYTES + (kk * 16 + (n & 1) * 4) * RB_B));
     } else {
-      const int f = n >> 1, h = n & 1;
-      if (f < FN) hb[buf][f][h] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((UDM_LDS s16x4_t*)(size_t)(fb_addr[f] + st * B_BYTES + (kk * 16 + h * 4) * RB_B));
-      else ha[buf][f - FN][h] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((UDM_LDS s16x4_t*)(size_t)(fa_addr[f - FN] + st * A_BYTES + (kk * 16 + h * 4) * RB_A));
+      const int m = n - NRD_B;
+      if (!TA) fa[buf][m] = *reinterpret_cast<UDM_LDS const bf16x8_t*>((size_t)(fa_addr[0] + st * A_BYTES + m * 4096 + so));
+      else ha[buf][m >> 1][m & 1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((UDM_LDS s16x4_t*)(size_t)(fa_addr[TA ? (m >> 1) : 0] + st * A_BYTES + (kk * 16 + (m & 1) * 4) * RB_A));
     }
   };
   auto frag_a = [&](int buf, int i) -> bf16x8_t {
-    if (!TN) return fa[buf][i];
+    if (!TA) return fa[buf][i];
     return __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(ha[buf][i][0], ha[buf][i][1], 0, 1, 2, 3, 4, 5, 6, 7));
   };
   auto frag_b = [&](int buf, int j) -> bf16x8_t {
-    if (!TN) return fb[buf][j];
+    if (!TB) return fb[buf][j];
     return __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(hb[buf][j][0], hb[buf][j][1], 0, 1, 2, 3, 4, 5, 6, 7));
   };
 
@@ -343,7 +349,7 @@ __global__ __launch_bounds__(256, 1) void gemm_quad_kernel(QuadArgs p) {
   }
 }
 
-template <int FM, bool TN, int EPI, bool OUT_F32>
+template <int FM, int MODE, int EPI, bool OUT_F32>
 int launch_quad_t(const QuadArgs& a0, hipStream_t stream) {
   QuadArgs a = a0;
   constexpr int BM = 64 * FM;
@@ -353,11 +359,11 @@ int launch_quad_t(const QuadArgs& a0, hipStream_t stream) {
   a.group_m = env_gm;
   const size_t lds = (size_t)2 * (BM + 256) * BK * 2;
   constexpr int GAP = 2;
-  auto kern = gemm_quad_kernel<FM, TN, EPI, OUT_F32, GAP>;
+  auto kern = gemm_quad_kernel<FM, MODE, EPI, OUT_F32, GAP>;
   if constexpr (EPI == UDM_EPI_NONE && FM >= 4) {   // timing-only ablations of the plain kernels (scripts/bench_gemm_quad.py)
     static const int abl = [] { const char* e = getenv("UDM_QUAD_ABL"); return e ? atoi(e) : 0; }();
-    if (abl == 1) kern = gemm_quad_kernel<FM, TN, EPI, OUT_F32, GAP, 1>;
-    if (abl == 2) kern = gemm_quad_kernel<FM, TN, EPI, OUT_F32, GAP, 2>;
+    if (abl == 1) kern = gemm_quad_kernel<FM, MODE, EPI, OUT_F32, GAP, 1>;
+    if (abl == 2) kern = gemm_quad_kernel<FM, MODE, EPI, OUT_F32, GAP, 2>;
   }
   static const void* attr_set = nullptr;
   if (attr_set != (const void*)kern) {
@@ -444,5 +450,16 @@ int udm_quad_launch_nt(const QuadArgs& a, int fm, int epilogue, int out_f32, hip
     case 4: return launch_quad_nt_fm<4>(a, epilogue, out_f32, stream);
     case 5: return launch_quad_nt_fm<5>(a, epilogue, out_f32, stream);
     default: udm_set_error("udm_quad_launch_nt: bad tile"); return 2;
+  }
+}
+
+// NN (dgrad) form: C[M, N] bf16 = A[M, K] B[K, N]; whole tiles, plain epilogue
+bool udm_quad_nn_ok(long M, long N, long K, int* fm) { return udm_quad_nt_ok(M, N, K, fm); }
+int udm_quad_launch_nn(const QuadArgs& a, int fm, hipStream_t stream) {
+  switch (fm) {
+    case 3: return launch_quad_t<3, 2, UDM_EPI_NONE, false>(a, stream);
+    case 4: return launch_quad_t<4, 2, UDM_EPI_NONE, false>(a, stream);
+    case 5: return launch_quad_t<5, 2, UDM_EPI_NONE, false>(a, stream);
+    default: udm_set_error("udm_quad_launch_nn: bad tile"); return 2;
   }
 }

@@ -154,16 +154,27 @@ class _Lin:
         self.out, self.inp = weight.shape
         self.outp = _ceil(self.out, out_pad)
         self.w16 = self.w16t = None
+        self.need_t = True   # False: every dgrad of this layer reads W itself (K.gemm_nn), the per-step cast writes no transposed shadow
 
     def alloc(self):
         dev = self.weight.device
         if self.w16 is None or self.w16.device != dev:
             self.w16 = torch.zeros((self.outp, self.inp), dtype=BF16, device=dev)
+            self.w16t = None
+        if self.need_t and self.w16t is None:
             self.w16t = torch.zeros((self.inp, self.outp), dtype=BF16, device=dev)
+        if not self.need_t:
+            self.w16t = None
 
     def refresh(self):
         self.alloc()
         K.cast_transpose(self.weight.detach(), self.w16, self.w16t)
+
+    def dgrad(self, dY, M_rows):
+        """dX [M, in] = dY [M, out] W: from W's forward shadow where the shape allows (no transposed shadow), else from the transposed one"""
+        if self.w16t is None:
+            return K.gemm_nn(dY, self.w16, N=self.inp)
+        return K.gemm_nt(dY, self.w16t, N=self.inp)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -264,6 +275,7 @@ class DIT(nn.Module, _HubMixin):
         # ... and with it everything of the LAST block behind its attention (out-proj, residual adds, MLP, final norm): only the head reads that
         # block's output, so its unmasked rows feed nothing and receive a zero gradient (exact; no adaLN: the row kernels would need the row -> sample map)
         self.compact_last_block = os.environ.get("UDM_COMPACT_LAST", "1") != "0"
+        self.dgrad_from_w = os.environ.get("UDM_DGRAD_NN", "1") != "0"   # dgrads from the forward's W shadow where the shape allows (see refresh_weight_shadows)
         self.grad_ready_callback = None   # fn(flat_grads, lo, hi): elements [lo, hi) of this backward's flat fp32 gradient buffer are final
         self.grad_sync_finish = None      # fn(): called at the end of backward (e.g. make the compute stream wait for the all-reduces)
         self.recast_every_forward = True  # mirror autocast: fp32 master -> bf16 shadow on every training forward
@@ -323,10 +335,20 @@ class DIT(nn.Module, _HubMixin):
             L["sig2"] = _Lin(self.sigma_map.mlp[2].weight, self.sigma_map.mlp[2].bias)
         self._lins = L
 
-    def refresh_weight_shadows(self, force=False):
+    def refresh_weight_shadows(self, force=False, rows=None):
         if self._lins is None or next(iter(self._lins.values())).weight.device != self.vocab_embed.embedding.device:
             self._build_lins()
             force = True
+        if rows is not None and self.dgrad_from_w and next(iter(self._lins.values())).weight.is_cuda:
+            # qkv / out-proj / mlp.0 dgrads read W itself (K.gemm_nn) where `rows` x in x out are whole tiles of that kernel: their transposed
+            # shadows - a quarter of the per-step cast traffic - are then not produced.  (mlp.2's dgrad carries the GELU' epilogue and the last
+            # block may run on a compacted row list: they keep the transposed shadow.)
+            last = len(self.blocks) - 1
+            for name, lin in self._lins.items():
+                blk, _, kind = name.partition(".")
+                want_t = not (kind in ("qkv", "out", "fc1") and not (self.compact_last_block and int(blk) == last) and K.gemm_nn_ok(rows, lin.inp, lin.out))
+                if want_t != lin.need_t:
+                    lin.need_t, force = want_t, True
         versions = [l.weight._version for l in self._lins.values()]
         self._cast_events = {}
         if force or self.recast_every_forward and self.training or versions != self._shadow_versions:
@@ -358,7 +380,7 @@ class DIT(nn.Module, _HubMixin):
                     for k in lins_k:
                         for lin in groups[k]:
                             lin.alloc()
-                key = tuple((l.weight.data_ptr(), l.w16.data_ptr(), l.w16t.data_ptr()) for k in order for l in groups[k])
+                key = tuple((l.weight.data_ptr(), l.w16.data_ptr(), l.w16t.data_ptr() if l.w16t is not None else 0) for k in order for l in groups[k])
                 if getattr(self, "_cast_parts_key", None) != key:
                     self._cast_parts = [K.cast_transpose_jobs([(l.weight.detach(), l.w16, l.w16t) for k in ks for l in groups[k]], dev) for ks in parts]
                     self._cast_parts_key = key
@@ -375,7 +397,7 @@ class DIT(nn.Module, _HubMixin):
                 lins = [lin for k in order for lin in groups[k]]
                 for lin in lins:
                     lin.alloc()
-                key = tuple((l.weight.data_ptr(), l.w16.data_ptr(), l.w16t.data_ptr()) for l in lins)
+                key = tuple((l.weight.data_ptr(), l.w16.data_ptr(), l.w16t.data_ptr() if l.w16t is not None else 0) for l in lins)
                 if getattr(self, "_cast_jobs_key", None) != key:
                     self._cast_jobs = K.cast_transpose_jobs([(l.weight.detach(), l.w16, l.w16t) for l in lins], dev)
                     self._cast_jobs_key = key
@@ -518,7 +540,7 @@ class DIT(nn.Module, _HubMixin):
         nt = K.norm_id(self.norm_type)
         tc, sw = self.time_conditioning, self.sandwich_normalization
         train = self.training
-        self.refresh_weight_shadows()
+        self.refresh_weight_shadows(rows=M)
         lin = self._lins
         p_drop = self.dropout if train else 0.0
         if train and save:   # only training forwards advance the dropout stream (eval / sampler passes draw no dropout masks)
@@ -939,7 +961,7 @@ class DIT(nn.Module, _HubMixin):
             # dgrad through mlp.2 with the GELU' multiply and the mlp.0 bias gradient (column sums of du1) fused into the epilogue
             du1 = K.gemm_nt(du2, f2.w16t, N=4 * d, epilogue=K.EPI_DGELU, aux=R["u1"], bias=G[id(f1.bias)])
             self._wgrad(du2, R["g"], f2, G, bias_done=not tc)
-            dh2 = K.gemm_nt(du1, f1.w16t, N=d)
+            dh2 = f1.dgrad(du1, du1.shape[0])
             self._wgrad(du1, R["h2"], f1, G, bias_done=True)
             del du1, du2
             # norm2 backward + attention branch
@@ -960,7 +982,7 @@ class DIT(nn.Module, _HubMixin):
                 else:
                     da = branch_bwd(p2, R["a_out"], p_drop=p_drop, seed=seed0 + 4 * i + 1)
             lo, lq = lin[f"{i}.out"], lin[f"{i}.qkv"]
-            do = K.gemm_nt(da, lo.w16t, N=d)
+            do = lo.dgrad(da, da.shape[0])
             if R.get("rows_c") is not None:
                 # back to all rows: the rows left out have a zero gradient in both the attention output and the residual stream
                 self._wgrad(da, R["o_c"], lo, G)
@@ -977,7 +999,7 @@ class DIT(nn.Module, _HubMixin):
                               gk=at.k_norm.weight.detach() if qn else None, stats=R["qstats"], dgq=G[id(at.q_norm.weight)] if qn else None,
                               dbq=G[id(at.q_norm.bias)] if qn else None, dgk=G[id(at.k_norm.weight)] if qn else None,
                               dbk=G[id(at.k_norm.bias)] if qn else None)
-            dh1 = K.gemm_nt(dqkv, lq.w16t, N=d)
+            dh1 = lq.dgrad(dqkv, dqkv.shape[0])
             self._wgrad(dqkv, R["h1"], lq, G)
             if tc:
                 K.norm_bwd(dh1, R["x_in"], R["rstd1"], R["mean1"], blk.norm1.weight.detach(), nt, L, dx, G[id(blk.norm1.weight)], accumulate=True,

@@ -80,6 +80,23 @@ def gemm_nt(a, b, out=None, *, out_dtype=BF16, M=None, N=None, K=None, lda=None,
     return out
 
 
+def gemm_nn_ok(M, N, K):
+    """Does the dgrad-from-W form (gemm_nn) cover this shape?  (whole tiles of the one-wave-per-SIMD kernel)"""
+    return bool(_lib.load().udm_gemm_nn_ok(int(M), int(N), int(K)))
+
+
+def gemm_nn(a, b, out=None, *, N=None):
+    """out[M,N] (bf16) = a[M,K] @ b[K,N]; a bf16 row-major (K contiguous), b bf16 row-major [K rows, N contiguous] - the dgrad dX = dY W from the
+    forward's W shadow [out, in].  Shapes must pass gemm_nn_ok."""
+    _chk(a, BF16, "gemm_nn a"), _chk(b, BF16, "gemm_nn b")
+    M, Kd = a.shape
+    N = b.shape[1] if N is None else N
+    if out is None:
+        out = torch.empty((M, N), dtype=BF16, device=a.device)
+    _lib.call("udm_gemm_nn_bf16", _p(a), _p(b), _p(out), M, N, Kd, a.stride(0), b.stride(0), out.stride(0), _s())
+    return out
+
+
 def gemm_tn(a, b, out, *, M=None, N=None, beta=0.0):
     """out[M,N] (fp32) = beta*out + a[K,M]^T @ b[K,N]; a, b bf16 row-major with K (rows) a multiple of 64."""
     _chk(a, BF16, "gemm_tn a"), _chk(b, BF16, "gemm_tn b"), _chk(out, F32, "gemm_tn out")
