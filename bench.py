@@ -104,7 +104,7 @@ def synthetic_batch(workload, B, seed):
                 txt_attention_mask=torch.ones(B, w["txt_length"], dtype=torch.bool))
 
 
-GEMM_ENTRY_POINTS = ("udm_gemm_nt_bf16", "udm_gemm_tn_bf16", "udm_gemm_nt_splitk_bf16", "udm_gemm_tn_splitk_bf16")   # (A, B, C, M, N, K, ...)
+GEMM_ENTRY_POINTS = ("udm_gemm_nt_bf16", "udm_gemm_tn_bf16", "udm_gemm_nn_bf16", "udm_gemm_nt_splitk_bf16", "udm_gemm_tn_splitk_bf16")   # (A, B, C, M, N, K, ...)
 
 
 def _work(name, a):
@@ -423,7 +423,7 @@ def main():
     if gs:
         ach = gs["flops"] / (gs["total_ms"] * 1e-3) / 1e12
         traffic, traffic_src = pmc_traffic("gemm_") if args.workload == "unidisc-1.4b-l1280" else (None, None)
-        result["roofline"] = {"bound": "mfma", "kernel": "GEMM family (udm_gemm_nt_bf16 / udm_gemm_tn_bf16 and their split-K forms)", "achieved": ach,
+        result["roofline"] = {"bound": "mfma", "kernel": "GEMM family (udm_gemm_nt_bf16 / udm_gemm_tn_bf16 / udm_gemm_nn_bf16 and the split-K forms)", "achieved": ach,
                               "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s",
                               "frac": ach / PEAK_BF16_DENSE_TFLOPS, "traffic": traffic, "traffic_source": traffic_src, "launches": gs["launches"],
                               "avg_launch_ms": gs["total_ms"] / gs["launches"], "share_of_step_time": gs["total_ms"] * 1e-3 / dt}

@@ -87,7 +87,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   // 1-D grid, tile-major: id = tile * (B*H) + (b*H + h).  Blocks are dispatched to XCD id % 8, so every tile of one (b,h) runs on the
   // same XCD and shares its K/V (or Q/dO) through that L2 instead of re-fetching them over the fabric (B*H is a multiple of 8 in practice).
-  const int bh = blockIdx.x % (a.B * a.H), tile_x = blockIdx.x / (a.B * a.H);
+  int bh, tile_x;
+  attn_block_to_work(blockIdx.x, a.B * a.H, bh, tile_x);
   const int b = bh / a.H, h = bh % a.H;
   const int qi = tile_x * BQ + wave * 32 + l31;
   const bool q_ok = qi < a.L;
@@ -268,7 +269,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   // 1-D grid, tile-major: id = tile * (B*H) + (b*H + h).  Blocks are dispatched to XCD id % 8, so every tile of one (b,h) runs on the
   // same XCD and shares its K/V (or Q/dO) through that L2 instead of re-fetching them over the fabric (B*H is a multiple of 8 in practice).
-  const int bh = blockIdx.x % (a.B * a.H), tile_x = blockIdx.x / (a.B * a.H);
+  int bh, tile_x;
+  attn_block_to_work(blockIdx.x, a.B * a.H, bh, tile_x);
   const int b = bh / a.H, h = bh % a.H;
   const int qi = tile_x * BQ + wave * 32 + l31;
   const bool q_ok = qi < a.L;
@@ -418,7 +420,8 @@ __global__ __launch_bounds__(256, WAVES) void attn_bwd_dkv_kernel(AttnArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   // 1-D grid, tile-major: id = tile * (B*H) + (b*H + h).  Blocks are dispatched to XCD id % 8, so every tile of one (b,h) runs on the
   // same XCD and shares its K/V (or Q/dO) through that L2 instead of re-fetching them over the fabric (B*H is a multiple of 8 in practice).
-  const int bh = blockIdx.x % (a.B * a.H), tile_x = blockIdx.x / (a.B * a.H);
+  int bh, tile_x;
+  attn_block_to_work(blockIdx.x, a.B * a.H, bh, tile_x);
   const int b = bh / a.H, h = bh % a.H;
   const int ki = tile_x * 128 + wave * 32 + l31;
   const bool k_ok = ki < a.L;

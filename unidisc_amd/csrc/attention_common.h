@@ -90,6 +90,22 @@ __device__ __forceinline__ bool attn_pair_ok(long code_q, long code_k) {
   return iq == ik && iq >= 0 && (qm & kb) != 0;
 }
 
+// 1-D grid -> ((b, h), tile).  Blocks go to XCD (block id % 8) in dispatch order.  All tiles of one (b, h) run on ONE XCD and share its K / V (or
+// Q / dO) through that L2 - and an XCD works through its (b, h) pairs ONE AFTER THE OTHER (tiles of a pair adjacent in dispatch order): with the
+// tile-major order used before, the ~64 blocks resident on an XCD spanned 16 pairs (10 MB of K / V against a 4 MB L2; PMC: the forward fetched
+// 414 MB over the fabric for 126 MB of operands).  Needs B*H % 8 == 0; otherwise the plain tile-major order.
+__device__ __forceinline__ void attn_block_to_work(int bid, int nbh, int& bh, int& tile) {
+  const int ntiles = gridDim.x / nbh;
+  if ((nbh & 7) == 0) {
+    const int x = bid & 7, j = bid >> 3;
+    bh = (j / ntiles) * 8 + x;
+    tile = j % ntiles;
+  } else {
+    bh = bid % nbh;
+    tile = bid / nbh;
+  }
+}
+
 constexpr int DOC_STRIDE = 8;   // ints per tile in doc_ranges: {lo, hi, idmin, idmax, exact, 0, 0, 0}
 // Document masks (packed samples): a 128-row block only has to walk the 64-row tiles of the other side that can hold one of its sample ids.
 // `doc_ranges` (udm_attention_doc_ranges) gives, per 64-row tile, {lo, hi, idmin, idmax, exact}: the [lo, hi) span of positions whose id lies inside the

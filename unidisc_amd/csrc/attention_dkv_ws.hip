@@ -218,7 +218,8 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_ws_kernel(AttnArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int role = wave >> 2, kw = wave & 3;   // role 0: score wave, 1: accum wave; both own keys kw*32 .. kw*32+31 of the block
   // 1-D grid, tile-major (id = tile * (B*H) + bh): all key blocks of one (b, h) land on the same XCD and share its Q / dO through that L2
-  const int bh = blockIdx.x % (a.B * a.H), tile_x = blockIdx.x / (a.B * a.H);
+  int bh, tile_x;
+  attn_block_to_work(blockIdx.x, a.B * a.H, bh, tile_x);
   const int b = bh / a.H, h = bh % a.H;
   const int ki = tile_x * 128 + kw * 32 + l31;
   const bool k_ok = ki < a.L;

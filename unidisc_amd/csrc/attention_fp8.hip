@@ -53,7 +53,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_fp8_kernel(Fp8Args a) {
   __shared__ long sid_s[2][BKV8];
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int bh = blockIdx.x % (a.B * a.H), tile_x = blockIdx.x / (a.B * a.H);   // tile-major 1-D grid: one (b,h) per XCD (see attention.hip)
+  int bh, tile_x;
+  attn_block_to_work(blockIdx.x, a.B * a.H, bh, tile_x);   // tile-major 1-D grid: one (b,h) per XCD (see attention.hip)
   const int b = bh / a.H, h = bh % a.H;
   const int qi = tile_x * BQ8 + wave * 32 + l31;
   const bool q_ok = qi < a.L;

@@ -130,7 +130,8 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w64_kernel(AttnArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   // tile-major 1-D grid as in attention.hip: all query blocks of one (b, h) run on one XCD (block id % 8) and share K / V through its L2
-  const int bh = blockIdx.x % (a.B * a.H), tile_x = blockIdx.x / (a.B * a.H);
+  int bh, tile_x;
+  attn_block_to_work(blockIdx.x, a.B * a.H, bh, tile_x);
   const int b = bh / a.H, h = bh % a.H;
   const long rowbase = (long)b * a.L;
   const float c = a.scale_log2;

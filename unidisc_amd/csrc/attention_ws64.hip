@@ -97,7 +97,8 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_ws64_kernel(AttnArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int pair = wave & 3;
   // tile-major 1-D grid as in attention.hip: all query blocks of one (b, h) run on one XCD (block id % 8) and share K / V through its L2
-  const int bh = blockIdx.x % (a.B * a.H), tile_x = blockIdx.x / (a.B * a.H);
+  int bh, tile_x;
+  attn_block_to_work(blockIdx.x, a.B * a.H, bh, tile_x);
   const int b = bh / a.H, h = bh % a.H;
   const long rowbase = (long)b * a.L;
   const int L = a.L;
