@@ -103,6 +103,49 @@ def main():
     res["gemm_cus_224"] = dict(worst_rel_vs_bf16_local=cu_err)
     if cu_err > 1e-2:
         fails.append(("gemm_cus", cu_err))
+    # sharded path (unidisc_amd/zero.py: reduce-to-owner, owner-only AdamW, broadcast of the masters) under RCCL: one rank owns every bucket, so three
+    # steps must track the replicated path's (all-reduce + FusedAdamW) parameters from the same start and batches
+    from unidisc_amd import FusedAdamW, zero
+    start = {k: v.detach().clone() for k, v in diff.backbone.state_dict().items()}
+
+    def three_steps(make):
+        diff.backbone.load_state_dict(start)
+        diff.backbone.invalidate_shadows()
+        if getattr(diff.backbone, "_grad_sync", None) is not None:
+            del diff.backbone._grad_sync
+        opt = make()
+        for it in range(3):
+            diff.backbone.zero_grad(set_to_none=True)
+            torch.manual_seed(20 + it)
+            diff.training_step(batch(20 + it), 1).loss.backward()
+            opt.step()
+        torch.cuda.synchronize()
+        return {k: p.detach().clone() for k, p in diff.backbone.named_parameters()}, opt
+
+    def replicated():
+        ddp.wrap(diff.backbone, min_bucket_elems=4 * 1024 * 1024, force_single_rank=True)
+        return FusedAdamW(diff.backbone, lr=1e-3, max_grad_norm=1.0)
+
+    def sharded():
+        sy = zero.wrap_sharded(diff.backbone, min_bucket_elems=4 * 1024 * 1024, force_single_rank=True)
+        return zero.ShardedAdamW(diff.backbone, sy, lr=1e-3, max_grad_norm=1.0)
+
+    p_rep, _ = three_steps(replicated)
+    p_rep2, _ = three_steps(replicated)
+    p_sh, opt_sh = three_steps(sharded)
+
+    def rms_rel(a, b):   # ||a - b|| over all parameters, relative to the size of the three updates
+        num = sum(float(((a[k] - b[k]).double() ** 2).sum()) for k in a)
+        den = sum(float(((b[k] - start[k]).double() ** 2).sum()) for k in a)
+        return (num / (den + 1e-300)) ** 0.5
+
+    # the backward is not bit-reproducible run to run (fp32 atomics) and Adam turns a sign flip of a near-zero gradient into a full-size update of that
+    # element: the yardstick is the replicated path against ITSELF
+    noise, z_err = rms_rel(p_rep2, p_rep), rms_rel(p_sh, p_rep)
+    res["sharded_optimizer"] = dict(rms_diff_vs_replicated_rel_to_update=z_err, replicated_run_to_run=noise, buckets=len(opt_sh.sync.ranges),
+                                    grad_norm=float(opt_sh.grad_norm), bytes_on_wire=opt_sh.sync.bytes_on_wire)
+    if z_err > 2.0 * noise + 0.02 or opt_sh.sync.bytes_on_wire == 0:
+        fails.append(("sharded", z_err, noise))
     dist.barrier()
     dist.destroy_process_group()
     res["backend"] = "nccl (RCCL)"

@@ -9,8 +9,9 @@ from .dit import DIT, ModalityMask  # noqa: F401
 from .diffusion import Diffusion, Loss  # noqa: F401
 from .noise_schedule import LogLinearNoise  # noqa: F401
 from .optim import FusedAdamW  # noqa: F401
+from .zero import ShardedAdamW, ShardedGradSync, wrap_sharded  # noqa: F401
 from .checkpoint import load_backbone_checkpoint, save_backbone_checkpoint, read_state_dict  # noqa: F401
 from .token_data import TokenShard, TokenBatcher, WeightedDatasetSampler, PackingCollate  # noqa: F401
 
 __all__ = ["DIT", "ModalityMask", "Diffusion", "Loss", "LogLinearNoise", "Cfg", "make_config", "MODEL_PRESETS", "load_backbone_checkpoint",
-           "save_backbone_checkpoint", "read_state_dict", "FusedAdamW", "TokenShard", "TokenBatcher", "WeightedDatasetSampler", "PackingCollate"]
+           "save_backbone_checkpoint", "read_state_dict", "FusedAdamW", "ShardedAdamW", "ShardedGradSync", "wrap_sharded", "TokenShard", "TokenBatcher", "WeightedDatasetSampler", "PackingCollate"]
