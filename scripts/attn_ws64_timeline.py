@@ -7,14 +7,23 @@ from unidisc_amd import kernels as K, _lib
 B, H, L, D = 8, 16, int(os.environ.get("L", 1280)), 128
 g = torch.Generator(device="cuda").manual_seed(0)
 q, k, v = ((torch.randn(B * L, H * D, device="cuda", generator=g)).to(torch.bfloat16) for _ in range(3))
-K.set_attention_w64(2)
-for _ in range(3): K.attention_fwd_generic(q, k, v, B, L, H, D)
+exp = _lib.load_experiments()   # the wave-specialised kernel lives in the experiments library (make -C unidisc_amd/csrc exp)
+d = H * D
+o = torch.empty((B * L, d), dtype=torch.bfloat16, device="cuda")
+lse = torch.empty((B, H, L), dtype=torch.float32, device="cuda")
+vp, i64 = (lambda t: ctypes.c_void_p(t.data_ptr())), ctypes.c_int64
+
+
+def run(tl):
+    rc = exp.udm_exp_attention_fwd_ws64(vp(q), vp(k), vp(v), vp(o), vp(lse), i64(B), i64(H), i64(L), i64(d), i64(d), i64(d), i64(d), ctypes.c_void_p(tl),
+                                        ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0, exp.udm_last_error().decode()
+
+
+for _ in range(3): run(0)
 buf = torch.zeros(8 * 64, dtype=torch.int64, device="cuda")
-lib = _lib.load()
-lib.udm_attention_w64_timeline(ctypes.c_void_p(buf.data_ptr()))
-K.attention_fwd_generic(q, k, v, B, L, H, D)
+run(buf.data_ptr())
 torch.cuda.synchronize()
-lib.udm_attention_w64_timeline(ctypes.c_void_p(0))
 t = buf.cpu().reshape(8, 64)
 t00 = int(t[:, 0].min())
 for w in (0, 1, 4, 5):

@@ -79,8 +79,9 @@ class HipLibraryMissing(RuntimeError):
 
 
 def build(verbose: bool = False) -> str:
-    """Compile the HIP sources for gfx950 in-tree (``make`` in ``csrc/``).  Cross-compiles without a GPU."""
-    out = subprocess.run(["make", "-C", CSRC, "-j4"], capture_output=True, text=True)
+    """Compile EVERY HIP source for gfx950 in-tree (``make`` in ``csrc/``): the product library and the experiments library scripts/ load
+    (the product never loads the latter).  Cross-compiles without a GPU."""
+    out = subprocess.run(["make", "-C", CSRC, "-j4", "all", "exp"], capture_output=True, text=True)
     if verbose or out.returncode != 0:
         print(out.stdout[-4000:])
         print(out.stderr[-4000:])

@@ -250,6 +250,6 @@ void udm_launch_attn_bwd_dkv_ws(const void* args, hipStream_t stream);
 bool udm_launch_attn_fwd_w64(const void* args, hipStream_t stream);
 // dQ kernel of the same family (attention_dq_w64.hip): head dim 128, no document mask, L % 128 == 0, k_stride == v_stride, dq_stride % 8 == 0
 void udm_launch_attn_bwd_dq_w64(const void* args, hipStream_t stream, unsigned long long* timeline);
-int udm_attn_w64_mode();   // 0 off, 1 one wave per SIMD, 2 wave-specialised forward (attention_w64.hip)
+int udm_attn_w64_mode();   // 0 off, 1 = the one-wave-per-SIMD forward / dQ kernels (attention_w64.hip, attention_dq_w64.hip)
 unsigned long long* udm_attn_w64_timeline();
-void udm_launch_attn_fwd_ws64(const void* args, hipStream_t stream);   // wave-specialised variant (attention_ws64.hip), same conditions plus L % 128 == 0
+void udm_launch_attn_fwd_ws64(const void* args, hipStream_t stream);   // wave-specialised variant (attention_ws64.hip: experiments library only)

@@ -437,7 +437,7 @@ extern "C" int udm_attention_w64_timeline(uint64_t* buf) {   // diagnostics: dev
   return 0;
 }
 extern "C" int udm_attention_set_w64(int enable) {
-  w64::g_enabled = enable;   // 0 = off, 1 = one wave per SIMD, 2 = wave-specialised (attention_ws64.hip)
+  w64::g_enabled = enable ? 1 : 0;   // 0 = off, 1 = the one-wave-per-SIMD forward / dQ kernels
   return 0;
 }
 
@@ -452,12 +452,6 @@ bool udm_launch_attn_fwd_w64(const void* args, hipStream_t stream) {
   using namespace w64;
   if (g_enabled < 0) { const char* e = getenv("UDM_ATTN_W64"); g_enabled = e ? atoi(e) : 0; }
   if (!g_enabled) return false;
-  if (g_enabled == 2) {
-    AttnArgs a2 = *reinterpret_cast<const AttnArgs*>(args);
-    a2.timeline = g_timeline;
-    udm_launch_attn_fwd_ws64(&a2, stream);
-    return true;
-  }
   AttnArgs a = *reinterpret_cast<const AttnArgs*>(args);
   a.timeline = g_timeline;
   static const int abl = [] { const char* e = getenv("UDM_ATTN_W64_ABL"); return e ? atoi(e) : 0; }();   // timing-only ablations (wrong results)

@@ -1,4 +1,5 @@
-// Attention forward, head dim 128, no document mask, L a multiple of 128: WAVE-SPECIALISED kernel, 64 queries per wave pair.
+// EXPERIMENT (libunidisc_exp.so, scripts/ only - measured slower than the kernels the product uses): attention forward, head dim 128,
+// no document mask, L a multiple of 128: WAVE-SPECIALISED kernel, 64 queries per wave pair.
 // (reference: flash_attn_qkvpacked_func / SDPA, models/dit.py:826-829, :843)
 //
 // Why: a cycle timeline of the one-wave-per-SIMD kernel (attention_w64.hip) shows it bound by ONE wave's instruction issue - about 540
@@ -378,4 +379,20 @@ void udm_launch_attn_fwd_ws64(const void* args, hipStream_t stream) {
   dim3 grid(((a.L + BQW - 1) / BQW) * a.H * a.B);
   if (a.timeline) hipLaunchKernelGGL(attn_fwd_ws64_kernel<true>, grid, dim3(512), LDS_BYTES, stream, a);
   else hipLaunchKernelGGL(attn_fwd_ws64_kernel<false>, grid, dim3(512), LDS_BYTES, stream, a);
+}
+
+// C entry of the experiments library (scripts/bench_attn_w64.py, scripts/attn_ws64_timeline.py): same arguments as udm_attention_fwd without the mask
+extern "C" int udm_exp_attention_fwd_ws64(const void* q, const void* k, const void* v, void* o, float* lse, int64_t B, int64_t H, int64_t L, int64_t q_stride,
+                                          int64_t k_stride, int64_t v_stride, int64_t o_stride, uint64_t* timeline, hipStream_t stream) {
+  UDM_CHECK_ARG(q && k && v && o && lse && B > 0 && H > 0 && L >= 128 && L % 128 == 0 && o_stride % 8 == 0, "udm_exp_attention_fwd_ws64: bad arguments");
+  AttnArgs a{};
+  a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.out = (bf16_t*)o; a.lse = lse;
+  a.q_stride = q_stride; a.k_stride = k_stride; a.v_stride = v_stride; a.out_stride = o_stride;
+  a.B = (int)B; a.H = (int)H; a.L = (int)L;
+  a.scale = 1.0f / sqrtf(128.0f);
+  a.scale_log2 = a.scale * 1.4426950408889634f;
+  a.timeline = reinterpret_cast<unsigned long long*>(timeline);
+  udm_launch_attn_fwd_ws64(&a, stream);
+  UDM_CHECK_LAUNCH("udm_exp_attention_fwd_ws64");
+  return 0;
 }

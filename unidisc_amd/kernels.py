@@ -501,7 +501,7 @@ def set_tr_read(enable: bool):
 
 def set_attention_w64(enable: bool):
     """A/B switch: the one-wave-per-SIMD forward kernel (head dim 128, no document mask) on / off."""
-    _lib.load().udm_attention_set_w64(int(enable))   # 0 off, 1 one wave per SIMD, 2 wave-specialised
+    _lib.load().udm_attention_set_w64(1 if enable else 0)
 
 
 # ------------------------------------------------------------------------------------------------ embedding / CE / adaLN helpers
