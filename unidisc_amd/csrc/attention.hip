@@ -126,8 +126,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
     Stg::issue(kbase, a.k_stride, t_begin * BKV, a.L, smem + (t_begin & 1) * TB, wave, lane);
     Stg::issue(vbase, a.v_stride, t_begin * BKV, a.L, smem + (2 + (t_begin & 1)) * TB, wave, lane);
   }
-  for (int t = t_begin; t < t_end; ++t) {
-    const int kv0 = t * BKV, st = (ABL & 4) ? 0 : (t & 1);
+  // One key tile; ST = t & 1 as a compile-time constant, so that every LDS fragment address of the tile is a hoisted per-lane register plus an
+  // IMMEDIATE (with the stage picked at run time each of the 48 fragment reads carried its own v_add_u32: 62 of ~370 instructions per tile and wave
+  // in a loop that is bound by instruction issue)
+  auto tile = [&](auto st_c, int t) {
+    constexpr int ST = decltype(st_c)::value;
+    const int kv0 = t * BKV;
+    constexpr int st = (ABL & 4) ? 0 : ST;
     const char* Ks = smem + st * TB;
     const char* Vs = smem + (2 + st) * TB;
     const long* sidk = sid_s + st * BKV;
@@ -232,6 +237,15 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
         oT[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vt, pb, oT[i], 0, 0, 0);
       }
     }
+  };
+  {
+    int t = t_begin;
+    if (t < t_end && (t & 1)) { tile(std::integral_constant<int, 1>{}, t); ++t; }
+    for (; t + 1 < t_end; t += 2) {
+      tile(std::integral_constant<int, 0>{}, t);
+      tile(std::integral_constant<int, 1>{}, t + 1);
+    }
+    if (t < t_end) tile(std::integral_constant<int, 0>{}, t);
   }
   const float ltot = lsum + __shfl_xor(lsum, 32, 64);
   const float inv = ltot > 0.f ? 1.f / ltot : 0.f;
@@ -323,6 +337,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
     Stg::issue(kbase, a.k_stride, t_begin * BKV, a.L, smem + (t_begin & 1) * TB, wave, lane);
     Stg::issue(vbase, a.v_stride, t_begin * BKV, a.L, smem + (2 + (t_begin & 1)) * TB, wave, lane);
   }
+  // (the forward kernel's compile-time stage index - fragment addresses as register + immediate - was tried here too: 174 vs 173-176 us, three spills; not kept)
   for (int t = t_begin; t < t_end; ++t) {
     const int kv0 = t * BKV, st = t & 1;
     const char* Ks = smem + st * TB;
