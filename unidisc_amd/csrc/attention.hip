@@ -337,7 +337,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
     Stg::issue(kbase, a.k_stride, t_begin * BKV, a.L, smem + (t_begin & 1) * TB, wave, lane);
     Stg::issue(vbase, a.v_stride, t_begin * BKV, a.L, smem + (2 + (t_begin & 1)) * TB, wave, lane);
   }
-  // (the forward kernel's compile-time stage index - fragment addresses as register + immediate - was tried here too: 174 vs 173-176 us, three spills; not kept)
+  // (fragment addresses as register + immediate - the forward kernel's compile-time stage index, or per-lane address registers that follow the stage by
+  // +-TB per tile - were both tried here: 174-175 us either way against 173-176; not kept)
   for (int t = t_begin; t < t_end; ++t) {
     const int kv0 = t * BKV, st = t & 1;
     const char* Ks = smem + st * TB;
