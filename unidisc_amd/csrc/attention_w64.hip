@@ -414,7 +414,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w64_kernel(AttnArgs a) {
             make_uint2(pack2bf(oT[q][i][rg * 4] * inv, oT[q][i][rg * 4 + 1] * inv), pack2bf(oT[q][i][rg * 4 + 2] * inv, oT[q][i][rg * 4 + 3] * inv));
       }
     const int qi = q0w + row;
-    if (qi < L && hi == 0) a.lse[((long)b * a.H + h) * L + qi] = ltot > 0.f ? m[q] * c + log2f(ltot) : INFINITY;
+    if (qi < L && hi == 0) a.lse[((long)b * a.H + h) * L + qi] = ltot > 0.f ? __builtin_fmaf(m[q], c, log2f(ltot)) : INFINITY;
   }
   stamp(62);
   // (each wave reads back only what it wrote: no barrier needed, the compiler orders this wave's LDS writes before its reads)
