@@ -238,3 +238,20 @@ def test_chunked_head_and_cross_entropy_on_gpu():
     assert l0 == l1 and torch.equal(n0, n1)
     for k in g0:
         assert rel_err(g1[k], g0[k]) < 2e-3, (k, rel_err(g1[k], g0[k]))
+
+
+def test_modality_range_check_is_deferred_but_still_raises():
+    """model.py:311's assert (both modalities present, nothing else) no longer synchronises the host at the top of the step, but a bad batch still raises
+    the same AssertionError inside the same training step, before a loss comes back."""
+    g = Golden("c_large")
+    diff = build_product(g, DEV)
+    torch.manual_seed(0)
+    batch = {k: (v.to(DEV) if isinstance(v, torch.Tensor) else v) for k, v in g.batch().items()}   # (a host batch is checked on the host, immediately)
+    out = diff.training_step(batch, 1)   # a good batch passes and leaves nothing pending
+    assert torch.isfinite(out.loss) and not diff._checks
+    bad = {k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in diff.update_batch(batch).items()}
+    diff._flush_checks()
+    bad["modality"] = torch.zeros_like(bad["modality"])   # text only: max() == 0
+    with pytest.raises(AssertionError):
+        diff.training_step({k: v for k, v in bad.items() if k in ("input_ids", "attention_mask", "modality")}, 2)
+    assert not diff._checks
