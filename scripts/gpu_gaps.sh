@@ -1,7 +1,7 @@
 #!/bin/bash
 # Where the step's idle time sits: rocprofv3 kernel trace of a short bench run, then per-predecessor gap sums over the last timed step
 # and the neighbourhood of every small library launch (copyBuffer / fill).  Usage: bash scripts/gpu_gaps.sh <tag>   (EXTRA = extra bench flags)
-TAG=${1:-x}; mkdir -p gpurun_out; export TMPDIR=/tmp; R=${GRAFT_REPO_ROOT:-$(pwd)}
+TAG=${1:-x}; LIST=${LIST:-0}; mkdir -p gpurun_out; export TMPDIR=/tmp; R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp
 timeout 900 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/gaps_$TAG -o trace -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-timing --table-steps 0 $EXTRA > $R/gpurun_out/gaps_$TAG.log 2>&1
 cd $R
@@ -24,6 +24,14 @@ for a, b in zip(step[:-1], step[1:]):
     gap_by[k][0] += g; gap_by[k][1] += 1
 for k, (g, n) in sorted(gap_by.items(), key=lambda kv: -kv[1][0])[:40]:
     print(f"{g/1e3:9.1f} us  n={n:4d}  avg {g/n/1e3:6.2f}   {k[0]:44s} -> {k[1]}")
+lib = [e for e in step if ("at::native" in e[2] or "rocprim" in e[2] or "rocclr" in e[2] or "elementwise" in e[2])]
+print(f"library (torch / rocprim / copy) launches in the step: {len(lib)}, {sum(e[1]-e[0] for e in lib)/1e6:.3f} ms")
+first_udm = next(i for i, e in enumerate(step) if e[2].startswith("gemm_") or e[2].startswith("norm_fwd"))
+print(f"step start -> first GEMM/norm launch: {(step[first_udm][0]-step[0][0])/1e6:.3f} ms over {first_udm} launches")
+if "$LIST" == "1":
+    for i, e in enumerate(step):
+        if e in lib:
+            print(f"{i:4d} {(e[1]-e[0])/1e3:7.1f} us  {e[2][:230]}")
 print("---- small library launches and their neighbours")
 seen = collections.Counter()
 for i, e in enumerate(step):
