@@ -1547,7 +1547,9 @@ extern "C" int udm_norm_residual_bwd(const void* dy, const float* x, const float
   UDM_CHECK_ARG(M > 0 && (d == 2048 || d == 4096), "udm_norm_residual_bwd: the fused form is built for d = 2048 / 4096 (got %ld); use udm_norm_bwd + udm_residual_bwd", (long)d);
   UDM_CHECK_ARG(norm_type == 0 || mean, "udm_norm_residual_bwd: LayerNorm needs the saved mean");
   UDM_CHECK_ARG(!w_b || (rstd_b && dw_b && (norm_type == 0 || mean_b)), "udm_norm_residual_bwd: sandwich norm needs rstd_b, dw_b (and mean_b for LayerNorm)");
-  const int grid = (int)(M < 1536 ? M : 1536);
+  // 3 blocks per CU: every block leaves a [3][d] fp32 partial for colreduce3, and at 1536 blocks that workspace (38 MB written + read per call) cost more
+  // than the extra occupancy gave (in the step: 3.95 ms at 1536 blocks, 4.12 at 1024, 3.73 at 768, 3.77 at 512)
+  const int grid = (int)(M < 768 ? M : 768);
   UDM_CHECK_ARG(ws_elems >= (int64_t)grid * 3 * d, "udm_norm_residual_bwd: workspace too small (need %ld floats)", (long)grid * 3 * d);
   NormResidBwdArgs a{(const bf16_t*)dy, x, rstd, mean, w, dx, dw, accumulate, (const bf16_t*)branch, (bf16_t*)dbranch, w_b, rstd_b, mean_b, dw_b, dbias, ws,
                      (int)M, (int)d, norm_type, p_drop, seed};
@@ -1604,7 +1606,7 @@ extern "C" int udm_qknorm_rope_bwd(const void* dqkr, const void* qkv, void* dqkv
   const int nch = nit <= 1 ? 1 : (nit == 2 ? 2 : (nit == 3 ? 3 : (nit == 4 ? 4 : 8)));
   const size_t lds = gq ? ((size_t)2 * d + 4096) * sizeof(float) : 0;
   if (d >= 2048 && d <= 4096) {
-    int g = (int)(M < 1024 ? M : 1024);
+    int g = (int)(M < 1024 ? M : 1024);   // (swept 256 .. 2048 in the step: 2.92 / 1.91 / 1.69 / 1.60 / 1.88 / 1.82 / 1.87 ms per step at 256 / 512 / 768 / 1024 / 1280 / 1536 / 2048)
     UDM_CHECK_ARG(!gq || (dbq == dgq + d && dgk == dgq + 2 * d && dbk == dgq + 3 * d) || !ws, "udm_qknorm_rope_bwd: the workspace form needs dgq|dbq|dgk|dbk contiguous");
     if (gq && ws && ws_elems >= (int64_t)g * 4 * d) a.ws = ws;
     else if (gq) g = g < 256 ? g : 256;
