@@ -766,7 +766,12 @@ int choose_tile(long M, long N, long K, long lda, long ldb) {
     const long tn = c == 0 ? (N + 127) / 128 : (N + 255) / 256;
     const long slots = c == 0 ? 512 : 256;  // co-resident blocks on the chip
     const long rounds = (tm * tn + slots - 1) / slots;
-    const double t = rounds * (double)bms[c] * (c == 0 ? 128 : 256) * (c == 0 ? 2.0 : 1.0) / eff[c];  // time ~ rounds x tile area (2 blocks/CU share a CU)
+    double t = rounds * (double)bms[c] * (c == 0 ? 128 : 256) * (c == 0 ? 2.0 : 1.0) / eff[c];  // time ~ rounds x tile area (2 blocks/CU share a CU)
+    // short contractions (UniDisc-S: K = 768, 12 K tiles per output tile): prologue and epilogue are a large part of a tile, and only the persistent
+    // form (256- / 320-row tiles, whole tiles, more than one round) overlaps the next tile's first loads with them.  Measured at M = 24576
+    // (scripts/bench_gemm_s.py): N = 3072 + GELU 162 us persistent 256 vs 178 (192) / 194 (320, ragged); + GELU' 166 vs 187 / 228; N = 2304 plain 111 vs 120 / 114.
+    const bool persistent = c >= 2 && M % bms[c] == 0 && N % 256 == 0 && tm * tn > 256;
+    if (K <= 1024 && !persistent) t *= 1.15;
     if (t < best || (t == best && c > 0)) { best = t; pick = c == 0 ? 0 : bms[c]; }  // ties go to the larger tile (fewer operand re-reads)
   }
   return pick;
