@@ -469,10 +469,11 @@ def test_residual_with_fused_next_norm_equals_separate_kernels(K, d, variant):
         assert torch.equal(mn1, mn2) and torch.equal(m1, m2)
 
 
-@pytest.mark.parametrize("d", [2048, 4096])
+@pytest.mark.parametrize("d", [2048, 4096, 768, 256, 1032])
 @pytest.mark.parametrize("nt,sandwich,p,acc", [(0, True, 0.0, True), (0, True, 0.1, True), (1, True, 0.0, True), (0, False, 0.1, True), (0, True, 0.0, False), (1, False, 0.0, False)])
 def test_norm_residual_bwd_fused_equals_the_two_kernels(K, d, nt, sandwich, p, acc):
-    """The fused norm-backward + residual-branch-backward pass (one kernel per row pair of the block backward at d = 2048 / 4096) against the
+    """The fused norm-backward + residual-branch-backward pass (one kernel per row pair of the block backward: block per row at d = 2048 / 4096,
+    wave per row below) against the
     two kernels it replaces run back to back, and - through them - against the fp32 references those are tested with: dx, d branch, both
     weight gradients; rms / LayerNorm, with and without the sandwich norm, dropout mask regenerated from the same (seed, index)."""
     M, L = 1000, 250     # not a multiple of the grid: the row loop's tail

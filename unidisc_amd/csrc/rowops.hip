@@ -1162,6 +1162,127 @@ __global__ __launch_bounds__(256) void norm_residual_bwd_kernel(NormResidBwdArgs
   }
 }
 
+// The same fused pass for narrow rows (d <= 2048, e.g. UniDisc-S d = 768): a WAVE per row (lane owns 8 columns of each 512-column chunk), no block-wide
+// barrier in the row loop; the four waves' column sums meet in LDS at the end and leave one [3][d] workspace row per block.
+template <int NCH>
+__global__ __launch_bounds__(256) void norm_residual_bwd_wrow_kernel(NormResidBwdArgs a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float dwn[NCH][8], dwb[NCH][8], dbs[NCH][8];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { dwn[i][k] = 0.f; dwb[i][k] = 0.f; dbs[i][k] = 0.f; }
+  const float keep_scale = 1.f / (1.f - a.p_drop);
+  for (long row = (long)blockIdx.x * ROWS_PER_BLOCK + wave; row < a.M; row += (long)gridDim.x * ROWS_PER_BLOCK) {
+    const float rs = a.rstd[row];
+    const float mu = a.norm_type ? a.mean[row] : 0.f;
+    const float rsb = a.w_b ? a.rstd_b[row] : 1.f;
+    const float mub = (a.w_b && a.norm_type) ? a.mean_b[row] : 0.f;
+    float xh[NCH][8], g[NCH][8], dxo[NCH][8], br[NCH][8];
+    float s_g = 0.f, s_gx = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = (i * 64 + lane) * 8;
+      if (c < a.d) {
+        float x8[8], dy8[8], w8[8];
+        load8_f32(a.x + row * a.d + c, x8);
+        load8_bf16(a.dy + row * a.d + c, dy8);
+        load8_bf16(a.branch + row * a.d + c, br[i]);
+        if (a.accumulate) load8_f32(a.dx + row * a.d + c, dxo[i]);
+        load8_f32(a.w + c, w8);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          xh[i][k] = (x8[k] - mu) * rs;
+          dwn[i][k] += dy8[k] * xh[i][k];
+          g[i][k] = dy8[k] * w8[k];
+          s_g += g[i][k];
+          s_gx += g[i][k] * xh[i][k];
+          if (!a.accumulate) dxo[i][k] = 0.f;
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { xh[i][k] = 0.f; g[i][k] = 0.f; dxo[i][k] = 0.f; br[i][k] = 0.f; }
+      }
+    }
+    s_gx = wave_sum(s_gx) / a.d;
+    s_g = a.norm_type ? wave_sum(s_g) / a.d : 0.f;
+    float nh[NCH][8], g2[NCH][8];
+    float r2_g = 0.f, r2_gx = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = (i * 64 + lane) * 8;
+      if (c >= a.d) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { nh[i][k] = 0.f; g2[i][k] = 0.f; }
+        continue;
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) dxo[i][k] += rs * (g[i][k] - s_g - xh[i][k] * s_gx);
+      store8_f32(a.dx + row * a.d + c, dxo[i]);
+      float dn[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) dn[k] = dxo[i][k];
+      if (a.p_drop > 0.f) {
+        bool keep[8];
+        dropout_keep8(a.seed, (uint64_t)row * a.d + c, a.p_drop, keep);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) dn[k] *= keep[k] ? keep_scale : 0.f;
+      }
+      if (a.w_b) {
+        float wb8[8];
+        load8_f32(a.w_b + c, wb8);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          nh[i][k] = (br[i][k] - mub) * rsb;
+          const float nr = (a.norm_type == 0) ? rbf(nh[i][k]) : nh[i][k];
+          dwb[i][k] += dn[k] * nr;
+          g2[i][k] = dn[k] * wb8[k];
+          r2_g += g2[i][k];
+          r2_gx += g2[i][k] * nh[i][k];
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { g2[i][k] = dn[k]; nh[i][k] = 0.f; }
+      }
+    }
+    float s2_gx = 0.f, s2_g = 0.f;
+    if (a.w_b) {
+      s2_gx = wave_sum(r2_gx) / a.d;
+      s2_g = a.norm_type ? wave_sum(r2_g) / a.d : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = (i * 64 + lane) * 8;
+      if (c >= a.d) continue;
+      float o[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) o[k] = a.w_b ? rsb * (g2[i][k] - s2_g - nh[i][k] * s2_gx) : g2[i][k];
+      store8_bf16(a.dbranch + row * a.d + c, o);
+      if (a.dbias) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) dbs[i][k] += rbf(o[k]);
+      }
+    }
+  }
+  // the four waves' column sums meet in LDS; one [3][d] workspace row per block (colreduce3 finishes it)
+  __shared__ float red[ROWS_PER_BLOCK][64 * 8 + 8];
+#pragma unroll
+  for (int which = 0; which < 3; ++which) {
+    if ((which == 1 && !a.w_b) || (which == 2 && !a.dbias)) continue;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < 8; ++k) red[wave][lane * 8 + k] = which == 0 ? dwn[i][k] : (which == 1 ? dwb[i][k] : dbs[i][k]);
+      __syncthreads();
+      for (int t = threadIdx.x; t < 512; t += 256) {
+        const int c = i * 512 + t;
+        if (c < a.d) a.ws[((long)blockIdx.x * 3 + which) * a.d + c] = red[0][t] + red[1][t] + red[2][t] + red[3][t];
+      }
+    }
+  }
+}
+
 // out_j[c] += sum_r ws[r][j][c], j = blockIdx.z in 0..2  (ws is [nrows][3][d]; out1 / out2 may be null)
 __global__ __launch_bounds__(256) void colreduce3_kernel(const float* __restrict__ ws, float* __restrict__ out0, float* __restrict__ out1, float* __restrict__ out2,
                                                          int nrows, int d) {
@@ -1544,16 +1665,25 @@ extern "C" int udm_norm_residual_bwd(const void* dy, const float* x, const float
                                      const void* branch, void* dbranch, const float* w_b, const float* rstd_b, const float* mean_b, float* dw_b, float* dbias,
                                      int64_t M, int64_t d, int norm_type, float p_drop, uint64_t seed, float* ws, int64_t ws_elems, hipStream_t stream) {
   UDM_CHECK_ARG(dy && x && rstd && w && dx && dw && branch && dbranch && ws, "udm_norm_residual_bwd: null pointer");
-  UDM_CHECK_ARG(M > 0 && (d == 2048 || d == 4096), "udm_norm_residual_bwd: the fused form is built for d = 2048 / 4096 (got %ld); use udm_norm_bwd + udm_residual_bwd", (long)d);
+  UDM_CHECK_ARG(M > 0 && (d == 2048 || d == 4096 || (d % 8 == 0 && d >= 64 && d < 2048)),
+                "udm_norm_residual_bwd: the fused form is built for d = 2048 / 4096 (block per row) and d < 2048, d %% 8 == 0 (wave per row); got %ld", (long)d);
   UDM_CHECK_ARG(norm_type == 0 || mean, "udm_norm_residual_bwd: LayerNorm needs the saved mean");
   UDM_CHECK_ARG(!w_b || (rstd_b && dw_b && (norm_type == 0 || mean_b)), "udm_norm_residual_bwd: sandwich norm needs rstd_b, dw_b (and mean_b for LayerNorm)");
   // 3 blocks per CU: every block leaves a [3][d] fp32 partial for colreduce3, and at 1536 blocks that workspace (38 MB written + read per call) cost more
   // than the extra occupancy gave (in the step: 3.95 ms at 1536 blocks, 4.12 at 1024, 3.73 at 768, 3.77 at 512)
-  const int grid = (int)(M < 768 ? M : 768);
+  const bool wrow = d < 2048;
+  const int grid = wrow ? min(grid_rows(M), 1024) : (int)(M < 768 ? M : 768);
   UDM_CHECK_ARG(ws_elems >= (int64_t)grid * 3 * d, "udm_norm_residual_bwd: workspace too small (need %ld floats)", (long)grid * 3 * d);
   NormResidBwdArgs a{(const bf16_t*)dy, x, rstd, mean, w, dx, dw, accumulate, (const bf16_t*)branch, (bf16_t*)dbranch, w_b, rstd_b, mean_b, dw_b, dbias, ws,
                      (int)M, (int)d, norm_type, p_drop, seed};
-  if (d == 2048) hipLaunchKernelGGL((norm_residual_bwd_kernel<1>), dim3(grid), dim3(256), 0, stream, a);
+  if (wrow) {
+    switch (nch_for(d)) {
+      case 1: hipLaunchKernelGGL((norm_residual_bwd_wrow_kernel<1>), dim3(grid), dim3(256), 0, stream, a); break;
+      case 2: hipLaunchKernelGGL((norm_residual_bwd_wrow_kernel<2>), dim3(grid), dim3(256), 0, stream, a); break;
+      case 3: hipLaunchKernelGGL((norm_residual_bwd_wrow_kernel<3>), dim3(grid), dim3(256), 0, stream, a); break;
+      default: hipLaunchKernelGGL((norm_residual_bwd_wrow_kernel<4>), dim3(grid), dim3(256), 0, stream, a); break;
+    }
+  } else if (d == 2048) hipLaunchKernelGGL((norm_residual_bwd_kernel<1>), dim3(grid), dim3(256), 0, stream, a);
   else hipLaunchKernelGGL((norm_residual_bwd_kernel<2>), dim3(grid), dim3(256), 0, stream, a);
   UDM_CHECK_LAUNCH("udm_norm_residual_bwd");
   hipLaunchKernelGGL(colreduce3_kernel, dim3((unsigned)((d + 63) / 64), 16, 3), dim3(256), 0, stream, (const float*)ws, dw, w_b ? dw_b : nullptr, dbias, grid, (int)d);

@@ -7,6 +7,8 @@ from __future__ import annotations
 
 from typing import Optional
 
+import os
+
 import torch
 
 from . import _lib
@@ -368,9 +370,10 @@ def residual_bwd(dx, branch, L, *, w_b=None, rstd=None, mean=None, norm_type=NOR
 def norm_residual_bwd(dy, x, rstd, mean, w, norm_type, L, dx, dw, branch, *, accumulate=True, w_b=None, rstd_b=None, mean_b=None, dw_b=None, p_drop=0.0, seed=0,
                       dbias=None):
     """Unmodulated norm backward (dx (+)= ..., dw += ...) followed by the residual-branch backward on the updated dx (returns d branch, bf16; dw_b += ...;
-    dbias += column sums of d branch when given).  One fused pass per row at d = 2048 / 4096, the separate kernels otherwise."""
+    dbias += column sums of d branch when given).  One fused pass per row at d = 2048 / 4096 (block per row) and at d < 2048 (wave per row), the separate
+    kernels otherwise."""
     M, d = x.shape
-    if d in (2048, 4096) and x.is_cuda:
+    if (d in (2048, 4096) or (d < 2048 and d % 8 == 0 and d >= 64)) and x.is_cuda:
         dbranch = torch.empty((M, d), dtype=BF16, device=x.device)
         ws = _scratch(min(M, 1536) * 3 * d, x.device)
         _lib.call("udm_norm_residual_bwd", _p(dy), _p(x), _p(rstd), _p(mean), _p(w), _p(dx), _p(dw), 1 if accumulate else 0, _p(branch), _p(dbranch), _p(w_b),
