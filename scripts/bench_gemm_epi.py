@@ -17,6 +17,7 @@ aux = [torch.rand(M, N, device="cuda", generator=g).to(torch.bfloat16) for _ in 
 bias = torch.zeros(N, dtype=torch.float32, device="cuda")
 cases = [("plain", dict(epilogue=K.EPI_NONE)), ("bias", dict(epilogue=K.EPI_BIAS, bias=bias)), ("bias+gelu", dict(epilogue=K.EPI_BIAS_GELU, bias=bias, aux=True)),
          ("gelu'", dict(epilogue=K.EPI_DGELU, aux=True)), ("gelu'+colsum", dict(epilogue=K.EPI_DGELU, aux=True, bias=bias))]
+K.gemm_set_tile(int(os.environ.get("TILE", "-1")))
 K.gemm_set_quad(0)   # the 8-wave persistent kernel for every case (what the GELU epilogues run on)
 for rnd in range(2):
     for name, kw in cases:
