@@ -81,3 +81,63 @@ def test_bench_flops_per_token_match_survey():
         assert w["desc"] and w["batch"] > 0 and w["txt_length"] + w["img_length"] > 0, name
     b = bench.synthetic_batch("unidisc-1.4b-interleaved-l4608", 2, 0)
     assert b["input_ids"].shape == (2, 4608) and int(b["sample_ids"].max()) == 3 and int((b["modality"] == 1).sum()) == 2 * 4096
+
+
+def test_bench_kernel_timer_samples_launches(monkeypatch):
+    """bench.py brackets 1 GEMM launch in `sample` with events inside the timed region (an event pair per launch costs 1.7 ms per step on the GPU box):
+    every call still reaches the library, the pick is reproducible, about 1 / sample of the GEMM launches is recorded and nothing else is."""
+    import importlib.util
+    import os
+
+    from unidisc_amd import _lib
+
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+
+    class _Ev:
+        def __init__(self, enable_timing=False):
+            pass
+
+        def record(self):
+            pass
+
+        def elapsed_time(self, other):
+            return 0.25
+
+    calls = []
+    monkeypatch.setattr(_lib, "call", lambda name, *a: calls.append(name))
+    monkeypatch.setattr(bench.torch.cuda, "Event", _Ev)
+    picks = []
+    for _ in range(2):
+        calls.clear()
+        t = bench.KernelTimer(sample=8)
+        t.install()
+        t.enabled = True
+        for i in range(800):
+            _lib.call("udm_gemm_nt_bf16", 0, 0, 0, 64, 64, 64)
+            _lib.call("udm_norm_fwd", *([0] * 12))
+        t.uninstall()
+        assert len(calls) == 1600 and t.seen == 800
+        assert 60 <= len(t.records) <= 140 and all(r[2] == "udm_gemm_nt_bf16" for r in t.records)
+        s = t.summary()
+        assert s["launches"] == len(t.records) and s["launches_seen"] == 800 and abs(s["total_ms"] - 0.25 * len(t.records)) < 1e-9
+        assert s["flops"] == 2.0 * 64 ** 3 * len(t.records)
+        picks.append(len(t.records))
+    assert picks[0] == picks[1]   # seeded: the same launches are bracketed on every run (and on every rank)
+    assert _lib.call("x") is None and calls[-1] == "x"   # uninstall restored the plain entry
+
+
+def test_modality_range_check_on_host_batches_is_immediate():
+    """model.py:311: a batch whose `modality` misses a modality (or holds anything but 0 / 1) is refused; on host tensors right away (the deferred form is a
+    device-side optimisation, tests/test_gpu_e2e.py)."""
+    import pytest as _pytest
+
+    from unidisc_amd.diffusion import Diffusion
+
+    d = Diffusion.__new__(Diffusion)
+    d._check_modality_range(torch.tensor([[0, 1, 1], [0, 0, 1]]))
+    for bad in (torch.zeros(2, 3, dtype=torch.int64), torch.tensor([[0, 1, 2]]), torch.ones(1, 4, dtype=torch.int64)):
+        with _pytest.raises(AssertionError):
+            d._check_modality_range(bad)
+    assert not d._checks
