@@ -679,6 +679,10 @@ def _doc_layouts(B, L):
         al[:, :n] = (torch.arange(n) // 256)[None]
         al[B - 1, n - 128:n] = -1
         out["aligned"] = al
+        a64 = torch.zeros(B, L, dtype=torch.int64)                 # documents that start / end on 64-row tiles but not on 128-row blocks, and one that ends off-tile
+        for i, c in enumerate((192, 448, L - 100)):
+            a64[:, c:] = i + 1
+        out["aligned64"] = a64
     return out
 
 

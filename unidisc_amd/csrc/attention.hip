@@ -97,13 +97,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
   bf16x8_t qf[KS];
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) qf[ks] = load_frag_global(a.q + (rowbase + qi) * a.q_stride + h * D + ks * 16 + hi * 8, q_ok);
-  long sid_q = 0;
-  if (HAS_SID) sid_q = q_ok ? a.sample_ids[rowbase + qi] : -1;
   // Touch the Q fragments here so the compiler's wait for their global loads lands BEFORE the loop: inside it the only outstanding
   // vector-memory operations are the inline-asm LDS-DMA refills, which it must not wait for (see DmaStager).
+  // (Sample ids: neither this lane's query id nor the tile's key ids are loaded unless the tile pair needs the element mask - `id_test`, block-uniform,
+  // false for every tile pair inside one document.  Kept live / staged per tile they cost 44 spilled registers and a waited load per key tile:
+  // packed 4 x 1152 rows 139.6 us against 105.7 us for the same work as separate samples.)
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[ks]));
-  if (HAS_SID) asm volatile("" : "+v"(sid_q));
 
   f32x16_t oT[DB];
 #pragma unroll
@@ -121,7 +121,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
   planv.init(a.v_stride, wave, lane);
   const int nkv = (a.L + BKV - 1) / BKV;
   int t_begin = 0, t_end = nkv, blk_id = -1;
-  if (HAS_SID) { const DocSpan sp = doc_tile_span(a.doc_ranges, b, a.L, tile_x, nkv); t_begin = sp.t_begin; t_end = sp.t_end; blk_id = sp.blk_id; }
+  bool doc_pure = false;   // the whole key span of this query block is the block's own document: no tile of the walk needs the element mask (nor its range entry)
+  if (HAS_SID) { const DocSpan sp = doc_tile_span(a.doc_ranges, b, a.L, tile_x, nkv); t_begin = sp.t_begin; t_end = sp.t_end; blk_id = sp.blk_id;
+                 doc_pure = sp.pure && sp.lo % BKV == 0 && (sp.hi % BKV == 0 || sp.hi == a.L); }   // (key tiles are walked from multiples of BKV: the span must start and end on one)
   if (t_begin < t_end) {
     Stg::issue(kbase, a.k_stride, t_begin * BKV, a.L, smem + (t_begin & 1) * TB, wave, lane);
     Stg::issue(vbase, a.v_stride, t_begin * BKV, a.L, smem + (2 + (t_begin & 1)) * TB, wave, lane);
@@ -129,15 +131,18 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
   // One key tile; ST = t & 1 as a compile-time constant, so that every LDS fragment address of the tile is a hoisted per-lane register plus an
   // IMMEDIATE (with the stage picked at run time each of the 48 fragment reads carried its own v_add_u32: 62 of ~370 instructions per tile and wave
   // in a loop that is bound by instruction issue)
-  auto tile = [&](auto st_c, int t) {
+  // IDS = false: the walk of a block whose whole key span is its own document - the tile body is then, instruction for instruction, the one of the kernel
+  // without sample ids (with the id code merely branched around, the same single-document work ran 16 % slower: 127 vs 110 us at B = 8, L = 1152)
+  auto tile = [&](auto st_c, int t, auto ids_c) {
     constexpr int ST = decltype(st_c)::value;
+    constexpr bool IDS = HAS_SID && decltype(ids_c)::value;
     const int kv0 = t * BKV;
     constexpr int st = (ABL & 4) ? 0 : ST;
     const char* Ks = smem + st * TB;
     const char* Vs = smem + (2 + st) * TB;
     const long* sidk = sid_s + st * BKV;
-    const bool id_test = HAS_SID && doc_pair_needs_mask(a.doc_ranges, b, a.L, t, blk_id);   // block-uniform
-    if (HAS_SID && tid < BKV) sid_s[st * BKV + tid] = (kv0 + tid < a.L) ? a.sample_ids[rowbase + kv0 + tid] : -2;
+    const bool id_test = IDS && doc_pair_needs_mask(a.doc_ranges, b, a.L, t, blk_id);   // block-uniform
+    if (IDS && id_test && tid < BKV) sid_s[st * BKV + tid] = (kv0 + tid < a.L) ? a.sample_ids[rowbase + kv0 + tid] : -2;
     if (!(ABL & 4) || t == 0) {
     wait_all_vmem();   // this wave's share of tile t has landed
     __syncthreads();   // ... and everybody's; all waves are also done with tile t-1, so its stage may be refilled
@@ -177,13 +182,15 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
       }
     }
     if (id_test || kv0 + BKV > a.L) {
+      long sid_q = 0;
+      if (IDS && id_test) sid_q = q_ok ? a.sample_ids[rowbase + qi] : -1;
 #pragma unroll
       for (int f = 0; f < 2; ++f)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int kl = f * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
           bool ok = kv0 + kl < a.L;
-          if (HAS_SID) ok = ok && (!id_test || attn_pair_ok(sid_q, sidk[kl]));
+          if (IDS) ok = ok && (!id_test || attn_pair_ok(sid_q, sidk[kl]));
           if (!ok) sT[f][r] = -INFINITY;
         }
     }
@@ -238,15 +245,18 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
       }
     }
   };
-  {
-    int t = t_begin;
-    if (t < t_end && (t & 1)) { tile(std::integral_constant<int, 1>{}, t); ++t; }
-    for (; t + 1 < t_end; t += 2) {
-      tile(std::integral_constant<int, 0>{}, t);
-      tile(std::integral_constant<int, 1>{}, t + 1);
-    }
-    if (t < t_end) tile(std::integral_constant<int, 0>{}, t);
+#define UDM_WALK(IDS_C)                                                                       \
+  {                                                                                            \
+    int t = t_begin;                                                                           \
+    if (t < t_end && (t & 1)) { tile(std::integral_constant<int, 1>{}, t, IDS_C); ++t; }       \
+    for (; t + 1 < t_end; t += 2) {                                                            \
+      tile(std::integral_constant<int, 0>{}, t, IDS_C);                                        \
+      tile(std::integral_constant<int, 1>{}, t + 1, IDS_C);                                    \
+    }                                                                                          \
+    if (t < t_end) tile(std::integral_constant<int, 0>{}, t, IDS_C);                           \
   }
+  if (HAS_SID && !doc_pure) UDM_WALK(std::true_type{}) else UDM_WALK(std::false_type{})
+#undef UDM_WALK
   const float ltot = lsum + __shfl_xor(lsum, 32, 64);
   const float inv = ltot > 0.f ? 1.f / ltot : 0.f;
   if (q_ok && hi == 0) a.lse[((long)b * a.H + h) * a.L + qi] = ltot > 0.f ? __builtin_fmaf(m, c, log2f(ltot)) : INFINITY;
@@ -296,8 +306,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
     qf[ks] = load_frag_global(a.q + (rowbase + qi) * a.q_stride + h * D + ks * 16 + hi * 8, q_ok);
     dof[ks] = load_frag_global(a.dout + (rowbase + qi) * a.do_stride + h * D + ks * 16 + hi * 8, q_ok);
   }
-  long sid_q = 0;
-  if (HAS_SID) sid_q = q_ok ? a.sample_ids[rowbase + qi] : -1;
   const long sidx = ((long)b * a.H + h) * a.L + qi;
   float lse_q = q_ok ? a.lse[sidx] : INFINITY;
   // delta = rowsum(dO * O) of this lane's query, from the dO fragments it holds anyway plus one read of the O row: the lane pair (hi = 0, 1) covers
@@ -316,7 +324,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[ks]), "+v"(dof[ks]));
   asm volatile("" : "+v"(lse_q), "+v"(delta_q));
-  if (HAS_SID) asm volatile("" : "+v"(sid_q));
 
   f32x16_t dqT[DB];
 #pragma unroll
@@ -332,7 +339,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
   planv.init(a.v_stride, wave, lane);
   const int nkv = (a.L + BKV - 1) / BKV;
   int t_begin = 0, t_end = nkv, blk_id = -1;
-  if (HAS_SID) { const DocSpan sp = doc_tile_span(a.doc_ranges, b, a.L, tile_x, nkv); t_begin = sp.t_begin; t_end = sp.t_end; blk_id = sp.blk_id; }
+  bool doc_pure = false;   // (see the forward kernel)
+  if (HAS_SID) { const DocSpan sp = doc_tile_span(a.doc_ranges, b, a.L, tile_x, nkv); t_begin = sp.t_begin; t_end = sp.t_end; blk_id = sp.blk_id;
+                 doc_pure = sp.pure && sp.lo % BKV == 0 && (sp.hi % BKV == 0 || sp.hi == a.L); }
   if (t_begin < t_end) {
     Stg::issue(kbase, a.k_stride, t_begin * BKV, a.L, smem + (t_begin & 1) * TB, wave, lane);
     Stg::issue(vbase, a.v_stride, t_begin * BKV, a.L, smem + (2 + (t_begin & 1)) * TB, wave, lane);
@@ -344,8 +353,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
     const char* Ks = smem + st * TB;
     const char* Vs = smem + (2 + st) * TB;
     const long* sidk = sid_s + st * BKV;
-    const bool id_test = HAS_SID && doc_pair_needs_mask(a.doc_ranges, b, a.L, t, blk_id);   // block-uniform
-    if (HAS_SID && tid < BKV) sid_s[st * BKV + tid] = (kv0 + tid < a.L) ? a.sample_ids[rowbase + kv0 + tid] : -2;
+    const bool id_test = HAS_SID && !doc_pure && doc_pair_needs_mask(a.doc_ranges, b, a.L, t, blk_id);   // block-uniform
+    if (HAS_SID && id_test && tid < BKV) sid_s[st * BKV + tid] = (kv0 + tid < a.L) ? a.sample_ids[rowbase + kv0 + tid] : -2;   // (see the forward)
     wait_all_vmem();   // this wave's share of tile t has landed
     __syncthreads();   // ... and everybody's; all waves are also done with tile t-1, so its stage may be refilled
     if (t + 1 >= t_end) {
@@ -371,6 +380,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
       // per-element masks only for document masks and the ragged last tile: full tiles have no out-of-range keys, and an out-of-range
       // QUERY has lse = +inf (p = 0) and zero operands
       if (id_test || kv0 + BKV > a.L) {
+        long sid_q = 0;
+        if (HAS_SID && id_test) sid_q = q_ok ? a.sample_ids[rowbase + qi] : -1;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int kl = f * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
