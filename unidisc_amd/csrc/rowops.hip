@@ -1408,6 +1408,95 @@ __global__ __launch_bounds__(256) void qknorm_rope_fwd_brow_kernel(QkArgs a) {
   }
 }
 
+// d = 2048 (one item per thread): R rows per block iteration.  The kernel is bound by bytes in flight, not by bandwidth: with one row per iteration and
+// 32 KB of LDS for the affine vectors, 5 blocks per CU hold 5 x 8 KB of loads in flight - at ~3 us of loaded memory latency that is 3.4 TB/s, what was
+// measured.  Here a thread keeps the affine values of its 16 columns in registers (they are the same for every row: no LDS at all), and every iteration
+// loads R rows before the first reduction, so the two block-wide reductions of a row are shared by R rows as well.
+template <int R>
+__global__ __launch_bounds__(256) void qknorm_rope_fwd_brow_rows_kernel(QkArgs a) {
+  __shared__ float sm[4 * 2 * R];
+  const int tid = threadIdx.x;
+  const int half = a.D / 2, per_head = a.D / 16, per_part = a.d / 16;
+  const bool do_norm = a.gq != nullptr;
+  const int part = tid / per_part, r = tid % per_part;   // 2 * per_part == 256
+  const int hc = (r / per_head) * a.D + (r % per_head) * 8;
+  const int pc = (r % per_head) * 8;
+  const int c = part * a.d + hc;
+  float g0[8], g1[8], b0[8], b1[8];
+  if (do_norm) {
+    const float* g = part ? a.gk : a.gq;
+    const float* bb = part ? a.bk : a.bq;
+    load8_f32(g + hc, g0); load8_f32(g + hc + half, g1); load8_f32(bb + hc, b0); load8_f32(bb + hc + half, b1);
+  }
+  for (long row0 = (long)blockIdx.x * R; row0 < a.M; row0 += (long)gridDim.x * R) {
+    float lo[R][8], hi[R][8];
+    float s[2 * R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+      const long row = row0 + j < a.M ? row0 + j : a.M - 1;   // (a ragged last group recomputes the last row: same values, benign)
+      load8_bf16(a.qkv + row * 3 * a.d + c, lo[j]);
+      load8_bf16(a.qkv + row * 3 * a.d + c + half, hi[j]);
+    }
+    float mrow[R], rrow[R];
+    if (do_norm) {
+#pragma unroll
+      for (int j = 0; j < R; ++j) {
+        float u = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) u += lo[j][k] + hi[j][k];
+        s[2 * j + part] = u;
+        s[2 * j + (part ^ 1)] = 0.f;
+      }
+      block_sum4<2 * R>(s, sm);
+      float v[2 * R];
+#pragma unroll
+      for (int j = 0; j < R; ++j) {
+        const float m = s[2 * j + part] / a.d;
+        mrow[j] = m;
+        float u = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { float x = lo[j][k] - m, y = hi[j][k] - m; u += x * x + y * y; }
+        v[2 * j + part] = u;
+        v[2 * j + (part ^ 1)] = 0.f;
+      }
+      block_sum4<2 * R>(v, sm);
+#pragma unroll
+      for (int j = 0; j < R; ++j) {
+        rrow[j] = rsqrtf(v[2 * j + part] / a.d + a.eps);
+        if (tid == 0 && row0 + j < a.M)
+          *reinterpret_cast<float4*>(a.stats + (row0 + j) * 4) = make_float4(s[2 * j] / a.d, rsqrtf(v[2 * j] / a.d + a.eps), s[2 * j + 1] / a.d, rsqrtf(v[2 * j + 1] / a.d + a.eps));
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+      if (row0 + j >= a.M) break;
+      const long row = row0 + j;
+      const long trow = a.rope_per_sample ? row : (row % a.L);
+      float xl[8], xh[8];
+      if (do_norm) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          xl[k] = rbf((lo[j][k] - mrow[j]) * rrow[j] * g0[k] + b0[k]);
+          xh[k] = rbf((hi[j][k] - mrow[j]) * rrow[j] * g1[k] + b1[k]);
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { xl[k] = lo[j][k]; xh[k] = hi[j][k]; }
+      }
+      float cs[8], sn[8], ol[8], oh[8];
+      load8_f32(a.cos_t + trow * half + pc, cs);
+      load8_f32(a.sin_t + trow * half + pc, sn);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        ol[k] = xl[k] * cs[k] - xh[k] * sn[k];
+        oh[k] = xh[k] * cs[k] + xl[k] * sn[k];
+      }
+      store8_bf16(a.qkr + row * 2 * a.d + part * a.d + hc, ol);
+      store8_bf16(a.qkr + row * 2 * a.d + part * a.d + hc + half, oh);
+    }
+  }
+}
+
 template <int NIB>
 __global__ __launch_bounds__(256) void qknorm_rope_bwd_brow_kernel(QkBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float aff[];  // gq | gk
@@ -1703,6 +1792,13 @@ extern "C" int udm_qknorm_rope_fwd(const void* qkv, void* qkr, const float* gq, 
   UDM_CHECK_ARG(nit <= 8, "udm_qknorm_rope_fwd: hidden size too large");
   const int nch = nit <= 1 ? 1 : (nit == 2 ? 2 : (nit == 3 ? 3 : (nit == 4 ? 4 : 8)));
   const size_t lds = gq ? (size_t)4 * d * sizeof(float) : 0;
+  if (d == 2048) {   // two rows per block iteration, 1024 blocks (in the step: 1.08-1.10 ms against 1.22-1.24 for one row per iteration; 3 rows 1.18, 4 rows 1.41)
+    const long groups = (M + 1) / 2;
+    const int g = (int)(groups < 1024 ? groups : 1024);
+    hipLaunchKernelGGL((qknorm_rope_fwd_brow_rows_kernel<2>), dim3(g), dim3(256), 0, stream, a);
+    UDM_CHECK_LAUNCH("udm_qknorm_rope_fwd");
+    return 0;
+  }
   if (d >= 2048 && d <= 4096) {
     const int g = (int)(M < 2048 ? M : 2048);
     if (d <= 2048) hipLaunchKernelGGL((qknorm_rope_fwd_brow_kernel<1>), dim3(g), dim3(256), lds, stream, a);
