@@ -341,7 +341,7 @@ def main():
     ap.add_argument("--fp8-attention", action="store_true", help="attention forward through the fp8 kernel (config E option; changes numerics, not the headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
-    ap.add_argument("--time-every", type=int, default=8, help="bracket 1 GEMM launch in this many with HIP events inside the timed region (1 = all: costs ~1.7 ms/step)")
+    ap.add_argument("--time-every", type=int, default=16, help="bracket 1 GEMM launch in this many with HIP events inside the timed region (1 = all: costs ~1.7 ms/step)")
     ap.add_argument("--table-steps", type=int, default=2, help="extra untimed steps after the timed region with every launch event-timed (roofline_table); 0 = off")
     args = ap.parse_args()
 
