@@ -160,6 +160,12 @@ int udm_subs_ce_bwd(void* logits, int64_t ld, const int64_t* x0, const int64_t* 
 int udm_subs_logprobs(const void* logits, int64_t ld, const int64_t* xt, const int64_t* modality, void* out, int64_t ld_out, int out_f32, int64_t M, int64_t V,
                       int64_t Vt, int64_t mask_id, int restrict_modality, hipStream_t stream);
 
+/* ---- loss arithmetic behind the per-token log-probabilities: Diffusion.compute_loss model.py:1010-1160 (schedule weights applied per row, masked mean or the
+ * modality-weighted text / image sum with the optional text-loss cap); nlls = -log_p w_std on attended tokens, coef = d loss / d log_p,
+ * scalars = {loss, txt_loss, img_loss, txt_frac, img_frac, valid_frac, txt_count, img_count}.  attention_mask: bool [B, L]; modality_mask: bool [B, L, 2] or NULL */
+int udm_diffusion_loss(const float* log_p, const float* w_loss, const float* w_std, const void* attention_mask, const void* modality_mask, float* nlls, float* coef,
+                       float* scalars, int64_t B, int64_t L, int weighted, int full_mask, float text_w, float img_w, float ratio, hipStream_t stream);
+
 /* ---- adaLN-Zero helpers: TimestepEmbedder models/dit.py:415-449, F.silu :1379 ------------------------- */
 int udm_timestep_embedding(const float* sigma, void* out, int64_t B, int64_t dim, hipStream_t stream);
 int udm_silu_fwd(const void* x, void* y, int64_t n, hipStream_t stream);

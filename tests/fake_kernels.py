@@ -345,6 +345,40 @@ def subs_ce_bwd(logits, x0, xt, modality, lse, g, V, Vt, mask_id, restrict):
     logits[:, :V] = dl.bfloat16()
 
 
+@torch.enable_grad()
+def diffusion_loss(log_p, w_loss, w_std, attention_mask, modality_mask, *, weighted, full_mask=False, text_w=1.0, img_w=1.0, ratio=None):
+    """CPU double of udm_diffusion_loss: the reference's own sequence of tensor statements (model.py:1010-1160), d loss / d log_p through autograd."""
+    lp = log_p.detach().clone().requires_grad_()
+    loss = -lp * w_loss[:, None]
+    nlls = (-log_p * w_std[:, None]) * attention_mask
+    sc = torch.zeros(8, dtype=torch.float32, device=log_p.device)
+    if modality_mask is not None:
+        txt_mask, img_mask = modality_mask[..., 0] & attention_mask, modality_mask[..., 1] & attention_mask
+        txt_count, img_count = txt_mask.sum(), img_mask.sum()
+        total = txt_count + img_count
+        txt_frac, img_frac = txt_count / total, img_count / total
+        sc[3], sc[4], sc[6], sc[7] = txt_frac, img_frac, txt_count, img_count
+    sc[5] = attention_mask.sum() / attention_mask.numel()
+    if weighted:
+        loss = loss * attention_mask
+        txt_loss = ((loss * txt_mask).sum() / txt_count) * txt_frac * text_w
+        img_loss = ((loss * img_mask).sum() / img_count) * img_frac * img_w
+        if ratio is not None:
+            max_txt_loss = float(ratio) * img_loss.detach()
+            scale = torch.minimum(torch.tensor(1.0, device=txt_loss.device), max_txt_loss / (txt_loss.detach() + 1e-8))
+            ok = ~(torch.isnan(img_loss.detach()) | torch.isnan(txt_loss.detach()))
+            txt_loss = txt_loss * torch.where(ok, scale, torch.ones_like(scale))
+        txt_loss, img_loss = torch.nan_to_num(txt_loss, nan=0.0), torch.nan_to_num(img_loss, nan=0.0)
+        total_loss = txt_loss + img_loss
+        sc[1], sc[2] = txt_loss.detach(), img_loss.detach()
+    else:
+        am = torch.ones_like(attention_mask) if full_mask else attention_mask
+        total_loss = torch.nan_to_num((loss * am).sum() / am.sum(), nan=0.0)
+    sc[0] = total_loss.detach()
+    (coef,) = torch.autograd.grad(total_loss, lp)
+    return nlls.float(), coef.float(), sc
+
+
 def timestep_embedding(sigma, out, B, dim=256):
     half = dim // 2
     freqs = torch.exp(-math.log(10000) * torch.arange(0, half, dtype=torch.float32) / half)

@@ -873,3 +873,49 @@ def test_error_reporting(K):
         K.gemm_nt(a, a)
     with pytest.raises(RuntimeError, match="GPU tensors"):
         K.gemm_nt(torch.zeros(8, 8, dtype=torch.bfloat16), torch.zeros(8, 8, dtype=torch.bfloat16))
+
+
+@pytest.mark.parametrize("case", ["weighted", "weighted_cap", "weighted_no_image", "mean", "mean_full_mask", "mean_no_modality", "all_padding"])
+def test_diffusion_loss_kernel_matches_the_tensor_statements(K, case):
+    """udm_diffusion_loss (the loss arithmetic of compute_loss in one launch) against the reference's own sequence of tensor statements (fake_kernels.diffusion_loss,
+    gradient through autograd): value, text / image terms, fractions, per-token NLLs and d loss / d log_p, including the NaN -> 0 conventions of an empty modality."""
+    import fake_kernels
+
+    B, L = 6, 200
+    g = torch.Generator().manual_seed(11)
+    log_p = -torch.rand(B, L, generator=g) * 9
+    sigma = torch.rand(B, generator=g) * 3 + 0.05
+    dsigma = 1 + torch.rand(B, generator=g)
+    w_std, w_loss = dsigma / torch.expm1(sigma), dsigma / (torch.expm1(sigma) + 0.2)
+    att = torch.rand(B, L, generator=g) < 0.9
+    is_img = torch.zeros(B, L, dtype=torch.bool)
+    is_img[:, 72:] = True
+    kw = dict(weighted=case.startswith("weighted"), text_w=0.7, img_w=1.3)
+    if case == "weighted_cap":
+        kw["ratio"] = 0.25
+    if case == "weighted_no_image":
+        is_img[:] = False
+    if case == "mean_full_mask":
+        kw["full_mask"] = True
+    if case == "all_padding":
+        att[:] = False
+        kw["weighted"] = False
+    mm = None if case == "mean_no_modality" else torch.stack([~is_img, is_img], -1)
+    n_r, c_r, s_r = fake_kernels.diffusion_loss(log_p, w_loss, w_std, att, mm, **kw)
+    dev = lambda t: t.to(DEV) if t is not None else None
+    n, c, s = K.diffusion_loss(dev(log_p), dev(w_loss), dev(w_std), dev(att), dev(mm), **kw)
+    n, c, s = n.cpu(), c.cpu(), s.cpu()
+    assert torch.allclose(n, n_r, rtol=1e-6, atol=0)
+    used = [0, 5] + ([1, 2] if kw["weighted"] else []) + ([3, 4, 6, 7] if mm is not None and case != "all_padding" else [])
+    assert torch.allclose(s[used], s_r[used], rtol=2e-6, atol=1e-7), (s, s_r)
+    assert torch.isfinite(s[0]) and torch.isfinite(c).all()
+    if case == "weighted_no_image":
+        # the empty modality contributes 0 (nan_to_num) and the other one is untouched; the tensor statements propagate 0 x inf = NaN into EVERY token's gradient
+        # here (the backward of a sum divided by a zero count) - the kernel deliberately returns the finite gradient of the non-empty term instead
+        assert float(s[2]) == 0.0 and float(s[1]) > 0.0 and torch.isnan(c_r).all()
+        n_txt = float((att & ~is_img).sum())
+        assert torch.allclose(c, -(w_loss[:, None] * att) * (0.7 / n_txt), rtol=2e-6, atol=0)
+    elif case == "all_padding":
+        assert float(s[0]) == 0.0 and float(c.abs().max()) == 0.0 and torch.isnan(c_r).all()   # (same remark: 0 / 0 -> loss 0, gradient 0 instead of NaN)
+    else:
+        assert torch.allclose(c, c_r, rtol=2e-6, atol=1e-10)

@@ -543,6 +543,24 @@ def subs_logprobs(logits, xt, modality, V, Vt, mask_id, restrict, out_dtype=BF16
     return out
 
 
+def diffusion_loss(log_p, w_loss, w_std, attention_mask, modality_mask, *, weighted, full_mask=False, text_w=1.0, img_w=1.0, ratio=None):
+    """The loss arithmetic of compute_loss in one launch: (nlls [B, L], coef [B, L] = d loss / d log_p, scalars [8] = loss, txt_loss, img_loss, txt_frac,
+    img_frac, valid_frac, txt_count, img_count).  log_p fp32 [B, L]; w_loss / w_std fp32 [B] (weights of the optimised loss and of the reported NLLs);
+    attention_mask bool [B, L]; modality_mask bool [B, L, 2] (text, image) or None."""
+    _chk(log_p, F32, "diffusion_loss log_p"), _chk(w_loss, F32, "diffusion_loss w_loss"), _chk(w_std, F32, "diffusion_loss w_std")
+    B, L = log_p.shape
+    att = attention_mask.contiguous()
+    mm = modality_mask.contiguous() if modality_mask is not None else None
+    if att.dtype != torch.bool or (mm is not None and mm.dtype != torch.bool):
+        raise TypeError("diffusion_loss: masks must be bool tensors")
+    nlls = torch.empty((B, L), dtype=F32, device=log_p.device)
+    coef = torch.empty((B, L), dtype=F32, device=log_p.device)
+    scalars = torch.empty(8, dtype=F32, device=log_p.device)
+    _lib.call("udm_diffusion_loss", _p(log_p.contiguous()), _p(w_loss.contiguous()), _p(w_std.contiguous()), _p(att), _p(mm), _p(nlls), _p(coef), _p(scalars), B, L,
+              1 if weighted else 0, 1 if full_mask else 0, float(text_w), float(img_w), -1.0 if ratio is None else float(ratio), _s())
+    return nlls, coef, scalars
+
+
 def timestep_embedding(sigma, out, B, dim=256):
     _lib.call("udm_timestep_embedding", _p(sigma), _p(out), B, dim, _s())
 
