@@ -9,6 +9,7 @@ Mask indices (xt, move_indices, token_mask) must be bit-exact.
 import pytest
 import torch
 
+import unidisc_amd.diffusion as diff_mod
 from golden_utils import CASE_NAMES, Golden, rel_err
 from ledger import check, record
 from oracle import unidisc_oracle as O
@@ -255,3 +256,26 @@ def test_modality_range_check_is_deferred_but_still_raises():
     with pytest.raises(AssertionError):
         diff.training_step({k: v for k, v in bad.items() if k in ("input_ids", "attention_mask", "modality")}, 2)
     assert not diff._checks
+
+
+def test_update_batch_device_token_batches_take_the_fused_assembly():
+    """A token batch that is already on the device in the dataset's dtypes is assembled by one launch (tokens.hip) instead of the reference's tensor statements:
+    same joint ids, attention mask, modality map and derived fields, bit for bit, as the host batch that goes through the statements."""
+    g = Golden("c_large")
+    diff = build_product(g, DEV)
+    host = g.batch()
+    assert host["txt_input_ids"].dtype == torch.int32 and host["img_input_ids"].dtype == torch.int16
+    a = diff.update_batch(host)
+    calls = []
+    orig = diff_mod.K.assemble_joint_tokens
+    diff_mod.K.assemble_joint_tokens = lambda *args, **kw: (calls.append(1), orig(*args, **kw))[1]
+    try:
+        b = diff.update_batch({k: (v.to(DEV) if isinstance(v, torch.Tensor) else v) for k, v in host.items()})
+    finally:
+        diff_mod.K.assemble_joint_tokens = orig
+    diff._flush_checks()
+    assert calls == [1]
+    assert set(a) == set(b)
+    for k in a:
+        if isinstance(a[k], torch.Tensor):
+            assert a[k].dtype == b[k].dtype and torch.equal(a[k].cpu(), b[k].cpu()), k

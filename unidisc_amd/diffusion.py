@@ -150,7 +150,10 @@ class Diffusion:
             return batch
         batch = dict(batch.items()) if not isinstance(batch, dict) else dict(batch)
         if self.image_model or cfg_get(cfg_get(cfg, "data"), "force_image_dataset", False):
-            if "txt_input_ids" in batch or "img_input_ids" in batch:  # :183-212
+            fused = self._assemble_on_device(batch, tr, m)
+            if fused:
+                pass
+            elif "txt_input_ids" in batch or "img_input_ids" in batch:  # :183-212
                 for key in ("img_input_ids", "txt_input_ids", "sample_ids"):
                     if key in batch:
                         if isinstance(batch[key], list):
@@ -215,6 +218,24 @@ class Diffusion:
         if cfg_get(tr, "interleaved", False) and "sample_ids" not in batch:
             batch["sample_ids"] = torch.zeros_like(batch["modality"], dtype=torch.int64)
         return batch
+
+    def _assemble_on_device(self, batch, tr, m):
+        """model.py:183-212 for a token batch that is already on the device in the dataset's own dtypes (int32 text, int16 image ids, bool text mask): joint ids
+        (image ids shifted by the text vocabulary), attention mask (text mask | ones) and modality map in ONE launch (tokens.hip, the TokenBatcher's kernel) instead
+        of nine tensor statements.  Same values bit for bit; `txt_input_ids` stays in the batch as int64 like in the reference."""
+        txt, img, tm = batch.get("txt_input_ids"), batch.get("img_input_ids"), batch.get("txt_attention_mask")
+        ok = (isinstance(txt, torch.Tensor) and isinstance(img, torch.Tensor) and isinstance(tm, torch.Tensor) and txt.is_cuda and img.is_cuda and tm.is_cuda
+              and txt.dtype == torch.int32 and img.dtype == torch.int16 and tm.dtype == torch.bool and txt.dim() == 2 and img.dim() == 2 and tm.shape == txt.shape
+              and txt.is_contiguous() and img.is_contiguous() and tm.is_contiguous() and txt.shape[0] == img.shape[0]
+              and "modality" not in batch and "sample_ids" not in batch and "attention_mask" not in batch and "input_ids" not in batch
+              and not cfg_get(tr, "ignore_text_in_unified", False) and cfg_get(m, "txt_length") > 0 and cfg_get(m, "img_length") > 0)
+        if not ok:
+            return False
+        ids, mask, modality = K.assemble_joint_tokens(txt, tm, img, self.text_vocab_size)
+        batch.pop("img_input_ids")
+        batch["txt_input_ids"] = txt.to(torch.int64)
+        batch["input_ids"], batch["attention_mask"], batch["modality"] = ids, mask, modality
+        return True
 
     _checks = ()   # queued device-side batch checks: (event, pinned result)
 
