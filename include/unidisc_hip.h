@@ -199,6 +199,11 @@ int udm_categorical_sample_rows(const void* logits, const void* logits_uncond, c
  * int64 (0 text / 1 image).  The caller guarantees 0 <= idx[b] < n. */
 int udm_assemble_joint_tokens(const int32_t* txt, const uint8_t* txt_mask, const int16_t* img, const int64_t* idx, int64_t B, int64_t Lt, int64_t Li,
                               int64_t Vt, int64_t* ids, uint8_t* mask, int64_t* modality, hipStream_t stream);
+/* q_xt model.py:424-587 for multimodal (non-interleaved) batches after its random draws: move = r_move < move_chance[b], whole-modality masking (a row drawn for both
+ * modalities masks neither), xt = move ? mask_id : x; outputs bool [B, L] move_indices and bool [B] rows (text masked, image masked, either).  r_txt / r_img NULL: no draw. */
+int udm_qxt_absorbing(const int64_t* x, const float* r_move, const float* move_chance, const float* r_txt, const float* r_img, float thr_txt, float thr_img,
+                      const void* modality_mask, int64_t B, int64_t L, int64_t mask_id, int64_t* xt, void* move_indices, void* row_txt, void* row_img, void* row_ignore,
+                      hipStream_t stream);
 
 /* ---- optimizer step: torch.optim.AdamW(fused=True) `model_setup.py:385-424` + accelerator.clip_grad_norm_ `model.py:1516-1520`.
  * fp32 masters and moments; `step` is the 1-based update count (bias corrections are computed from it); `grad_norm_sq` (nullable) is a DEVICE

@@ -514,6 +514,22 @@ def categorical_sample_rows(logits, V, Vt, mask_id, *, modality=None, restrict=F
 
 
 # ------------------------------------------------------------------------------------------------ token data path (csrc/tokens.hip)
+def qxt_absorbing(x, r_move, move_chance, mask_id, *, r_txt=None, r_img=None, p_txt=0.0, p_img=0.0, modality_mask=None):
+    """CPU double of udm_qxt_absorbing: the reference's statements (model.py:424-587, multimodal non-interleaved branch)"""
+    move = r_move < move_chance.reshape(-1, 1)
+    txt = img = ign = None
+    if r_txt is not None or r_img is not None:
+        txt = (r_txt < p_txt) if r_txt is not None else torch.zeros((x.shape[0], 1), dtype=torch.bool, device=x.device)
+        img = (r_img < p_img) if r_img is not None else torch.zeros((x.shape[0], 1), dtype=torch.bool, device=x.device)
+        both = txt & img
+        txt = torch.where(both, False, txt)
+        img = torch.where(both, False, img)
+        move = torch.where(txt, modality_mask[..., 0], move)
+        move = torch.where(img, modality_mask[..., 1], move)
+        ign = img | txt
+    return torch.where(move, mask_id, x), move, txt, img, ign
+
+
 def assemble_joint_tokens(txt, txt_mask, img, Vt, idx=None):
     if idx is not None:
         txt, img = txt[idx], img[idx]

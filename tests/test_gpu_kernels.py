@@ -919,3 +919,40 @@ def test_diffusion_loss_kernel_matches_the_tensor_statements(K, case):
         assert float(s[0]) == 0.0 and float(c.abs().max()) == 0.0 and torch.isnan(c_r).all()   # (same remark: 0 / 0 -> loss 0, gradient 0 instead of NaN)
     else:
         assert torch.allclose(c, c_r, rtol=2e-6, atol=1e-10)
+
+
+@pytest.mark.parametrize("draws", ["none", "txt_only", "both"])
+def test_qxt_absorbing_kernel_matches_the_tensor_statements(K, draws):
+    """udm_qxt_absorbing (q_xt after its random draws, one launch) against the reference's statements: bit-identical xt, move_indices and per-row flags,
+    including rows drawn for both modalities (which mask neither) and draws that sit exactly on the fp32-rounded threshold."""
+    import fake_kernels
+
+    B, L, mask_id = 64, 333, 4242
+    g = torch.Generator().manual_seed(5)
+    x = torch.randint(0, 4000, (B, L), generator=g)
+    r_move = torch.rand(B, L, generator=g)
+    mc = torch.rand(B, 1, generator=g)
+    r_move[3, :7] = mc[3]                      # equality: `<` must stay strict
+    mm = torch.zeros(B, L, 2, dtype=torch.bool)
+    mm[:, :100, 0] = True
+    mm[:, 100:, 1] = True
+    p = 0.3
+    r_txt = r_img = None
+    kw = {}
+    if draws != "none":
+        r_txt = torch.rand(B, 1, generator=g)
+        r_txt[0] = torch.tensor(p / 2 if draws == "both" else p, dtype=torch.float32)   # exactly the threshold as the comparison sees it: not masked
+        kw = dict(r_txt=r_txt, p_txt=p if draws == "txt_only" else p / 2, modality_mask=mm)
+        if draws == "both":
+            r_img = torch.rand(B, 1, generator=g)
+            r_txt[1], r_img[1] = 0.0, 0.0                                                  # drawn for both: neither
+            kw.update(r_img=r_img, p_img=p / 2)
+    ref = fake_kernels.qxt_absorbing(x, r_move, mc, mask_id, **kw)
+    dev = {k: (v.to(DEV) if isinstance(v, torch.Tensor) else v) for k, v in kw.items()}
+    out = K.qxt_absorbing(x.to(DEV), r_move.to(DEV), mc.to(DEV), mask_id, **dev)
+    for a, b in zip(out, ref):
+        assert (a is None) == (b is None)
+        if a is not None:
+            assert a.dtype == b.dtype and a.shape == b.shape and torch.equal(a.cpu(), b)
+    if draws == "both":
+        assert not bool(out[2][1]) and not bool(out[3][1]) and not bool(out[4][1])

@@ -46,3 +46,45 @@ extern "C" int udm_assemble_joint_tokens(const int32_t* txt, const uint8_t* txt_
   UDM_CHECK_LAUNCH("udm_assemble_joint_tokens");
   return 0;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Absorbing-state forward process for multimodal (non-interleaved) batches, q_xt model.py:424-587, AFTER its random draws (which stay torch.rand calls in the
+// reference's order): move = r_move < move_chance[b]; whole-modality masking - a row drawn for text AND image masks neither; a row drawn for one modality
+// moves exactly that modality's positions; xt = move ? [MASK] : x.  Thirteen tensor statements on [B, L] / [B, 1] in the reference, comparisons and selects
+// only: the fused form is bit-identical by construction.  thr_* are the thresholds already rounded to fp32 (what `tensor < python_float` compares with).
+// ---------------------------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void qxt_absorbing_kernel(const int64_t* __restrict__ x, const float* __restrict__ r_move, const float* __restrict__ move_chance,
+                                                            const float* __restrict__ r_txt, const float* __restrict__ r_img, float thr_txt, float thr_img,
+                                                            const uint8_t* __restrict__ mm, int L, int64_t mask_id, int64_t* __restrict__ xt,
+                                                            uint8_t* __restrict__ move, uint8_t* __restrict__ row_txt, uint8_t* __restrict__ row_img,
+                                                            uint8_t* __restrict__ row_ignore) {
+  const int b = blockIdx.y;
+  const int l = blockIdx.x * 256 + threadIdx.x;
+  bool mt = false, mi = false;
+  if (r_txt) mt = r_txt[b] < thr_txt;
+  if (r_img) mi = r_img[b] < thr_img;
+  const bool both = mt && mi;
+  if (both) { mt = false; mi = false; }
+  if (blockIdx.x == 0 && threadIdx.x == 0 && row_txt) { row_txt[b] = mt; row_img[b] = mi; row_ignore[b] = mt || mi; }
+  if (l >= L) return;
+  const long o = (long)b * L + l;
+  bool mv = r_move[o] < move_chance[b];
+  if (mt) mv = mm[2 * o] != 0;
+  if (mi) mv = mm[2 * o + 1] != 0;
+  move[o] = mv;
+  xt[o] = mv ? mask_id : x[o];
+}
+}  // namespace
+
+extern "C" int udm_qxt_absorbing(const int64_t* x, const float* r_move, const float* move_chance, const float* r_txt, const float* r_img, float thr_txt,
+                                 float thr_img, const void* modality_mask, int64_t B, int64_t L, int64_t mask_id, int64_t* xt, void* move_indices, void* row_txt,
+                                 void* row_img, void* row_ignore, hipStream_t stream) {
+  UDM_CHECK_ARG(x && r_move && move_chance && xt && move_indices && B > 0 && L > 0, "udm_qxt_absorbing: bad arguments");
+  UDM_CHECK_ARG((!r_txt && !r_img) || (modality_mask && row_txt && row_img && row_ignore), "udm_qxt_absorbing: whole-modality masking needs the modality mask and the row outputs");
+  UDM_CHECK_ARG(B <= 65535, "udm_qxt_absorbing: batch of %lld rows not supported", (long long)B);
+  hipLaunchKernelGGL(qxt_absorbing_kernel, dim3((unsigned)((L + 255) / 256), (unsigned)B), dim3(256), 0, stream, x, r_move, move_chance, r_txt, r_img, thr_txt, thr_img,
+                     (const uint8_t*)modality_mask, (int)L, mask_id, xt, (uint8_t*)move_indices, (uint8_t*)row_txt, (uint8_t*)row_img, (uint8_t*)row_ignore);
+  UDM_CHECK_LAUNCH("udm_qxt_absorbing");
+  return 0;
+}

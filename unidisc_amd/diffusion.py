@@ -284,10 +284,31 @@ class Diffusion:
         tr = cfg_get(self.config, "trainer")
         if mask_image_square or mask_text_region:
             raise NotImplementedError("unidisc_amd: square / region masking are evaluation-time options outside the hot path")
-        move_indices = self._rand(*x.shape, device=x.device) < move_chance
+        r_move = self._rand(*x.shape, device=x.device)
+        mask_prob = cfg_get(tr, "mask_entire_modality", None)
+        whole = mask_prob is not None and self.backbone.training
+        if (allow_move_mask is None and cfg_get(tr, "discrete_diffusion_mode", "absorbing") == "absorbing" and x.dim() == 2 and x.dtype == torch.int64
+                and move_chance.numel() == x.shape[0] and cfg_get(tr, "joint_ar_nar_prob", None) is None and cfg_get(tr, "first_token_dropout", None) is None
+                and (not whole or (cfg_get(tr, "multimodal_batches", False) and not cfg_get(tr, "interleaved", False)))):
+            # the statements below (comparisons and selects on [B, L] / [B, 1]) as ONE launch; the random draws stay here, in the reference's order
+            r_txt = r_img = None
+            p_txt = p_img = 0.0
+            if whole:
+                assert batch is not None
+                if cfg_get(tr, "mask_txt_only", False):
+                    r_txt, p_txt = self._rand(x.shape[0], 1, device=x.device), mask_prob
+                else:
+                    r_txt, p_txt = self._rand(x.shape[0], 1, device=x.device), mask_prob / 2
+                    r_img, p_img = self._rand(x.shape[0], 1, device=x.device), mask_prob / 2
+            xt, move_indices, should_mask_txt, should_mask_img, ignore = K.qxt_absorbing(
+                x.contiguous(), r_move.float().contiguous(), move_chance.float(), self.mask_index, r_txt=r_txt, r_img=r_img, p_txt=p_txt, p_img=p_img,
+                modality_mask=batch["modality_mask"].contiguous() if whole else None)
+            if return_ignore_batch_mask_for_metrics:
+                return xt, ignore, None, should_mask_txt, should_mask_img, move_indices
+            return xt
+        move_indices = r_move < move_chance
         ignore_batch_mask_for_metrics = None
         should_mask_txt, should_mask_img = None, None
-        mask_prob = cfg_get(tr, "mask_entire_modality", None)
         if mask_prob is not None and self.backbone.training:
             assert batch is not None
             batch_size, seq_len = x.shape

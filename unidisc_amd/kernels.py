@@ -175,6 +175,29 @@ def assemble_joint_tokens(txt, txt_mask, img, Vt, idx=None):
     return ids, mask, modality
 
 
+def qxt_absorbing(x, r_move, move_chance, mask_id, *, r_txt=None, r_img=None, p_txt=0.0, p_img=0.0, modality_mask=None):
+    """q_xt after its random draws, multimodal non-interleaved batches: (xt int64 [B, L], move_indices bool [B, L], should_mask_txt, should_mask_img, ignore: bool [B, 1]
+    or None without whole-modality draws).  x int64 [B, L]; r_move fp32 [B, L]; move_chance fp32 [B] / [B, 1]; r_txt / r_img fp32 [B, 1]; modality_mask bool [B, L, 2]."""
+    B, L = x.shape
+    _chk(r_move, F32, "qxt_absorbing r_move"), _chk(move_chance, F32, "qxt_absorbing move_chance")
+    if x.dtype != torch.int64 or not x.is_contiguous() or not r_move.is_contiguous() or move_chance.numel() != B:
+        raise TypeError("qxt_absorbing: x must be contiguous int64 [B, L], r_move contiguous fp32 [B, L], move_chance one value per row")
+    xt = torch.empty_like(x)
+    move = torch.empty((B, L), dtype=torch.bool, device=x.device)
+    rows = None
+    if r_txt is not None or r_img is not None:
+        if modality_mask is None or modality_mask.dtype != torch.bool or not modality_mask.is_contiguous() or modality_mask.shape != (B, L, 2):
+            raise TypeError("qxt_absorbing: whole-modality masking needs a contiguous bool modality_mask [B, L, 2]")
+        rows = torch.empty((3, B, 1), dtype=torch.bool, device=x.device)
+    thr = lambda p: float(torch.tensor(p, dtype=torch.float32))   # `tensor < python_float` compares with the scalar rounded to the tensor's dtype
+    _lib.call("udm_qxt_absorbing", _p(x), _p(r_move), _p(move_chance.contiguous()), _p(r_txt.contiguous() if r_txt is not None else None),
+              _p(r_img.contiguous() if r_img is not None else None), thr(p_txt), thr(p_img), _p(modality_mask), B, L, int(mask_id), _p(xt), _p(move),
+              _p(rows[0]) if rows is not None else None, _p(rows[1]) if rows is not None else None, _p(rows[2]) if rows is not None else None, _s())
+    if rows is None:
+        return xt, move, None, None, None
+    return xt, move, rows[0], rows[1], rows[2]
+
+
 def categorical_sample_rows(logits, V, Vt, mask_id, *, modality=None, restrict=False, u=None, seed=0, given=None, logits_u=None, w=None):
     """(token, log p(token)) per row of `logits` [rows, ld] bf16 under the SUBS distribution: the `maskgit` predictor's multinomial draw + confidence.
     `given` int64 [rows]: take these tokens instead of drawing (replay)."""
