@@ -204,6 +204,10 @@ int udm_assemble_joint_tokens(const int32_t* txt, const uint8_t* txt_mask, const
 int udm_qxt_absorbing(const int64_t* x, const float* r_move, const float* move_chance, const float* r_txt, const float* r_img, float thr_txt, float thr_img,
                       const void* modality_mask, int64_t B, int64_t L, int64_t mask_id, int64_t* xt, void* move_indices, void* row_txt, void* row_img, void* row_ignore,
                       hipStream_t stream);
+/* _sample_t model.py:589-619 + LogLinearNoise models/noise_schedule.py:128-157 from the uniform draws u [n]: t, sigma, dsigma, move chance (fp32 [n] each), every
+ * statement rounded like the reference's tensor statements.  sampling_eps_complement = fp32(1 - sampling_eps), noise_eps_complement = fp32(1 - eps). */
+int udm_sample_t_noise(const float* u, int64_t n, int antithetic, float sampling_eps_complement, float sampling_eps, float noise_eps_complement, float* t, float* sigma,
+                       float* dsigma, float* move_chance, hipStream_t stream);
 
 /* ---- optimizer step: torch.optim.AdamW(fused=True) `model_setup.py:385-424` + accelerator.clip_grad_norm_ `model.py:1516-1520`.
  * fp32 masters and moments; `step` is the 1-based update count (bias corrections are computed from it); `grad_norm_sq` (nullable) is a DEVICE

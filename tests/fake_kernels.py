@@ -514,6 +514,18 @@ def categorical_sample_rows(logits, V, Vt, mask_id, *, modality=None, restrict=F
 
 
 # ------------------------------------------------------------------------------------------------ token data path (csrc/tokens.hip)
+def sample_t_noise(u, *, antithetic, sampling_eps, noise_eps):
+    """CPU double of udm_sample_t_noise: the reference's statements (model.py:589-619, models/noise_schedule.py:128-157)"""
+    n = u.numel()
+    e = u
+    if antithetic:
+        e = (e / n + torch.arange(n, device=u.device) / n) % 1
+    t = ((1 - sampling_eps) * e + sampling_eps).to(torch.float32)
+    sigma = -torch.log1p(-(1 - noise_eps) * t)
+    dsigma = (1 - noise_eps) / (1 - (1 - noise_eps) * t)
+    return t, sigma, dsigma, 1 - torch.exp(-sigma)
+
+
 def qxt_absorbing(x, r_move, move_chance, mask_id, *, r_txt=None, r_img=None, p_txt=0.0, p_img=0.0, modality_mask=None):
     """CPU double of udm_qxt_absorbing: the reference's statements (model.py:424-587, multimodal non-interleaved branch)"""
     move = r_move < move_chance.reshape(-1, 1)

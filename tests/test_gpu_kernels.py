@@ -956,3 +956,21 @@ def test_qxt_absorbing_kernel_matches_the_tensor_statements(K, draws):
             assert a.dtype == b.dtype and a.shape == b.shape and torch.equal(a.cpu(), b)
     if draws == "both":
         assert not bool(out[2][1]) and not bool(out[3][1]) and not bool(out[4][1])
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 7, 8, 12, 64, 100, 1000, 4099])
+@pytest.mark.parametrize("antithetic", [True, False])
+def test_sample_t_noise_kernel_is_bit_identical_to_the_tensor_statements(K, n, antithetic):
+    """udm_sample_t_noise against the reference's statements RUN ON THE DEVICE (the product's previous path): t, sigma, dsigma and the move chance bit for bit -
+    t and the move chance feed exact mask comparisons.  Batch sizes that are not powers of two exercise the divide-as-multiply-by-reciprocal rounding."""
+    import fake_kernels
+
+    g = torch.Generator().manual_seed(n)
+    for rep in range(20):
+        u = torch.rand(n, generator=g).to(DEV)
+        if rep == 0:
+            u[0] = 0.0
+        ref = fake_kernels.sample_t_noise(u, antithetic=antithetic, sampling_eps=1e-3, noise_eps=1e-3)
+        out = K.sample_t_noise(u, antithetic=antithetic, sampling_eps=1e-3, noise_eps=1e-3)
+        for name, a, b in zip(("t", "sigma", "dsigma", "move_chance"), out, ref):
+            assert torch.equal(a, b), (name, n, rep, (a != b).nonzero().flatten()[:4], a[a != b][:4], b[a != b][:4])

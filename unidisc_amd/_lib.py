@@ -52,6 +52,7 @@ PROTOTYPES = {
     "udm_attention_set_w64": [_I],
     "udm_attention_w64_timeline": [_P],
     "udm_assemble_joint_tokens": [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _P, _P, _P, _P],
+    "udm_sample_t_noise": [_P, _I64, _I, _F, _F, _F, _P, _P, _P, _P, _P],
     "udm_qxt_absorbing": [_P, _P, _P, _P, _P, _F, _F, _P, _I64, _I64, _I64, _P, _P, _P, _P, _P, _P],
     "udm_categorical_sample_rows": [_P, _P, _P, _I64, _P, _P, _I64, _U64, _P, _P, _P, _I64, _I64, _I64, _I64, _I, _P],
     "udm_ddpm_sample_rows_cfg": [_P, _P, _P, _I64, _P, _P, _P, _P, _I64, _U64, _P, _I64, _I64, _I64, _I64, _I, _I, _P],

@@ -88,3 +88,43 @@ extern "C" int udm_qxt_absorbing(const int64_t* x, const float* r_move, const fl
   UDM_CHECK_LAUNCH("udm_qxt_absorbing");
   return 0;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Timestep sampling and the log-linear noise schedule for one batch (model.py:589-619, models/noise_schedule.py:128-157): from the uniform draws u [n] to
+// t, sigma = -log1p(-(1 - eps) t), dsigma = (1 - eps) / (1 - (1 - eps) t) and the move chance 1 - exp(-sigma) - seventeen launches on n-element tensors in the
+// reference.  The statements are mirrored operation by operation, each rounded to fp32 (no contraction), INCLUDING torch's habit of dividing by a host scalar as a
+// multiplication with its fp32 reciprocal and of `scalar / tensor` as reciprocal-then-multiply: t feeds bit-exact mask comparisons.
+// ---------------------------------------------------------------------------------------------
+namespace {
+#pragma clang fp contract(off)
+__global__ void sample_t_noise_kernel(const float* __restrict__ u, int n, int antithetic, float inv_n, float one_minus_seps, float seps, float neg_one_minus_eps,
+                                      float one_minus_eps, float* __restrict__ t_out, float* __restrict__ sigma, float* __restrict__ dsigma,
+                                      float* __restrict__ move_chance) {
+#pragma clang fp contract(off)
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float e = u[i];
+  if (antithetic) {
+    const float off = (float)i * inv_n;        // torch.arange(n) / n
+    e = e * inv_n + off;                        // _eps_t / n + offset   (two roundings: contraction is off)
+    e = fmodf(e, 1.0f);                         // % 1 (operands are non-negative)
+  }
+  const float t = one_minus_seps * e + seps;    // (1 - sampling_eps) * _eps_t + sampling_eps
+  t_out[i] = t;
+  const float sg = -log1pf(neg_one_minus_eps * t);
+  sigma[i] = sg;
+  const float den = 1.0f - one_minus_eps * t;
+  dsigma[i] = (1.0f / den) * one_minus_eps;     // scalar / tensor = reciprocal(tensor) * scalar
+  move_chance[i] = 1.0f - expf(-sg);
+}
+}  // namespace
+
+extern "C" int udm_sample_t_noise(const float* u, int64_t n, int antithetic, float sampling_eps_complement, float sampling_eps, float noise_eps_complement,
+                                  float* t, float* sigma, float* dsigma, float* move_chance, hipStream_t stream) {
+  UDM_CHECK_ARG(u && t && sigma && dsigma && move_chance && n > 0, "udm_sample_t_noise: bad arguments");
+  const float inv_n = 1.0f / (float)n;
+  hipLaunchKernelGGL(sample_t_noise_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, u, (int)n, antithetic, inv_n, sampling_eps_complement, sampling_eps,
+                     -noise_eps_complement, noise_eps_complement, t, sigma, dsigma, move_chance);
+  UDM_CHECK_LAUNCH("udm_sample_t_noise");
+  return 0;
+}

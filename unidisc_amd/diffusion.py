@@ -24,7 +24,7 @@ import torch.nn.functional as F
 
 from . import kernels as K
 from .dit import DIT, ModalityMask, cfg_get
-from .noise_schedule import get_noise
+from .noise_schedule import LogLinearNoise, get_noise
 
 
 @dataclass
@@ -821,10 +821,17 @@ class Diffusion:
         x0, attention_mask = batch["input_ids"], batch.get("attention_mask", None)
         if x0.shape[1] > cfg_get(cfg_get(cfg, "model"), "length"):
             raise NotImplementedError("unidisc_amd: sequence sub-sampling (text8-crop) is not on the denoising hot path")
-        t = self._sample_t(x0.shape[0], x0.device)
-        sigma, dsigma = self.noise(t)
+        if (isinstance(self.noise, LogLinearNoise) and cfg_get(tr, "joint_ar_nar_timestep_warmup_steps", None) is None
+                and cfg_get(tr, "force_timestep", None) is None):
+            # `_sample_t` + the schedule + the move chance: seventeen statements on [B] tensors as one launch, bit-identical (tests/test_gpu_kernels.py); the draw stays here
+            t, sigma, dsigma, mc = K.sample_t_noise(self._rand(x0.shape[0], device=x0.device).float(), antithetic=bool(self.antithetic_sampling),
+                                                    sampling_eps=self.sampling_eps, noise_eps=self.noise.eps)
+            move_chance = mc[:, None]
+        else:
+            t = self._sample_t(x0.shape[0], x0.device)
+            sigma, dsigma = self.noise(t)
+            move_chance = 1 - torch.exp(-sigma[:, None])
         unet_conditioning = sigma[:, None]
-        move_chance = 1 - torch.exp(-sigma[:, None])
         xt, ignore_batch_mask_for_metrics, joint_ar_nar_mask, should_mask_txt, should_mask_img, move_indices = self.q_xt(
             x0, move_chance, return_ignore_batch_mask_for_metrics=True, batch=batch)
         m = cfg_get(cfg, "model")

@@ -175,6 +175,17 @@ def assemble_joint_tokens(txt, txt_mask, img, Vt, idx=None):
     return ids, mask, modality
 
 
+def sample_t_noise(u, *, antithetic, sampling_eps, noise_eps):
+    """(t, sigma, dsigma, move_chance), fp32 [n] each, from the uniform draws u [n]: `_sample_t` + the log-linear schedule in one launch, rounded like the statements."""
+    _chk(u, F32, "sample_t_noise u")
+    n = u.numel()
+    out = torch.empty((4, n), dtype=F32, device=u.device)
+    f32 = lambda v: float(torch.tensor(v, dtype=torch.float32))
+    _lib.call("udm_sample_t_noise", _p(u.contiguous()), n, 1 if antithetic else 0, f32(1 - sampling_eps), f32(sampling_eps), f32(1 - noise_eps), _p(out[0]), _p(out[1]),
+              _p(out[2]), _p(out[3]), _s())
+    return out[0], out[1], out[2], out[3]
+
+
 def qxt_absorbing(x, r_move, move_chance, mask_id, *, r_txt=None, r_img=None, p_txt=0.0, p_img=0.0, modality_mask=None):
     """q_xt after its random draws, multimodal non-interleaved batches: (xt int64 [B, L], move_indices bool [B, L], should_mask_txt, should_mask_img, ignore: bool [B, 1]
     or None without whole-modality draws).  x int64 [B, L]; r_move fp32 [B, L]; move_chance fp32 [B] / [B, 1]; r_txt / r_img fp32 [B, 1]; modality_mask bool [B, L, 2]."""
