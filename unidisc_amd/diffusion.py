@@ -149,6 +149,7 @@ class Diffusion:
         if batch is None:
             return batch
         batch = dict(batch.items()) if not isinstance(batch, dict) else dict(batch)
+        fused = False
         if self.image_model or cfg_get(cfg_get(cfg, "data"), "force_image_dataset", False):
             fused = self._assemble_on_device(batch, tr, m)
             if fused:
@@ -199,8 +200,9 @@ class Diffusion:
             elif cfg_get(cfg_get(cfg, "data"), "txt_only", False):
                 batch["modality"] = torch.zeros_like(batch["input_ids"], dtype=torch.int64)
         if "modality" in batch:  # :309-315
-            batch["modality"][batch["modality"] == -1] = 0
-            self._check_modality_range(batch["modality"])
+            if not fused:   # (the assembly kernel writes 0 on the text positions and 1 on the image positions of a batch that has both: nothing to fix or to check)
+                batch["modality"][batch["modality"] == -1] = 0
+                self._check_modality_range(batch["modality"])
             batch["modality_mask"] = F.one_hot(batch["modality"], num_classes=2).to(torch.bool)
             batch["batch_contains_img"] = (batch["modality"] == 1).any(dim=-1)
             batch["txt_sl"] = self.txt_sl(batch)
