@@ -147,3 +147,23 @@ def test_val_and_test_prefixes_update_attached_metrics(fake_k):
     assert diff.test_metrics.n == diff.valid_metrics.n
     with pytest.raises(ValueError):
         diff.compute_loss(diff.update_batch(g.batch()), prefix="bogus")
+
+
+def test_zero_modality_loss_weight_is_kept(fake_k):
+    """trainer.text_loss_weight = 0.0 is an image-only objective (model.py:1041-1044 multiplies by the configured value); an `or 1.0` default once turned it into 1.0."""
+    g = Golden("c_large")
+    losses = {}
+    for tw, iw in ((0.0, 0.5), (1.0, 0.5), (1.0, 0.0)):
+        case = dict(g.case, text_loss_weight=tw, img_loss_weight=iw)
+        from product_utils import product_config
+        from unidisc_amd import Diffusion
+        diff = Diffusion(product_config(case), None, "cpu")
+        diff.backbone.load_state_dict(g.params(), strict=True)
+        diff.backbone.train()
+        diff.rng_device = "cpu"
+        torch.manual_seed(g.case["step_seed"])
+        out = diff.training_step(g.batch(), 1)
+        losses[(tw, iw)] = (float(out.loss.detach()), float(out.txt_loss), float(out.img_loss))
+    full, img_only, txt_only = losses[(1.0, 0.5)], losses[(0.0, 0.5)], losses[(1.0, 0.0)]
+    assert img_only[1] == 0.0 and abs(img_only[0] - full[2]) <= 1e-6 * abs(full[2]) and img_only[0] != full[0]
+    assert txt_only[2] == 0.0 and abs(txt_only[0] - full[1]) <= 1e-6 * abs(full[1])

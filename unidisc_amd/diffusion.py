@@ -877,8 +877,9 @@ class Diffusion:
             raise ValueError("unidisc_amd: trainer.text_loss_weight / img_loss_weight need batches with a modality map")
         std_nlls, coef, sc = K.diffusion_loss(
             log_p_theta.detach().float(), w_loss.float(), w_std.float(), attention_mask, modality_mask if use_mm else None, weighted=weighted,
-            full_mask=bool(cfg_get(tr, "force_full_attention_mask_loss_only", False)), text_w=cfg_get(tr, "text_loss_weight", None) or 1.0,
-            img_w=cfg_get(tr, "img_loss_weight", None) or 1.0, ratio=cfg_get(tr, "set_max_txt_loss_ratio", None) if weighted else None)
+            full_mask=bool(cfg_get(tr, "force_full_attention_mask_loss_only", False)),
+            text_w=float(cfg_get(tr, "text_loss_weight", None)) if weighted else 1.0,   # an explicit 0.0 stays 0.0 (model.py:1041-1044 multiplies by the configured value)
+            img_w=float(cfg_get(tr, "img_loss_weight", None)) if weighted else 1.0, ratio=cfg_get(tr, "set_max_txt_loss_ratio", None) if weighted else None)
         loss = _LinearLoss.apply(log_p_theta, coef, sc[0])
         loss_dict = dict(loss=loss, extra_losses=dict())
         if cfg_get(tr, "log_seperate_modal_losses", False):

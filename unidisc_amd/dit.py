@@ -154,6 +154,7 @@ class _Lin:
         self.out, self.inp = weight.shape
         self.outp = _ceil(self.out, out_pad)
         self.w16 = self.w16t = None
+        self.sticky_t = False
         self.need_t = True   # False: every dgrad of this layer reads W itself (K.gemm_nn), the per-step cast writes no transposed shadow
 
     def alloc(self):
@@ -173,6 +174,8 @@ class _Lin:
     def dgrad(self, dY, M_rows):
         """dX [M, in] = dY [M, out] W: from W's forward shadow where the shape allows (no transposed shadow), else from the transposed one"""
         if self.w16t is None:
+            if not K.gemm_nn_ok(M_rows, self.inp, self.out):
+                raise RuntimeError(f"unidisc_amd: dgrad of a {self.out}x{self.inp} Linear over {M_rows} rows has no transposed weight shadow and the shape is outside gemm_nn")
             return K.gemm_nn(dY, self.w16, N=self.inp)
         return K.gemm_nt(dY, self.w16t, N=self.inp)
 
@@ -347,6 +350,10 @@ class DIT(nn.Module, _HubMixin):
             for name, lin in self._lins.items():
                 blk, _, kind = name.partition(".")
                 want_t = not (kind in ("qkv", "out", "fc1") and not (self.compact_last_block and int(blk) == last) and K.gemm_nn_ok(rows, lin.inp, lin.out))
+                # sticky: once some forward needed the transposed shadow it stays (a second forward with another row count - micro-batches, an eval pass inside
+                # a training step - must not drop the shadow a still-pending backward dispatches on, nor force a full recast at every alternation)
+                lin.sticky_t = lin.sticky_t or want_t
+                want_t = lin.sticky_t
                 if want_t != lin.need_t:
                     lin.need_t, force = want_t, True
         versions = [l.weight._version for l in self._lins.values()]

@@ -13,7 +13,9 @@ they become final), not an even split of a flat parameter:
     broadcast from their owner (the other half of the all-reduce's traffic) and the bf16 weight shadows are rebuilt by the next forward.
 
 Every rank ends a step with bit-identical parameters, equal to what the replicated path (bucketed all-reduce + FusedAdamW on every rank) produces from the
-same reduced gradients.  Gradient accumulation with ``enabled = False`` micro-steps is not built for the sharded path (raises).
+same reduced gradients.  Gradient accumulation (``sync.enabled = False`` micro-steps, model.py:1412,1505-1506): local passes keep their gradients, the
+closing pass reduces the accumulated ``p.grad`` to the same owners bucket by bucket at the end of its backward.  The parameter EMA (models/ema.py) is
+sharded like the moments: the owner updates its slice inside the fused AdamW kernel; ``ema_store_and_copy`` broadcasts the EMA weights from their owners.
 """
 from __future__ import annotations
 
@@ -34,6 +36,7 @@ class ShardedGradSync(BucketedGradSync):
         self.owners: Dict[int, int] = {}                     # bucket start (element offset in the flat buffer) -> owner rank
         self.ranges: List[Tuple[int, int, int]] = []         # (lo, hi, owner) of the last backward, in completion order
         self._load = [0] * self.world
+        self.ranges_open = False
 
     def _owner(self, lo: int, n: int) -> int:
         o = self.owners.get(lo)
@@ -43,23 +46,81 @@ class ShardedGradSync(BucketedGradSync):
             self._load[o] += n
         return o
 
+    # The bucket walk runs in EVERY backward - also in local (enabled = False) micro-steps and in the pass that closes an accumulation - so that the
+    # bucket ranges and their owners are the same whichever way the gradients get reduced; only `live` passes launch reductions from inside the backward.
     def _on_ready(self, flat, lo, hi):
-        if self.active and not self.enabled:
-            raise NotImplementedError("ShardedGradSync: gradient accumulation (enabled = False) is not built for the sharded path")
-        if self.active and self._pending is None and not self.ranges_open:
+        if not self.active:
+            return
+        if not self.ranges_open:
             self.ranges, self.ranges_open = [], True
-        super()._on_ready(flat, lo, hi)
+        if self._pending is not None and self._pending[0] is flat and self._pending[2] == lo:
+            lo = self._pending[1]
+        elif self._pending is not None:
+            self._close(*self._pending)
+        self._pending = (flat, lo, hi)
+        if hi - lo >= self.min_bucket:
+            self._close(flat, lo, hi)
+            self._pending = None
 
-    ranges_open = False
-
-    def _launch(self, flat, lo, hi):
+    def _close(self, flat, lo, hi):
         owner = self._owner(lo, hi - lo)
         self.ranges.append((lo, hi, owner))
-        self._reduce_to(flat[lo:hi], ("flat", lo), owner)
+        if self.enabled and not self._unsynced_passes:
+            self._reduce_to(flat[lo:hi], ("flat", lo), owner)
 
     def finish(self):
-        super().finish()
+        if not self.active:
+            return
+        if self._pending is not None:
+            self._close(*self._pending)
+            self._pending = None
         self.ranges_open = False
+        if not self.enabled:      # gradient accumulation micro-step (DDP no_sync, model.py:1412,1505-1506): gradients stay local
+            self._unsynced_passes += 1
+            return
+        if self._unsynced_passes:   # the accumulated p.grad exist once autograd has added this pass's gradients
+            torch.autograd.Variable._execution_engine.queue_callback(self.reduce_accumulated)
+            return
+        self._join()
+
+    def allreduce_accumulated(self):
+        self.reduce_accumulated()
+
+    def reduce_accumulated(self):
+        """Reduce what is in ``p.grad`` now (the sum of this rank's micro-step gradients) to the bucket owners, bucket by bucket with the ranges and
+        owners of the in-backward path."""
+        pr = self.module._grad_ranges
+        by_id = {id(p): p for p in self.module._ordered_params()}
+        for lo, hi, owner in self.ranges:
+            bucket = [by_id[pid] for pid, (o, _e) in pr.items() if lo <= o < hi and by_id[pid].grad is not None]
+            bucket.sort(key=lambda q: pr[id(q)][0])
+            if bucket:
+                self._reduce_params_to(bucket, owner, ("acc", lo))
+        self._unsynced_passes = 0
+        self._join()
+
+    def _reduce_params_to(self, bucket, owner, key):
+        grads = [p.grad for p in bucket]
+        first = grads[0]
+        if all(g.is_contiguous() and g.dtype == torch.float32 for g in grads):   # views of one flat buffer laid out back to back: reduce in place
+            end, same = first.data_ptr(), True
+            for g in grads:
+                gap = g.data_ptr() - end
+                same = same and 0 <= gap < 64 * 4 and g.untyped_storage().data_ptr() == first.untyped_storage().data_ptr()
+                end = g.data_ptr() + g.numel() * 4
+            if same:
+                n = (end - first.data_ptr()) // 4
+                self._reduce_to(torch.as_strided(first, (n,), (1,), first.storage_offset()), key, owner)
+                return
+        cat = torch.cat([g.reshape(-1).float() for g in grads])
+        self._reduce_to(cat, key, owner)
+        if self.rank == owner:
+            if cat.is_cuda:
+                torch.cuda.current_stream().wait_stream(self.comm_stream)
+            off = 0
+            for g in grads:
+                g.copy_(cat[off:off + g.numel()].view_as(g))
+                off += g.numel()
 
     def _reduce_to(self, seg: torch.Tensor, key, owner: int):
         n = seg.numel()
@@ -88,7 +149,7 @@ class ShardedGradSync(BucketedGradSync):
         """id(parameter) -> owner rank, from the bucket ranges of the last backward and the engine's parameter ranges in the flat gradient buffer"""
         pr = getattr(self.module, "_grad_ranges", None)
         if not pr or not self.ranges:
-            raise RuntimeError("ShardedGradSync: no synchronised backward has run yet")
+            raise RuntimeError("ShardedGradSync: no backward has run yet")
         out = {}
         for pid, (o, _end) in pr.items():
             for lo, hi, owner in self.ranges:
@@ -114,9 +175,8 @@ class ShardedAdamW(FusedAdamW):
     """``sync = wrap_sharded(backbone); opt = ShardedAdamW(backbone, sync, lr=...)``; then ``loss.backward(); opt.step(); opt.zero_grad()`` as usual."""
 
     def __init__(self, backbone, sync: ShardedGradSync, **kw):
-        if kw.get("ema_decay"):
-            raise NotImplementedError("ShardedAdamW: the parameter EMA is not built for the sharded path")
         params = kw.pop("params", None)
+        ema_decay = kw.pop("ema_decay", None)
         super().__init__(backbone, params=[], **kw)   # (no moments yet: they are allocated for OWNED parameters only, once ownership is known)
         self.params = [p for p in (params if params is not None else backbone.parameters()) if p.requires_grad]
         for p in self.params:
@@ -124,9 +184,55 @@ class ShardedAdamW(FusedAdamW):
                 raise ValueError("ShardedAdamW: parameters must be contiguous fp32 masters")
         self.sync = sync
         self._owner: Optional[Dict[int, int]] = None
+        self._groups: Optional[List[Tuple[int, List[torch.nn.Parameter]]]] = None   # (owner, parameters of one bucket) in bucket order
+        self._bcast_bufs: Dict[int, torch.Tensor] = {}
+        self.ema_decay = float(ema_decay) if ema_decay else None
+        self.ema = {} if self.ema_decay else None     # EMA shadows of the OWNED parameters (models/ema.py; stepped with the optimizer, model.py:1541-1545)
+        if self.ema is not None and not sync.active:
+            self.ema = {id(p): p.detach().clone() for p in self.params}
 
     def owned(self, p) -> bool:
         return self._owner is not None and self._owner[id(p)] == self.sync.rank
+
+    def _resolve_ownership(self):
+        sync = self.sync
+        self._owner = sync.owner_of_params()
+        missing = [p for p in self.params if id(p) not in self._owner]
+        if missing:
+            raise RuntimeError("ShardedAdamW: parameters outside the engine's flat gradient buffer")
+        pr = sync.module._grad_ranges
+        groups = []
+        for lo, hi, owner in sync.ranges:
+            ps = sorted([p for p in self.params if lo <= pr[id(p)][0] < hi], key=lambda q: pr[id(q)][0])
+            if ps:
+                groups.append((owner, ps))
+        self._groups = groups
+        for p in self.params:   # (a loaded shard keeps its moments / EMA)
+            if self._owner[id(p)] == sync.rank:
+                if id(p) not in self.state:
+                    self.state[id(p)] = (torch.zeros_like(p), torch.zeros_like(p))
+                if self.ema is not None and id(p) not in self.ema:
+                    self.ema[id(p)] = p.detach().clone()
+
+    def _broadcast_from_owners(self, tensors_of):
+        """One broadcast per bucket: the owner packs `tensors_of(p)` of the bucket's parameters into a persistent flat buffer, the others unpack into
+        their parameters (a 1.4 B model has ~600 parameters but ~26 buckets)."""
+        sync = self.sync
+        works = []
+        for gi, (owner, ps) in enumerate(self._groups):
+            n = sum(p.numel() for p in ps)
+            buf = self._bcast_bufs.get(gi)
+            if buf is None or buf.numel() != n or buf.device != ps[0].device:
+                buf = torch.empty(n, dtype=torch.float32, device=ps[0].device)
+                self._bcast_bufs[gi] = buf
+            if owner == sync.rank:
+                torch.cat([tensors_of(p).reshape(-1) for p in ps], out=buf)
+            src = dist.get_global_rank(sync.pg, owner) if sync.pg is not None else owner
+            works.append((dist.broadcast(buf, src=src, group=sync.pg, async_op=True), owner, ps, buf))
+        for w, owner, ps, buf in works:
+            w.wait()
+            if owner != sync.rank:
+                torch._foreach_copy_([p.data.view(-1) for p in ps], list(buf.split([p.numel() for p in ps])))
 
     @torch.no_grad()
     def step(self):
@@ -136,16 +242,10 @@ class ShardedAdamW(FusedAdamW):
                 self.state = {id(p): (torch.zeros_like(p), torch.zeros_like(p)) for p in self.params}
             return super().step()
         todo = [p for p in self.params if p.grad is not None]
-        if not todo:
-            return
+        if not todo:   # every rank must take part in the collectives below: an early return here would hang the others
+            raise RuntimeError("ShardedAdamW.step(): no gradients on this rank (every rank has to run a backward before step)")
         if self._owner is None:
-            self._owner = sync.owner_of_params()
-            missing = [p for p in self.params if id(p) not in self._owner]
-            if missing:
-                raise RuntimeError("ShardedAdamW: parameters outside the engine's flat gradient buffer")
-            for p in self.params:   # (a loaded shard keeps its moments)
-                if self._owner[id(p)] == sync.rank and id(p) not in self.state:
-                    self.state[id(p)] = (torch.zeros_like(p), torch.zeros_like(p))
+            self._resolve_ownership()
         mine = [p for p in todo if self._owner[id(p)] == sync.rank]
         self.step_count += 1
         dev = todo[0].device
@@ -159,26 +259,43 @@ class ShardedAdamW(FusedAdamW):
             dist.all_reduce(gsq, op=dist.ReduceOp.SUM, group=sync.pg)
             self.grad_norm = gsq.sqrt()
         b1, b2 = self.betas
+        ed = self._ema_decay_now() if self.ema is not None else 0.0
         for p in mine:
             m, v = self.state[id(p)]
-            K.adamw_step(p, p.grad, m, v, self.lr, b1, b2, self.eps, self.weight_decay, self.step_count, gsq, self.max_grad_norm)
-        # updated masters: every parameter from its owner (asynchronous collectives, one wait at the end)
-        works = []
-        for p in self.params:
-            src = self._owner[id(p)]
-            works.append(dist.broadcast(p.data, src=dist.get_global_rank(sync.pg, src) if sync.pg is not None else src, group=sync.pg, async_op=True))
-        for w in works:
-            w.wait()
+            e = self.ema[id(p)] if self.ema is not None else None
+            K.adamw_step(p, p.grad, m, v, self.lr, b1, b2, self.eps, self.weight_decay, self.step_count, gsq, self.max_grad_norm, ema=e, ema_decay=ed)
+        self._broadcast_from_owners(lambda p: p.data)   # updated masters: every bucket from its owner
         if hasattr(self.backbone, "invalidate_shadows"):   # the bf16 shadows of every rank follow on the next forward
             self.backbone.invalidate_shadows()
             self.backbone.recast_every_forward = True
 
+    @torch.no_grad()
+    def ema_store_and_copy(self):
+        """`ema.store(params); ema.copy_to(params)`: every rank's parameters <- the EMA weights, broadcast from their owners; originals kept for `ema_restore`."""
+        if self.ema is None:
+            raise RuntimeError("ShardedAdamW: no EMA (ema_decay not set)")
+        if not self.sync.active:
+            return super().ema_store_and_copy()
+        if self._owner is None:
+            raise RuntimeError("ShardedAdamW: ema_store_and_copy before the first step")
+        self._ema_backup = [p.detach().clone() for p in self.params]
+        self._broadcast_from_owners(lambda p: self.ema[id(p)])
+        for p in self.params:   # (the owner has packed its EMA slice but not yet taken it itself)
+            if self._owner[id(p)] == self.sync.rank:
+                p.copy_(self.ema[id(p)])
+        if hasattr(self.backbone, "refresh_weight_shadows"):
+            self.backbone.refresh_weight_shadows(force=True)
+
     def state_dict(self):
+        own = [(i, p) for i, p in enumerate(self.params) if id(p) in self.state]
         sd = dict(step=self.step_count, lr=self.lr, betas=self.betas, eps=self.eps, weight_decay=self.weight_decay, max_grad_norm=self.max_grad_norm,
                   rank=self.sync.rank, world=self.sync.world,
-                  owned=[i for i, p in enumerate(self.params) if id(p) in self.state],
-                  exp_avg=[self.state[id(p)][0] for p in self.params if id(p) in self.state],
-                  exp_avg_sq=[self.state[id(p)][1] for p in self.params if id(p) in self.state])
+                  owned=[i for i, _ in own],
+                  exp_avg=[self.state[id(p)][0] for _, p in own],
+                  exp_avg_sq=[self.state[id(p)][1] for _, p in own],
+                  ema_decay=self.ema_decay, ema_num_updates=self.ema_num_updates,
+                  ema=[self.ema[id(p)] for _, p in own] if self.ema is not None and all(id(p) in self.ema for _, p in own) else None,
+                  dropout_fwd_count=int(getattr(self.backbone, "_fwd_count", 0)))   # position of the engine's dropout stream (a resume must not replay masks)
         return sd
 
     def load_state_dict(self, sd):
@@ -189,6 +306,12 @@ class ShardedAdamW(FusedAdamW):
         for i, m, v in zip(sd["owned"], sd["exp_avg"], sd["exp_avg_sq"]):
             p = self.params[i]
             self.state[id(p)] = (m.to(p.device).clone(), v.to(p.device).clone())
+        if self.ema is not None and sd.get("ema") is not None:
+            self.ema_num_updates = sd.get("ema_num_updates", self.ema_num_updates)
+            for i, e in zip(sd["owned"], sd["ema"]):
+                self.ema[id(self.params[i])] = e.to(self.params[i].device).clone()
+        if "dropout_fwd_count" in sd and hasattr(self.backbone, "_fwd_count"):
+            self.backbone._fwd_count = int(sd["dropout_fwd_count"])
         if hasattr(self.backbone, "invalidate_shadows"):
             self.backbone.invalidate_shadows()
             self.backbone.recast_every_forward = True
