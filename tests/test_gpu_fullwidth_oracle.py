@@ -44,6 +44,10 @@ FULLWIDTH = {
     "config_c_1block_b8": (dict(_LARGE, n_blocks=1), 8, dict(loss=5e-5, nll=1e-3, grad_max=3.2e-2, grad_med=2e-2)),
     # the same width, two blocks composed (block -> block fused residual+norm), B = 2
     "config_c_2blocks_b2": (dict(_LARGE, n_blocks=2), 2, dict(loss=5e-5, nll=1e-3, grad_max=1.1e-1, grad_med=2.2e-2)),
+    # BASELINE configs[2] at its FULL DEPTH: all 24 blocks, d = 2048, L = 1280, one and two sequences (the fp32 oracle's fwd+bwd takes ~25 s per sequence on the GPU
+    # box's host; provisional bounds until the first ledger of the round)
+    "config_c_24blocks_b1": (dict(_LARGE, n_blocks=24), 1, dict(loss=5e-5, nll=1.5e-3, grad_max=3e-1, grad_med=4e-2)),
+    "config_c_24blocks_b2": (dict(_LARGE, n_blocks=24), 2, dict(loss=5e-5, nll=1.5e-3, grad_max=3e-1, grad_med=4e-2)),
     # BASELINE configs[1]: UniDisc-S, all 12 blocks, L = 128 + 256
     "unidisc_s_12blocks_b4": (dict(_SMALL, n_blocks=12), 4, dict(loss=5e-5, nll=1.2e-3, grad_max=2e-1, grad_med=3e-2)),
     # BASELINE configs[0]: 2-layer d = 256 text-only adaLN DiT, L = 128, vocabulary 1k (+ [MASK])

@@ -859,7 +859,7 @@ class Diffusion:
                                                  sample_ids=kwargs.get("sample_ids"), restrict_modality=self._restrict(),
                                                  block_mask=kwargs.get("block_mask"))
         self._flush_checks()   # (the forward has already waited for this step's [MASK]-row count: the queued batch checks are complete, no extra wait)
-        self._last = dict(t=t, sigma=sigma, dsigma=dsigma, xt=xt, move_indices=move_indices, log_p_theta=log_p_theta)
+        self._last = dict(t=t, sigma=sigma, dsigma=dsigma, xt=xt, move_indices=move_indices, log_p_theta=log_p_theta, modality=kwargs.get("modality"))
 
         # The loss arithmetic of model.py:1010-1160 (schedule weights, masked mean or the modality-weighted text / image sum with the optional text-loss cap,
         # the reported per-token NLLs and fractions) runs as ONE launch - K.diffusion_loss - instead of ~75 small tensor statements between the forward and
