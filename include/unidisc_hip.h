@@ -116,6 +116,10 @@ int udm_norm_residual_bwd(const void* dy, const float* x, const float* rstd, con
  * qkv bf16 [M,3d] -> qkr bf16 [M,2d] (normalised, rotated q | k).  cos/sin fp32 [L,D/2] or per-sample [M,D/2]. */
 int udm_qknorm_rope_fwd(const void* qkv, void* qkr, const float* gq, const float* bq, const float* gk, const float* bk, float* stats, const float* cos_t,
                         const float* sin_t, int rope_per_sample, int64_t M, int64_t d, int64_t L, int64_t D, float eps, hipStream_t stream);
+/* fp8 attention path (BASELINE config E): as udm_qknorm_rope_fwd, plus qk8 [M,2d] e4m3 bytes and qk_e8 [M, 2 d/D] E8M0 scales (one per row and head) of the
+ * rotated q | k; qkr then holds the dequantised values.  Fused into the row kernel at d = 2048. */
+int udm_qknorm_rope_fwd_fp8(const void* qkv, void* qkr, void* qk8, uint8_t* qk_e8, const float* gq, const float* bq, const float* gk, const float* bk, float* stats,
+                            const float* cos_t, const float* sin_t, int rope_per_sample, int64_t M, int64_t d, int64_t L, int64_t D, float eps, hipStream_t stream);
 int udm_qknorm_rope_bwd(const void* dqkr, const void* qkv, void* dqkv, const float* gq, const float* gk, const float* stats, const float* cos_t,
                         const float* sin_t, int rope_per_sample, float* dgq, float* dbq, float* dgk, float* dbk, int64_t M, int64_t d, int64_t L, int64_t D,
                         float* ws, int64_t ws_elems, hipStream_t stream); /* ws: optional fp32 scratch (>= 4096*d); then dgq|dbq|dgk|dbk must be contiguous */
@@ -134,13 +138,18 @@ int udm_attention_fwd(const void* q, const void* k, const void* v, void* o, floa
 int udm_attention_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse, float* delta, void* dq, void* dk,
                       void* dv, const int64_t* sample_ids, const int32_t* doc_ranges, int64_t B, int64_t H, int64_t L, int64_t D, int64_t q_stride, int64_t k_stride, int64_t v_stride,
                       int64_t o_stride, int64_t do_stride, int64_t dq_stride, int64_t dk_stride, int64_t dv_stride, hipStream_t stream);
-/* fp8 (OCP e4m3) forward, BASELINE config E; no reference counterpart - parity target is udm_attention_fwd under a looser tolerance.
- * udm_attention_quantize_fp8: q, k, v bf16 (same addressing as above) -> q8, k8 [B*L, H*D] bytes, v8t [B*H, D, Lp] bytes (Lp = ceil(L/64)*64, per-head
- * transposed, keys of each 16-chunk in the order 0-3, 8-11, 4-7, 12-15, zero padded), scales fp32 [3] = amax/448 of q, k, v; amax_ws: 3 x uint32 scratch.
- * udm_attention_fwd_fp8: O bf16 and lse as udm_attention_fwd; S and PV through v_mfma_f32_32x32x16_fp8_fp8, softmax in fp32, P scaled by 2^8. */
-int udm_attention_quantize_fp8(const void* q, const void* k, const void* v, void* q8, void* k8, void* v8t, float* scales, uint32_t* amax_ws, int64_t B,
-                               int64_t H, int64_t L, int64_t D, int64_t q_stride, int64_t k_stride, int64_t v_stride, hipStream_t stream);
-int udm_attention_fwd_fp8(const void* q8, const void* k8, const void* v8t, const float* scales, void* o, float* lse, const int64_t* sample_ids,
+/* fp8 (OCP e4m3) forward, BASELINE config E; no reference counterpart - parity target is udm_attention_fwd under a stated tolerance.
+ * S and PV run through v_mfma_scale_f32_32x32x64_f8f6f4 (twice the bf16 matrix rate); every scale is a power of two carried as an E8M0 byte the
+ * instruction applies itself.  Operands:
+ *   qk8   [B*L, 2d] bytes   e4m3 of the normalised + rotated q | k, qk_e8 [B*L, 2H] one E8M0 scale per (row, q head | k head):
+ *                            written by udm_qknorm_rope_fwd_fp8 (below), or from an existing bf16 qkr by udm_attention_quantize_qk_fp8, which also
+ *                            rewrites qkr with the DEQUANTISED values (what the bf16 backward must read);
+ *   v8t   [B*H, ceil(L/64), D, 64] bytes  per 64-key tile V^T, keys of a row in the order the kernel holds its probabilities
+ *                            (byte hi*32 + f*16 + r = key f*32 + (r&3) + 8 (r>>2) + 4 hi; keys past L zero), v_e8 [B*H, ceil(L/64)] int32 E8M0 per tile.
+ * udm_attention_fwd_fp8: O bf16 and lse as udm_attention_fwd; softmax in fp32, probabilities converted as 2^8 p with an exact running maximum. */
+int udm_attention_quantize_qk_fp8(void* qkr, void* qk8, uint8_t* qk_e8, int64_t M, int64_t d, int64_t D, hipStream_t stream);
+int udm_attention_quantize_v_fp8(const void* v, int64_t v_stride, void* v8t, int32_t* v_e8, int64_t B, int64_t H, int64_t L, int64_t D, hipStream_t stream);
+int udm_attention_fwd_fp8(const void* qk8, const uint8_t* qk_e8, const void* v8t, const int32_t* v_e8, void* o, float* lse, const int64_t* sample_ids,
                           const int32_t* doc_ranges, int64_t B, int64_t H, int64_t L, int64_t D, int64_t o_stride, hipStream_t stream);
 int udm_attention_set_tr_read(int enable); /* diagnostics: 0 = gather Vᵀ fragments with scalar LDS reads */
 int udm_attention_w64_timeline(uint64_t* buf); /* diagnostics: device buffer of 512 cycle stamps (2 blocks x 4 waves x 64 tags) written by the next forward launches; null = off */

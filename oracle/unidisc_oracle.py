@@ -189,21 +189,69 @@ def modality_dropout_mask(txt_drop, img_drop, txt_length, L):
     return txt_case & img_case
 
 
-def attention_core(q, k, v, sample_ids=None, allow_mask=None):
+_FLASH_ROUNDING = [False]   # set by compute_loss(bf16=True, flash_rounding=True) around its forward
+
+
+class _FlashRoundingAttention(torch.autograd.Function):
+    """The rounding points INSIDE the reference's attention kernel (flash_attn 2.x `flash_attn_qkvpacked_func`, dit.py:843; the library is a third-party wheel,
+    absent here - restated from its published algorithm, FlashAttention-2, Dao 2023, Algorithms 1-2): with bf16 inputs the probabilities are cast to bf16
+    before P V (forward) and before dV = P^T dO (backward), dS = P (dP - delta) is cast to bf16 before dQ = dS K and dK = dS^T Q, and
+    delta = rowsum(dO * O) uses the STORED bf16 output; the softmax statistics and all accumulations are fp32.  Used only by the bf16 noise-floor comparator
+    (`compute_loss(bf16=True, flash_rounding=True)`): tensor-boundary rounding alone (autograd through `_r`) runs this backward in fp32 and understates the
+    noise the reference's own gradients carry in dq / dk - and therefore in the qk-norm vectors, whose gradients are column sums of them."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, neg_mask):
+        rb = lambda t: t.to(torch.bfloat16).to(torch.float32)
+        scale = 1.0 / math.sqrt(q.shape[-1])
+        s = (q @ k.transpose(-1, -2)) * scale
+        if neg_mask is not None:
+            s = s.masked_fill(neg_mask, float("-inf"))
+        lse = torch.logsumexp(s, -1, keepdim=True)
+        lse = torch.where(torch.isfinite(lse), lse, torch.zeros_like(lse))
+        p = torch.exp(s - lse)
+        o = rb(p) @ v
+        ctx.save_for_backward(q, k, v, lse, rb(o), neg_mask if neg_mask is not None else torch.zeros(0, dtype=torch.bool))
+        ctx.scale = scale
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        rb = lambda t: t.to(torch.bfloat16).to(torch.float32)
+        q, k, v, lse, o16, neg_mask = ctx.saved_tensors
+        do = rb(do)
+        s = (q @ k.transpose(-1, -2)) * ctx.scale
+        if neg_mask.numel():
+            s = s.masked_fill(neg_mask, float("-inf"))
+        p = torch.exp(s - lse)
+        dv = rb(p).transpose(-1, -2) @ do
+        dp = do @ v.transpose(-1, -2)
+        delta = (do * o16).sum(-1, keepdim=True)
+        ds = rb(p * (dp - delta))
+        return ds @ k * ctx.scale, ds.transpose(-1, -2) @ q * ctx.scale, dv, None
+
+
+def attention_core(q, k, v, sample_ids=None, allow_mask=None, flash_rounding=False):
     """softmax(q kᵀ/√D) v, bidirectional (dit.py:826-829 SDPA ≡ :843 FA2); optional document mask
     ``sid[q]==sid[kv] & sid[q]!=-1`` (model_utils.py:740-771) or a dense allowed[b, q, kv] mask (FlexAttention block_mask, dit.py:784-812).
-    q,k,v: [B, L, H, D] → [B, L, H*D]."""
+    q,k,v: [B, L, H, D] → [B, L, H*D].  flash_rounding: see _FlashRoundingAttention (bf16 comparator only)."""
     B, L, H, D = q.shape
     q, k, v = (t.transpose(1, 2) for t in (q, k, v))
-    s = (q @ k.transpose(-1, -2)) / math.sqrt(D)
+    neg = None
     if allow_mask is not None:
-        s = s.masked_fill(~allow_mask[:, None], float("-inf"))
+        neg = ~allow_mask[:, None]
     if sample_ids is not None:
         sid = sample_ids.clone()
         allpad = (sid == -1).all(-1)
         sid[allpad, 0] = 0
         allow = (sid[:, :, None] == sid[:, None, :]) & (sid[:, :, None] != -1)
-        s = s.masked_fill(~allow[:, None], float("-inf"))
+        neg = ~allow[:, None] if neg is None else (neg | ~allow[:, None])
+    if flash_rounding:
+        o = _FlashRoundingAttention.apply(q, k, v, neg.expand(B, H, L, L) if neg is not None else None)
+        return o.transpose(1, 2).reshape(B, L, H * D)
+    s = (q @ k.transpose(-1, -2)) / math.sqrt(D)
+    if neg is not None:
+        s = s.masked_fill(neg, float("-inf"))
     p = torch.softmax(s, dim=-1)
     p = torch.nan_to_num(p, nan=0.0)
     o = p @ v
@@ -329,7 +377,7 @@ def dit_block(cfg, P, pre, x, cos, sin, c, modality, sample_ids, bf16, allow_mas
     qk = torch.stack([q, k], 2).reshape(B, L, 2 * H, D)  # "b s (three h d)" → q heads then k heads
     qk = _r(apply_rotary(qk, cos, sin), bf16)  # dit.py:723-726
     q, k = qk[:, :, :H], qk[:, :, H:]
-    a = _r(attention_core(q, k, v.reshape(B, L, H, D), sample_ids, allow_mask), bf16)
+    a = _r(attention_core(q, k, v.reshape(B, L, H, D), sample_ids, allow_mask, flash_rounding=bool(bf16 and _FLASH_ROUNDING[0])), bf16)
     a = linear(a, P[pre + "attention.attn_out.weight"], None, bf16)
     if cfg.sandwich_normalization:  # dit.py:993-994 (gate_msa unused, :983)
         x = x_skip + (rms_norm_lowp_input(a, P[pre + "pre_residual_norm.weight"], bf16=bf16) if cfg.norm_type == "rms"
@@ -563,7 +611,7 @@ def reduce_loss(cfg: OracleConfig, log_p, sigma, dsigma, attention_mask, modalit
                       extra_losses=rec["extra_losses"], modality_mask=modality_mask)
 
 
-def compute_loss(cfg: OracleConfig, P, buffers, batch, generator=None, bf16=False, training=True):
+def compute_loss(cfg: OracleConfig, P, buffers, batch, generator=None, bf16=False, training=True, flash_rounding=False):
     """model.py:797-1173, SUBS / continuous-time / absorbing branch.  ``batch`` must come from update_batch."""
     x0, am = batch["input_ids"], batch["attention_mask"]
     modality_mask = batch.get("modality_mask")
@@ -582,7 +630,11 @@ def compute_loss(cfg: OracleConfig, P, buffers, batch, generator=None, bf16=Fals
             img_drop = img_drop & ~smi.squeeze(-1)
         allow_mask = modality_dropout_mask(txt_drop, img_drop, cfg.txt_length, x0.shape[1])
         ignore = (txt_drop | img_drop).unsqueeze(-1) if ignore is None else (ignore | (txt_drop | img_drop).unsqueeze(-1))
-    logits = dit_forward(cfg, P, buffers, xt, sigma, modality, batch["sample_ids"] if cfg.interleaved else None, bf16, allow_mask=allow_mask)
+    _FLASH_ROUNDING[0] = bool(flash_rounding)
+    try:
+        logits = dit_forward(cfg, P, buffers, xt, sigma, modality, batch["sample_ids"] if cfg.interleaved else None, bf16, allow_mask=allow_mask)
+    finally:
+        _FLASH_ROUNDING[0] = False
     lp = subs_parameterization(cfg, logits, xt, modality, batch, bf16).float()
     log_p = torch.gather(lp, -1, x0[:, :, None]).squeeze(-1)
     out = reduce_loss(cfg, log_p, sigma, dsigma, am, modality_mask, ignore)

@@ -155,8 +155,9 @@ def test_subs_logprobs_forward_contract():
 def test_fp8_attention_forward_training_step(heads):
     """model.fp8_attention (BASELINE config E; no reference counterpart): the same step with the attention forward in fp8, at width 768 with head
     dim 64 / 128 (the fp8 kernel's head dims), 2 blocks.  Stated tolerances against this repository's bf16 path on the same inputs: masks
-    bit-exact, loss 2e-2 relative, per-token nll 5e-2 rel-RMS, gradients 0.25 rel-RMS (forward e4m3 noise on q, k, v and P; the bf16 backward
-    reuses the fp8 forward's log-sum-exp)."""
+    bit-exact, loss 5e-3 relative, per-token nll 3e-2 rel-RMS, worst-parameter gradient 3e-2 rel-RMS (forward e4m3 noise on q, k, v and P; the bf16
+    backward runs on the DEQUANTISED q, k the forward saw, with the forward's log-sum-exp - round 2 paired the fp8 forward with the unquantised q, k and
+    sat at 7-14 %)."""
     case = dict(hidden_size=768, n_heads=heads, cond_dim=128, n_blocks=2, batch_size=2, txt_length=64, img_length=64, text_vocab_size=32001,
                 vocab_size=40193, norm_type="rms", qk_norm=True, sandwich_normalization=True, modality_embed=True, rope_2d=False,
                 time_conditioning=False, multimodal_batches=True, force_argmax_valid_indices=True, mask_entire_modality=0.1, softmin_snr=5,
@@ -188,11 +189,11 @@ def test_fp8_attention_forward_training_step(heads):
     (x0, l0, n0, g0), (x1, l1, n1, g1) = res
     assert torch.equal(x0, x1)
     T = f"fp8_attention_step[heads={heads}]"
-    check(T, "loss_rel_vs_bf16_path", abs(l1 - l0) / abs(l0), 2e-2)
-    check(T, "nll_relrms_vs_bf16_path", rel_err(n1, n0), 5e-2)
+    check(T, "loss_rel_vs_bf16_path", abs(l1 - l0) / abs(l0), 5e-3)
+    check(T, "nll_relrms_vs_bf16_path", rel_err(n1, n0), 3e-2)
     assert l1 != l0                                             # the fp8 kernel really ran
     errs = sorted(((rel_err(g1[k], g0[k]), k) for k in g0), reverse=True)
-    check(T, "grad_relrms_worst_param_vs_bf16_path", errs[0][0], 0.25, note=errs[0][1])
+    check(T, "grad_relrms_worst_param_vs_bf16_path", errs[0][0], 3e-2, note=errs[0][1])
 
 
 @pytest.mark.parametrize("frac", [0.0, 1.0])

@@ -726,38 +726,70 @@ def test_attention_tile_skipping_is_exact(K, D, H, L):
 
 
 # ------------------------------------------------------------------------------------------------ fp8 attention forward (config E; no reference counterpart)
+def _fp8_key_order():
+    """position of key kappa (0..63) inside a 64-byte V^T row: byte hi*32 + f*16 + r holds key f*32 + (r&3) + 8 (r>>2) + 4 hi"""
+    pos = torch.zeros(64, dtype=torch.long)
+    for hi in range(2):
+        for f in range(2):
+            for r in range(16):
+                pos[f * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi] = hi * 32 + f * 16 + r
+    return pos
+
+
 def _fp8_dequant(quant, B, L, H, D):
-    """(q8, k8, v8t, scales) of the quantize kernel -> fp32 q, k, v [B*L, H*D] (undoing the per-head transpose and the 16-key permutation)."""
-    q8, k8, v8t, scales = (t.cpu() for t in quant)
-    sq, sk, sv = scales.tolist()
-    q = q8.view(torch.float8_e4m3fn).float() * sq
-    k = k8.view(torch.float8_e4m3fn).float() * sk
-    Lp = v8t.shape[-1]
-    pos = torch.arange(Lp)
-    j = pos & 15
-    src = (pos & ~15) + ((j & 3) | ((j & 4) << 1) | ((j & 8) >> 1))     # storage position of key `pos`
-    vt = v8t.view(torch.float8_e4m3fn).float()[:, :, src] * sv          # [B*H, D, Lp] in key order
-    v = vt[:, :, :L].reshape(B, H, D, L).permute(0, 3, 1, 2).reshape(B * L, H * D)
-    return q, k, v, (sq, sk, sv), vt[:, :, L:]
+    """(qkr_dequantised, qk8, qk_e8, v8t, v_e8) of the quantise kernels -> fp32 q, k, v [B*L, H*D] (undoing the per-tile transpose and the key order)."""
+    qkr, qk8, qk_e8, v8t, v_e8 = (t.cpu() for t in quant)
+    d = H * D
+    qk = qk8.view(torch.float8_e4m3fn).float() * torch.exp2(qk_e8.float() - 127).repeat_interleave(D, dim=-1)
+    nt = v8t.shape[1]
+    vt = v8t.view(torch.float8_e4m3fn).float()[..., _fp8_key_order()] * torch.exp2(v_e8.float() - 127)[:, :, None, None]     # [B*H, nt, D, 64] in key order
+    v = vt.permute(0, 1, 3, 2).reshape(B, H, nt * 64, D)
+    tail = v[:, :, L:]
+    v = v[:, :, :L].permute(0, 2, 1, 3).reshape(B * L, d)
+    return qk[:, :d], qk[:, d:], v, tail
 
 
 @pytest.mark.parametrize("D,H", [(64, 3), (128, 2)])
 @pytest.mark.parametrize("L", [100, 640, 1500])
 def test_attention_fp8_quantize(K, D, H, L):
+    """q, k: one power-of-two scale per (row, head), bytes, scales and the dequantised bf16 copy EXACTLY as the reference quantiser (fake_kernels.e4m3_pow2_quant:
+    amax 2^-k <= 448, round to nearest even); v: one scale per (head, 64-key tile), transposed into the forward kernel's operand order, zero past L."""
+    import fake_kernels
     B = 2
     M, d = B * L, H * D
     q, k, v = (bf(rnd(M, d, seed=s)) for s in (330, 331, 332))
+    q[5] = q[5] * 37.0                    # rows of very different magnitude: the scale is per row and head
+    k[7, :D] = k[7, :D] * 1e-3
     v = bf(v.float() * 3.0)
     o, lse, quant = K.attention_fwd_fp8_generic(q.to(DEV), k.to(DEV), v.to(DEV), B, L, H, D, return_quantized=True)
-    qd, kd, vd, (sq, sk, sv), tail = _fp8_dequant(quant, B, L, H, D)
-    for src, deq, s in ((q, qd, sq), (k, kd, sk), (v, vd, sv)):
-        assert abs(s - src.float().abs().max().item() / 448.0) < 1e-6 * s
-        ref = (src.float() / s).to(torch.float8_e4m3fn).float() * s          # round-to-nearest-even e4m3, as v_cvt_pk_fp8_f32
-        # bf16 inputs sit exactly half-way between two e4m3 values about once in 32; x * (1/s) (kernel) and x / s (here) break those ties differently
-        assert (deq != ref).float().mean().item() < 2e-2 and rel_err(deq, ref) < 1e-2
-        assert ((deq - ref).abs() <= 0.13 * ref.abs().clamp_min(s * 2.0 ** -6)).all()          # ... and never by more than one e4m3 step
-        assert rel_err(deq, src.float()) < 4e-2                                            # 3 mantissa bits
-    assert (tail == 0).all()                                                               # keys past L are zero
+    qd, kd, vd, tail = _fp8_dequant(quant, B, L, H, D)
+    ref_deq, ref_q8, ref_e8 = fake_kernels.e4m3_pow2_quant(torch.cat([q, k], 1), D)
+    assert torch.equal(quant[2].cpu().long(), ref_e8.long())                                  # E8M0 scales
+    assert torch.equal(quant[1].cpu(), ref_q8.view(torch.uint8))                                # bytes
+    assert torch.equal(quant[0].float().cpu(), ref_deq) and torch.equal(torch.cat([qd, kd], 1), ref_deq)   # the bf16 copy the backward reads = what the MFMA sees
+    assert rel_err(qd, q.float()) < 4e-2 and rel_err(kd, k.float()) < 4e-2                      # 3 mantissa bits
+    Lp = (L + 63) // 64 * 64
+    vp = torch.zeros(B, Lp, H, D)
+    vp[:, :L] = v.float().reshape(B, L, H, D)
+    vt = vp.reshape(B, Lp // 64, 64, H, D).permute(0, 1, 3, 2, 4).reshape(B, Lp // 64, H, 64 * D)
+    ref_v = fake_kernels.e4m3_pow2_quant(vt, 64 * D)[0].reshape(B, Lp // 64, H, 64, D).permute(0, 1, 3, 2, 4).reshape(B, Lp, H, D)[:, :L].reshape(M, d)
+    assert torch.equal(vd, ref_v)
+    assert (tail == 0).all()                                                                    # keys past L are zero
+
+
+def test_qknorm_rope_fwd_fp8_fused_equals_two_pass(K):
+    """d = 2048: the qk-norm + rope row kernel quantises while the row is in registers; bit-identical to the plain kernel followed by the generic quantiser."""
+    M, d, D, L = 6 * 96, 2048, 128, 96
+    qkv = bf(rnd(M, 3 * d, seed=350))
+    ang = rnd(L, D // 2, seed=355)
+    cos, sin = ang.cos().contiguous(), ang.sin().contiguous()
+    gq, bq, gk, bk = (rnd(d, seed=s) * 0.2 + (1.0 if s % 2 else 0.0) for s in (351, 352, 353, 354))
+    g = lambda t: t.to(DEV)
+    kw = dict(gq=g(gq), bq=g(bq), gk=g(gk), bk=g(bk))
+    qkr_f, st_f, (qk8_f, e8_f) = K.qknorm_rope_fwd(g(qkv), g(cos), g(sin), L, D, fp8=True, **kw)
+    qkr_p, st_p = K.qknorm_rope_fwd(g(qkv), g(cos), g(sin), L, D, **kw)
+    qk8_p, e8_p = K.attention_quantize_qk_fp8(qkr_p, D)
+    assert torch.equal(st_f, st_p) and torch.equal(qk8_f, qk8_p) and torch.equal(e8_f, e8_p) and torch.equal(qkr_f, qkr_p)
 
 
 @pytest.mark.parametrize("D,H", [(64, 3), (128, 2)])
@@ -770,22 +802,31 @@ def test_attention_fp8_forward(K, D, H, L, use_sid):
     B = 3
     M, d = B * L, H * D
     q, k, v = (bf(rnd(M, d, seed=s)) for s in (340, 341, 342))
+    q[11] = q[11] * 8.0     # per-row scales at work
     g = lambda t: t.to(DEV) if t is not None else None
     layouts = _doc_layouts(B, L) if use_sid else {"none": None}
+    if use_sid:   # mask CODES (modality attention dropout): asymmetric text / image visibility, no doc_ranges - the fp8 kernel must apply attn_pair_ok like the bf16 one
+        drop = torch.tensor([True, False, True])
+        layouts["modality_codes"] = K.modality_mask_codes(drop.to(DEV), torch.tensor([False, True, True]).to(DEV), L // 3, L).cpu()
     for name, sid in layouts.items():
-        r = K.attention_doc_ranges(g(sid)) if sid is not None else None
+        r = K.attention_doc_ranges(g(sid)) if (sid is not None and name != "modality_codes") else None
         o, lse, quant = K.attention_fwd_fp8_generic(g(q), g(k), g(v), B, L, H, D, g(sid), r, return_quantized=True)
-        qd, kd, vd, _, _ = _fp8_dequant(quant, B, L, H, D)
-        o_ref = R._attn(qd, kd, vd, B, L, H, D, sid)
-        assert rel_err(o.float().cpu(), o_ref) < 3e-2, name
+        qd, kd, vd, _ = _fp8_dequant(quant, B, L, H, D)
         o16, lse16 = K.attention_fwd_generic(g(q), g(k), g(v), B, L, H, D, g(sid), r)
         assert rel_err(o.float().cpu(), o16.float().cpu()) < 8e-2, name
         fin = torch.isfinite(lse16)
         assert torch.equal(torch.isfinite(lse), fin) and torch.allclose(lse[fin], lse16[fin], atol=0.25, rtol=0), name      # log2 units; q, k rounding
+        # the bf16 kernel on the DEQUANTISED q, k, v computes the same scores (exact products) and differs only by the rounding of P: the backward's view of this forward
+        o16q, lse16q = K.attention_fwd_generic(g(qd.bfloat16()), g(kd.bfloat16()), g(vd.bfloat16()), B, L, H, D, g(sid), r)
+        assert rel_err(o.float().cpu(), o16q.float().cpu()) < 3e-2, name
+        assert torch.allclose(lse[fin], lse16q[fin], atol=2e-3, rtol=0), name
+        if name != "modality_codes":
+            o_ref = R._attn(qd, kd, vd, B, L, H, D, sid)
+            assert rel_err(o.float().cpu(), o_ref) < 3e-2, name
         if sid is None:   # the softmax statistics themselves are fp32: tight against the exact scores of the quantised operands
             sc = (qd.reshape(B, L, H, D).transpose(1, 2) @ kd.reshape(B, L, H, D).transpose(1, 2).transpose(-1, -2)) / math.sqrt(D)
             assert torch.allclose(lse.cpu() * math.log(2.0), torch.logsumexp(sc, -1), atol=5e-3, rtol=1e-4), name
-        if sid is not None:
+        if sid is not None and r is not None:
             o_noskip, _ = K.attention_fwd_fp8_generic(g(q), g(k), g(v), B, L, H, D, g(sid), None)
             assert torch.equal(o, o_noskip), name                       # tile skipping changes nothing
             assert (o.float().cpu()[sid.reshape(-1) < 0] == 0).all(), name

@@ -46,7 +46,9 @@ PROTOTYPES = {
     "udm_attention_doc_ranges": [_P, _I64, _I64, _P, _P],
     "udm_attention_fwd": [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _P],
     "udm_attention_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _P],
-    "udm_attention_quantize_fp8": [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _P],
+    "udm_qknorm_rope_fwd_fp8": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I64, _I64, _I64, _I64, _F, _P],
+    "udm_attention_quantize_qk_fp8": [_P, _P, _P, _I64, _I64, _I64, _P],
+    "udm_attention_quantize_v_fp8": [_P, _I64, _P, _P, _I64, _I64, _I64, _I64, _P],
     "udm_attention_fwd_fp8": [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _P],
     "udm_attention_set_tr_read": [_I],
     "udm_attention_set_w64": [_I],

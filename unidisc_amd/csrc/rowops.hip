@@ -7,6 +7,7 @@
 // (bias_dropout_add_scale), :263-304 (modulate_fused), :680-682 (qk LayerNorm), models/standalone_rotary.py:14-31
 // (rotary), :1036-1043 + :1402-1411 (embedding + modality embedding), :415-449 (timestep embedding).
 #include "common.h"
+#include "fp8_common.h"
 #include <stdlib.h>
 #include "../../include/unidisc_hip.h"
 
@@ -519,6 +520,8 @@ struct QkArgs {
   const float* sin_t;
   int M, d, L, D, rope_per_sample;
   float eps;
+  uint8_t* qk8 = nullptr;     // fp8 path (udm_qknorm_rope_fwd_fp8): [M, 2d] e4m3 bytes of the rotated q | k ...
+  uint8_t* qk_e8 = nullptr;   // ... and one E8M0 scale per (row, q head | k head): [M, 2 d / D]
 };
 
 __device__ __forceinline__ void load4_bf16(const bf16_t* p, float (&v)[4]) {
@@ -1412,7 +1415,11 @@ __global__ __launch_bounds__(256) void qknorm_rope_fwd_brow_kernel(QkArgs a) {
 // 32 KB of LDS for the affine vectors, 5 blocks per CU hold 5 x 8 KB of loads in flight - at ~3 us of loaded memory latency that is 3.4 TB/s, what was
 // measured.  Here a thread keeps the affine values of its 16 columns in registers (they are the same for every row: no LDS at all), and every iteration
 // loads R rows before the first reduction, so the two block-wide reductions of a row are shared by R rows as well.
-template <int R>
+// FP8 (BASELINE config E): the rotated values are additionally quantised to e4m3 with one power-of-two scale per (row, head) - the amax of a head lives in
+// the D / 16 neighbouring lanes that hold it - written as bytes (qk8) + E8M0 scales (qk_e8); `qkr` then holds the DEQUANTISED values, which is what the bf16
+// backward attention kernels must see to differentiate the function the fp8 forward computed.  Bit-identical to the plain kernel followed by
+// udm_attention_quantize_qk_fp8 (the bf16 rounding of the rotated value is kept in front of the quantisation).
+template <int R, bool FP8 = false>
 __global__ __launch_bounds__(256) void qknorm_rope_fwd_brow_rows_kernel(QkArgs a) {
   __shared__ float sm[4 * 2 * R];
   const int tid = threadIdx.x;
@@ -1490,6 +1497,18 @@ __global__ __launch_bounds__(256) void qknorm_rope_fwd_brow_rows_kernel(QkArgs a
       for (int k = 0; k < 8; ++k) {
         ol[k] = xl[k] * cs[k] - xh[k] * sn[k];
         oh[k] = xh[k] * cs[k] + xl[k] * sn[k];
+      }
+      if (FP8) {
+        float amax = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { ol[k] = rbf(ol[k]); oh[k] = rbf(oh[k]); amax = fmaxf(amax, fmaxf(fabsf(ol[k]), fabsf(oh[k]))); }
+        for (int o = per_head >> 1; o >= 1; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+        const int e8 = udm::e8m0_for_amax(amax);
+        const uint2 l8 = udm::quant8_e4m3(ol, e8), h8 = udm::quant8_e4m3(oh, e8);
+        uint8_t* q8 = a.qk8 + row * 2 * a.d + part * a.d + hc;
+        *reinterpret_cast<uint2*>(q8) = l8;
+        *reinterpret_cast<uint2*>(q8 + half) = h8;
+        if (r % per_head == 0) a.qk_e8[row * 2 * (a.d / a.D) + part * (a.d / a.D) + r / per_head] = (uint8_t)e8;
       }
       store8_bf16(a.qkr + row * 2 * a.d + part * a.d + hc, ol);
       store8_bf16(a.qkr + row * 2 * a.d + part * a.d + hc + half, oh);
@@ -1780,9 +1799,31 @@ extern "C" int udm_norm_residual_bwd(const void* dy, const float* x, const float
   return 0;
 }
 
+extern "C" int udm_attention_quantize_qk_fp8(void* qkr, void* qk8, uint8_t* qk_e8, int64_t M, int64_t d, int64_t D, hipStream_t stream);   // attention_fp8.hip
+
+static int qknorm_rope_fwd_impl(const void* qkv, void* qkr, const float* gq, const float* bq, const float* gk, const float* bk, float* stats,
+                                const float* cos_t, const float* sin_t, int rope_per_sample, int64_t M, int64_t d, int64_t L, int64_t D, float eps,
+                                void* qk8, uint8_t* qk_e8, hipStream_t stream);
+
 extern "C" int udm_qknorm_rope_fwd(const void* qkv, void* qkr, const float* gq, const float* bq, const float* gk, const float* bk, float* stats,
                                    const float* cos_t, const float* sin_t, int rope_per_sample, int64_t M, int64_t d, int64_t L, int64_t D, float eps,
                                    hipStream_t stream) {
+  return qknorm_rope_fwd_impl(qkv, qkr, gq, bq, gk, bk, stats, cos_t, sin_t, rope_per_sample, M, d, L, D, eps, nullptr, nullptr, stream);
+}
+
+// fp8 attention path (BASELINE config E): as udm_qknorm_rope_fwd, plus qk8 [M, 2d] e4m3 bytes and qk_e8 [M, 2 d / D] E8M0 scales of the rotated q | k; `qkr`
+// receives the dequantised values.  Fused into the row kernel at d = 2048; other widths run the plain kernel followed by udm_attention_quantize_qk_fp8.
+extern "C" int udm_qknorm_rope_fwd_fp8(const void* qkv, void* qkr, void* qk8, uint8_t* qk_e8, const float* gq, const float* bq, const float* gk, const float* bk,
+                                       float* stats, const float* cos_t, const float* sin_t, int rope_per_sample, int64_t M, int64_t d, int64_t L, int64_t D,
+                                       float eps, hipStream_t stream) {
+  UDM_CHECK_ARG(qk8 && qk_e8, "udm_qknorm_rope_fwd_fp8: null pointer");
+  UDM_CHECK_ARG(D == 64 || D == 128, "udm_qknorm_rope_fwd_fp8: head_dim 64 or 128");
+  return qknorm_rope_fwd_impl(qkv, qkr, gq, bq, gk, bk, stats, cos_t, sin_t, rope_per_sample, M, d, L, D, eps, qk8, qk_e8, stream);
+}
+
+static int qknorm_rope_fwd_impl(const void* qkv, void* qkr, const float* gq, const float* bq, const float* gk, const float* bk, float* stats,
+                                const float* cos_t, const float* sin_t, int rope_per_sample, int64_t M, int64_t d, int64_t L, int64_t D, float eps,
+                                void* qk8, uint8_t* qk_e8, hipStream_t stream) {
   UDM_CHECK_ARG(qkv && qkr && cos_t && sin_t, "udm_qknorm_rope_fwd: null pointer");
   UDM_CHECK_ARG(M > 0 && d > 0 && D > 0 && d % D == 0 && D % 16 == 0, "udm_qknorm_rope_fwd: bad shape d=%ld D=%ld", (long)d, (long)D);
   UDM_CHECK_ARG(!gq || (bq && gk && bk && stats), "udm_qknorm_rope_fwd: qk-norm needs all four affine vectors and stats");
@@ -1795,7 +1836,10 @@ extern "C" int udm_qknorm_rope_fwd(const void* qkv, void* qkr, const float* gq, 
   if (d == 2048) {   // two rows per block iteration, 1024 blocks (in the step: 1.08-1.10 ms against 1.22-1.24 for one row per iteration; 3 rows 1.18, 4 rows 1.41)
     const long groups = (M + 1) / 2;
     const int g = (int)(groups < 1024 ? groups : 1024);
-    hipLaunchKernelGGL((qknorm_rope_fwd_brow_rows_kernel<2>), dim3(g), dim3(256), 0, stream, a);
+    if (qk8) {
+      a.qk8 = (uint8_t*)qk8; a.qk_e8 = qk_e8;
+      hipLaunchKernelGGL((qknorm_rope_fwd_brow_rows_kernel<2, true>), dim3(g), dim3(256), 0, stream, a);
+    } else hipLaunchKernelGGL((qknorm_rope_fwd_brow_rows_kernel<2>), dim3(g), dim3(256), 0, stream, a);
     UDM_CHECK_LAUNCH("udm_qknorm_rope_fwd");
     return 0;
   }
@@ -1804,7 +1848,7 @@ extern "C" int udm_qknorm_rope_fwd(const void* qkv, void* qkr, const float* gq, 
     if (d <= 2048) hipLaunchKernelGGL((qknorm_rope_fwd_brow_kernel<1>), dim3(g), dim3(256), lds, stream, a);
     else hipLaunchKernelGGL((qknorm_rope_fwd_brow_kernel<2>), dim3(g), dim3(256), lds, stream, a);
     UDM_CHECK_LAUNCH("udm_qknorm_rope_fwd");
-    return 0;
+    return qk8 ? udm_attention_quantize_qk_fp8(qkr, qk8, qk_e8, M, d, D, stream) : 0;
   }
   const int grid = min(grid_rows(M), 1024);
   switch (nch) {
@@ -1815,7 +1859,7 @@ extern "C" int udm_qknorm_rope_fwd(const void* qkv, void* qkr, const float* gq, 
     default: hipLaunchKernelGGL((qknorm_rope_fwd_kernel<8>), dim3(grid), dim3(256), lds, stream, a); break;
   }
   UDM_CHECK_LAUNCH("udm_qknorm_rope_fwd");
-  return 0;
+  return qk8 ? udm_attention_quantize_qk_fp8(qkr, qk8, qk_e8, M, d, D, stream) : 0;
 }
 
 extern "C" int udm_qknorm_rope_bwd(const void* dqkr, const void* qkv, void* dqkv, const float* gq, const float* gk, const float* stats, const float* cos_t,

@@ -228,8 +228,8 @@ class DIT(nn.Module, _HubMixin):
         self.txt_length, self.img_length, self.total_length = cfg_get(m, "txt_length"), cfg_get(m, "img_length"), cfg_get(m, "length")
         self.multimodal_batches = bool(cfg_get(tr, "multimodal_batches", False))
         self.rope_2d = bool(cfg_get(m, "rope_2d", False))
-        # BASELINE config E: attention FORWARD through the fp8 (e4m3) MFMA kernel (no reference counterpart).  The backward stays
-        # bf16 and reuses the forward's log-sum-exp, so gradients carry the forward's quantisation noise (tolerances in tests/test_gpu_e2e.py).
+        # BASELINE config E: attention FORWARD through the fp8 (e4m3) block-scaled MFMA kernel (no reference counterpart).  The backward
+        # stays bf16 and runs on the dequantised q, k the forward saw, with the forward's log-sum-exp (tolerances in tests/test_gpu_e2e.py, test_gpu_fullsize.py).
         self.fp8_attention = bool(cfg_get(m, "fp8_attention", False))
         # model.head_chunk_rows (extension key, 0 = off): fused vocabulary head + SUBS cross-entropy that never materialises [rows, V] logits - the head
         # runs on chunks of this many rows (forward: logits chunk -> log p, dropped; backward: the chunk's logits are recomputed, d logits formed in
@@ -632,12 +632,16 @@ class DIT(nn.Module, _HubMixin):
                 h1, rstd1, mean1 = K.norm_fwd(x, blk.norm1.weight.detach(), nt, L, mod=mod, mod_idx=(0, 1), modality=mod_flat, any_img=any_img)
             qkv = K.gemm_nt(h1, lin[f"{i}.qkv"].w16, N=3 * d)
             at = blk.attention
-            qkr, qstats = K.qknorm_rope_fwd(qkv, cos, sin, L, D, gq=at.q_norm.weight.detach() if self.qk_norm else None,
-                                            bq=at.q_norm.bias.detach() if self.qk_norm else None, gk=at.k_norm.weight.detach() if self.qk_norm else None,
-                                            bk=at.k_norm.bias.detach() if self.qk_norm else None)
+            qn_kw = dict(gq=at.q_norm.weight.detach() if self.qk_norm else None, bq=at.q_norm.bias.detach() if self.qk_norm else None,
+                         gk=at.k_norm.weight.detach() if self.qk_norm else None, bk=at.k_norm.bias.detach() if self.qk_norm else None)
             if self.fp8_attention:
-                o, lse = K.attention_fwd_fp8(qkr, qkv, B, L, H, D, sid, S["doc_ranges"])
+                # config E: the qk-norm + rope kernel also emits the e4m3 bytes + per-(row, head) power-of-two scales and leaves the DEQUANTISED q, k in qkr.
+                # Backward rule: the bf16 backward kernels read that qkr (their recomputed scores are bit-identical to the fp8 forward's: products of e4m3
+                # values are exact in fp32), the forward's log-sum-exp and v; the rounding itself is a straight-through estimator.
+                qkr, qstats, (qk8, qk_e8) = K.qknorm_rope_fwd(qkv, cos, sin, L, D, fp8=True, **qn_kw)
+                o, lse = K.attention_fwd_fp8(qk8, qk_e8, qkv, B, L, H, D, sid, S["doc_ranges"])
             else:
+                qkr, qstats = K.qknorm_rope_fwd(qkv, cos, sin, L, D, **qn_kw)
                 o, lse = K.attention_fwd(qkr, qkv, B, L, H, D, sid, S["doc_ranges"])
             rows_c = None
             if i + 1 == self.n_blocks and head_plan is not None and mode == "logp" and self.compact_last_block and not tc:

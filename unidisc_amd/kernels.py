@@ -315,7 +315,7 @@ def cast_transpose_jobs(items, device):
         buf += struct.pack("<QQQqqqiiii", _p(w), _p(out) or 0, _p(out_t) or 0, w.stride(0), out.stride(0) if out is not None else 0,
                            out_t.stride(0) if out_t is not None else 0, R, C, tile0, tiles_c)
         tile0 += ((R + 63) // 64) * tiles_c
-    table = torch.frombuffer(bytes(buf), dtype=torch.uint8).to(device)
+    table = torch.frombuffer(buf, dtype=torch.uint8).to(device)   # (a bytearray is writable: no non-writable-buffer warning)
     return table, len(items), tile0
 
 
@@ -421,12 +421,20 @@ def norm_residual_bwd(dy, x, rstd, mean, w, norm_type, L, dx, dw, branch, *, acc
 
 
 # ------------------------------------------------------------------------------------------------ attention
-def qknorm_rope_fwd(qkv, cos, sin, L, D, *, gq=None, bq=None, gk=None, bk=None):
+def qknorm_rope_fwd(qkv, cos, sin, L, D, *, gq=None, bq=None, gk=None, bk=None, fp8=False):
+    """qkv bf16 [M, 3d] -> qkr bf16 [M, 2d] (normalised + rotated q | k), LayerNorm statistics.  fp8=True (BASELINE config E): additionally the e4m3 bytes
+    qk8 [M, 2d] and the per-(row, head) E8M0 scales qk_e8 [M, 2H] the fp8 attention forward reads; qkr then holds the dequantised values."""
     M, d3 = qkv.shape
     d = d3 // 3
     qkr = torch.empty((M, 2 * d), dtype=BF16, device=qkv.device)
     stats = torch.empty((M, 4), dtype=F32, device=qkv.device) if gq is not None else None
     per_sample = 1 if cos.dim() == 3 else 0
+    if fp8:
+        qk8 = torch.empty((M, 2 * d), dtype=torch.uint8, device=qkv.device)
+        qk_e8 = torch.empty((M, 2 * (d // D)), dtype=torch.uint8, device=qkv.device)
+        _lib.call("udm_qknorm_rope_fwd_fp8", _p(qkv), _p(qkr), _p(qk8), _p(qk_e8), _p(gq), _p(bq), _p(gk), _p(bk), _p(stats), _p(cos), _p(sin), per_sample, M, d, L, D,
+                  1e-5, _s())
+        return qkr, stats, (qk8, qk_e8)
     _lib.call("udm_qknorm_rope_fwd", _p(qkv), _p(qkr), _p(gq), _p(bq), _p(gk), _p(bk), _p(stats), _p(cos), _p(sin), per_sample, M, d, L, D, 1e-5, _s())
     return qkr, stats
 
@@ -476,32 +484,47 @@ def attention_fwd(qkr, qkv, B, L, H, D, sample_ids=None, doc_ranges=None):
     return o, lse
 
 
-def _attention_fwd_fp8(q_ptr, k_ptr, v_ptr, qs, ks, vs, B, L, H, D, device, sample_ids, doc_ranges):
-    d, M, Lp = H * D, B * L, (L + 63) // 64 * 64
-    q8 = torch.empty((M, d), dtype=torch.uint8, device=device)
-    k8 = torch.empty((M, d), dtype=torch.uint8, device=device)
-    v8t = torch.empty((B * H, D, Lp), dtype=torch.uint8, device=device)
-    scales = torch.empty(3, dtype=F32, device=device)
-    amax = torch.empty(3, dtype=torch.int32, device=device)
-    _lib.call("udm_attention_quantize_fp8", q_ptr, k_ptr, v_ptr, _p(q8), _p(k8), _p(v8t), _p(scales), _p(amax), B, H, L, D, qs, ks, vs, _s())
-    o = torch.empty((M, d), dtype=BF16, device=device)
-    lse = torch.empty((B, H, L), dtype=F32, device=device)
-    _lib.call("udm_attention_fwd_fp8", _p(q8), _p(k8), _p(v8t), _p(scales), _p(o), _p(lse), _p(sample_ids), _p(doc_ranges), B, H, L, D, d, _s())
-    return o, lse, (q8, k8, v8t, scales)
+def attention_quantize_qk_fp8(qkr, D):
+    """In place on qkr bf16 [M, 2d] (normalised + rotated q | k): e4m3 bytes qk8 [M, 2d] + per-(row, head) E8M0 scales qk_e8 [M, 2H]; qkr <- dequantised values.
+    (The generic form of what udm_qknorm_rope_fwd_fp8 does inside the row kernel at d = 2048.)"""
+    M, d2 = qkr.shape
+    d = d2 // 2
+    qk8 = torch.empty((M, d2), dtype=torch.uint8, device=qkr.device)
+    qk_e8 = torch.empty((M, 2 * (d // D)), dtype=torch.uint8, device=qkr.device)
+    _lib.call("udm_attention_quantize_qk_fp8", _p(qkr), _p(qk8), _p(qk_e8), M, d, D, _s())
+    return qk8, qk_e8
 
 
-def attention_fwd_fp8(qkr, qkv, B, L, H, D, sample_ids=None, doc_ranges=None):
-    """fp8 (e4m3) forward on q, k from qkr [M,2d] and v from qkv [M,3d] (config E; no reference counterpart).  Returns o bf16 [M,d], lse."""
+def attention_quantize_v_fp8(v_ptr, v_stride, B, L, H, D, device):
+    """v (bf16, row stride v_stride elements) -> v8t [B*H, ceil(L/64), D, 64] e4m3 bytes in the forward kernel's operand order + one E8M0 scale per tile."""
+    nt = (L + 63) // 64
+    v8t = torch.empty((B * H, nt, D, 64), dtype=torch.uint8, device=device)
+    v_e8 = torch.empty((B * H, nt), dtype=torch.int32, device=device)
+    _lib.call("udm_attention_quantize_v_fp8", v_ptr, v_stride, _p(v8t), _p(v_e8), B, H, L, D, _s())
+    return v8t, v_e8
+
+
+def attention_fwd_fp8(qk8, qk_e8, qkv, B, L, H, D, sample_ids=None, doc_ranges=None):
+    """fp8 (e4m3) forward through the block-scaled 32x32x64 MFMA (config E; no reference counterpart): q, k bytes + scales from qknorm_rope_fwd(fp8=True),
+    v quantised here from qkv [M, 3d] columns [2d, 3d).  Returns o bf16 [M, d], lse."""
     d = H * D
-    o, lse, _ = _attention_fwd_fp8(qkr.data_ptr(), qkr.data_ptr() + 2 * d, qkv.data_ptr() + 4 * d, 2 * d, 2 * d, 3 * d, B, L, H, D, qkr.device, sample_ids, doc_ranges)
+    v8t, v_e8 = attention_quantize_v_fp8(qkv.data_ptr() + 4 * d, 3 * d, B, L, H, D, qkv.device)
+    o = torch.empty((B * L, d), dtype=BF16, device=qkv.device)
+    lse = torch.empty((B, H, L), dtype=F32, device=qkv.device)
+    _lib.call("udm_attention_fwd_fp8", _p(qk8), _p(qk_e8), _p(v8t), _p(v_e8), _p(o), _p(lse), _p(sample_ids), _p(doc_ranges), B, H, L, D, d, _s())
     return o, lse
 
 
 def attention_fwd_fp8_generic(q, k, v, B, L, H, D, sample_ids=None, doc_ranges=None, return_quantized=False):
-    """q, k, v: separate contiguous bf16 [B*L, H*D] (unit tests)."""
+    """q, k, v: separate contiguous bf16 [B*L, H*D] (unit tests).  With return_quantized: also (qkr_dequantised, qk8, qk_e8, v8t, v_e8)."""
     d = H * D
-    o, lse, quant = _attention_fwd_fp8(q.data_ptr(), k.data_ptr(), v.data_ptr(), d, d, d, B, L, H, D, q.device, sample_ids, doc_ranges)
-    return (o, lse, quant) if return_quantized else (o, lse)
+    qkr = torch.cat([q, k], 1).contiguous()
+    qk8, qk_e8 = attention_quantize_qk_fp8(qkr, D)
+    v8t, v_e8 = attention_quantize_v_fp8(v.data_ptr(), d, B, L, H, D, q.device)
+    o = torch.empty((B * L, d), dtype=BF16, device=q.device)
+    lse = torch.empty((B, H, L), dtype=F32, device=q.device)
+    _lib.call("udm_attention_fwd_fp8", _p(qk8), _p(qk_e8), _p(v8t), _p(v_e8), _p(o), _p(lse), _p(sample_ids), _p(doc_ranges), B, H, L, D, d, _s())
+    return (o, lse, (qkr, qk8, qk_e8, v8t, v_e8)) if return_quantized else (o, lse)
 
 
 def attention_bwd(qkr, qkv, o, do, lse, dqkr, dqkv, B, L, H, D, sample_ids=None, doc_ranges=None):
