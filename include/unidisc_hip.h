@@ -38,6 +38,9 @@ typedef struct ihipStream_t* hipStream_t;
                                OUTPUT accumulating the column sums of C (the bias gradient of the upstream Linear)         */
 
 const char* udm_last_error(void);
+/* Diagnostics / A-B switches, none of them needed by a caller (process-global; values as documented in csrc/capi.hip): keys "gemm_tile", "gemm_quad",
+ * "gemm_persist", "gemm_streamk", "attention_tr_read", "attention_w64", "attention_w64_timeline" (value = device pointer or 0).  Returns 2 for an unknown key. */
+int udm_debug_set(const char* key, int64_t value);
 int udm_abi_version(void);
 
 /* ---- GEMM family: nn.Linear forward / dgrad / wgrad under bf16 autocast -------------------------
@@ -62,12 +65,14 @@ int udm_gemm_tn_splitk_bf16(const void* A, const void* B, void* C, int64_t M, in
  * (>= slices*M*N), reduce pass rounds to bf16; falls back to udm_gemm_nt_bf16 when splitting does not apply. */
 int udm_gemm_nt_splitk_bf16(const void* A, const void* B, void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, float* ws,
                             int64_t ws_elems, hipStream_t stream);
-int udm_gemm_set_tile(int tile); /* diagnostics: force the tile family (-1 auto, 0 = 128x128 kernel, 192/256/320 = BMx256 kernel) */
-int udm_gemm_set_quad(int mode); /* diagnostics: one-wave-per-SIMD GEMM kernels: 0 = off, 1 = auto (default; env UDM_GEMM_QUAD), 2 = wherever the shape fits */
-int udm_gemm_set_persist(int enable); /* diagnostics: 0 = one block per output tile (default 1: persistent blocks for multi-round NT shapes) */
-/* data-parallel runs: cap the persistent NT grid at `cus` blocks (multiple of 8 in [8, 256]; 0 = all 256 CUs) so RCCL's channel kernels of the
- * gradient all-reduce overlapped with backward (main.py:641-656) find free CUs; also env UDM_GEMM_CUS */
+/* data-parallel runs: the GEMMs use at most `cus` CUs (multiple of 8 in [8, 256]; 0 = all 256) so RCCL's channel kernels of the gradient all-reduce
+ * overlapped with backward (main.py:641-656) find free CUs; also env UDM_GEMM_CUS.  The persistent NT kernel caps its grid; the one-wave-per-SIMD
+ * kernels (wgrads, dgrads, single-round forwards) switch to stream-K over `cus` blocks when their tile count is not a multiple of it. */
 int udm_gemm_set_cus(int cus);
+/* stream-K workspace of the one-wave-per-SIMD kernels: caller-owned device memory that must outlive its use, >= 16 KiB + 2 * 320*256*4 B per CU
+ * (160.02 MiB covers everything); arrival counters in the first 16 KiB are zeroed here.  (NULL, 0) unregisters.  GEMM launches sharing it must be ordered on
+ * one stream.  Without it every GEMM runs one tile per block in whole rounds. */
+int udm_gemm_set_workspace(void* ws, int64_t bytes, hipStream_t stream);
 /* out[C,R] = in[R,C]ᵀ (bf16); optional colsum[c] += Σ_r in[r,c] (bias gradient).  Feeds the wgrad GEMMs. */
 int udm_transpose_bf16(const void* in, void* out, int64_t R, int64_t C, int64_t ld_in, int64_t ld_out, float* colsum, hipStream_t stream);
 /* fp32 master weights -> bf16 shadow (and Kᵀ-major shadow for dgrad): the per-forward autocast weight cast. */
@@ -116,7 +121,7 @@ int udm_norm_residual_bwd(const void* dy, const float* x, const float* rstd, con
  * qkv bf16 [M,3d] -> qkr bf16 [M,2d] (normalised, rotated q | k).  cos/sin fp32 [L,D/2] or per-sample [M,D/2]. */
 int udm_qknorm_rope_fwd(const void* qkv, void* qkr, const float* gq, const float* bq, const float* gk, const float* bk, float* stats, const float* cos_t,
                         const float* sin_t, int rope_per_sample, int64_t M, int64_t d, int64_t L, int64_t D, float eps, hipStream_t stream);
-/* fp8 attention path (BASELINE config E): as udm_qknorm_rope_fwd, plus qk8 [M,2d] e4m3 bytes and qk_e8 [M, 2 d/D] E8M0 scales (one per row and head) of the
+/* fp8 attention path (BASELINE config E): as udm_qknorm_rope_fwd, plus qk8 [M,2d] e4m3 bytes and qk_e8 [M, 2 Hp] E8M0 scales (one per row and head; Hp = d/D rounded up to 4: q heads at [0, H), k heads at [Hp, Hp + H)) of the
  * rotated q | k; qkr then holds the dequantised values.  Fused into the row kernel at d = 2048. */
 int udm_qknorm_rope_fwd_fp8(const void* qkv, void* qkr, void* qk8, uint8_t* qk_e8, const float* gq, const float* bq, const float* gk, const float* bk, float* stats,
                             const float* cos_t, const float* sin_t, int rope_per_sample, int64_t M, int64_t d, int64_t L, int64_t D, float eps, hipStream_t stream);
@@ -141,7 +146,7 @@ int udm_attention_bwd(const void* q, const void* k, const void* v, const void* o
 /* fp8 (OCP e4m3) forward, BASELINE config E; no reference counterpart - parity target is udm_attention_fwd under a stated tolerance.
  * S and PV run through v_mfma_scale_f32_32x32x64_f8f6f4 (twice the bf16 matrix rate); every scale is a power of two carried as an E8M0 byte the
  * instruction applies itself.  Operands:
- *   qk8   [B*L, 2d] bytes   e4m3 of the normalised + rotated q | k, qk_e8 [B*L, 2H] one E8M0 scale per (row, q head | k head):
+ *   qk8   [B*L, 2d] bytes   e4m3 of the normalised + rotated q | k, qk_e8 [B*L, 2 Hp] (Hp = H rounded up to 4) one E8M0 scale per (row, q head | k head):
  *                            written by udm_qknorm_rope_fwd_fp8 (below), or from an existing bf16 qkr by udm_attention_quantize_qk_fp8, which also
  *                            rewrites qkr with the DEQUANTISED values (what the bf16 backward must read);
  *   v8t   [B*H, ceil(L/64), D, 64] bytes  per 64-key tile V^T, keys of a row in the order the kernel holds its probabilities
@@ -151,9 +156,6 @@ int udm_attention_quantize_qk_fp8(void* qkr, void* qk8, uint8_t* qk_e8, int64_t 
 int udm_attention_quantize_v_fp8(const void* v, int64_t v_stride, void* v8t, int32_t* v_e8, int64_t B, int64_t H, int64_t L, int64_t D, hipStream_t stream);
 int udm_attention_fwd_fp8(const void* qk8, const uint8_t* qk_e8, const void* v8t, const int32_t* v_e8, void* o, float* lse, const int64_t* sample_ids,
                           const int32_t* doc_ranges, int64_t B, int64_t H, int64_t L, int64_t D, int64_t o_stride, hipStream_t stream);
-int udm_attention_set_tr_read(int enable); /* diagnostics: 0 = gather Vᵀ fragments with scalar LDS reads */
-int udm_attention_w64_timeline(uint64_t* buf); /* diagnostics: device buffer of 512 cycle stamps (2 blocks x 4 waves x 64 tags) written by the next forward launches; null = off */
-int udm_attention_set_w64(int enable);     /* diagnostics / A-B runs: 0 = the 8-wave forward kernel also at head dim 128 without a document mask (default 1; env UDM_ATTN_W64) */
 
 /* ---- embeddings: EmbeddingLayer models/dit.py:1036-1043 (+modality embedding :1402-1411) ------------- */
 int udm_embedding_fwd(const int64_t* ids, const float* E, const int64_t* modality, const float* Em, float* x, int64_t M, int64_t d, int64_t V,

@@ -12,10 +12,10 @@ o, lse = K.attention_fwd_generic(q, k, v, B, L, H, D)
 for _ in range(3): K.attention_bwd_generic(q, k, v, o, do, lse, B, L, H, D)
 buf = torch.zeros(8 * 64, dtype=torch.int64, device="cuda")
 lib = _lib.load()
-lib.udm_attention_w64_timeline(ctypes.c_void_p(buf.data_ptr()))
+lib.udm_debug_set(b"attention_w64_timeline", ctypes.c_int64(buf.data_ptr()))
 K.attention_bwd_generic(q, k, v, o, do, lse, B, L, H, D)
 torch.cuda.synchronize()
-lib.udm_attention_w64_timeline(ctypes.c_void_p(0))
+lib.udm_debug_set(b"attention_w64_timeline", ctypes.c_int64(0))
 t = buf.cpu().reshape(8, 64)
 nkv = L // 64
 for w in range(2):

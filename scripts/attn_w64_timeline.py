@@ -10,10 +10,10 @@ q, k, v = ((torch.randn(B * L, H * D, device="cuda", generator=g)).to(torch.bflo
 for _ in range(3): K.attention_fwd_generic(q, k, v, B, L, H, D)
 buf = torch.zeros(2 * 4 * 64, dtype=torch.int64, device="cuda")
 lib = _lib.load()
-lib.udm_attention_w64_timeline(ctypes.c_void_p(buf.data_ptr()))
+lib.udm_debug_set(b"attention_w64_timeline", ctypes.c_int64(buf.data_ptr()))
 K.attention_fwd_generic(q, k, v, B, L, H, D)
 torch.cuda.synchronize()
-lib.udm_attention_w64_timeline(ctypes.c_void_p(0))
+lib.udm_debug_set(b"attention_w64_timeline", ctypes.c_int64(0))
 t = buf.cpu().reshape(2, 4, 64)
 nkv = (L + 63) // 64
 for blk in range(2):

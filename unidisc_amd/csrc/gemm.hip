@@ -701,7 +701,7 @@ int g_gemm_persist = 1;   // diagnostics (UDM_GEMM_PERSIST=0): 0 = one block per
 // Data-parallel runs: the persistent blocks of a multi-round NT GEMM occupy every CU for the whole launch, and RCCL's channel kernels (the
 // gradient all-reduce overlapped with backward) then only get CUs between launches.  UDM_GEMM_CUS = n (or udm_gemm_set_cus) caps the
 // persistent grid at n blocks (a multiple of 8: one block per CU, XCD round-robin), leaving 256 - n CUs to the collective.  0 = all 256.
-int g_gemm_cus = 0;
+// (g_gemm_cus and the stream-K workspace live in gemm_quad.hip: shared by both translation units through gemm_quad.h)
 
 template <int BMX, int EPI, bool OUT_F32, bool TN = false>
 int launch_big_t(const GemmArgs& a0, hipStream_t stream) {
@@ -721,7 +721,7 @@ int launch_big_t(const GemmArgs& a0, hipStream_t stream) {
     // more than one round of whole tiles: 256 persistent blocks walk them (see PERSIST above)
     static const bool env_once = [] {
       if (const char* e = getenv("UDM_GEMM_PERSIST")) g_gemm_persist = atoi(e);
-      if (const char* e = getenv("UDM_GEMM_CUS")) { const int n = atoi(e); if (n >= 8 && n <= 256) g_gemm_cus = n / 8 * 8; }
+      (void)udm_gemm_cus();
       return true;
     }();
     (void)env_once;
@@ -1041,6 +1041,17 @@ extern "C" int udm_gemm_nn_bf16(const void* A, const void* B, void* C, int64_t M
   q.A = (const bf16_t*)A; q.B = (const bf16_t*)B; q.C = C; q.lda = lda; q.ldb = ldb; q.ldc = ldc;
   q.M = (int)M; q.N = (int)N; q.K = (int)K; q.beta = 0.f; q.splitk = 1;
   return udm_quad_launch_nn(q, fm, stream);
+}
+
+// Stream-K workspace (caller-owned device memory, kept alive by the caller): [0, 16 KiB) per-tile arrival counters - zeroed here, self-resetting afterwards -
+// then two fp32 partial-tile slots per block.  256 blocks x 2 x 320 x 256 x 4 B + 16 KiB = 160.02 MiB covers every tile shape; without it (or with
+// UDM_GEMM_STREAMK=0) the GEMMs run one tile per block in whole rounds as before.  GEMM launches that share the workspace must be ordered on one stream.
+extern "C" int udm_gemm_set_workspace(void* ws, int64_t bytes, hipStream_t stream) {
+  UDM_CHECK_ARG((ws == nullptr && bytes == 0) || (ws && bytes >= 16384 && ((uintptr_t)ws % 256) == 0), "udm_gemm_set_workspace: need a 256-byte aligned buffer of at least 16 KiB (or null, 0)");
+  if (ws && hipMemsetAsync(ws, 0, 16384, stream) != hipSuccess) { udm_set_error("udm_gemm_set_workspace: memset failed"); return 1; }
+  g_gemm_ws = ws;
+  g_gemm_ws_bytes = bytes;
+  return 0;
 }
 
 extern "C" int udm_gemm_set_cus(int cus) {   // 0 = all CUs; otherwise the persistent NT grid (a multiple of 8 in [8, 256])

@@ -521,7 +521,7 @@ struct QkArgs {
   int M, d, L, D, rope_per_sample;
   float eps;
   uint8_t* qk8 = nullptr;     // fp8 path (udm_qknorm_rope_fwd_fp8): [M, 2d] e4m3 bytes of the rotated q | k ...
-  uint8_t* qk_e8 = nullptr;   // ... and one E8M0 scale per (row, q head | k head): [M, 2 d / D]
+  uint8_t* qk_e8 = nullptr;   // ... and one E8M0 scale per (row, q head | k head): [M, 2 Hp], Hp = d / D rounded up to 4
 };
 
 __device__ __forceinline__ void load4_bf16(const bf16_t* p, float (&v)[4]) {
@@ -1508,7 +1508,7 @@ __global__ __launch_bounds__(256) void qknorm_rope_fwd_brow_rows_kernel(QkArgs a
         uint8_t* q8 = a.qk8 + row * 2 * a.d + part * a.d + hc;
         *reinterpret_cast<uint2*>(q8) = l8;
         *reinterpret_cast<uint2*>(q8 + half) = h8;
-        if (r % per_head == 0) a.qk_e8[row * 2 * (a.d / a.D) + part * (a.d / a.D) + r / per_head] = (uint8_t)e8;
+        if (r % per_head == 0) { const int Hp = (a.d / a.D + 3) & ~3; a.qk_e8[row * 2 * Hp + part * Hp + r / per_head] = (uint8_t)e8; }
       }
       store8_bf16(a.qkr + row * 2 * a.d + part * a.d + hc, ol);
       store8_bf16(a.qkr + row * 2 * a.d + part * a.d + hc + half, oh);
@@ -1811,7 +1811,7 @@ extern "C" int udm_qknorm_rope_fwd(const void* qkv, void* qkr, const float* gq, 
   return qknorm_rope_fwd_impl(qkv, qkr, gq, bq, gk, bk, stats, cos_t, sin_t, rope_per_sample, M, d, L, D, eps, nullptr, nullptr, stream);
 }
 
-// fp8 attention path (BASELINE config E): as udm_qknorm_rope_fwd, plus qk8 [M, 2d] e4m3 bytes and qk_e8 [M, 2 d / D] E8M0 scales of the rotated q | k; `qkr`
+// fp8 attention path (BASELINE config E): as udm_qknorm_rope_fwd, plus qk8 [M, 2d] e4m3 bytes and qk_e8 [M, 2 Hp] E8M0 scales (Hp = d / D rounded up to 4) of the rotated q | k; `qkr`
 // receives the dequantised values.  Fused into the row kernel at d = 2048; other widths run the plain kernel followed by udm_attention_quantize_qk_fp8.
 extern "C" int udm_qknorm_rope_fwd_fp8(const void* qkv, void* qkr, void* qk8, uint8_t* qk_e8, const float* gq, const float* bq, const float* gk, const float* bk,
                                        float* stats, const float* cos_t, const float* sin_t, int rope_per_sample, int64_t M, int64_t d, int64_t L, int64_t D,

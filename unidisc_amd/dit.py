@@ -323,6 +323,9 @@ class DIT(nn.Module, _HubMixin):
         return out
 
     def _build_lins(self):
+        dev = self.vocab_embed.embedding.device
+        if dev.type == "cuda" and hasattr(K, "gemm_workspace"):
+            K.gemm_workspace(dev)   # stream-K workspace of the one-wave-per-SIMD GEMMs (160 MiB, once per process)
         L: Dict[str, _Lin] = {}
         for i, blk in enumerate(self.blocks):
             L[f"{i}.qkv"] = _Lin(blk.attention.attn_qkv.weight, None)

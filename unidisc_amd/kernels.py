@@ -265,23 +265,49 @@ def colsum(x, out):
     return out
 
 
+def debug_set(key: str, value: int):
+    """Diagnostics / A-B switches of the library (udm_debug_set; keys in include/unidisc_hip.h)."""
+    _lib.call("udm_debug_set", key.encode(), int(value))
+
+
 def gemm_set_persist(enable: int):
-    _lib.call("udm_gemm_set_persist", int(enable))
+    debug_set("gemm_persist", int(enable))
 
 
 def gemm_set_quad(mode: int):
     """Diagnostics: one-wave-per-SIMD GEMM kernels (gemm_quad.hip): 0 = off, 1 = auto, 2 = wherever the shape fits."""
-    _lib.call("udm_gemm_set_quad", int(mode))
+    debug_set("gemm_quad", int(mode))
+
+
+def gemm_set_streamk(enable: int):
+    """Diagnostics: 0 = the one-wave-per-SIMD GEMMs never split tiles over blocks (whole rounds of one tile per block, as without a workspace)."""
+    debug_set("gemm_streamk", int(enable))
 
 
 def gemm_set_cus(cus: int):
-    """Cap the persistent NT GEMM grid at `cus` blocks (multiple of 8; 0 = all 256 CUs): leaves CUs to RCCL's kernels in data-parallel runs."""
+    """The GEMMs use at most `cus` CUs (multiple of 8; 0 = all 256): leaves CUs to RCCL's kernels in data-parallel runs.  The persistent NT kernel caps its
+    grid, the one-wave-per-SIMD kernels go stream-K over `cus` blocks (needs the workspace: gemm_workspace)."""
     _lib.call("udm_gemm_set_cus", int(cus))
+
+
+_GEMM_WS = {}
+
+
+def gemm_workspace(device, nbytes: int = 16384 + 256 * 2 * 320 * 256 * 4):
+    """Register the stream-K workspace of the one-wave-per-SIMD GEMMs (udm_gemm_set_workspace) on `device` once: 160 MiB that stay allocated for the life of
+    the process.  Called by the engine before its first GEMM; without it every GEMM runs one tile per block in whole rounds."""
+    key = (device.type, device.index)
+    if key not in _GEMM_WS:
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        _lib.call("udm_gemm_set_workspace", _p(ws), nbytes, _s())
+        _GEMM_WS.clear()      # (one device per process: the library holds ONE workspace pointer)
+        _GEMM_WS[key] = ws
+    return _GEMM_WS[key]
 
 
 def gemm_set_tile(tile: int):
     """Diagnostics: force the GEMM tile family (-1 auto, 0 small kernel, 192/256/320)."""
-    _lib.call("udm_gemm_set_tile", tile)
+    debug_set("gemm_tile", tile)
 
 
 def transpose(x, out=None, colsum=None, R=None, C=None):
@@ -423,7 +449,7 @@ def norm_residual_bwd(dy, x, rstd, mean, w, norm_type, L, dx, dw, branch, *, acc
 # ------------------------------------------------------------------------------------------------ attention
 def qknorm_rope_fwd(qkv, cos, sin, L, D, *, gq=None, bq=None, gk=None, bk=None, fp8=False):
     """qkv bf16 [M, 3d] -> qkr bf16 [M, 2d] (normalised + rotated q | k), LayerNorm statistics.  fp8=True (BASELINE config E): additionally the e4m3 bytes
-    qk8 [M, 2d] and the per-(row, head) E8M0 scales qk_e8 [M, 2H] the fp8 attention forward reads; qkr then holds the dequantised values."""
+    qk8 [M, 2d] and the per-(row, head) E8M0 scales qk_e8 [M, 2 Hp] (Hp = H rounded up to 4) the fp8 attention forward reads; qkr then holds the dequantised values."""
     M, d3 = qkv.shape
     d = d3 // 3
     qkr = torch.empty((M, 2 * d), dtype=BF16, device=qkv.device)
@@ -431,7 +457,7 @@ def qknorm_rope_fwd(qkv, cos, sin, L, D, *, gq=None, bq=None, gk=None, bk=None, 
     per_sample = 1 if cos.dim() == 3 else 0
     if fp8:
         qk8 = torch.empty((M, 2 * d), dtype=torch.uint8, device=qkv.device)
-        qk_e8 = torch.empty((M, 2 * (d // D)), dtype=torch.uint8, device=qkv.device)
+        qk_e8 = torch.full((M, 2 * _hp(d // D)), 127, dtype=torch.uint8, device=qkv.device)
         _lib.call("udm_qknorm_rope_fwd_fp8", _p(qkv), _p(qkr), _p(qk8), _p(qk_e8), _p(gq), _p(bq), _p(gk), _p(bk), _p(stats), _p(cos), _p(sin), per_sample, M, d, L, D,
                   1e-5, _s())
         return qkr, stats, (qk8, qk_e8)
@@ -484,13 +510,17 @@ def attention_fwd(qkr, qkv, B, L, H, D, sample_ids=None, doc_ranges=None):
     return o, lse
 
 
+def _hp(H):
+    return (H + 3) // 4 * 4
+
+
 def attention_quantize_qk_fp8(qkr, D):
-    """In place on qkr bf16 [M, 2d] (normalised + rotated q | k): e4m3 bytes qk8 [M, 2d] + per-(row, head) E8M0 scales qk_e8 [M, 2H]; qkr <- dequantised values.
+    """In place on qkr bf16 [M, 2d] (normalised + rotated q | k): e4m3 bytes qk8 [M, 2d] + per-(row, head) E8M0 scales qk_e8 [M, 2 Hp] (q heads at [0, H), k heads at [Hp, Hp + H)); qkr <- dequantised values.
     (The generic form of what udm_qknorm_rope_fwd_fp8 does inside the row kernel at d = 2048.)"""
     M, d2 = qkr.shape
     d = d2 // 2
     qk8 = torch.empty((M, d2), dtype=torch.uint8, device=qkr.device)
-    qk_e8 = torch.empty((M, 2 * (d // D)), dtype=torch.uint8, device=qkr.device)
+    qk_e8 = torch.full((M, 2 * _hp(d // D)), 127, dtype=torch.uint8, device=qkr.device)
     _lib.call("udm_attention_quantize_qk_fp8", _p(qkr), _p(qk8), _p(qk_e8), M, d, D, _s())
     return qk8, qk_e8
 
@@ -556,12 +586,12 @@ def attention_bwd_generic(q, k, v, o, do, lse, B, L, H, D, sample_ids=None, doc_
 
 
 def set_tr_read(enable: bool):
-    _lib.load().udm_attention_set_tr_read(1 if enable else 0)
+    debug_set("attention_tr_read", 1 if enable else 0)
 
 
 def set_attention_w64(enable: bool):
     """A/B switch: the one-wave-per-SIMD forward kernel (head dim 128, no document mask) on / off."""
-    _lib.load().udm_attention_set_w64(1 if enable else 0)
+    debug_set("attention_w64", 1 if enable else 0)
 
 
 # ------------------------------------------------------------------------------------------------ embedding / CE / adaLN helpers
