@@ -8,7 +8,7 @@
 //     tile (the lane's 32 score registers, converted to e4m3, ARE the 32-byte B operand: byte f*16 + r = key f*32 + (r&3) + 8 (r>>2) + 4 hi).
 //   * Scales are powers of two (E8M0 bytes) applied by the instruction itself: one per (row, head) for q and k (written by the qk-norm + rope kernel,
 //     udm_qknorm_rope_fwd_fp8, which also leaves the DEQUANTISED values in the bf16 `qkr` the backward reads), one per 64-key tile and head for v, and
-//     the constant 2^-8 that undoes the 2^8 the probabilities are scaled by before their conversion (p <= 1: the running maximum is exact here).
+//     the constant 2^-8 that undoes the 2^8 the probabilities are scaled by before their conversion (p <= 2^0.75: the reference exponent is lazy within e4m3's head-room).
 //     No scale arithmetic in the softmax.
 //   * Operands: qk8 [B*L][2d] bytes (q | k), K tiles staged by LDS-DMA as [64 keys][D bytes]; v8t [B*H][Lp/64][D][64] bytes - per tile V^T with the
 //     keys of a row in the order the P operand holds them (udm_attention_quantize_v_fp8) - one contiguous 64 D-byte piece per tile.
@@ -178,8 +178,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_fp8_kernel(Fp8Args a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, sT[f][r]);
     mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
-    // exact running maximum: p <= 1, so 2^8 p <= 256 < 448 converts without saturation
-    if (__builtin_amdgcn_ballot_w64(q_ok && mloc > m) != 0) {
+    // Lazy reference (as in the bf16 kernel, with the head-room e4m3 leaves): m is the reference exponent of this query and only moves when some query of
+    // the wave saw a score more than 0.75 (log2 units) above its reference - then 2^8 p <= 2^8.75 = 431 < 448 still converts without saturation.  With the
+    // exact running maximum the wave rescaled O^T (64 multiplies per lane) in most tiles: one of its 32 queries almost always sets a new record.
+    if (__builtin_amdgcn_ballot_w64(q_ok && (mloc * c > m * c + 0.75f)) != 0) {
       const float m_new = fmaxf(m, mloc);
       const float alpha = __builtin_amdgcn_exp2f((m - ((m_new == -INFINITY) ? 0.f : m_new)) * c);
       lsum *= alpha;

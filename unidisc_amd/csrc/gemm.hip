@@ -817,11 +817,16 @@ extern "C" int udm_gemm_nt_bf16(const void* A, const void* B, void* C, int64_t M
       const long qt = (M / (64 * fm)) * (N / 256);
       const int t8 = choose_tile(M, N, K, lda, ldb);
       const long t8n = t8 ? ((M + t8 - 1) / t8) * ((N + 255) / 256) : 0;
-      const double q_cost = (double)((qt + 255) / 256) * 64 * fm, o_cost = t8 ? (double)((t8n + 255) / 256) * t8 : 1e30;
+      // cost = tile rows a CU works through: whole rounds of the CUs the GEMM may use, or - where the quad kernel goes stream-K (tile count not a multiple of
+      // them, workspace registered) - the even share plus an allowance for the partial-tile exchange
+      const int cus = udm_gemm_cus();
+      const bool sk = udm_gemm_streamk() && g_gemm_ws != nullptr && qt % cus != 0 && qt >= cus;
+      const double q_cost = sk ? (double)qt * 64 * fm / cus + 16 : (double)((qt + cus - 1) / cus) * 64 * fm;
+      const double o_cost = t8 ? (double)((t8n + cus - 1) / cus) * t8 : 1e30;
       // measured (scripts/bench_gemm_quad.py, 1.4 B shapes, random operands): the quad kernel wins 1-3 % on single-round shapes with a plain or
       // bias epilogue and loses 3 % where the GELU / GELU' epilogue runs (one wave per SIMD has nothing to overlap its VALU with);
       // multi-round shapes stay with the persistent 8-wave blocks
-      if (udm_quad_mode() == 2 || (qt >= 128 && qt <= 256 && q_cost <= o_cost && epilogue <= UDM_EPI_BIAS)) {
+      if (udm_quad_mode() == 2 || (qt >= 128 && qt <= (sk ? 2 * cus : 256) && q_cost <= o_cost && epilogue <= UDM_EPI_BIAS)) {
         QuadArgs q{};
         q.A = a.A; q.B = a.B; q.C = C; q.bias = bias; q.aux = (bf16_t*)aux; q.lda = lda; q.ldb = ldb; q.ldc = ldc; q.ldaux = ldaux;
         q.M = a.M; q.N = a.N; q.K = a.K; q.beta = 0.f; q.splitk = 1;

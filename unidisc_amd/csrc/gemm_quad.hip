@@ -316,13 +316,16 @@ __global__ __launch_bounds__(256, 1) void gemm_quad_kernel(QuadArgs p) {
     __syncthreads();
     if (!last) {
       float* mine = slot_of(sk_r);
+      // (one 32 x 32 accumulator block at a time, fenced for the scheduler: hoisting all 64-80 blocks' copies out of the accumulator file at once spills)
 #pragma unroll
       for (int i = 0; i < FM; ++i)
 #pragma unroll
-        for (int j = 0; j < FN; ++j)
+        for (int j = 0; j < FN; ++j) {
 #pragma unroll
           for (int q = 0; q < 4; ++q)
             *reinterpret_cast<float4*>(mine + (((i * FN + j) * 4 + q) * 256 + tid) * 4) = make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
       __threadfence();   // release: the partial is visible device-wide before the arrival is
       __syncthreads();
       if (tid == 0) sk_flag = __hip_atomic_fetch_add(ctr, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
@@ -339,12 +342,14 @@ __global__ __launch_bounds__(256, 1) void gemm_quad_kernel(QuadArgs p) {
 #pragma unroll
         for (int i = 0; i < FM; ++i)
 #pragma unroll
-          for (int j = 0; j < FN; ++j)
+          for (int j = 0; j < FN; ++j) {
+            float4 v[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              const float4 v = *reinterpret_cast<const float4*>(theirs + (((i * FN + j) * 4 + q) * 256 + tid) * 4);
-              acc[i][j][4 * q] += v.x; acc[i][j][4 * q + 1] += v.y; acc[i][j][4 * q + 2] += v.z; acc[i][j][4 * q + 3] += v.w;
-            }
+            for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const float4*>(theirs + (((i * FN + j) * 4 + q) * 256 + tid) * 4);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { acc[i][j][4 * q] += v[q].x; acc[i][j][4 * q + 1] += v[q].y; acc[i][j][4 * q + 2] += v[q].z; acc[i][j][4 * q + 3] += v[q].w; }
+            __builtin_amdgcn_sched_barrier(0);
+          }
       }
       if (tid == 0) __hip_atomic_store(ctr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch (launches of one stream are ordered)
     }
@@ -462,7 +467,7 @@ int launch_quad_t(const QuadArgs& a0, hipStream_t stream) {
   const int cus = udm_gemm_cus();
   const long tiles = (long)a.tiles_m * a.tiles_n;
   constexpr long SLOT_BYTES = (long)BM * 256 * 4;
-  if (udm_gemm_streamk() && a.splitk <= 1 && g_gemm_ws && tiles % cus != 0 && tiles <= 4096 && tiles * 8 >= cus && a.K / BK >= 2 &&
+  if (udm_gemm_streamk() && a.splitk <= 1 && g_gemm_ws && tiles % cus != 0 && tiles <= 4096 && tiles >= cus && a.K / BK >= 2 &&   // (tiles >= cus: at most two contributors per tile - a deterministic sum)
       g_gemm_ws_bytes >= 16384 + (long)cus * 2 * SLOT_BYTES) {
     a.sk_blocks = cus;
     a.sk_counters = reinterpret_cast<int*>(g_gemm_ws);
@@ -485,7 +490,7 @@ int pick_fm(long M, long N, const int* cands, int n) {
     if (M % bm != 0) continue;
     const long tiles = (M / bm) * (N / 256);
     const int cus = udm_gemm_cus();
-    if (sk && tiles % cus != 0 && tiles * 8 >= cus && tiles <= 4096 && g_gemm_ws_bytes >= 16384 + (long)cus * 2 * bm * 256 * 4) return pick ? pick : cands[c];
+    if (sk && tiles % cus != 0 && tiles >= cus && tiles <= 4096 && g_gemm_ws_bytes >= 16384 + (long)cus * 2 * bm * 256 * 4) return pick ? pick : cands[c];
     const long rounds = (tiles + cus - 1) / cus;
     const double t = (double)rounds * bm;
     if (t < best) { best = t; pick = cands[c]; }
@@ -507,7 +512,9 @@ int udm_gemm_cus() {
   return g_gemm_cus ? g_gemm_cus : 256;
 }
 bool udm_gemm_streamk() {
-  if (g_gemm_streamk < 0) { const char* e = getenv("UDM_GEMM_STREAMK"); g_gemm_streamk = e ? (atoi(e) != 0) : 1; }
+  // default OFF: measured (round 3) - with the tile count close to the block count every tile is split and the fp32 partial exchange (one
+  // 256-320 KB tile written and read per block, all at the end of the launch) costs more than the rounds it saves
+  if (g_gemm_streamk < 0) { const char* e = getenv("UDM_GEMM_STREAMK"); g_gemm_streamk = e ? (atoi(e) != 0) : 0; }
   return g_gemm_streamk != 0;
 }
 
