@@ -371,6 +371,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--time-every", type=int, default=16, help="bracket 1 GEMM launch in this many with HIP events inside the timed region (1 = all: costs ~1.7 ms/step)")
+    ap.add_argument("--hog-cus", type=int, default=0, help="diagnostics: hold this many CUs with a spinning kernel for the whole run (stand-in for RCCL's channel kernels; "
+                    "combine with UDM_GEMM_CUS = 256 - n so the GEMMs plan for the remaining CUs)")
     ap.add_argument("--table-steps", type=int, default=2, help="extra untimed steps after the timed region with every launch event-timed (roofline_table); 0 = off")
     args = ap.parse_args()
 
@@ -430,9 +432,19 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    hog = None
+    if args.hog_cus > 0:
+        from unidisc_amd import _lib
+        hog_flag = torch.zeros(1, dtype=torch.int32).pin_memory()
+        hog_stream = torch.cuda.Stream(device=device)
+        _lib.call("udm_debug_cu_hog", int(args.hog_cus), hog_flag.data_ptr(), hog_stream.cuda_stream)
+        hog = (hog_flag, hog_stream)
     for i in range(args.warmup):
         out = step(i)
-    fence()
+    if hog is None:
+        fence()
+    else:   # (a device-wide synchronise would wait for the spinning kernel)
+        torch.cuda.current_stream().synchronize()
     if sync is not None:
         sync.measure_exposed = True
     timer.enabled = True
@@ -442,8 +454,14 @@ def main():
     for i in range(args.steps):
         out = step(args.warmup + i)
         marks[i + 1].record()
-    fence()
+    if hog is None:
+        fence()
+    else:
+        torch.cuda.current_stream().synchronize()
     dt = time.perf_counter() - t0
+    if hog is not None:
+        hog[0][0] = 1          # release the held CUs
+        hog[1].synchronize()
     timer.enabled = False
     per_step_ms = sorted(a.elapsed_time(b) for a, b in zip(marks[:-1], marks[1:]))
     median_ms = per_step_ms[len(per_step_ms) // 2] if len(per_step_ms) % 2 else 0.5 * (per_step_ms[len(per_step_ms) // 2 - 1] + per_step_ms[len(per_step_ms) // 2])
@@ -465,7 +483,7 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "config": {"workload": w["desc"], "per_gpu_batch": B, "global_batch": B * world, "seq_len": L, "parallelism": f"dp{world}",
                    "dropout": args.dropout, "weights": "random init (zero_linear_init=false)",
-                   "attention_forward": "fp8 e4m3" if args.fp8_attention else "bf16"},
+                   "attention_forward": "fp8 e4m3" if args.fp8_attention else "bf16", **({"cus_held_by_a_spinning_kernel": args.hog_cus} if args.hog_cus else {})},
         "tokens_per_s_per_gpu": value / world, "loss": loss, "flops_per_token": f_tok,
         "step_mfu": (value / world) * f_tok / (PEAK_BF16_DENSE_TFLOPS * 1e12),   # dense head, no recompute credit
     }

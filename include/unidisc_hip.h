@@ -39,8 +39,11 @@ typedef struct ihipStream_t* hipStream_t;
 
 const char* udm_last_error(void);
 /* Diagnostics / A-B switches, none of them needed by a caller (process-global; values as documented in csrc/capi.hip): keys "gemm_tile", "gemm_quad",
- * "gemm_persist", "gemm_streamk", "attention_tr_read", "attention_w64", "attention_w64_timeline" (value = device pointer or 0).  Returns 2 for an unknown key. */
+ * "gemm_persist", "attention_tr_read", "attention_w64", "attention_w64_timeline" (value = device pointer or 0).  Returns 2 for an unknown key. */
 int udm_debug_set(const char* key, int64_t value);
+/* Diagnostics: hold `blocks` CUs (1..128; one 160 KiB-LDS block each) until *flag != 0 (pinned host or device memory) - the stand-in for a collective's channel
+ * kernels when the GEMMs' behaviour under a CU reservation is measured on one GPU. */
+int udm_debug_cu_hog(int64_t blocks, const int* flag, hipStream_t stream);
 int udm_abi_version(void);
 
 /* ---- GEMM family: nn.Linear forward / dgrad / wgrad under bf16 autocast -------------------------
@@ -65,14 +68,9 @@ int udm_gemm_tn_splitk_bf16(const void* A, const void* B, void* C, int64_t M, in
  * (>= slices*M*N), reduce pass rounds to bf16; falls back to udm_gemm_nt_bf16 when splitting does not apply. */
 int udm_gemm_nt_splitk_bf16(const void* A, const void* B, void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, float* ws,
                             int64_t ws_elems, hipStream_t stream);
-/* data-parallel runs: the GEMMs use at most `cus` CUs (multiple of 8 in [8, 256]; 0 = all 256) so RCCL's channel kernels of the gradient all-reduce
- * overlapped with backward (main.py:641-656) find free CUs; also env UDM_GEMM_CUS.  The persistent NT kernel caps its grid; the one-wave-per-SIMD
- * kernels (wgrads, dgrads, single-round forwards) switch to stream-K over `cus` blocks when their tile count is not a multiple of it. */
+/* data-parallel runs: cap the persistent NT grid at `cus` blocks (multiple of 8 in [8, 256]; 0 = all 256 CUs) so RCCL's channel kernels of the
+ * gradient all-reduce overlapped with backward (main.py:641-656) find free CUs; also env UDM_GEMM_CUS */
 int udm_gemm_set_cus(int cus);
-/* stream-K workspace of the one-wave-per-SIMD kernels: caller-owned device memory that must outlive its use, >= 16 KiB + 2 * 320*256*4 B per CU
- * (160.02 MiB covers everything); arrival counters in the first 16 KiB are zeroed here.  (NULL, 0) unregisters.  GEMM launches sharing it must be ordered on
- * one stream.  Without it every GEMM runs one tile per block in whole rounds. */
-int udm_gemm_set_workspace(void* ws, int64_t bytes, hipStream_t stream);
 /* out[C,R] = in[R,C]ᵀ (bf16); optional colsum[c] += Σ_r in[r,c] (bias gradient).  Feeds the wgrad GEMMs. */
 int udm_transpose_bf16(const void* in, void* out, int64_t R, int64_t C, int64_t ld_in, int64_t ld_out, float* colsum, hipStream_t stream);
 /* fp32 master weights -> bf16 shadow (and Kᵀ-major shadow for dgrad): the per-forward autocast weight cast. */

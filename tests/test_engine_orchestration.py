@@ -167,3 +167,43 @@ def test_zero_modality_loss_weight_is_kept(fake_k):
     full, img_only, txt_only = losses[(1.0, 0.5)], losses[(0.0, 0.5)], losses[(1.0, 0.0)]
     assert img_only[1] == 0.0 and abs(img_only[0] - full[2]) <= 1e-6 * abs(full[2]) and img_only[0] != full[0]
     assert txt_only[2] == 0.0 and abs(txt_only[0] - full[1]) <= 1e-6 * abs(full[1])
+
+
+def test_key_padding_mask_use_attention_mask(fake_k):
+    """`model.use_attention_mask` (model.py:405-406 -> sdpa(attn_mask=attention_mask), models/dit.py:829): the batch's padding mask hides padded KEYS from every
+    query of the sample.  Logits against the oracle with the same dense allow-mask; padded keys really are invisible (changing their tokens changes nothing at
+    the valid positions); combined with modality attention dropout both masks apply."""
+    from oracle import unidisc_oracle as O
+    from unidisc_amd import ModalityMask
+
+    g = Golden("c_large")
+    diff = build_product(g, device="cpu")
+    diff.backbone.eval()
+    xt, mod = g.t("fp32/xt"), g.t("fp32/modality")
+    B, L = xt.shape
+    km = torch.ones(B, L, dtype=torch.bool)
+    km[0, 5:9] = False
+    km[1, L - 7:] = False
+    P, buf = g.params(), g.buffers()
+    allow = km[:, None, :].expand(B, L, L)
+    with torch.no_grad():
+        got = diff.backbone(xt, None, modality=mod, attention_mask=km).float()
+        ref = O.dit_forward(g.cfg, P, buf, xt, None, mod, None, False, allow_mask=allow)
+        base = diff.backbone(xt, None, modality=mod).float()
+        x2 = xt.clone()
+        x2[0, 5:9] = (x2[0, 5:9] + 3) % 17
+        got2 = diff.backbone(x2, None, modality=mod, attention_mask=km).float()
+    assert rel_err(got, ref) <= 3 * rel_err(g.t("bf16/logits"), g.t("fp32/logits")) + 5e-3
+    assert rel_err(base, ref) > 10 * rel_err(got, ref)            # the mask matters
+    valid0 = km[0]
+    assert rel_err(got2[0][valid0], got[0][valid0]) < 1e-6 and torch.equal(got2[1], got[1])   # padded keys are invisible to the valid positions
+    # together with modality attention dropout: both restrictions hold
+    drop = ModalityMask(torch.tensor([True] + [False] * (B - 1)), torch.zeros(B, dtype=torch.bool), g.case["txt_length"])
+    with torch.no_grad():
+        both = diff.backbone(xt, None, modality=mod, attention_mask=km, block_mask=drop).float()
+    is_txt = torch.arange(L) < g.case["txt_length"]
+    allow2 = allow.clone()
+    allow2[0] &= ~(is_txt[:, None] & ~is_txt[None, :])            # sample 0: text queries see text keys only
+    with torch.no_grad():
+        ref2 = O.dit_forward(g.cfg, P, buf, xt, None, mod, None, False, allow_mask=allow2)
+    assert rel_err(both, ref2) <= 3 * rel_err(g.t("bf16/logits"), g.t("fp32/logits")) + 5e-3

@@ -286,3 +286,39 @@ def test_update_batch_device_token_batches_take_the_fused_assembly():
     for k in a:
         if isinstance(a[k], torch.Tensor):
             assert a[k].dtype == b[k].dtype and torch.equal(a[k].cpu(), b[k].cpu()), k
+
+
+def test_key_padding_mask_use_attention_mask_gpu():
+    """`model.use_attention_mask` on the HIP path (padding mask -> key mask codes in the attention kernels, forward and backward): logits against the oracle with
+    the same dense allow-mask, and the training step (config switch -> get_cond_dict -> backbone) differs from the unmasked one and has finite gradients."""
+    g = Golden("c_large")
+    diff = build_product(g, DEV)
+    diff.backbone.eval()
+    xt, mod = g.t("fp32/xt"), g.t("fp32/modality")
+    B, L = xt.shape
+    km = torch.ones(B, L, dtype=torch.bool)
+    km[0, 5:9] = False
+    km[1, L - 7:] = False
+    with torch.no_grad():
+        got = diff.backbone(xt.to(DEV), None, modality=mod.to(DEV), attention_mask=km.to(DEV)).float().cpu()
+        base = diff.backbone(xt.to(DEV), None, modality=mod.to(DEV)).float().cpu()
+        ref = O.dit_forward(g.cfg, g.params(), g.buffers(), xt, None, mod, None, False, allow_mask=km[:, None, :].expand(B, L, L))
+    floor = rel_err(g.t("bf16/logits"), g.t("fp32/logits"))
+    assert rel_err(got, ref) <= 3 * floor + 5e-3 and rel_err(base, ref) > 10 * rel_err(got, ref)
+    # through the config switch, with a backward
+    diff.backbone.train()
+    diff.config.model.use_attention_mask = True
+    diff.rng_device = "cpu"
+    batch = g.batch()
+    batch["txt_attention_mask"] = batch["txt_attention_mask"].clone()
+    batch["txt_attention_mask"][0, -3:] = False
+    torch.manual_seed(g.case["step_seed"])
+    out = diff.training_step(batch, 1)
+    out.loss.backward()
+    torch.cuda.synchronize()
+    assert torch.isfinite(out.loss) and all(torch.isfinite(p.grad).all() for p in diff.backbone.parameters() if p.grad is not None)
+    diff.config.model.use_attention_mask = False
+    diff.backbone.zero_grad(set_to_none=True)
+    torch.manual_seed(g.case["step_seed"])
+    out0 = diff.training_step(batch, 1)
+    assert float(out0.loss.detach()) != float(out.loss.detach())

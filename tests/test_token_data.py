@@ -67,6 +67,37 @@ def test_shard_schema_round_trip(tmp_path):
         TD.TokenShard(dict(txt_input_ids=f["txt_input_ids"]))
 
 
+@pytest.mark.parametrize("variant", ["no_torch_prefix", "nested_entries", "sample_count_only", "wrong_size"])
+def test_shard_open_tolerates_layout_variants(tmp_path, variant):
+    """The TensorDict memmap layout is restated, not pinned (tensordict is not installed): the reader accepts dtype names without the `torch.` prefix,
+    per-key entries under a nested mapping, and a meta.json that only carries the sample count (dtypes from the schema, row length from the file size);
+    a file whose size does not fit the sample count is an error, not a silent reshape."""
+    import json
+    _, f = _golden_batch()
+    d = tmp_path / "shard"
+    TD.TokenShard.write(str(d), f)
+    meta = json.load(open(d / "meta.json"))
+    keys = [k for k in meta if isinstance(meta[k], dict)]
+    if variant == "no_torch_prefix":
+        for k in keys:
+            meta[k]["dtype"] = meta[k]["dtype"].replace("torch.", "")
+    elif variant == "nested_entries":
+        meta = {"shape": meta["shape"], "data": {k: meta[k] for k in keys}}
+    else:
+        meta = {"shape": meta["shape"]}
+        if variant == "wrong_size":
+            with open(d / "img_input_ids.memmap", "ab") as fh:
+                fh.write(b"\0\0")
+    json.dump(meta, open(d / "meta.json", "w"))
+    if variant == "wrong_size":
+        with pytest.raises(TypeError):
+            TD.TokenShard.open(str(d))
+        return
+    sh = TD.TokenShard.open(str(d))
+    for k in f:
+        assert np.array_equal(np.asarray(sh.fields[k]), f[k]), k
+
+
 def _check_batcher(device, resident, monkey_K=None):
     z, f = _golden_batch()
     n = f["txt_input_ids"].shape[0]

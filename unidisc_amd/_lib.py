@@ -27,8 +27,8 @@ PROTOTYPES = {
     "udm_gemm_nt_splitk_bf16": [_P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _P, _I64, _P],
     "udm_gemm_tn_splitk_bf16": [_P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _F, _P, _I64, _P],
     "udm_gemm_set_cus": [_I],
-    "udm_gemm_set_workspace": [_P, _I64, _P],
     "udm_debug_set": [ctypes.c_char_p, _I64],
+    "udm_debug_cu_hog": [_I64, _P, _P],
     "udm_transpose_bf16": [_P, _P, _I64, _I64, _I64, _I64, _P, _P],
     "udm_cast_transpose_f32_bf16": [_P, _P, _P, _I64, _I64, _I64, _I64, _I64, _P],
     "udm_cast_transpose_multi_f32_bf16": [_P, _I64, _I64, _P],

@@ -23,7 +23,6 @@ extern "C" int udm_abi_version(void) { return UDM_ABI_VERSION; }
 extern "C" int udm_gemm_set_tile(int tile);      // gemm.hip: force the tile family (-1 auto, 0 = 128x128 kernel, 192 / 256 / 320 = BM x 256 kernel)
 extern "C" int udm_gemm_set_quad(int mode);      // gemm.hip: one-wave-per-SIMD kernels 0 = off, 1 = auto (default; env UDM_GEMM_QUAD), 2 = wherever the shape fits
 extern "C" int udm_gemm_set_persist(int enable); // gemm.hip: 0 = one block per output tile (default 1: persistent blocks for multi-round NT shapes)
-extern int g_gemm_streamk;                       // gemm.hip: 0 = no stream-K (default 1; env UDM_GEMM_STREAMK)
 extern "C" int udm_attention_set_tr_read(int enable);        // attention.hip: 0 = gather V^T fragments with scalar LDS reads
 extern "C" int udm_attention_set_w64(int enable);            // attention_w64.hip: the one-wave-per-SIMD forward / dQ kernels (default off; env UDM_ATTN_W64)
 extern "C" int udm_attention_w64_timeline(uint64_t* buf);    // attention_w64.hip: device buffer of 512 cycle stamps written by the next forward launches; null = off
@@ -34,10 +33,28 @@ extern "C" int udm_debug_set(const char* key, int64_t value) {
   if (is("gemm_tile")) return udm_gemm_set_tile((int)value);
   if (is("gemm_quad")) return udm_gemm_set_quad((int)value);
   if (is("gemm_persist")) return udm_gemm_set_persist((int)value);
-  if (is("gemm_streamk")) { g_gemm_streamk = value ? 1 : 0; return 0; }
   if (is("attention_tr_read")) return udm_attention_set_tr_read((int)value);
   if (is("attention_w64")) return udm_attention_set_w64((int)value);
   if (is("attention_w64_timeline")) return udm_attention_w64_timeline(reinterpret_cast<uint64_t*>((uintptr_t)value));
   udm_set_error("udm_debug_set: unknown key '%s'", key);
   return 2;
+}
+
+// Diagnostics: occupy `blocks` CUs (one block each: 160 KiB of LDS, so no LDS-using kernel can share the CU) until *flag != 0 - the stand-in for a collective's
+// channel kernels when the CU-reservation behaviour of the GEMMs is measured on one GPU (bench.py --hog-cus).  `flag` must be host-visible pinned memory or
+// device memory another stream writes; the kernel polls it with system-scope loads.
+__global__ __launch_bounds__(64) void cu_hog_kernel(const int* flag) {
+  extern __shared__ char hog_lds[];
+  if (threadIdx.x == 0) {
+    hog_lds[0] = 1;
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0) __builtin_amdgcn_s_sleep(32);
+  }
+}
+extern "C" int udm_debug_cu_hog(int64_t blocks, const int* flag, hipStream_t stream) {
+  UDM_CHECK_ARG(blocks > 0 && blocks <= 128 && flag, "udm_debug_cu_hog: 1..128 blocks and a flag pointer");
+  static bool attr = false;
+  if (!attr) { (void)hipFuncSetAttribute((const void*)cu_hog_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+  hipLaunchKernelGGL(cu_hog_kernel, dim3((unsigned)blocks), dim3(64), 160 * 1024, stream, flag);
+  UDM_CHECK_LAUNCH("udm_debug_cu_hog");
+  return 0;
 }

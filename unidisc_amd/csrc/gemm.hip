@@ -701,7 +701,7 @@ int g_gemm_persist = 1;   // diagnostics (UDM_GEMM_PERSIST=0): 0 = one block per
 // Data-parallel runs: the persistent blocks of a multi-round NT GEMM occupy every CU for the whole launch, and RCCL's channel kernels (the
 // gradient all-reduce overlapped with backward) then only get CUs between launches.  UDM_GEMM_CUS = n (or udm_gemm_set_cus) caps the
 // persistent grid at n blocks (a multiple of 8: one block per CU, XCD round-robin), leaving 256 - n CUs to the collective.  0 = all 256.
-// (g_gemm_cus and the stream-K workspace live in gemm_quad.hip: shared by both translation units through gemm_quad.h)
+int g_gemm_cus = 0;
 
 template <int BMX, int EPI, bool OUT_F32, bool TN = false>
 int launch_big_t(const GemmArgs& a0, hipStream_t stream) {
@@ -721,7 +721,7 @@ int launch_big_t(const GemmArgs& a0, hipStream_t stream) {
     // more than one round of whole tiles: 256 persistent blocks walk them (see PERSIST above)
     static const bool env_once = [] {
       if (const char* e = getenv("UDM_GEMM_PERSIST")) g_gemm_persist = atoi(e);
-      (void)udm_gemm_cus();
+      if (const char* e = getenv("UDM_GEMM_CUS")) { const int n = atoi(e); if (n >= 8 && n <= 256) g_gemm_cus = n / 8 * 8; }
       return true;
     }();
     (void)env_once;
@@ -817,16 +817,11 @@ extern "C" int udm_gemm_nt_bf16(const void* A, const void* B, void* C, int64_t M
       const long qt = (M / (64 * fm)) * (N / 256);
       const int t8 = choose_tile(M, N, K, lda, ldb);
       const long t8n = t8 ? ((M + t8 - 1) / t8) * ((N + 255) / 256) : 0;
-      // cost = tile rows a CU works through: whole rounds of the CUs the GEMM may use, or - where the quad kernel goes stream-K (tile count not a multiple of
-      // them, workspace registered) - the even share plus an allowance for the partial-tile exchange
-      const int cus = udm_gemm_cus();
-      const bool sk = udm_gemm_streamk() && g_gemm_ws != nullptr && qt % cus != 0 && qt >= cus;
-      const double q_cost = sk ? (double)qt * 64 * fm / cus + 16 : (double)((qt + cus - 1) / cus) * 64 * fm;
-      const double o_cost = t8 ? (double)((t8n + cus - 1) / cus) * t8 : 1e30;
+      const double q_cost = (double)((qt + 255) / 256) * 64 * fm, o_cost = t8 ? (double)((t8n + 255) / 256) * t8 : 1e30;
       // measured (scripts/bench_gemm_quad.py, 1.4 B shapes, random operands): the quad kernel wins 1-3 % on single-round shapes with a plain or
       // bias epilogue and loses 3 % where the GELU / GELU' epilogue runs (one wave per SIMD has nothing to overlap its VALU with);
       // multi-round shapes stay with the persistent 8-wave blocks
-      if (udm_quad_mode() == 2 || (qt >= 128 && qt <= (sk ? 2 * cus : 256) && q_cost <= o_cost && epilogue <= UDM_EPI_BIAS)) {
+      if (udm_quad_mode() == 2 || (qt >= 128 && qt <= 256 && q_cost <= o_cost && epilogue <= UDM_EPI_BIAS)) {
         QuadArgs q{};
         q.A = a.A; q.B = a.B; q.C = C; q.bias = bias; q.aux = (bf16_t*)aux; q.lda = lda; q.ldb = ldb; q.ldc = ldc; q.ldaux = ldaux;
         q.M = a.M; q.N = a.N; q.K = a.K; q.beta = 0.f; q.splitk = 1;
@@ -1046,17 +1041,6 @@ extern "C" int udm_gemm_nn_bf16(const void* A, const void* B, void* C, int64_t M
   q.A = (const bf16_t*)A; q.B = (const bf16_t*)B; q.C = C; q.lda = lda; q.ldb = ldb; q.ldc = ldc;
   q.M = (int)M; q.N = (int)N; q.K = (int)K; q.beta = 0.f; q.splitk = 1;
   return udm_quad_launch_nn(q, fm, stream);
-}
-
-// Stream-K workspace (caller-owned device memory, kept alive by the caller): [0, 16 KiB) per-tile arrival counters - zeroed here, self-resetting afterwards -
-// then two fp32 partial-tile slots per block.  256 blocks x 2 x 320 x 256 x 4 B + 16 KiB = 160.02 MiB covers every tile shape; without it (or with
-// UDM_GEMM_STREAMK=0) the GEMMs run one tile per block in whole rounds as before.  GEMM launches that share the workspace must be ordered on one stream.
-extern "C" int udm_gemm_set_workspace(void* ws, int64_t bytes, hipStream_t stream) {
-  UDM_CHECK_ARG((ws == nullptr && bytes == 0) || (ws && bytes >= 16384 && ((uintptr_t)ws % 256) == 0), "udm_gemm_set_workspace: need a 256-byte aligned buffer of at least 16 KiB (or null, 0)");
-  if (ws && hipMemsetAsync(ws, 0, 16384, stream) != hipSuccess) { udm_set_error("udm_gemm_set_workspace: memset failed"); return 1; }
-  g_gemm_ws = ws;
-  g_gemm_ws_bytes = bytes;
-  return 0;
 }
 
 extern "C" int udm_gemm_set_cus(int cus) {   // 0 = all CUs; otherwise the persistent NT grid (a multiple of 8 in [8, 256])

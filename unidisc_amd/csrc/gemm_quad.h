@@ -15,19 +15,7 @@ struct QuadArgs {
   int splitk;          // > 1 (fp32 output only): K cut into slices, slice s stores its partial tile at C + s * slice_stride
   long slice_stride;
   int group_m;
-  // stream-K (set by launch_quad_t when the tile count is not a multiple of the CUs the GEMM may use and a workspace is registered): grid = sk_blocks
-  int sk_blocks = 0;
-  float* sk_ws = nullptr;      // 2 partial-tile slots (BM x 256 fp32, accumulator-register order) per block
-  int* sk_counters = nullptr;  // one arrival counter per tile, zero between launches
 };
-
-// workspace registered through udm_gemm_set_workspace (gemm.hip): [0, 16 KiB) arrival counters (4096 tiles), the rest partial-tile slots
-extern void* g_gemm_ws;
-extern long g_gemm_ws_bytes;
-extern int g_gemm_cus;
-extern int g_gemm_streamk;
-int udm_gemm_cus();        // CUs a GEMM may use: UDM_GEMM_CUS / udm_gemm_set_cus, default 256
-bool udm_gemm_streamk();   // UDM_GEMM_STREAMK (default 1) / udm_debug_set("gemm_streamk", v)
 
 extern int g_quad_mode;
 int udm_quad_mode();   // 0 off, 1 auto (shapes that fill the chip), 2 force wherever the shape fits

@@ -63,32 +63,15 @@ __global__ __launch_bounds__(256, 1) void gemm_quad_kernel(QuadArgs p) {
 
   const int S = p.splitk > 1 ? p.splitk : 1;
   const int nwg = p.tiles_m * p.tiles_n;
-  const int nk_all = p.K / BK;
-  // Stream-K (p.sk_blocks = G > 0): the launch is G blocks - one per CU the GEMM may use - and the nwg * nk_all K-tile iterations of the whole
-  // problem, tiles in the XCD-grouped order, are cut into G equal contiguous ranges.  A block walks the SEGMENTS of its range: (tail of a tile) (whole
-  // tiles) (head of a tile).  Whole tiles end in the usual epilogue; the contributors of a split tile meet at a per-tile counter - whoever arrives last adds
-  // the others' fp32 partials (workspace, in accumulator-register order: 4 KiB per store instruction) to its registers and runs the epilogue, so nobody ever
-  // waits for another block (no co-residency assumption, no deadlock when a collective holds CUs).  With nwg a multiple of G nothing is split and the plain
-  // one-tile-per-block launch is used instead.
-  const int G = p.sk_blocks;
-  const long sk_total = (long)nwg * nk_all;
-  auto sk_bound = [&](int r) -> long { return sk_total * r / G; };
-  auto sk_owner = [&](long x) -> int { int r = (int)(x * G / sk_total); while (sk_bound(r + 1) <= x) ++r; return r; };   // the range holding iteration x
-  const int sk_r = G > 0 ? xcd_remap(blockIdx.x, G) : 0;   // (the ranges of one XCD's blocks are neighbours: shared operand panels in that L2)
-  long sk_it = G > 0 ? sk_bound(sk_r) : 0;
-  const long sk_it1 = G > 0 ? sk_bound(sk_r + 1) : 0;
   int pid = xcd_remap(blockIdx.x, nwg * S);
   const int slice = pid % S;
   pid /= S;
   const int grp_rows = p.group_m > 0 ? p.group_m : GROUP_M_DEFAULT;
   const int per_group = grp_rows * p.tiles_n;
-  int row0 = 0, col0 = 0, kt0 = 0, nk = 0;
-  auto place_tile = [&](int v) {
-    const int grp = v / per_group, first_m = grp * grp_rows;
-    const int gsz = min(p.tiles_m - first_m, grp_rows);
-    const int tm = first_m + (v % per_group) % gsz, tn = (v % per_group) / gsz;
-    row0 = tm * BM; col0 = tn * BN;
-  };
+  const int grp = pid / per_group, first_m = grp * grp_rows;
+  const int gsz = min(p.tiles_m - first_m, grp_rows);
+  const int tm = first_m + (pid % per_group) % gsz, tn = (pid % per_group) / gsz;
+  const int row0 = tm * BM, col0 = tn * BN;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -126,10 +109,13 @@ __global__ __launch_bounds__(256, 1) void gemm_quad_kernel(QuadArgs p) {
       }
     }
   }
+  const int nk_all = p.K / BK;
+  const int kt0 = (int)((long)nk_all * slice / S), kt1 = (int)((long)nk_all * (slice + 1) / S);
+  const int nk = kt1 - kt0;
   const long kstep_a = TA ? (long)BK * p.lda * 2 : BK * 2, kstep_b = TB ? (long)BK * p.ldb * 2 : BK * 2;   // bytes per K tile
   // running tile bases (wave-uniform, SGPR pairs): ap / bp = the K tile being COMPUTED; refills read one or two tiles ahead of it
-  const char* ap = nullptr;
-  const char* bp = nullptr;
+  const char* ap = uniform_ptr(reinterpret_cast<const char*>(TA ? p.A + row0 : p.A + (long)row0 * p.lda) + kt0 * kstep_a);
+  const char* bp = uniform_ptr(reinterpret_cast<const char*>(TB ? p.B + col0 : p.B + (long)col0 * p.ldb) + kt0 * kstep_b);
   const uint32_t dsta = lds0 + A0 + wave * A_PW * 1024, dstb = lds0 + B0 + wave * B_PW * 1024;
   auto dma_piece = [&](int ahead, int stage, int j) {   // the tile `ahead` K tiles after the current one into `stage`; j < A_PW: A piece j, else B piece j - A_PW
     if ((ABL & 1) && ahead == 2) return;
@@ -178,30 +164,13 @@ __global__ __launch_bounds__(256, 1) void gemm_quad_kernel(QuadArgs p) {
     return __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(hb[buf][j][0], hb[buf][j][1], 0, 1, 2, 3, 4, 5, 6, 7));
   };
 
-  constexpr int FMA = FM < 4 ? FM : 4;   // rows in the accumulator file
-  f32x16_t acc[FM][FN];
-  __shared__ int sk_flag;
-  for (;;) {   // one pass per segment (exactly one without stream-K)
-  int sk_tile = 0;
-  bool sk_partial = false;
-  if (G > 0) {
-    sk_tile = (int)(sk_it / nk_all);
-    kt0 = (int)(sk_it - (long)sk_tile * nk_all);
-    nk = (int)min((long)(nk_all - kt0), sk_it1 - sk_it);
-    sk_partial = nk != nk_all;
-    place_tile(sk_tile);
-  } else {
-    kt0 = (int)((long)nk_all * slice / S);
-    nk = (int)((long)nk_all * (slice + 1) / S) - kt0;
-    place_tile(pid);
-  }
-  ap = uniform_ptr(reinterpret_cast<const char*>(TA ? p.A + row0 : p.A + (long)row0 * p.lda) + kt0 * kstep_a);
-  bp = uniform_ptr(reinterpret_cast<const char*>(TB ? p.B + col0 : p.B + (long)col0 * p.ldb) + kt0 * kstep_b);
   // Accumulators are zeroed BY the matrix pipe (MFMA of an opaque zero fragment onto the constant 0): hundreds of v_mov + copies into the
   // accumulator file would put that many live VGPRs here and make the allocator spill the loop's addresses and fragments.
   // The compiler puts every builtin MFMA's accumulator into the 256-register accumulator file (all or nothing per kernel), which holds four
   // rows of fragments.  A fifth row (FM = 5: 320-row tiles) lives in 64 ARCH VGPRs instead and is driven by inline-asm MFMAs in VGPR form;
   // their only readers are the next MFMA of the same chain (no wait states needed) and the epilogue (far behind the last one).
+  constexpr int FMA = FM < 4 ? FM : 4;   // rows in the accumulator file
+  f32x16_t acc[FM][FN];
   {
     bf16x8_t zf = {};
     asm volatile("" : "+v"(zf));
@@ -301,60 +270,6 @@ __global__ __launch_bounds__(256, 1) void gemm_quad_kernel(QuadArgs p) {
   for (; t < nk; ++t) tile_body(t, std::integral_constant<int, -1>{});
   if (FM > FMA) asm volatile("s_nop 15" ::: "memory");   // inline-asm MFMA results -> first reader (wait states the compiler does not know it owes)
   __syncthreads();  // all LDS tile reads are done: the wave-private epilogue patches may overwrite stage memory
-  bool sk_epilogue = true;
-  if (G > 0 && sk_partial) {
-    // contributors of this tile = the ranges that hold its first .. last iteration; this block's partial lives in slot 0 if the segment opens its range
-    // (the tile began in an earlier range), else in slot 1 (the tile begins inside this range and runs past its end)
-    const long tfirst = (long)sk_tile * nk_all;
-    const int r_lo = sk_owner(tfirst), r_hi = sk_owner(tfirst + nk_all - 1), n_contrib = r_hi - r_lo + 1;
-    int* ctr = p.sk_counters + sk_tile;
-    constexpr long SLOT = (long)BM * BN;
-    auto slot_of = [&](int r) -> float* { return p.sk_ws + ((long)r * 2 + (tfirst > sk_bound(r) ? 1 : 0)) * SLOT; };
-    if (tid == 0) sk_flag = __hip_atomic_load(ctr, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    bool last = sk_flag == n_contrib - 1;   // everybody else has already delivered: no need to write this block's partial at all
-    __syncthreads();
-    if (!last) {
-      float* mine = slot_of(sk_r);
-      // (one 32 x 32 accumulator block at a time, fenced for the scheduler: hoisting all 64-80 blocks' copies out of the accumulator file at once spills)
-#pragma unroll
-      for (int i = 0; i < FM; ++i)
-#pragma unroll
-        for (int j = 0; j < FN; ++j) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-            *reinterpret_cast<float4*>(mine + (((i * FN + j) * 4 + q) * 256 + tid) * 4) = make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      __threadfence();   // release: the partial is visible device-wide before the arrival is
-      __syncthreads();
-      if (tid == 0) sk_flag = __hip_atomic_fetch_add(ctr, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-      __syncthreads();
-      last = sk_flag == n_contrib - 1;
-      __syncthreads();
-    }
-    sk_epilogue = last;
-    if (last) {
-      __threadfence();   // acquire
-      for (int r = r_lo; r <= r_hi; ++r) {
-        if (r == sk_r) continue;
-        const float* theirs = slot_of(r);
-#pragma unroll
-        for (int i = 0; i < FM; ++i)
-#pragma unroll
-          for (int j = 0; j < FN; ++j) {
-            float4 v[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const float4*>(theirs + (((i * FN + j) * 4 + q) * 256 + tid) * 4);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) { acc[i][j][4 * q] += v[q].x; acc[i][j][4 * q + 1] += v[q].y; acc[i][j][4 * q + 2] += v[q].z; acc[i][j][4 * q + 3] += v[q].w; }
-            __builtin_amdgcn_sched_barrier(0);
-          }
-      }
-      if (tid == 0) __hip_atomic_store(ctr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch (launches of one stream are ordered)
-    }
-  }
-  if (sk_epilogue) {
 
   // ---- epilogue: each 32 x 32 accumulator block goes through a wave-private 4 KiB LDS patch so a lane owns 4 consecutive columns of a row
   float* patch0 = reinterpret_cast<float*>(smem) + wave * 2048;
@@ -432,12 +347,6 @@ __global__ __launch_bounds__(256, 1) void gemm_quad_kernel(QuadArgs p) {
         if (er == 0) atomicAdd(colsum + col0 + wn * 128 + j * 32 + ec + e, v);
       }
   }
-  }   // sk_epilogue
-  if (G <= 0) break;
-  sk_it += nk;
-  if (sk_it >= sk_it1) break;
-  __syncthreads();   // the epilogue patches / this segment's stages are dead before the next segment's prologue refills them
-  }   // segments
 }
 
 template <int FM, int MODE, int EPI, bool OUT_F32>
@@ -461,62 +370,11 @@ int launch_quad_t(const QuadArgs& a0, hipStream_t stream) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = (const void*)kern;
   }
-  // stream-K wherever the tiles do not fill whole rounds of the CUs this GEMM may use (UDM_GEMM_CUS / udm_gemm_set_cus; all 256 by default) and the
-  // workspace (udm_gemm_set_workspace) holds two partial tiles per block
-  unsigned grid = (unsigned)(a.tiles_m * a.tiles_n * (a.splitk > 1 ? a.splitk : 1));
-  const int cus = udm_gemm_cus();
-  const long tiles = (long)a.tiles_m * a.tiles_n;
-  constexpr long SLOT_BYTES = (long)BM * 256 * 4;
-  if (udm_gemm_streamk() && a.splitk <= 1 && g_gemm_ws && tiles % cus != 0 && tiles <= 4096 && tiles >= cus && a.K / BK >= 2 &&   // (tiles >= cus: at most two contributors per tile - a deterministic sum)
-      g_gemm_ws_bytes >= 16384 + (long)cus * 2 * SLOT_BYTES) {
-    a.sk_blocks = cus;
-    a.sk_counters = reinterpret_cast<int*>(g_gemm_ws);
-    a.sk_ws = reinterpret_cast<float*>(reinterpret_cast<char*>(g_gemm_ws) + 16384);
-    grid = (unsigned)cus;
-  }
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, a);
+  hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n * (a.splitk > 1 ? a.splitk : 1)), dim3(256), lds, stream, a);
   UDM_CHECK_LAUNCH("udm_gemm (quad)");
   return 0;
 }
-
-// tile height for M rows: with stream-K available the round count no longer matters (the work is cut evenly over the CUs), so the largest wave tile that
-// divides M wins (fewest LDS bytes per MFMA); otherwise the height that fills whole rounds of 256 CUs best (ties: the larger tile)
-int pick_fm(long M, long N, const int* cands, int n) {
-  const bool sk = udm_gemm_streamk() && g_gemm_ws != nullptr;
-  double best = 1e30;
-  int pick = 0;
-  for (int c = 0; c < n; ++c) {
-    const int bm = 64 * cands[c];
-    if (M % bm != 0) continue;
-    const long tiles = (M / bm) * (N / 256);
-    const int cus = udm_gemm_cus();
-    if (sk && tiles % cus != 0 && tiles >= cus && tiles <= 4096 && g_gemm_ws_bytes >= 16384 + (long)cus * 2 * bm * 256 * 4) return pick ? pick : cands[c];
-    const long rounds = (tiles + cus - 1) / cus;
-    const double t = (double)rounds * bm;
-    if (t < best) { best = t; pick = cands[c]; }
-  }
-  return pick;
-}
 }  // namespace
-
-int g_gemm_cus = 0;           // CUs the GEMMs may use (0 = all 256): UDM_GEMM_CUS / udm_gemm_set_cus
-void* g_gemm_ws = nullptr;     // stream-K workspace, registered by the host: udm_gemm_set_workspace (gemm.hip)
-long g_gemm_ws_bytes = 0;
-int g_gemm_streamk = -1;
-int udm_gemm_cus() {
-  static const bool once = [] {
-    if (const char* e = getenv("UDM_GEMM_CUS")) { const int n = atoi(e); if (n >= 8 && n <= 256) g_gemm_cus = n / 8 * 8; }
-    return true;
-  }();
-  (void)once;
-  return g_gemm_cus ? g_gemm_cus : 256;
-}
-bool udm_gemm_streamk() {
-  // default OFF: measured (round 3) - with the tile count close to the block count every tile is split and the fp32 partial exchange (one
-  // 256-320 KB tile written and read per block, all at the end of the launch) costs more than the rounds it saves
-  if (g_gemm_streamk < 0) { const char* e = getenv("UDM_GEMM_STREAMK"); g_gemm_streamk = e ? (atoi(e) != 0) : 0; }
-  return g_gemm_streamk != 0;
-}
 
 int g_quad_mode = -1;   // -1: read UDM_GEMM_QUAD (default 1); 0 = off, 1 = where it fills the chip, 2 = wherever the shape fits (tests)
 int udm_quad_mode() {
@@ -529,8 +387,18 @@ int udm_quad_mode() {
 
 bool udm_quad_tn_ok(long M, long N, long K, int* fm) {
   if (!udm_quad_mode() || K % 64 != 0 || K < 128 || N % 256 != 0) return false;
+  // the tile height that fills whole rounds of the 256 CUs best (ties: the larger wave tile)
   const int cands[2] = {4, 3};   // (FM = 5 spills in the TN form: 2 x 9 fragment halves beside 320 accumulators)
-  const int pick = pick_fm(M, N, cands, 2);
+  double best = 1e30;
+  int pick = 0;
+  for (int c = 0; c < 2; ++c) {
+    const int bm = 64 * cands[c];
+    if (M % bm != 0) continue;
+    const long tiles = (M / bm) * (N / 256);
+    const long rounds = (tiles + 255) / 256;
+    const double t = (double)rounds * bm;
+    if (t < best) { best = t; pick = cands[c]; }
+  }
   if (!pick) return false;
   *fm = pick;
   return true;
@@ -547,7 +415,16 @@ int udm_quad_launch_tn(const QuadArgs& a, int fm, hipStream_t stream) {
 bool udm_quad_nt_ok(long M, long N, long K, int* fm) {
   if (!udm_quad_mode() || K % 64 != 0 || K < 128 || N % 256 != 0) return false;
   const int cands[3] = {5, 4, 3};
-  const int pick = pick_fm(M, N, cands, 3);
+  double best = 1e30;
+  int pick = 0;
+  for (int c = 0; c < 3; ++c) {
+    const int bm = 64 * cands[c];
+    if (M % bm != 0) continue;
+    const long tiles = (M / bm) * (N / 256);
+    const long rounds = (tiles + 255) / 256;
+    const double t = (double)rounds * bm;
+    if (t < best) { best = t; pick = cands[c]; }
+  }
   if (!pick) return false;
   *fm = pick;
   return true;

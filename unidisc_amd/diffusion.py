@@ -270,8 +270,8 @@ class Diffusion:
         ret = dict()
         if "cond_input_ids" in batch or "img_label" in batch:
             raise NotImplementedError("unidisc_amd: image / label conditioning is outside the denoising hot path")
-        if cfg_get(cfg_get(self.config, "model"), "use_attention_mask", False):
-            raise NotImplementedError("unidisc_amd: model.use_attention_mask (SDPA padding mask) is not implemented; shipped configs leave it off")
+        if cfg_get(cfg_get(self.config, "model"), "use_attention_mask", False):   # model.py:405-406: the padding mask goes to the backbone's attention (a key mask)
+            ret["attention_mask"] = batch["attention_mask"]
         if cfg_get(cfg_get(self.config, "trainer"), "multimodal_batches", False):
             ret["modality"] = batch["modality"]
         return ret
@@ -857,7 +857,7 @@ class Diffusion:
         # fused backbone + SUBS + gather: log p_theta(x0 | xt) per token, fp32 (model.py:908-925, :967)
         log_p_theta = self.backbone.forward_logp(xt, x0, self._process_sigma(unet_conditioning), modality=kwargs.get("modality"),
                                                  sample_ids=kwargs.get("sample_ids"), restrict_modality=self._restrict(),
-                                                 block_mask=kwargs.get("block_mask"))
+                                                 block_mask=kwargs.get("block_mask"), attention_mask=kwargs.get("attention_mask"))
         self._flush_checks()   # (the forward has already waited for this step's [MASK]-row count: the queued batch checks are complete, no extra wait)
         self._last = dict(t=t, sigma=sigma, dsigma=dsigma, xt=xt, move_indices=move_indices, log_p_theta=log_p_theta, modality=kwargs.get("modality"))
 

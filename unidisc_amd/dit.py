@@ -323,9 +323,6 @@ class DIT(nn.Module, _HubMixin):
         return out
 
     def _build_lins(self):
-        dev = self.vocab_embed.embedding.device
-        if dev.type == "cuda" and hasattr(K, "gemm_workspace"):
-            K.gemm_workspace(dev)   # stream-K workspace of the one-wave-per-SIMD GEMMs (160 MiB, once per process)
         L: Dict[str, _Lin] = {}
         for i, blk in enumerate(self.blocks):
             L[f"{i}.qkv"] = _Lin(blk.attention.attn_qkv.weight, None)
@@ -435,19 +432,31 @@ class DIT(nn.Module, _HubMixin):
     def forward(self, indices, sigma=None, label=None, x_cond=None, attention_mask=None, continuous_mode=False, x_img_emb=None, modality=None,
                 start_pos=None, block_mask=None, update_cache_slice=None, sample_ids=None):
         """→ logits [B, L, V] (bf16).  Signature of the reference's DIT.forward (models/dit.py:1324-1338)."""
-        self._check_unsupported(label, x_cond, attention_mask, continuous_mode, x_img_emb, start_pos, block_mask, update_cache_slice, sample_ids)
+        self._check_unsupported(label, x_cond, None, continuous_mode, x_img_emb, start_pos, block_mask, update_cache_slice, sample_ids)
         params = self._ordered_params()
         inputs = dict(indices=indices, sigma=sigma, modality=modality, sample_ids=sample_ids, x0=None, save=self._needs_grad(params),
-                      block_mask=block_mask if isinstance(block_mask, ModalityMask) else None)
+                      block_mask=block_mask if isinstance(block_mask, ModalityMask) else None, key_mask=self._key_mask(attention_mask, indices))
         return _DitFn.apply(self, "logits", inputs, *params)
 
-    def forward_logp(self, xt, x0, sigma=None, modality=None, sample_ids=None, restrict_modality=False, block_mask=None):
+    @staticmethod
+    def _key_mask(attention_mask, indices):
+        """`model.use_attention_mask` (model.py:405-406 -> `sdpa(..., attn_mask=attention_mask)`, models/dit.py:829): the batch's [B, L] bool mask reaches SDPA
+        unchanged, where a 2-D mask aligns with the (query, key) axes - i.e. it broadcasts (B = 1; for B > 1 the reference call does not broadcast and
+        fails) as a KEY mask: padded keys are hidden from every query of their sample, padded queries still attend to the valid keys."""
+        if attention_mask is None:
+            return None
+        if attention_mask.dtype != torch.bool or tuple(attention_mask.shape) != tuple(indices.shape):
+            raise NotImplementedError("unidisc_amd.DIT.forward: attention_mask must be the batch's bool [B, L] padding mask (dense [B, 1, L, L] masks - the "
+                                      "transfusion path - are outside the denoising hot path)")
+        return attention_mask
+
+    def forward_logp(self, xt, x0, sigma=None, modality=None, sample_ids=None, restrict_modality=False, block_mask=None, attention_mask=None):
         """Fused training path: log p_theta(x0 | xt) per token [B, L] fp32 under the SUBS parameterisation
         (== gather(_subs_parameterization(logits, xt), x0), model.py:621-658 + :967) without materialising log-probs.
-        block_mask: a `ModalityMask` (modality attention dropout) or None."""
+        block_mask: a `ModalityMask` (modality attention dropout) or None.  attention_mask: the key-padding mask of `model.use_attention_mask` or None."""
         params = self._ordered_params()
         inputs = dict(indices=xt, sigma=sigma, modality=modality, sample_ids=sample_ids, x0=x0, restrict=restrict_modality, save=self._needs_grad(params),
-                      block_mask=block_mask)
+                      block_mask=block_mask, key_mask=self._key_mask(attention_mask, xt))
         return _DitFn.apply(self, "logp", inputs, *params)
 
     @torch.no_grad()
@@ -578,6 +587,19 @@ class DIT(nn.Module, _HubMixin):
             # modality attention dropout (model.py:863-878): an asymmetric per-sample mask, carried to the attention kernels as mask codes in
             # the sample-id slot (class bits: no tile skipping, every tile takes the per-element test)
             sid = K.modality_mask_codes(bm.txt_drop.to(dev), bm.img_drop.to(dev), bm.txt_length, L)
+        raw_sid = sid if sample_ids is not None else None   # (document ids as given: the per-sample rotary positions below need them without class bits)
+        km = inp.get("key_mask")
+        if km is not None:
+            # key-padding mask (model.use_attention_mask): padded keys get a key class (4) no query mask contains; positions without other codes become
+            # sample 0 / key class 1 / query mask "classes 1 | 2".  Class bits switch tile skipping off (doc_ranges = None): every tile takes the element test.
+            km = km.to(dev).reshape(B, L)
+            base = sid if sid is not None else torch.zeros((B, L), dtype=torch.int64, device=dev)
+            kbits = (base >> 32) & 0xff
+            qbits = (base >> 40) & 0xff
+            kbits = torch.where(km, torch.where(kbits == 0, torch.ones_like(kbits), kbits), torch.full_like(kbits, 4))
+            qbits = torch.where(qbits == 0, torch.full_like(qbits, 3), qbits)
+            sid = ((base & 0xffffffff) | (kbits << 32) | (qbits << 40)).contiguous()
+            doc_ranges = None
         S = dict(B=B, L=L, ids=ids, modality=mod_flat, emb_mod=emb_mod, sid=sid, p_drop=p_drop, seed0=seed0, blocks=[])
         S["doc_ranges"] = doc_ranges
         # SUBS: only [MASK] rows have a non-zero log-probability (model.py:621-658), so in "logp" mode the vocabulary head (GEMM fwd,
@@ -590,9 +612,9 @@ class DIT(nn.Module, _HubMixin):
         x = K.embedding_fwd(ids, self.vocab_embed.embedding.detach(), emb_mod if self.modality_embed is not None else None,
                             self.modality_embed.embedding.detach() if self.modality_embed is not None else None)
         if self.rope_2d and self.require_sample_ids:
-            if sid is None:
+            if raw_sid is None:
                 raise ValueError("unidisc_amd.DIT: data.require_sample_ids needs sample_ids")
-            cos, sin, count_idx = self._rotary_interleaved(modality.to(torch.int64), sid)
+            cos, sin, count_idx = self._rotary_interleaved(modality.to(torch.int64), raw_sid)
             cnt_rows = (count_idx.view(-1) >= 0).nonzero().view(-1)
             cnt_j = count_idx.view(-1).index_select(0, cnt_rows)
             if cnt_rows.numel():  # x[b, l] += img_count_embedding[j] on the positions of supported image blocks

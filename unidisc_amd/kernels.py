@@ -279,30 +279,9 @@ def gemm_set_quad(mode: int):
     debug_set("gemm_quad", int(mode))
 
 
-def gemm_set_streamk(enable: int):
-    """Diagnostics: 0 = the one-wave-per-SIMD GEMMs never split tiles over blocks (whole rounds of one tile per block, as without a workspace)."""
-    debug_set("gemm_streamk", int(enable))
-
-
 def gemm_set_cus(cus: int):
-    """The GEMMs use at most `cus` CUs (multiple of 8; 0 = all 256): leaves CUs to RCCL's kernels in data-parallel runs.  The persistent NT kernel caps its
-    grid, the one-wave-per-SIMD kernels go stream-K over `cus` blocks (needs the workspace: gemm_workspace)."""
+    """Cap the persistent NT GEMM grid at `cus` blocks (multiple of 8; 0 = all 256 CUs): leaves CUs to RCCL's kernels in data-parallel runs."""
     _lib.call("udm_gemm_set_cus", int(cus))
-
-
-_GEMM_WS = {}
-
-
-def gemm_workspace(device, nbytes: int = 16384 + 256 * 2 * 320 * 256 * 4):
-    """Register the stream-K workspace of the one-wave-per-SIMD GEMMs (udm_gemm_set_workspace) on `device` once: 160 MiB that stay allocated for the life of
-    the process.  Called by the engine before its first GEMM; without it every GEMM runs one tile per block in whole rounds."""
-    key = (device.type, device.index)
-    if key not in _GEMM_WS:
-        ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
-        _lib.call("udm_gemm_set_workspace", _p(ws), nbytes, _s())
-        _GEMM_WS.clear()      # (one device per process: the library holds ONE workspace pointer)
-        _GEMM_WS[key] = ws
-    return _GEMM_WS[key]
 
 
 def gemm_set_tile(tile: int):

@@ -68,17 +68,48 @@ class TokenShard:
 
     @classmethod
     def open(cls, path: str, name: Optional[str] = None) -> "TokenShard":
-        with open(os.path.join(path, "meta.json")) as f:
-            meta = json.load(f)
+        """Open a token TensorDict directory.  The layout is restated (tensordict is not installed here: NOT pinned against the library), so the reader is tolerant
+        where library versions differ: dtype names with or without the ``torch.`` prefix, per-key entries at the top level of meta.json or under a nested
+        mapping, and - for a key without a usable entry - the dtype the schema prescribes with the row length inferred from the file size and the sample count."""
+        meta = {}
+        mpath = os.path.join(path, "meta.json")
+        if os.path.exists(mpath):
+            with open(mpath) as f:
+                meta = json.load(f)
+        n = None
+        if isinstance(meta.get("shape"), (list, tuple)) and meta["shape"]:
+            n = int(meta["shape"][0])
+
+        def entry(k):
+            for holder in (meta, *(v for v in meta.values() if isinstance(v, dict))):
+                e = holder.get(k) if isinstance(holder, dict) else None
+                if isinstance(e, dict) and "shape" in e and "dtype" in e:
+                    return e
+            return None
+
         fields = {}
-        for k in _FIELDS:
-            if k not in meta:
+        pending = []
+        for k, want in _FIELDS.items():
+            fpath = os.path.join(path, k + ".memmap")
+            if not os.path.exists(fpath):
                 continue
-            info = meta[k]
-            dt = _NP_OF.get(info["dtype"])
+            info = entry(k)
+            if info is None:
+                pending.append((k, want, fpath))
+                continue
+            tname = str(info["dtype"])
+            dt = _NP_OF.get(tname if tname.startswith("torch.") else "torch." + tname)
             if dt is None:
                 raise TypeError(f"{path}: unsupported dtype {info['dtype']} for {k}")
-            fields[k] = np.memmap(os.path.join(path, k + ".memmap"), dtype=dt, mode="r", shape=tuple(info["shape"]))
+            fields[k] = np.memmap(fpath, dtype=dt, mode="r", shape=tuple(int(x) for x in info["shape"]))
+            n = fields[k].shape[0] if n is None else n
+        for k, want, fpath in pending:   # no usable meta entry: the schema's dtype, row length from the file size
+            if n is None or n <= 0:
+                raise KeyError(f"{path}: no shape information for {k} (meta.json lists neither the field nor the sample count)")
+            size = os.path.getsize(fpath) // np.dtype(want).itemsize
+            if size % n != 0:
+                raise TypeError(f"{path}: {k}.memmap holds {size} elements, not a multiple of the {n} samples")
+            fields[k] = np.memmap(fpath, dtype=want, mode="r", shape=(n, size // n))
         return cls(fields, name or os.path.basename(os.path.normpath(path)))
 
     @staticmethod
