@@ -207,3 +207,23 @@ def test_key_padding_mask_use_attention_mask(fake_k):
     with torch.no_grad():
         ref2 = O.dit_forward(g.cfg, P, buf, xt, None, mod, None, False, allow_mask=allow2)
     assert rel_err(both, ref2) <= 3 * rel_err(g.t("bf16/logits"), g.t("fp32/logits")) + 5e-3
+
+
+@pytest.mark.parametrize("name", ["c_large", "d_adaln_mm", "f_interleaved"])
+def test_gradient_checkpointing_recomputes_blocks_bit_identically(name, fake_k):
+    """trainer.use_gradient_checkpointing (models/dit.py:1486-1490): only each block's input is kept, the block is re-run right before its backward.  Same loss
+    and bit-identical gradients as the activation-keeping engine."""
+    g = Golden(name)
+    res = []
+    for ck in (False, True):
+        diff = build_product(g, device="cpu")
+        diff.rng_device = "cpu"
+        diff.backbone.use_gradient_checkpointing = ck
+        torch.manual_seed(g.case["step_seed"])
+        out = diff.training_step(g.batch(), 1)
+        out.loss.backward()
+        res.append((float(out.loss.detach()), {k: p.grad.clone() for k, p in diff.backbone.named_parameters() if p.grad is not None}))
+    assert res[0][0] == res[1][0]
+    assert set(res[0][1]) == set(res[1][1])
+    for k in res[0][1]:
+        assert torch.equal(res[0][1][k], res[1][1][k]), k

@@ -305,7 +305,9 @@ def test_key_padding_mask_use_attention_mask_gpu():
         ref = O.dit_forward(g.cfg, g.params(), g.buffers(), xt, None, mod, None, False, allow_mask=km[:, None, :].expand(B, L, L))
     floor = rel_err(g.t("bf16/logits"), g.t("fp32/logits"))
     assert rel_err(got, ref) <= 3 * floor + 5e-3 and rel_err(base, ref) > 10 * rel_err(got, ref)
-    # through the config switch, with a backward
+    # through the config switch, with a backward (a case whose update_batch keeps the padding mask: c_large forces the full mask)
+    g = Golden("d_adaln_mm")
+    diff = build_product(g, DEV)
     diff.backbone.train()
     diff.config.model.use_attention_mask = True
     diff.rng_device = "cpu"
@@ -322,3 +324,26 @@ def test_key_padding_mask_use_attention_mask_gpu():
     torch.manual_seed(g.case["step_seed"])
     out0 = diff.training_step(batch, 1)
     assert float(out0.loss.detach()) != float(out.loss.detach())
+
+
+@pytest.mark.parametrize("name", ["c_large", "f_interleaved"])
+def test_gradient_checkpointing_on_gpu(name):
+    """trainer.use_gradient_checkpointing on the HIP path: each block is re-run from its saved input right before its backward (same kernels, same dropout
+    seeds).  Same loss bit for bit; gradients equal up to the run-to-run noise of the backward's fp32 atomics; peak memory of the step is lower."""
+    g = Golden(name)
+    res = []
+    for ck in (False, True):
+        diff = build_product(g, DEV)
+        diff.rng_device = "cpu"
+        diff.backbone.use_gradient_checkpointing = ck
+        diff.backbone.dropout = 0.1 if hasattr(diff.backbone, "dropout") else 0.0
+        torch.manual_seed(g.case["step_seed"])
+        torch.cuda.reset_peak_memory_stats()
+        out = diff.training_step(g.batch(), 1)
+        out.loss.backward()
+        torch.cuda.synchronize()
+        res.append((float(out.loss.detach()), {k: p.grad.float().cpu() for k, p in diff.backbone.named_parameters() if p.grad is not None}, torch.cuda.max_memory_allocated()))
+    assert res[0][0] == res[1][0]
+    assert set(res[0][1]) == set(res[1][1])
+    for k in res[0][1]:
+        assert rel_err(res[1][1][k], res[0][1][k]) < 2e-3, k

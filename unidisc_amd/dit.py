@@ -193,12 +193,11 @@ class DIT(nn.Module, _HubMixin):
         self.vocab_size, self.text_vocab_size, self.mask_index = vocab_size, text_vocab_size, mask_index
         self.time_conditioning = bool(cfg_get(config, "time_conditioning", False) or cfg_get(m, "force_time_conditioning", False))
         self.use_gradient_checkpointing = cfg_get(tr, "use_gradient_checkpointing", False)
-        if self.use_gradient_checkpointing:
-            # models/dit.py:1486-1490 recomputes every block in the backward to fit 48 GB parts.  The engine keeps a block's activations
-            # (0.92 GB per block at 1.4 B, B = 8: 22 GB of 288 GB) and never recomputes: results are identical, the flag only trades memory.
-            import warnings
-            warnings.warn("unidisc_amd.DIT: trainer.use_gradient_checkpointing=true is accepted but activations are KEPT, not recomputed "
-                          "(identical results; ~0.92 GB per block per 10k tokens at d=2048 stay resident)", stacklevel=2)
+        # trainer.use_gradient_checkpointing (models/dit.py:1486-1490: every block is recomputed in the backward; the reference needs it on 48 GB parts): the
+        # engine then keeps only each block's input (and the head's activations) and re-runs the block's forward right before its backward - same kernels,
+        # same dropout seeds, bit-identical gradients (tests/test_engine_orchestration.py, tests/test_gpu_e2e.py).  Off, a block's activations stay resident
+        # (0.92 GB per block at 1.4 B, B = 8: 22 GB of 288 GB), which is the faster choice whenever they fit.
+        self.use_gradient_checkpointing = bool(self.use_gradient_checkpointing)
         self.sandwich_normalization = cfg_get(m, "sandwich_normalization", False)
         self.static_img_sl, self.static_txt_sl = static_img_sl, static_txt_sl
         for flag, why in (("img_cond", "cross-attention image conditioning"), ("cond_label", "class-label conditioning"),
@@ -642,11 +641,17 @@ class DIT(nn.Module, _HubMixin):
                 any_img = (mod_flat != 0).any().to(torch.int32).reshape(1)
             S.update(Bp=Bp, te=te, l1=l1, s1=s1, l2=l2, c=c, any_img=any_img)
 
-        pre = None
-        for i, blk in enumerate(self.blocks):
+        ckpt = bool(self.use_gradient_checkpointing) and save
+
+        def block_fwd(i, x, pre, last_rows=None, recompute=False):
+            """One DiT block: x [M, d] fp32 -> (x_out, pre_out, R).  R holds what the block's backward reads.  `recompute` (activation checkpointing,
+            models/dit.py:1486-1490): the backward re-runs the block from its saved input - same kernels, same dropout seeds, the fused next-block pre-norm
+            replaced by the block's own norm kernel (bit-identical) - so only x_in (and the compacted row list of the last block) is kept per block."""
+            blk = self.blocks[i]
             R = {}
             mod = None
-            self._await_cast(i)
+            if not recompute:
+                self._await_cast(i)
             if tc:
                 a = lin[f"{i}.ada"]
                 mod = K.gemm_nt(S["c"], a.w16, N=a.out, epilogue=K.EPI_BIAS, bias=a.bias.detach())  # [Bp, 6d] bf16
@@ -668,8 +673,8 @@ class DIT(nn.Module, _HubMixin):
             else:
                 qkr, qstats = K.qknorm_rope_fwd(qkv, cos, sin, L, D, **qn_kw)
                 o, lse = K.attention_fwd(qkr, qkv, B, L, H, D, sid, S["doc_ranges"])
-            rows_c = None
-            if i + 1 == self.n_blocks and head_plan is not None and mode == "logp" and self.compact_last_block and not tc:
+            rows_c = last_rows
+            if not recompute and i + 1 == self.n_blocks and head_plan is not None and mode == "logp" and self.compact_last_block and not tc:
                 head_rows_c = self._masked_rows(head_plan, M)   # (the count was queued at the top of this forward: the host does not wait for the device here)
                 if head_rows_c is not None:
                     rows_c = head_rows_c[0]
@@ -704,11 +709,21 @@ class DIT(nn.Module, _HubMixin):
             x_out, rstd_m, mean_m = res[:3]
             pre = res[3] if nxt_w is not None else None
             if save:
-                R.update(x_in=x_full, h1=h1, rstd1=rstd1, mean1=mean1, qkv=qkv, qkr=qkr, qstats=qstats, o=o_full, lse=lse, a_out=a_out, rstd_a=rstd_a, mean_a=mean_a,
-                         x_mid=x_mid, h2=h2, rstd2=rstd2, mean2=mean2, u1=u1, g=g, u2=u2, rstd_m=rstd_m, mean_m=mean_m, rows_c=rows_c,
-                         o_c=o if rows_c is not None else None)
+                if ckpt and not recompute:
+                    R = dict(x_in=x_full, rows_c=rows_c, ckpt=True)
+                else:
+                    R.update(x_in=x_full, h1=h1, rstd1=rstd1, mean1=mean1, qkv=qkv, qkr=qkr, qstats=qstats, o=o_full, lse=lse, a_out=a_out, rstd_a=rstd_a,
+                             mean_a=mean_a, x_mid=x_mid, h2=h2, rstd2=rstd2, mean2=mean2, u1=u1, g=g, u2=u2, rstd_m=rstd_m, mean_m=mean_m, rows_c=rows_c,
+                             o_c=o if rows_c is not None else None)
+            return x_out, pre, R
+
+        pre = None
+        for i in range(self.n_blocks):
+            x, pre, R = block_fwd(i, x, pre)
+            if save:
                 S["blocks"].append(R)
-            x = x_out
+        if ckpt:
+            S["block_fwd"] = block_fwd
 
         fl = self.output_layer
         fmod = None
@@ -980,6 +995,9 @@ class DIT(nn.Module, _HubMixin):
 
         for i in reversed(range(self.n_blocks)):
             blk, R = self.blocks[i], S["blocks"][i]
+            if R.get("ckpt"):   # activation checkpointing: rebuild this block's activations from its saved input, right before they are consumed
+                with torch.no_grad():
+                    R = S["block_fwd"](i, R["x_in"], None, last_rows=R["rows_c"], recompute=True)[2]
             at = blk.attention
             mod = R.get("mod")
             dmod = torch.zeros((Bp, 6 * d), dtype=F32, device=dev) if tc else None
