@@ -435,6 +435,10 @@ def subs_logprobs(logits, xt, modality, V, Vt, mask_id, restrict, out_dtype=BF16
     return out.to(out_dtype)
 
 
+def gemm_tn_pair_ok(M0, M1, N, K):
+    return False   # (CPU doubles: the two wgrads stay separate calls)
+
+
 def gemm_nn_ok(M, N, K):
     return N % 256 == 0 and K % 64 == 0 and K >= 128 and any(M % t == 0 for t in (192, 256, 320))
 

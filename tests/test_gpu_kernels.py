@@ -154,6 +154,35 @@ def test_gemm_tn_splitk_workspace(K, Kc, M, N):
     assert rel_err(out.cpu(), 2 * ref) < 2e-5
 
 
+@pytest.mark.parametrize("M0,M1,N,Kc", [(6144, 2048, 2048, 10240), (768, 256, 512, 1024), (256, 256, 256, 128), (2304, 768, 768, 24576)])
+@pytest.mark.parametrize("beta", [0.0, 1.0])
+def test_gemm_tn_pair_equals_two_launches(K, M0, M1, N, Kc, beta):
+    """Two wgrads in one launch (udm_gemm_tn_pair_bf16: the qkv + out-proj weight gradients of a DiT block share a grid of 256 x 256 tiles): bit-identical to
+    the 256-row-tile kernel run on each problem alone (same tiles, same k order), and equal to the fp32 products; different leading dimensions per problem."""
+    a0, b0 = bf(rnd(Kc, M0 + 8, seed=490, scale=0.5)), bf(rnd(Kc, N, seed=491, scale=0.5))
+    a1, b1 = bf(rnd(Kc, M1, seed=492, scale=0.5)), bf(rnd(Kc, N + 16, seed=493, scale=0.5))
+    ga0, gb0, ga1, gb1 = a0.to(DEV)[:, :M0], b0.to(DEV), a1.to(DEV), b1.to(DEV)[:, :N]
+    c0, c1 = rnd(M0, N, seed=494), rnd(M1, N, seed=495)
+    o0, o1 = c0.clone().to(DEV), c1.clone().to(DEV)
+    K.gemm_tn_pair(ga0, gb0, o0, ga1, gb1, o1, beta=beta)
+    ref0 = a0[:, :M0].float().t() @ b0.float() + beta * c0
+    ref1 = a1.float().t() @ b1[:, :N].float() + beta * c1
+    assert rel_err(o0.cpu(), ref0) < 1e-5 and rel_err(o1.cpu(), ref1) < 1e-5
+    try:
+        K.gemm_set_quad(2)
+        K.gemm_set_tile(-1)
+        s0, s1 = c0.clone().to(DEV), c1.clone().to(DEV)
+        K.gemm_tn(ga0, gb0, s0, M=M0, N=N, beta=beta)
+        K.gemm_tn(ga1, gb1, s1, M=M1, N=N, beta=beta)
+    finally:
+        K.gemm_set_quad(1)
+    if M0 % 256 == 0 and M1 % 256 == 0 and (M0 // 256) * (N // 256) >= 1:
+        # (the single-problem launch may pick 192-row tiles where they fill the chip better: the same k order per output element either way)
+        assert torch.equal(o0, s0) and torch.equal(o1, s1)
+    with pytest.raises(ValueError):
+        K.gemm_tn_pair(ga0[:, :200], gb0, o0[:200], ga1, gb1, o1)
+
+
 @pytest.mark.parametrize("M,N,K_", [(512, 512, 128), (512, 256, 192), (768, 512, 448), (384, 256, 256), (1024, 768, 1024), (640, 512, 320), (2560, 2048, 2048)])
 def test_gemm_nt_quad_one_wave_per_simd_every_epilogue(K, M, N, K_):
     """The one-wave-per-SIMD NT kernel (gemm_quad.hip) forced on every shape it fits (192-, 256- and 320-row tiles - the last with its fifth accumulator row in arch VGPRs -, K-tile counts 2 / 3 / 4 / 5 / 7 / 16 / 32):

@@ -181,7 +181,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_fp8_kernel(Fp8Args a) {
     // Lazy reference (as in the bf16 kernel, with the head-room e4m3 leaves): m is the reference exponent of this query and only moves when some query of
     // the wave saw a score more than 0.75 (log2 units) above its reference - then 2^8 p <= 2^8.75 = 431 < 448 still converts without saturation.  With the
     // exact running maximum the wave rescaled O^T (64 multiplies per lane) in most tiles: one of its 32 queries almost always sets a new record.
-    if (__builtin_amdgcn_ballot_w64(q_ok && (mloc * c > m * c + 0.75f)) != 0) {
+    // (explicit fused multiply-adds: the decision and the exponents must not depend on how each instantiation of this body happens to be contracted -
+    // walks with and without the per-element id code are compared bit for bit)
+    if (__builtin_amdgcn_ballot_w64(q_ok && (mloc * c > __builtin_fmaf(m, c, 0.75f))) != 0) {
       const float m_new = fmaxf(m, mloc);
       const float alpha = __builtin_amdgcn_exp2f((m - ((m_new == -INFINITY) ? 0.f : m_new)) * c);
       lsum *= alpha;
@@ -191,7 +193,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_fp8_kernel(Fp8Args a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) oT[i][r] *= alpha;
     }
-    const float mc8 = ((m == -INFINITY) ? 0.f : m * c) - 8.0f;
+    const float mc8 = (m == -INFINITY) ? -8.0f : __builtin_fmaf(m, c, -8.0f);
     float psum = 0.f;
     i32x8_t pb;
 #pragma unroll
@@ -199,7 +201,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_fp8_kernel(Fp8Args a) {
       float pv[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        pv[j] = __builtin_amdgcn_exp2f(sT[w >> 2][4 * (w & 3) + j] * c - mc8);
+        pv[j] = __builtin_amdgcn_exp2f(__builtin_fmaf(sT[w >> 2][4 * (w & 3) + j], c, -mc8));
         psum += pv[j];
       }
       int u = 0;

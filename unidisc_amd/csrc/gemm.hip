@@ -1043,6 +1043,24 @@ extern "C" int udm_gemm_nn_bf16(const void* A, const void* B, void* C, int64_t M
   return udm_quad_launch_nn(q, fm, stream);
 }
 
+// Two weight gradients of one backward step in ONE launch: C0[M0, N] (+)= A0[K, M0]^T B0[K, N] and C1[M1, N] (+)= A1[K, M1]^T B1[K, N] (fp32, beta as
+// udm_gemm_tn_bf16), same N and K, M0 / M1 / N multiples of 256, K a multiple of 64: the 256 x 256 one-wave-per-SIMD tiles of both problems share a grid, so
+// that e.g. the qkv (6144 x 2048: 192 tiles) and the out-proj (2048 x 2048: 64 tiles) weight gradients of a DiT block fill the 256 CUs exactly once.
+// Returns 3 (and does nothing) when the shapes do not qualify: the caller then issues the two plain calls.
+extern "C" int udm_gemm_tn_pair_bf16(const void* A0, const void* B0, void* C0, int64_t M0, int64_t lda0, int64_t ldb0, int64_t ldc0, const void* A1,
+                                     const void* B1, void* C1, int64_t M1, int64_t lda1, int64_t ldb1, int64_t ldc1, int64_t N, int64_t K, float beta,
+                                     hipStream_t stream) {
+  UDM_CHECK_ARG(A0 && B0 && C0 && A1 && B1 && C1, "udm_gemm_tn_pair_bf16: null operand");
+  if (!udm_quad_mode() || M0 <= 0 || M1 <= 0 || M0 % 256 || M1 % 256 || N <= 0 || N % 256 || K < 128 || K % 64) return 3;
+  if (lda0 % 8 || ldb0 % 8 || lda1 % 8 || ldb1 % 8 || ldc0 % 4 || ldc1 % 4 || lda0 < M0 || lda1 < M1 || ldb0 < N || ldb1 < N) return 3;
+  if (((uintptr_t)A0 | (uintptr_t)B0 | (uintptr_t)C0 | (uintptr_t)A1 | (uintptr_t)B1 | (uintptr_t)C1) % 16) return 3;
+  QuadArgs q{};
+  q.A = (const bf16_t*)A0; q.B = (const bf16_t*)B0; q.C = C0; q.lda = lda0; q.ldb = ldb0; q.ldc = ldc0;
+  q.A2 = (const bf16_t*)A1; q.B2 = (const bf16_t*)B1; q.C2 = C1; q.lda2 = lda1; q.ldb2 = ldb1; q.ldc2 = ldc1;
+  q.M = (int)M0; q.N = (int)N; q.K = (int)K; q.beta = beta; q.splitk = 1;
+  return udm_quad_launch_tn_pair(q, M1, stream);
+}
+
 extern "C" int udm_gemm_set_cus(int cus) {   // 0 = all CUs; otherwise the persistent NT grid (a multiple of 8 in [8, 256])
   UDM_CHECK_ARG(cus == 0 || (cus >= 8 && cus <= 256 && cus % 8 == 0), "udm_gemm_set_cus: 0 or a multiple of 8 in [8, 256]");
   g_gemm_cus = cus;

@@ -15,6 +15,14 @@ struct QuadArgs {
   int splitk;          // > 1 (fp32 output only): K cut into slices, slice s stores its partial tile at C + s * slice_stride
   long slice_stride;
   int group_m;
+  // paired launch (TN wgrad form): a SECOND problem with the same N and K stacked below the first one's row tiles - tiles [0, tiles_m_split) of the tile rows are
+  // problem one, the rest problem two (its own operands and output).  One launch of exactly 256 tiles instead of a 256-tile launch of 192-row tiles plus a
+  // split-K launch + reduce (qkv and out-proj weight gradients: 192 + 64 tiles of 256 x 256).  0 = single problem.
+  int tiles_m_split = 0;
+  const bf16_t* A2 = nullptr;
+  const bf16_t* B2 = nullptr;
+  void* C2 = nullptr;
+  long lda2 = 0, ldb2 = 0, ldc2 = 0;
 };
 
 extern int g_quad_mode;
@@ -22,6 +30,8 @@ int udm_quad_mode();   // 0 off, 1 auto (shapes that fill the chip), 2 force whe
 // TN (wgrad) form: does a quad tile fit (whole tiles, K % 64 == 0)?  *fm receives the tile height / 64 (3, 4 or 5).
 bool udm_quad_tn_ok(long M, long N, long K, int* fm);
 int udm_quad_launch_tn(const QuadArgs& a, int fm, hipStream_t stream);
+// two wgrads C = A^T B, C2 = A2^T B2 with the same N and K in one launch of 256 x 256 tiles (a.M / a.tiles_m_split describe problem one, M2 rows problem two)
+int udm_quad_launch_tn_pair(const QuadArgs& a, long M2, hipStream_t stream);
 // NT (forward / dgrad) form
 bool udm_quad_nt_ok(long M, long N, long K, int* fm);
 int udm_quad_launch_nt(const QuadArgs& a, int fm, int epilogue, int out_f32, hipStream_t stream);

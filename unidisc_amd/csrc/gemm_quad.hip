@@ -48,7 +48,8 @@ __device__ __forceinline__ const char* uniform_ptr(const char* ptr) {   // pin a
 // 2 = NN (C = A B: A K-contiguous, B K-major - the dgrad form dX = dY W read from the forward's own W shadow, so no W^T shadow has to be cast).
 // Every operand is staged and gathered by its own layout (TA / TB): NN is the NT kernel's A side next to the TN kernel's B side.
 template <int FM, int MODE, int EPI, bool OUT_F32, int DMA_GAP, int ABL = 0>
-__global__ __launch_bounds__(256, 1) void gemm_quad_kernel(QuadArgs p) {
+__global__ __launch_bounds__(256, 1) void gemm_quad_kernel(QuadArgs p0) {
+  QuadArgs p = p0;   // (the paired launch redirects the operand fields of the blocks that belong to the second problem, once, before anything reads them)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr bool TA = MODE == 1, TB = MODE >= 1;
   constexpr int FN = 4, BM = 64 * FM, BN = 256;
@@ -70,7 +71,12 @@ __global__ __launch_bounds__(256, 1) void gemm_quad_kernel(QuadArgs p) {
   const int per_group = grp_rows * p.tiles_n;
   const int grp = pid / per_group, first_m = grp * grp_rows;
   const int gsz = min(p.tiles_m - first_m, grp_rows);
-  const int tm = first_m + (pid % per_group) % gsz, tn = (pid % per_group) / gsz;
+  int tm = first_m + (pid % per_group) % gsz;
+  const int tn = (pid % per_group) / gsz;
+  if (p.tiles_m_split > 0 && tm >= p.tiles_m_split) {   // block-uniform
+    tm -= p.tiles_m_split;
+    p.A = p.A2; p.B = p.B2; p.C = p.C2; p.lda = p.lda2; p.ldb = p.ldb2; p.ldc = p.ldc2;
+  }
   const int row0 = tm * BM, col0 = tn * BN;
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -402,6 +408,13 @@ bool udm_quad_tn_ok(long M, long N, long K, int* fm) {
   if (!pick) return false;
   *fm = pick;
   return true;
+}
+
+int udm_quad_launch_tn_pair(const QuadArgs& a0, long M2, hipStream_t stream) {
+  QuadArgs a = a0;
+  a.tiles_m_split = a.M / 256;
+  a.M = a.M + (int)M2;        // launch_quad_t derives the tile rows of BOTH problems from M
+  return launch_quad_t<4, true, UDM_EPI_NONE, true>(a, stream);
 }
 
 int udm_quad_launch_tn(const QuadArgs& a, int fm, hipStream_t stream) {

@@ -277,6 +277,7 @@ class DIT(nn.Module, _HubMixin):
         # ... and with it everything of the LAST block behind its attention (out-proj, residual adds, MLP, final norm): only the head reads that
         # block's output, so its unmasked rows feed nothing and receive a zero gradient (exact; no adaLN: the row kernels would need the row -> sample map)
         self.compact_last_block = os.environ.get("UDM_COMPACT_LAST", "1") != "0"
+        self.pair_wgrads = os.environ.get("UDM_PAIR_WGRADS", "1") != "0"   # qkv + out-proj weight gradients in one 256-tile launch (K.gemm_tn_pair)
         self.dgrad_from_w = os.environ.get("UDM_DGRAD_NN", "1") != "0"   # dgrads from the forward's W shadow where the shape allows (see refresh_weight_shadows)
         self.grad_ready_callback = None   # fn(flat_grads, lo, hi): elements [lo, hi) of this backward's flat fp32 gradient buffer are final
         self.grad_sync_finish = None      # fn(): called at the end of backward (e.g. make the compute stream wait for the all-reduces)
@@ -1036,6 +1037,7 @@ class DIT(nn.Module, _HubMixin):
                 else:
                     da = branch_bwd(p2, R["a_out"], p_drop=p_drop, seed=seed0 + 4 * i + 1)
             lo, lq = lin[f"{i}.out"], lin[f"{i}.qkv"]
+            pair_out = None
             do = lo.dgrad(da, da.shape[0])
             if R.get("rows_c") is not None:
                 # back to all rows: the rows left out have a zero gradient in both the attention output and the residual stream
@@ -1044,7 +1046,13 @@ class DIT(nn.Module, _HubMixin):
                 do = torch.zeros((M, d), dtype=do.dtype, device=dev).index_copy_(0, rows_c, do)
                 dx = torch.zeros((M, d), dtype=F32, device=dev).index_copy_(0, rows_c, dx)
             else:
-                self._wgrad(da, R["o"], lo, G)
+                # The out-proj weight gradient (2048 x 2048: 64 tiles) waits for the qkv one (6144 x 2048: 192 tiles of 256 rows) where the two fill the chip
+                # exactly once TOGETHER (K.gemm_tn_pair): one launch instead of 256 tiles of 192 rows + a split-K launch + its reduce pass
+                if (self.pair_wgrads and da.is_cuda and lo.bias is None and lq.bias is None and lo.inp == lq.inp
+                        and K.gemm_tn_pair_ok(lq.out, lo.out, lq.inp, M) and (lq.out // 256 + lo.out // 256) * (lq.inp // 256) % 256 == 0):
+                    pair_out = (da, R["o"])
+                else:
+                    self._wgrad(da, R["o"], lo, G)
             dqkr = torch.empty((M, 2 * d), dtype=BF16, device=dev)
             dqkv = torch.empty((M, 3 * d), dtype=BF16, device=dev)
             K.attention_bwd(R["qkr"], R["qkv"], R["o"], do, R["lse"], dqkr, dqkv, B, L, H, D, S["sid"], S["doc_ranges"])
@@ -1054,7 +1062,11 @@ class DIT(nn.Module, _HubMixin):
                               dbq=G[id(at.q_norm.bias)] if qn else None, dgk=G[id(at.k_norm.weight)] if qn else None,
                               dbk=G[id(at.k_norm.bias)] if qn else None)
             dh1 = lq.dgrad(dqkv, dqkv.shape[0])
-            self._wgrad(dqkv, R["h1"], lq, G)
+            if pair_out is not None:
+                K.gemm_tn_pair(dqkv, R["h1"], G[id(lq.weight)], pair_out[0], pair_out[1], G[id(lo.weight)])
+                pair_out = None
+            else:
+                self._wgrad(dqkv, R["h1"], lq, G)
             if tc:
                 K.norm_bwd(dh1, R["x_in"], R["rstd1"], R["mean1"], blk.norm1.weight.detach(), nt, L, dx, G[id(blk.norm1.weight)], accumulate=True,
                            mod=mod, dmod=dmod, mod_idx=(0, 1), modality=mod_flat, any_img=any_img)

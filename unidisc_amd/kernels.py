@@ -109,6 +109,26 @@ def gemm_tn(a, b, out, *, M=None, N=None, beta=0.0):
     return out
 
 
+def gemm_tn_pair_ok(M0, M1, N, K):
+    """Can two wgrads share one launch of 256 x 256 tiles (gemm_tn_pair)?"""
+    return M0 > 0 and M1 > 0 and M0 % 256 == 0 and M1 % 256 == 0 and N % 256 == 0 and K % 64 == 0 and K >= 128
+
+
+def gemm_tn_pair(a0, b0, out0, a1, b1, out1, *, beta=0.0):
+    """out0[M0,N] = beta*out0 + a0[K,M0]^T b0[K,N] and out1[M1,N] = beta*out1 + a1[K,M1]^T b1[K,N] (fp32) in ONE launch: the 256 x 256 tiles of both wgrads
+    share a grid (qkv + out-proj weight gradients of a DiT block: 192 + 64 tiles = the 256 CUs exactly once).  Shapes must pass gemm_tn_pair_ok."""
+    for t, n in ((a0, "a0"), (b0, "b0"), (a1, "a1"), (b1, "b1")):
+        _chk(t, BF16, "gemm_tn_pair " + n)
+    _chk(out0, F32, "gemm_tn_pair out0"), _chk(out1, F32, "gemm_tn_pair out1")
+    K = a0.shape[0]
+    M0, N = out0.shape
+    M1 = out1.shape[0]
+    if a1.shape[0] != K or b0.shape[0] != K or b1.shape[0] != K or out1.shape[1] != N or not gemm_tn_pair_ok(M0, M1, N, K):
+        raise ValueError("gemm_tn_pair: the two problems need the same N and K, with M0, M1, N multiples of 256 and K of 64")
+    _lib.call("udm_gemm_tn_pair_bf16", _p(a0), _p(b0), _p(out0), M0, a0.stride(0), b0.stride(0), out0.stride(0), _p(a1), _p(b1), _p(out1), M1, a1.stride(0),
+              b1.stride(0), out1.stride(0), N, K, float(beta), _s())
+
+
 def gemm_tn_splitk(a, b, out, *, M=None, N=None, beta=0.0):
     """gemm_tn for few output tiles over a long contraction: K split across CUs through an fp32 workspace (no atomics)."""
     _chk(a, BF16, "gemm_tn_splitk a"), _chk(b, BF16, "gemm_tn_splitk b"), _chk(out, F32, "gemm_tn_splitk out")
