@@ -72,14 +72,16 @@ def test_masked_row_head_compaction_is_exact(name, fake_k):
     must give the same loss and the same gradients as the full-row run."""
     g = Golden(name)
     res = []
-    for compact, last in ((False, False), (True, False), (True, True)):
+    splits = []
+    for compact, last, split in ((False, False, True), (True, False, True), (True, True, True), (True, True, False)):
         diff = build_product(g, device="cpu")
         diff.rng_device = "cpu"
         diff.backbone.compact_head = compact
         diff.backbone.compact_last_block = last
+        diff.backbone.split_head = split     # (text rows x text ids) + (image rows x image ids) instead of rows x all ids: exact under force_argmax_valid_indices
         seen = []
         orig = type(diff.backbone)._engine_backward
-        diff.backbone._engine_backward = lambda S, grad, mode, orig=orig, bb=diff.backbone: (seen.append((S["hf"].shape[0], bool(S.get("stream_compact")))), orig(bb, S, grad, mode))[1]
+        diff.backbone._engine_backward = lambda S, grad, mode, orig=orig, bb=diff.backbone: (seen.append((S["hf"].shape[0], bool(S.get("stream_compact")))), splits.append((compact, split, S.get("head_groups"))), orig(bb, S, grad, mode))[2]
         torch.manual_seed(g.case["step_seed"])
         batch = {k: torch.cat([v] * 4) for k, v in g.batch().items()}   # 512 rows: the padded [MASK] row list is shorter than the batch
         out = diff.training_step(batch, 1)
@@ -93,6 +95,12 @@ def test_masked_row_head_compaction_is_exact(name, fake_k):
         assert set(g0) == set(g1)
         for k in g0:
             assert torch.allclose(g0[k], g1[k], rtol=1e-5, atol=1e-7), k
+    restrict = bool(g.case["force_argmax_valid_indices"]) and g.case["img_length"] > 0
+    for compact, split, groups in splits:   # the split really ran where it applies (two non-empty groups, multiples of 64), and only there
+        if compact and split and restrict:
+            assert groups is not None and all(n % 64 == 0 for n in groups) and sum(groups) > 0, (compact, split, groups)
+        else:
+            assert groups is None, (compact, split, groups)
 
 
 @pytest.mark.parametrize("name", ["b_small", "c_large", "d_adaln_mm"])

@@ -277,6 +277,9 @@ class DIT(nn.Module, _HubMixin):
         # ... and with it everything of the LAST block behind its attention (out-proj, residual adds, MLP, final norm): only the head reads that
         # block's output, so its unmasked rows feed nothing and receive a zero gradient (exact; no adaLN: the row kernels would need the row -> sample map)
         self.compact_last_block = os.environ.get("UDM_COMPACT_LAST", "1") != "0"
+        # SUBS with force_argmax_valid_indices: a text row's logits matter on the text ids only, an image row's on the image ids only (everything else is -inf in the
+        # forward and has a zero gradient) - the head (forward, dgrad, wgrad) then runs as (text rows x text ids) + (image rows x image ids) instead of rows x all ids
+        self.split_head = os.environ.get("UDM_SPLIT_HEAD", "1") != "0"
         self.pair_wgrads = os.environ.get("UDM_PAIR_WGRADS", "1") != "0"   # qkv + out-proj weight gradients in one 256-tile launch (K.gemm_tn_pair)
         self.dgrad_from_w = os.environ.get("UDM_DGRAD_NN", "1") != "0"   # dgrads from the forward's W shadow where the shape allows (see refresh_weight_shadows)
         self.grad_ready_callback = None   # fn(flat_grads, lo, hi): elements [lo, hi) of this backward's flat fp32 gradient buffer are final
@@ -607,7 +610,10 @@ class DIT(nn.Module, _HubMixin):
         # stream NOW and only read back right before the head, when the host has already queued every block of this forward -- the
         # device never waits for the host.
         plan_ids = inp.get("plan_ids")
-        head_plan = self._plan_masked_rows(ids if plan_ids is None else plan_ids.reshape(ids.shape)) if ((mode == "logp" and self.compact_head) or mode == "rows") else None
+        split_ok = (mode == "logp" and self.compact_head and self.split_head and bool(inp.get("restrict", False)) and mod_flat is not None and plan_ids is None
+                    and 0 < self.text_vocab_size < self.vocab_size and self.head_chunk_rows <= 0)
+        head_plan = (self._plan_masked_rows(ids if plan_ids is None else plan_ids.reshape(ids.shape), mod_flat if split_ok else None)
+                     if ((mode == "logp" and self.compact_head) or mode == "rows") else None)
 
         x = K.embedding_fwd(ids, self.vocab_embed.embedding.detach(), emb_mod if self.modality_embed is not None else None,
                             self.modality_embed.embedding.detach() if self.modality_embed is not None else None)
@@ -788,38 +794,60 @@ class DIT(nn.Module, _HubMixin):
         else:
             chunk = 0
             logits = torch.empty((M, Vp), dtype=BF16, device=dev)[:Mh]
-            K.gemm_nt(hf_h, head.w16, out=logits, N=V, epilogue=K.EPI_BIAS, bias=head.bias.detach())
+            groups = head_plan.get("groups") if (head_plan is not None and head_rows is not None and restrict) else None
+            if groups is not None:
+                # (text rows) x ids [0, c_up) and (image rows) x ids [c_al, V): the boundary Vt is rounded to multiples of 8 outwards so that every operand and
+                # output pointer keeps its alignment; the few extra columns are never read (the cross-entropy reads a row's valid ids only)
+                n_tp, n_ip = groups
+                Vt = self.text_vocab_size
+                c_al, c_up = Vt // 8 * 8, _ceil(Vt, 8)
+                bias = head.bias.detach()
+                if n_tp:
+                    K.gemm_nt(hf_h[:n_tp], head.w16, out=logits[:n_tp], N=c_up, epilogue=K.EPI_BIAS, bias=bias)
+                if n_ip:
+                    K.gemm_nt(hf_h[n_tp:], head.w16[c_al:], out=logits[n_tp:, c_al:], N=V - c_al, epilogue=K.EPI_BIAS, bias=bias[c_al:])
+            else:
+                K.gemm_nt(hf_h, head.w16, out=logits, N=V, epilogue=K.EPI_BIAS, bias=head.bias.detach())
             log_p, lse_ce = K.subs_ce_fwd(logits, x0, ids_h, ce_mod, V, self.text_vocab_size, self.mask_index, restrict)
-        if head_rows is not None:
-            full = torch.zeros(M, dtype=log_p.dtype, device=dev)
-            full.index_copy_(0, rows_p[:n_masked], log_p[:n_masked])
-            log_p = full
+        if head_rows is not None:   # (padding rows are unmasked: their log p is exactly 0, like every row left out)
+            log_p = torch.zeros(M, dtype=log_p.dtype, device=dev).index_copy_(0, rows_p, log_p)
         if save:
             S.update(x_final=x, hf=hf_h, rstdf=rstdf, meanf=meanf, fmod=fmod, logits=logits, head_rows=head_rows, ids_h=ids_h,
-                     x0=x0, ce_mod=ce_mod, restrict=restrict, lse_ce=lse_ce, stream_compact=stream_compact, head_chunk=chunk)
+                     x0=x0, ce_mod=ce_mod, restrict=restrict, lse_ce=lse_ce, stream_compact=stream_compact, head_chunk=chunk,
+                     head_groups=(head_plan.get("groups") if (head_plan is not None and head_rows is not None and restrict and not chunk) else None))
         return log_p.view(B, L), S
 
-    def _plan_masked_rows(self, ids):
-        """Queue (without synchronising) a stable partition of the row indices with the [MASK] rows first and their count."""
+    def _plan_masked_rows(self, ids, mod=None):
+        """Queue (without synchronising) a stable partition of the row indices with the [MASK] rows first and their count.  With `mod` (the rows' modality,
+        0 = text / 1 = image) the [MASK] rows are ordered text first, then image, and both counts are reported: the vocabulary head can then run as two
+        (rows of one modality) x (ids valid for that modality) problems (`_masked_rows`, split_head)."""
         is_mask = ids == self.mask_index
+        if mod is not None:
+            key = (~is_mask).to(torch.int8) * 2 + (mod == 1).to(torch.int8)     # 0 masked text, 1 masked image, 2 / 3 unmasked
+            counts = lambda: torch.stack([(is_mask & (mod != 1)).sum(), (is_mask & (mod == 1)).sum()])
+        else:
+            key = (~is_mask).to(torch.int8)
+            counts = lambda: is_mask.sum().view(1)
         if not ids.is_cuda:  # CPU orchestration tests
-            return dict(order=torch.argsort((~is_mask).to(torch.int8), stable=True), count=int(is_mask.sum()), event=None)
+            c = counts()
+            return dict(order=torch.argsort(key, stable=True), count=int(c.sum()), count2=(int(c[0]), int(c[1])) if mod is not None else None, event=None)
         dev = ids.device
         main = torch.cuda.current_stream(dev)
         side = self._side_streams.get(dev) if getattr(self, "_side_streams", None) else None
         if side is None:   # one side stream per device the module has run on
             self._side_streams = dict(getattr(self, "_side_streams", None) or {})
             side = self._side_streams[dev] = torch.cuda.Stream(device=dev)
-        count_host = torch.empty(1, dtype=torch.int64).pin_memory()   # per call: forwards on two streams / threads must not share the counter
+        count_host = torch.empty(2 if mod is not None else 1, dtype=torch.int64).pin_memory()   # per call: forwards on two streams / threads must not share the counter
         side.wait_stream(main)
         with torch.cuda.stream(side):
-            order = torch.argsort((~is_mask).to(torch.int8), stable=True)
-            count_host.copy_(is_mask.sum().view(1), non_blocking=True)
+            order = torch.argsort(key, stable=True)
+            count_host.copy_(counts(), non_blocking=True)
             event = torch.cuda.Event()
             event.record(side)
         is_mask.record_stream(side)
+        key.record_stream(side)
         order.record_stream(main)
-        return dict(order=order, count=None, event=event, count_host=count_host, side=side)
+        return dict(order=order, count=None, count2=None, event=event, count_host=count_host, side=side, by_modality=mod is not None)
 
     def _masked_rows(self, plan, M, always=False):
         """(row indices: the [MASK] rows, then as many unmasked rows as pad the list to a multiple of 64; number of masked rows), or
@@ -828,15 +856,34 @@ class DIT(nn.Module, _HubMixin):
             n = plan["n"]
         elif plan["event"] is not None:
             plan["event"].synchronize()
-            n = int(plan["count_host"][0])
+            ch = plan["count_host"]
+            if plan.get("by_modality"):
+                plan["count2"] = (int(ch[0]), int(ch[1]))
+            n = int(ch.sum())
             torch.cuda.current_stream().wait_stream(plan["side"])
         else:
             n = plan["count"]
         plan["n"] = n
+        if "rows" in plan:       # (decided once per forward: the last block's compaction and the head must see the same list)
+            return plan["rows"]
+        plan["groups"] = None
         n_pad = _ceil(max(n, 1), 64)
         if n_pad >= M:
-            return (plan["order"], n) if always else None   # always: every row, [MASK] rows first
-        return plan["order"][:n_pad], n
+            plan["rows"] = (plan["order"], n) if always else None   # always: every row, [MASK] rows first
+            return plan["rows"]
+        c2 = plan.get("count2")
+        if c2 is not None and not always and self.split_head and n > 0:
+            # two groups - [MASK] text rows, [MASK] image rows - each padded to a multiple of 64 with unmasked rows (zero loss, zero gradient: exact)
+            n_t, n_i = c2
+            n_tp, n_ip = (_ceil(n_t, 64) if n_t else 0), (_ceil(n_i, 64) if n_i else 0)
+            pad_t, pad_i = n_tp - n_t, n_ip - n_i
+            if n_tp + n_ip < M and pad_t + pad_i <= M - n:
+                o = plan["order"]
+                plan["rows"] = (torch.cat([o[:n_t], o[n:n + pad_t], o[n_t:n], o[n + pad_t:n + pad_t + pad_i]]), n)
+                plan["groups"] = (n_tp, n_ip)
+                return plan["rows"]
+        plan["rows"] = (plan["order"][:n_pad], n)
+        return plan["rows"]
 
     # -------------------------------------------------------------------------------------------- engine: backward
     def _alloc_grads(self, params, dev):
@@ -945,15 +992,40 @@ class DIT(nn.Module, _HubMixin):
             else:
                 dlogits = torch.zeros_like(logits)
                 dlogits[:, :V].copy_(grad_out.reshape(M, V))
-            # few output tiles (compacted rows x d) over K = V: split K so that all CUs work (falls back to the plain kernel otherwise)
-            dhf = K.gemm_nt_splitk(dlogits, head.w16t, N=d, out=torch.empty((M, d), dtype=BF16, device=dev)[: dlogits.shape[0]])
-            self._wgrad(dlogits, S["hf"], head, G)
+            groups = S.get("head_groups") if mode == "logp" else None
+            if groups is not None:   # the same two (rows of one modality) x (ids of that modality) problems as the forward; d logits is zero everywhere else
+                n_tp, n_ip = groups
+                Vt, Vp = self.text_vocab_size, head.outp
+                c_al, c_up = Vt // 8 * 8, _ceil(Vt, 8)
+                k_t = min(_ceil(Vt, 64), Vp)
+                hf_h = S["hf"]
+                dhf = torch.empty((M, d), dtype=BF16, device=dev)[: dlogits.shape[0]]
+                Gw = G[id(head.weight)]
+                db = torch.zeros(Vp, dtype=F32, device=dev)   # (column sums over widths that are multiples of 8; d logits is zero in the padding columns)
+                if n_tp:
+                    K.gemm_nt_splitk(dlogits[:n_tp, :k_t], head.w16t[:, :k_t], N=d, out=dhf[:n_tp])
+                    K.colsum(dlogits[:n_tp, :c_up], db[:c_up])
+                    if c_al:
+                        K.gemm_tn(dlogits[:n_tp, :c_al], hf_h[:n_tp], Gw[:c_al], M=c_al, N=d)
+                elif c_al:
+                    Gw[:c_al].zero_()
+                if n_ip:
+                    K.gemm_nt_splitk(dlogits[n_tp:, c_al:], head.w16t[:, c_al:], N=d, out=dhf[n_tp:])
+                    K.colsum(dlogits[n_tp:, c_al:], db[c_al:])
+                    K.gemm_tn(dlogits[n_tp:, c_up:V], hf_h[n_tp:], Gw[c_up:], M=V - c_up, N=d)
+                else:
+                    Gw[c_up:].zero_()
+                if c_up > c_al:   # the ids between the two aligned boundaries (at most 15) take every row
+                    K.gemm_tn(dlogits[:, c_al:c_up], hf_h, Gw[c_al:c_up], M=c_up - c_al, N=d)
+                G[id(head.bias)].copy_(db[:V])
+            else:
+                # few output tiles (compacted rows x d) over K = V: split K so that all CUs work (falls back to the plain kernel otherwise)
+                dhf = K.gemm_nt_splitk(dlogits, head.w16t, N=d, out=torch.empty((M, d), dtype=BF16, device=dev)[: dlogits.shape[0]])
+                self._wgrad(dlogits, S["hf"], head, G)
         stream_compact = bool(S.get("stream_compact"))
         if head_rows is not None and not stream_compact:  # scatter the masked rows' gradient back; every other row of d(final norm output) is exactly zero
             rows_p, n_masked = head_rows
-            full = torch.zeros((M, d), dtype=dhf.dtype, device=dev)
-            full.index_copy_(0, rows_p[:n_masked], dhf[:n_masked])
-            dhf = full
+            dhf = torch.zeros((M, d), dtype=dhf.dtype, device=dev).index_copy_(0, rows_p, dhf)   # (padding rows: d logits = 0, so their rows of dhf are 0 too)
         del dlogits
         S["logits"] = None
 
