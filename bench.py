@@ -113,7 +113,7 @@ GEMM_ENTRY_POINTS = ("udm_gemm_nt_bf16", "udm_gemm_tn_bf16", "udm_gemm_nn_bf16",
 def _work(name, a):
     """Algorithmic work of one launch from the C-ABI arguments: ("flop" | "byte", amount) or None.  Bytes follow DESIGN.md §4 (per-element
     figures of the HBM-bound kernels: what the op must read and write once), flops count what the MFMA pipe is asked to do."""
-    if name == "udm_gemm_tn_pair_bf16":   # (A0, B0, C0, M0, lda0, ldb0, ldc0, A1, B1, C1, M1, lda1, ldb1, ldc1, N, K, beta)
+    if name == "udm_gemm_tn_pair_bf16":   # (A0, B0, C0, M0, lda0, ldb0, ldc0, A1, B1, C1, M1, lda1, ldb1, ldc1, N, K, beta, ws, ws_elems)
         return "flop", 2.0 * (a[3] + a[10]) * a[14] * a[15]
     if name in GEMM_ENTRY_POINTS:
         return "flop", 2.0 * a[3] * a[4] * a[5]

@@ -67,7 +67,8 @@ int udm_gemm_tn_splitk_bf16(const void* A, const void* B, void* C, int64_t M, in
 /* two wgrads of one backward step in ONE launch (same N and K; M0, M1, N multiples of 256, K of 64): their 256 x 256 tiles share a grid - the qkv (192 tiles) and
  * out-proj (64 tiles) weight gradients of a DiT block fill the 256 CUs exactly once.  Returns 3 without doing anything when the shapes do not qualify. */
 int udm_gemm_tn_pair_bf16(const void* A0, const void* B0, void* C0, int64_t M0, int64_t lda0, int64_t ldb0, int64_t ldc0, const void* A1, const void* B1, void* C1,
-                          int64_t M1, int64_t lda1, int64_t ldb1, int64_t ldc1, int64_t N, int64_t K, float beta, hipStream_t stream);
+                          int64_t M1, int64_t lda1, int64_t ldb1, int64_t ldc1, int64_t N, int64_t K, float beta, float* ws, int64_t ws_elems, hipStream_t stream);
+/* (few tiles over a long K: split in K through `ws` - fp32, >= slices * (M0 + M1) * N elements, slices = min(256 / tiles, K / 512, 32); NULL = never split) */
 /* NT form of the same idea with a bf16 result (head dgrad on the compacted [MASK] rows: few 320 x 256 tiles over K = V): fp32 partial tiles in ws
  * (>= slices*M*N), reduce pass rounds to bf16; falls back to udm_gemm_nt_bf16 when splitting does not apply. */
 int udm_gemm_nt_splitk_bf16(const void* A, const void* B, void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, float* ws,

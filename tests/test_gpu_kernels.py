@@ -176,8 +176,10 @@ def test_gemm_tn_pair_equals_two_launches(K, M0, M1, N, Kc, beta):
         K.gemm_tn(ga1, gb1, s1, M=M1, N=N, beta=beta)
     finally:
         K.gemm_set_quad(1)
-    if M0 % 256 == 0 and M1 % 256 == 0 and (M0 // 256) * (N // 256) >= 1:
-        # (the single-problem launch may pick 192-row tiles where they fill the chip better: the same k order per output element either way)
+    split = ((M0 + M1) // 256) * (N // 256) <= 128 and Kc >= 1024      # few tiles over a long K: the pair is split in K through the workspace
+    if split:    # slice sums in another order than the unsplit kernel: equal up to fp32 rounding
+        assert rel_err(o0, s0) < 2e-6 and rel_err(o1, s1) < 2e-6
+    else:        # (the single-problem launch may pick 192-row tiles where they fill the chip better: the same k order per output element either way)
         assert torch.equal(o0, s0) and torch.equal(o1, s1)
     with pytest.raises(ValueError):
         K.gemm_tn_pair(ga0[:, :200], gb0, o0[:200], ga1, gb1, o1)

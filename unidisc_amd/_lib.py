@@ -26,7 +26,7 @@ PROTOTYPES = {
     "udm_gemm_nn_ok": [_I64, _I64, _I64],
     "udm_gemm_nt_splitk_bf16": [_P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _P, _I64, _P],
     "udm_gemm_tn_splitk_bf16": [_P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _F, _P, _I64, _P],
-    "udm_gemm_tn_pair_bf16": [_P, _P, _P, _I64, _I64, _I64, _I64, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _F, _P],
+    "udm_gemm_tn_pair_bf16": [_P, _P, _P, _I64, _I64, _I64, _I64, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _F, _P, _I64, _P],
     "udm_gemm_set_cus": [_I],
     "udm_debug_set": [ctypes.c_char_p, _I64],
     "udm_debug_cu_hog": [_I64, _P, _P],

@@ -11,6 +11,7 @@
 // through LDS so the epilogue (bias / GELU / GELU' / accumulate) runs on coalesced 16-byte rows.
 // Tile order is XCD-aware (8 private L2s) with a grouped-M sweep.
 #include "common.h"
+#include <algorithm>
 #include "gemm_quad.h"
 #include "../../include/unidisc_hip.h"
 
@@ -1046,10 +1047,13 @@ extern "C" int udm_gemm_nn_bf16(const void* A, const void* B, void* C, int64_t M
 // Two weight gradients of one backward step in ONE launch: C0[M0, N] (+)= A0[K, M0]^T B0[K, N] and C1[M1, N] (+)= A1[K, M1]^T B1[K, N] (fp32, beta as
 // udm_gemm_tn_bf16), same N and K, M0 / M1 / N multiples of 256, K a multiple of 64: the 256 x 256 one-wave-per-SIMD tiles of both problems share a grid, so
 // that e.g. the qkv (6144 x 2048: 192 tiles) and the out-proj (2048 x 2048: 64 tiles) weight gradients of a DiT block fill the 256 CUs exactly once.
-// Returns 3 (and does nothing) when the shapes do not qualify: the caller then issues the two plain calls.
+// Few tiles over a long contraction (UniDisc-S: 27 + 9 tiles, K = 24 576): K is split as in udm_gemm_tn_splitk_bf16 - as many slices as fill the CUs once -
+// through the workspace `ws` (>= slices * (M0 + M1) * N floats), followed by one reduce pass per output; without a (large enough) workspace the launch is unsplit.
+// C0 / C1 must be contiguous (ldc == N) when the split is taken.  Returns 3 (and does nothing) when the shapes do not qualify: the caller then issues the
+// two plain calls.
 extern "C" int udm_gemm_tn_pair_bf16(const void* A0, const void* B0, void* C0, int64_t M0, int64_t lda0, int64_t ldb0, int64_t ldc0, const void* A1,
                                      const void* B1, void* C1, int64_t M1, int64_t lda1, int64_t ldb1, int64_t ldc1, int64_t N, int64_t K, float beta,
-                                     hipStream_t stream) {
+                                     float* ws, int64_t ws_elems, hipStream_t stream) {
   UDM_CHECK_ARG(A0 && B0 && C0 && A1 && B1 && C1, "udm_gemm_tn_pair_bf16: null operand");
   if (!udm_quad_mode() || M0 <= 0 || M1 <= 0 || M0 % 256 || M1 % 256 || N <= 0 || N % 256 || K < 128 || K % 64) return 3;
   if (lda0 % 8 || ldb0 % 8 || lda1 % 8 || ldb1 % 8 || ldc0 % 4 || ldc1 % 4 || lda0 < M0 || lda1 < M1 || ldb0 < N || ldb1 < N) return 3;
@@ -1058,6 +1062,23 @@ extern "C" int udm_gemm_tn_pair_bf16(const void* A0, const void* B0, void* C0, i
   q.A = (const bf16_t*)A0; q.B = (const bf16_t*)B0; q.C = C0; q.lda = lda0; q.ldb = ldb0; q.ldc = ldc0;
   q.A2 = (const bf16_t*)A1; q.B2 = (const bf16_t*)B1; q.C2 = C1; q.lda2 = lda1; q.ldb2 = ldb1; q.ldc2 = ldc1;
   q.M = (int)M0; q.N = (int)N; q.K = (int)K; q.beta = beta; q.splitk = 1;
+  const long tiles = ((M0 + M1) / 256) * (N / 256), nkt = K / 64;
+  long skl = 256 / tiles;
+  if (skl > nkt / 8) skl = nkt / 8;
+  if (skl > 32) skl = 32;
+  const int sk = skl < 2 ? 1 : (int)skl;
+  const long area = (long)(M0 + M1) * N;
+  if (sk > 1 && ws && ws_elems >= (int64_t)sk * area && ldc0 == N && ldc1 == N && ((uintptr_t)ws % 16) == 0) {
+    // slice s of problem one at ws + s * area, of problem two at ws + M0 * N + s * area (both with leading dimension N)
+    q.C = ws; q.C2 = ws + (long)M0 * N; q.ldc = N; q.ldc2 = N; q.beta = 0.f; q.splitk = sk; q.slice_stride = area;
+    if (int rc = udm_quad_launch_tn_pair(q, M1, stream)) return rc;
+    const long n40 = (long)M0 * N / 4, n41 = (long)M1 * N / 4;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)std::min<long>((n40 + 255) / 256, 2048)), dim3(256), 0, stream, (const float*)ws, (float*)C0, n40, sk, area, beta);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)std::min<long>((n41 + 255) / 256, 2048)), dim3(256), 0, stream, (const float*)(ws + (long)M0 * N), (float*)C1, n41, sk,
+                       area, beta);
+    UDM_CHECK_LAUNCH("udm_gemm_tn_pair_bf16(reduce)");
+    return 0;
+  }
   return udm_quad_launch_tn_pair(q, M1, stream);
 }
 

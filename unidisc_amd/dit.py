@@ -1119,9 +1119,11 @@ class DIT(nn.Module, _HubMixin):
                 dx = torch.zeros((M, d), dtype=F32, device=dev).index_copy_(0, rows_c, dx)
             else:
                 # The out-proj weight gradient (2048 x 2048: 64 tiles) waits for the qkv one (6144 x 2048: 192 tiles of 256 rows) where the two fill the chip
-                # exactly once TOGETHER (K.gemm_tn_pair): one launch instead of 256 tiles of 192 rows + a split-K launch + its reduce pass
+                # exactly once TOGETHER (K.gemm_tn_pair): one launch instead of 256 tiles of 192 rows + a split-K launch + its reduce pass; few tiles over a long
+                # contraction (UniDisc-S: 27 + 9) share ONE split-K launch
                 if (self.pair_wgrads and da.is_cuda and lo.bias is None and lq.bias is None and lo.inp == lq.inp
-                        and K.gemm_tn_pair_ok(lq.out, lo.out, lq.inp, M) and (lq.out // 256 + lo.out // 256) * (lq.inp // 256) % 256 == 0):
+                        and K.gemm_tn_pair_ok(lq.out, lo.out, lq.inp, M)
+                        and ((lq.out // 256 + lo.out // 256) * (lq.inp // 256) % 256 == 0 or (lq.out // 256 + lo.out // 256) * (lq.inp // 256) <= 128)):
                     pair_out = (da, R["o"])
                 else:
                     self._wgrad(da, R["o"], lo, G)

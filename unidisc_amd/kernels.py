@@ -125,8 +125,11 @@ def gemm_tn_pair(a0, b0, out0, a1, b1, out1, *, beta=0.0):
     M1 = out1.shape[0]
     if a1.shape[0] != K or b0.shape[0] != K or b1.shape[0] != K or out1.shape[1] != N or not gemm_tn_pair_ok(M0, M1, N, K):
         raise ValueError("gemm_tn_pair: the two problems need the same N and K, with M0, M1, N multiples of 256 and K of 64")
+    tiles = ((M0 + M1) // 256) * (N // 256)
+    sk = max(1, min(256 // tiles, (K // 64) // 8, 32))   # the rule of udm_gemm_tn_pair_bf16 (sizes the workspace): few tiles over a long K are split in K
+    ws = _scratch(sk * (M0 + M1) * N, a0.device) if sk > 1 else None
     _lib.call("udm_gemm_tn_pair_bf16", _p(a0), _p(b0), _p(out0), M0, a0.stride(0), b0.stride(0), out0.stride(0), _p(a1), _p(b1), _p(out1), M1, a1.stride(0),
-              b1.stride(0), out1.stride(0), N, K, float(beta), _s())
+              b1.stride(0), out1.stride(0), N, K, float(beta), _p(ws), ws.numel() if ws is not None else 0, _s())
 
 
 def gemm_tn_splitk(a, b, out, *, M=None, N=None, beta=0.0):
