@@ -5,7 +5,7 @@
 # Usage: bash scripts/gpu_round_artifacts.sh r03     (outputs under gpurun_out/, copied to profiles/ by scripts/collect_profiles.sh)
 TAG=${1:-r03}; R=${GRAFT_REPO_ROOT:-$(pwd)}; mkdir -p $R/gpurun_out; export TMPDIR=/tmp
 cd $R
-UDM_DUMP_GRAD_ERRS=gpurun_out/graderrs_$TAG UDM_LEDGER=gpurun_out/parity_ledger_$TAG.json timeout 2400 python -m pytest tests -m gpu -q -p no:cacheprovider --timeout 1500 2>&1 | tail -15 > gpurun_out/gputests_$TAG.log
+[ -n "$SKIP_TESTS" ] || UDM_DUMP_GRAD_ERRS=gpurun_out/graderrs_$TAG UDM_LEDGER=gpurun_out/parity_ledger_$TAG.json timeout 2400 python -m pytest tests -m gpu -q -p no:cacheprovider --timeout 1500 2>&1 | tail -15 > gpurun_out/gputests_$TAG.log
 timeout 900 python bench.py --steps 25 --warmup 5 > gpurun_out/bench_1.4b_b8_$TAG.json 2> gpurun_out/bench_1.4b_b8_$TAG.err
 timeout 600 python bench.py --workload unidisc-s-l384 --steps 12 --warmup 3 --no-cpu-baseline > gpurun_out/bench_unidisc_s_b64_$TAG.json 2>/dev/null
 timeout 600 python bench.py --workload unidisc-1.4b-interleaved-l4608 --steps 12 --warmup 3 --no-cpu-baseline > gpurun_out/bench_1.4b_interleaved_l4608_b2_$TAG.json 2>/dev/null

@@ -1,7 +1,7 @@
 """End-to-end parity on a real MI355X (pytest -m gpu): the HIP path vs the golden vectors of the imported
 reference and vs the CPU oracle on the same seeded inputs.
 
-Tolerances: every comparison is recorded in the parity ledger (tests/ledger.py -> profiles/r02_parity_ledger.json) together with the
+Tolerances: every comparison is recorded in the parity ledger (tests/ledger.py -> profiles/r03_parity_ledger.json) together with the
 reference's own bf16-vs-fp32 deviation (~1e-3 on the loss, ~3e-3 rel-RMS on logits), and asserted against a STATED bound that is
 <= 3x the error achieved there: loss 1e-3 relative (north_star's figure), logits / NLL / gradients as rel-RMS against the reference's fp32 run.
 Mask indices (xt, move_indices, token_mask) must be bit-exact.
@@ -18,7 +18,7 @@ from product_utils import build_product, product_config
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
-# Stated bounds (<= 3x the errors recorded in profiles/r02_parity_ledger.json; d = 64 goldens, so per-parameter gradients of 64-element vectors are
+# Stated bounds (<= 3x the errors recorded in profiles/r03_parity_ledger.json; d = 64 goldens, so per-parameter gradients of 64-element vectors are
 # the noisiest quantity): relative error of the loss, rel-RMS of logits / per-token NLL / per-parameter gradients against the reference's fp32 run.
 LOSS_BOUND, LOGITS_BOUND, NLL_BOUND, GRAD_BOUND = 1e-3, 1e-2, 4.5e-3, 6e-2
 

@@ -5,7 +5,7 @@ width — block-per-row norm kernels (d >= 2048), wave-specialised dK/dV (D = 12
 dgrad on compacted rows, the 48 512-padded vocabulary head — against `oracle.compute_loss` (reference: model.py:797-1173, models/dit.py:948-1033)
 on one or two blocks, which the oracle finishes in well under a minute.
 
-Every comparison is recorded in the parity ledger (tests/ledger.py -> profiles/r02_parity_ledger.json) and asserted at <= 3x the error
+Every comparison is recorded in the parity ledger (tests/ledger.py -> profiles/r03_parity_ledger.json) and asserted at <= 3x the error
 achieved there.  Masks (xt, move_indices, token_mask) and t are bit-exact.  Two comparators are reported for floating point:
   * `fp32`: the oracle in fp32 (truth);
   * `bf16`: the oracle with the reference's autocast rounding points emulated — the reference's own bf16 numerics, which is what north_star's
@@ -37,7 +37,7 @@ _PLUMB = dict(hidden_size=256, n_heads=4, cond_dim=128, txt_length=128, img_leng
               force_argmax_valid_indices=False)
 
 # name -> (case, batch size, asserted bounds).  Bounds: loss relative error vs the fp32 oracle; per-token NLL rel-RMS; worst / median
-# per-parameter gradient rel-RMS vs the fp32 oracle.  Numbers are <= 3x the errors recorded in profiles/r02_parity_ledger.json, except the loss:
+# per-parameter gradient rel-RMS vs the fp32 oracle.  Numbers are <= 3x the errors recorded in profiles/r03_parity_ledger.json, except the loss:
 # achieved 5e-7 .. 4e-6 (a mean over thousands of tokens), asserted at 5e-5 - twenty times inside north_star's 1e-3.  The worst gradient is
 # always a 768- / 2048-element qk-norm vector deep in the stack (bf16 noise of every layer above it); the reference's own bf16 run (oracle with
 # its rounding points emulated) is recorded next to it as the floor.
@@ -46,10 +46,11 @@ FULLWIDTH = {
     "config_c_1block_b8": (dict(_LARGE, n_blocks=1), 8, dict(loss=5e-5, nll=1e-3, grad_max=3.2e-2, grad_med=2e-2)),
     # the same width, two blocks composed (block -> block fused residual+norm), B = 2
     "config_c_2blocks_b2": (dict(_LARGE, n_blocks=2), 2, dict(loss=5e-5, nll=1e-3, grad_max=1.1e-1, grad_med=2.2e-2)),
-    # BASELINE configs[2] at its FULL DEPTH: all 24 blocks, d = 2048, L = 1280, one and two sequences (the fp32 oracle's fwd+bwd takes ~25 s per sequence on the GPU
-    # box's host; provisional bounds until the first ledger of the round)
-    "config_c_24blocks_b1": (dict(_LARGE, n_blocks=24), 1, dict(loss=5e-5, nll=1.5e-3, grad_max=3e-1, grad_med=4e-2)),
-    "config_c_24blocks_b2": (dict(_LARGE, n_blocks=24), 2, dict(loss=5e-5, nll=1.5e-3, grad_max=3e-1, grad_med=4e-2)),
+    # BASELINE configs[2] at its FULL DEPTH: all 24 blocks, d = 2048, L = 1280, one and two sequences (the fp32 oracle's fwd+bwd takes ~23 s per sequence on the GPU
+    # box's host).  Achieved (profiles/r03_parity_ledger.json): loss 3.5e-6 / 5.5e-6, NLL 3.7e-4 / 3.9e-4, median gradient 8.9e-3 / 9.2e-3; the worst parameter (a
+    # qk-norm vector, 1.06e-1 / 1.55e-1) is additionally held to 1.5x the reference's own floor with the flash-attention rounding points (below)
+    "config_c_24blocks_b1": (dict(_LARGE, n_blocks=24), 1, dict(loss=5e-5, nll=1.2e-3, grad_max=3e-1, grad_med=2.7e-2)),
+    "config_c_24blocks_b2": (dict(_LARGE, n_blocks=24), 2, dict(loss=5e-5, nll=1.2e-3, grad_max=3e-1, grad_med=2.7e-2)),
     # BASELINE configs[1]: UniDisc-S, all 12 blocks, L = 128 + 256
     "unidisc_s_12blocks_b4": (dict(_SMALL, n_blocks=12), 4, dict(loss=5e-5, nll=1.2e-3, grad_max=2e-1, grad_med=3e-2)),
     # BASELINE configs[0]: 2-layer d = 256 text-only adaLN DiT, L = 128, vocabulary 1k (+ [MASK])
