@@ -169,8 +169,11 @@ int udm_embedding_bwd(const int64_t* ids, const int64_t* modality, const float* 
 /* ---- SUBS cross-entropy: Diffusion._subs_parameterization model.py:621-658 + gather :967 -------------- */
 int udm_subs_ce_fwd(const void* logits, int64_t ld, const int64_t* x0, const int64_t* xt, const int64_t* modality, float* log_p, float* lse, int64_t M,
                     int64_t V, int64_t Vt, int64_t mask_id, int restrict_modality, hipStream_t stream);
+/* udm_subs_ce_bwd, narrow_txt_rows >= 0 (needs restrict_modality; the head runs per modality on a compacted row list whose first narrow_txt_rows rows are the text
+ * group): only the columns the row's group of head GEMMs reads are written - text group [0, ceil64(Vt)), image group [floor8(Vt), ld) - the rest of the buffer is left
+ * as it is.  -1 = write whole rows. */
 int udm_subs_ce_bwd(void* logits, int64_t ld, const int64_t* x0, const int64_t* xt, const int64_t* modality, const float* lse, const float* g, int64_t M,
-                    int64_t V, int64_t Vt, int64_t mask_id, int restrict_modality, hipStream_t stream);
+                    int64_t V, int64_t Vt, int64_t mask_id, int restrict_modality, int64_t narrow_txt_rows, hipStream_t stream);
 int udm_subs_logprobs(const void* logits, int64_t ld, const int64_t* xt, const int64_t* modality, void* out, int64_t ld_out, int out_f32, int64_t M, int64_t V,
                       int64_t Vt, int64_t mask_id, int restrict_modality, hipStream_t stream);
 

@@ -358,7 +358,7 @@ def subs_ce_fwd(logits, x0, xt, modality, V, Vt, mask_id, restrict):
     return log_p, torch.where(masked, lse, torch.zeros_like(lse))
 
 
-def subs_ce_bwd(logits, x0, xt, modality, lse, g, V, Vt, mask_id, restrict):
+def subs_ce_bwd(logits, x0, xt, modality, lse, g, V, Vt, mask_id, restrict, narrow_txt_rows=-1):
     M = logits.shape[0]
     valid = _valid(M, V, Vt, mask_id, modality, restrict)
     z = logits[:, :V].float()
@@ -366,6 +366,15 @@ def subs_ce_bwd(logits, x0, xt, modality, lse, g, V, Vt, mask_id, restrict):
     onehot = F.one_hot(x0, V).float() * valid
     dl = g[:, None] * (onehot - p)
     dl = torch.where((xt == mask_id)[:, None], dl, torch.zeros_like(dl))
+    if narrow_txt_rows >= 0 and restrict:   # only the columns the row's GROUP of head GEMMs reads are defined: poison the rest, as the kernel leaves it unwritten
+        ld = logits.shape[1]
+        img_group = (torch.arange(M) >= narrow_txt_rows)[:, None]
+        col = torch.arange(ld)[None]
+        keep = torch.where(img_group, col >= Vt // 8 * 8, col < min((Vt + 63) // 64 * 64, ld))
+        full = torch.zeros_like(logits, dtype=torch.float32)
+        full[:, :V] = dl
+        logits.copy_(torch.where(keep, full, torch.full_like(full, float("nan"))).bfloat16())
+        return
     logits.zero_()
     logits[:, :V] = dl.bfloat16()
 

@@ -927,6 +927,16 @@ def test_subs_ce(K, V, Vt, restrict):
     K.subs_ce_bwd(gl, x0.to(DEV), xt.to(DEV), modality.to(DEV), lse, g_up.to(DEV), V, Vt, mask_id, restrict)
     assert rel_err(gl.float().cpu(), ref.float()) < 6e-3
     assert torch.all(gl.cpu()[:, V:] == 0) and torch.all(gl.cpu()[1::2] == 0)
+    if restrict:   # narrow form (head per modality): rows [0, n) are the text GROUP, the rest the image group - only the group's columns are written
+        n = 20
+        sentinel = torch.full_like(logits, 7.0)
+        sentinel[:, :V] = logits[:, :V]
+        gn = sentinel.clone().to(DEV)
+        K.subs_ce_bwd(gn, x0.to(DEV), xt.to(DEV), modality.to(DEV), lse, g_up.to(DEV), V, Vt, mask_id, restrict, narrow_txt_rows=n)
+        gn, full_b = gn.cpu(), gl.cpu()
+        hi_t, lo_i = min((Vt + 63) // 64 * 64, Vp), Vt // 8 * 8
+        assert torch.equal(gn[:n, :hi_t], full_b[:n, :hi_t]) and torch.equal(gn[n:, lo_i:], full_b[n:, lo_i:])       # what it writes equals the whole-row form
+        assert torch.equal(gn[:n, hi_t:], sentinel[:n, hi_t:]) and torch.equal(gn[n:, :lo_i], sentinel[n:, :lo_i])   # ... and nothing else is touched
 
 
 def test_small_ops(K):

@@ -64,7 +64,7 @@ PROTOTYPES = {
     "udm_embedding_fwd": [_P, _P, _P, _P, _P, _I64, _I64, _I64, _P],
     "udm_embedding_bwd": [_P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _P],
     "udm_subs_ce_fwd": [_P, _I64, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I, _P],
-    "udm_subs_ce_bwd": [_P, _I64, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I, _P],
+    "udm_subs_ce_bwd": [_P, _I64, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I, _I64, _P],
     "udm_subs_logprobs": [_P, _I64, _P, _P, _P, _I64, _I, _I64, _I64, _I64, _I64, _I, _P],
     "udm_diffusion_loss": [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I, _I, _F, _F, _F, _P],
     "udm_timestep_embedding": [_P, _P, _I64, _I64, _P],

@@ -22,6 +22,7 @@ struct CeArgs {
   float* lse;          // [M] natural-log LSE over valid ids (masked rows)
   const float* g;      // [M] upstream d loss / d log_p (backward)
   int M, V, Vt, mask_id, restrict_modality;
+  int narrow_txt_rows = -1;   // backward, head per modality (dit.py split_head): rows [0, n) belong to the text group, the rest to the image group; -1 = off
 };
 
 __device__ __forceinline__ void valid_range(const CeArgs& a, long row, int& lo, int& hi) {
@@ -107,15 +108,22 @@ __global__ __launch_bounds__(256) void subs_ce_bwd_kernel(CeArgs a) {
   bf16_t* z = a.logits + row * a.ld;
   const long xt = a.xt[row];
   const float g = a.g[row];
+  // head per modality (dit.py split_head): only the columns the row's GROUP of GEMMs reads are written - rows of the text group [0, ceil64(Vt)), rows of the
+  // image group [floor8(Vt), ld) - instead of the whole row; the rest of the buffer is never read.  The group is the row's position in the compacted list, not
+  // its modality: padding rows (unmasked, any modality) sit in either group.
+  int w_lo = 0, w_hi = (int)a.ld;
+  if (a.narrow_txt_rows >= 0) {
+    if (row >= a.narrow_txt_rows) w_lo = a.Vt / 8 * 8; else w_hi = min((a.Vt + 63) / 64 * 64, (int)a.ld);
+  }
   if (xt != a.mask_id || g == 0.f) {
-    for (int c = tid * 8; c < a.ld; c += 256 * 8) *reinterpret_cast<uint4*>(z + c) = make_uint4(0, 0, 0, 0);
+    for (int c = w_lo + tid * 8; c < w_hi; c += 256 * 8) *reinterpret_cast<uint4*>(z + c) = make_uint4(0, 0, 0, 0);
     return;
   }
   int lo, hi;
   valid_range(a, row, lo, hi);
   const long x0 = a.x0[row];
   const float lse = a.lse[row];
-  for (int c = tid * 8; c < a.ld; c += 256 * 8) {
+  for (int c = w_lo + tid * 8; c < w_hi; c += 256 * 8) {
     uint4 u = *reinterpret_cast<const uint4*>(z + c);
     const uint32_t w[4] = {u.x, u.y, u.z, u.w};
     float v[8];
@@ -190,11 +198,13 @@ extern "C" int udm_subs_ce_fwd(const void* logits, int64_t ld, const int64_t* x0
 }
 
 extern "C" int udm_subs_ce_bwd(void* logits, int64_t ld, const int64_t* x0, const int64_t* xt, const int64_t* modality, const float* lse, const float* g,
-                               int64_t M, int64_t V, int64_t Vt, int64_t mask_id, int restrict_modality, hipStream_t stream) {
+                               int64_t M, int64_t V, int64_t Vt, int64_t mask_id, int restrict_modality, int64_t narrow_txt_rows, hipStream_t stream) {
   if (int rc = check("udm_subs_ce_bwd", logits, M, V, ld, Vt, mask_id)) return rc;
   UDM_CHECK_ARG(x0 && xt && lse && g, "udm_subs_ce_bwd: null pointer");
   UDM_CHECK_ARG(!restrict_modality || modality, "udm_subs_ce_bwd: restrict_modality needs the modality map");
+  UDM_CHECK_ARG(narrow_txt_rows < 0 || (restrict_modality && narrow_txt_rows <= M), "udm_subs_ce_bwd: narrow_txt_rows needs restrict_modality and lies in [0, M]");
   CeArgs a{(bf16_t*)logits, (long)ld, x0, xt, modality, nullptr, const_cast<float*>(lse), g, (int)M, (int)V, (int)Vt, (int)mask_id, restrict_modality};
+  a.narrow_txt_rows = (int)narrow_txt_rows;
   hipLaunchKernelGGL(subs_ce_bwd_kernel, dim3((unsigned)M), dim3(256), 0, stream, a);
   UDM_CHECK_LAUNCH("udm_subs_ce_bwd");
   return 0;

@@ -987,7 +987,8 @@ class DIT(nn.Module, _HubMixin):
             dlogits = None
         else:
             if mode == "logp":
-                K.subs_ce_bwd(logits, S["x0"], S["ids_h"], S["ce_mod"], S["lse_ce"], g, V, self.text_vocab_size, self.mask_index, S["restrict"])
+                K.subs_ce_bwd(logits, S["x0"], S["ids_h"], S["ce_mod"], S["lse_ce"], g, V, self.text_vocab_size, self.mask_index, S["restrict"],
+                              narrow_txt_rows=S["head_groups"][0] if S.get("head_groups") is not None else -1)
                 dlogits = logits
             else:
                 dlogits = torch.zeros_like(logits)

@@ -619,9 +619,12 @@ def subs_ce_fwd(logits, x0, xt, modality, V, Vt, mask_id, restrict):
     return log_p, lse
 
 
-def subs_ce_bwd(logits, x0, xt, modality, lse, g, V, Vt, mask_id, restrict):
+def subs_ce_bwd(logits, x0, xt, modality, lse, g, V, Vt, mask_id, restrict, narrow_txt_rows=-1):
+    """d logits in place.  narrow_txt_rows >= 0 (with restrict; dit.py split_head): the first narrow_txt_rows rows are the text group of a per-modality head, the
+    rest its image group - only the columns the group's GEMMs read are written (text group [0, ceil64(Vt)), image group [floor8(Vt), ld))."""
     M, ld = logits.shape[0], logits.stride(0)
-    _lib.call("udm_subs_ce_bwd", _p(logits), ld, _p(x0), _p(xt), _p(modality), _p(lse), _p(g), M, V, Vt, mask_id, 1 if restrict else 0, _s())
+    _lib.call("udm_subs_ce_bwd", _p(logits), ld, _p(x0), _p(xt), _p(modality), _p(lse), _p(g), M, V, Vt, mask_id, 1 if restrict else 0,
+              int(narrow_txt_rows) if restrict else -1, _s())
 
 
 def subs_logprobs(logits, xt, modality, V, Vt, mask_id, restrict, out_dtype=BF16):
