@@ -350,6 +350,9 @@ __global__ __launch_bounds__(256) void cast_transpose_multi_kernel(const CastJob
 // Epilogue: per wave, each 32x32 accumulator fragment is transposed through a wave-private 4 KiB LDS patch so a
 // lane owns 4 consecutive columns of a row (8/16-byte global accesses); bias / GELU / GELU' / beta are applied there.
 // =================================================================================================
+#ifndef UDM_EPI_WIDE
+#define UDM_EPI_WIDE 1
+#endif
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -576,6 +579,110 @@ __global__ __launch_bounds__(512) void gemm_nt_stagger_kernel(GemmArgs p) {
   float* patch0 = reinterpret_cast<float*>(smem + (PERSIST ? ((nk - 1 + par) & 1) * STAGE_BYTES : 0)) + wave * 2048;
   const int er = lane >> 3, ec = (lane & 7) * 4;               // read side: this lane's row (within 8) and 4-column chunk
   const bool interior = (row0 + BMX <= p.M) && (col0 + BNX <= p.N) && (p.ldc % 4 == 0) && (EPI < UDM_EPI_BIAS_GELU || p.ldaux % 4 == 0);
+  // EPI_DGELU + non-null `bias`: the pointer is an fp32 [N] OUTPUT that receives the column sums of the (bf16-rounded) result,
+  // i.e. the bias gradient of the Linear whose dgrad this is — saves a separate pass over the [M, 4d] gradient.
+  float* colsum = (EPI == UDM_EPI_DGELU) ? const_cast<float*>(p.bias) : nullptr;
+  // Wide form (interior tiles, rows of C / aux 16-byte aligned): the wave's TWO 32-column fragments of a 32-row strip go through the two patches together and a
+  // lane then owns 8 consecutive columns of the 64 - every global access of the epilogue is 16 bytes per lane and a whole 128-byte line per 8 lanes (the narrow
+  // form below: 8 bytes per lane, 64-byte half lines, twice the instructions).  Patch j stores column c at c ^ 4j, so the lanes that read patch 0 and the lanes
+  // that read patch 1 in the same instruction hit disjoint banks.
+  // Compiled into the persistent form only (whole tiles and the alignment are launch conditions there; both forms in one kernel cost the main loop registers).
+  constexpr bool wide = UDM_EPI_WIDE && PERSIST && FN == 2;
+  if constexpr (wide) {
+    const int s8 = lane & 7, jsel = s8 >> 2, ec8 = (s8 & 3) * 8;
+    const int gn = col0 + wn * WN + s8 * 8;
+    const float* rd = patch0 + jsel * 1024 + er * 32;
+    const int ca = ec8 ^ (4 * jsel), cb = (ec8 + 4) ^ (4 * jsel);
+    // per-lane row bases once per tile; every access below is base + (compile-time row) x (uniform leading dimension): scalar arithmetic, one 64-bit add per
+    // access (with the row index per lane the compiler multiplied in 64 bits for every store: three quarter-rate integer multiplies per 8 elements and stream)
+    const long lrow = (long)(row0 + wm * WM + er);
+    char* cbase = reinterpret_cast<char*>(p.C) + ((S > 1 ? slice * p.slice_stride : 0) + lrow * p.ldc + gn) * (OUT_F32 ? 4 : 2);
+    bf16_t* abase = (EPI >= UDM_EPI_BIAS_GELU) ? p.aux + lrow * p.ldaux + gn : nullptr;
+    float bias8[8], csum8[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      bias8[e] = (EPI == UDM_EPI_BIAS || EPI == UDM_EPI_BIAS_GELU) ? p.bias[gn + e] : 0.f;
+      csum8[e] = 0.f;
+    }
+#pragma clang loop unroll(full)
+    for (int i = 0; i < FM; ++i) {
+#pragma clang loop unroll(full)
+      for (int j = 0; j < 2; ++j)
+#pragma clang loop unroll(full)
+        for (int r = 0; r < 16; ++r) patch0[j * 1024 + ((r & 3) + 8 * (r >> 2) + 4 * hi) * 32 + (l31 ^ (4 * j))] = acc[i][j][r];
+      uint4 au[4];
+      if (EPI == UDM_EPI_DGELU) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) au[q] = *reinterpret_cast<const uint4*>(abase + (long)(i * 32 + q * 8) * p.ldaux);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 va = *reinterpret_cast<const float4*>(rd + q * 256 + ca), vb = *reinterpret_cast<const float4*>(rd + q * 256 + cb);
+        float x[8] = {va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w};
+        if (EPI == UDM_EPI_BIAS || EPI == UDM_EPI_BIAS_GELU) {   // (not `+ 0.f` otherwise: the compiler keeps that add for the sign of zero)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) x[e] += bias8[e];
+        }
+        const long ro = (long)(i * 32 + q * 8);
+        if (EPI == UDM_EPI_BIAS_GELU) {
+          float dg[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) gelu_tanh_both(bf2f(f2bf(x[e])), x[e], dg[e]);
+          *reinterpret_cast<uint4*>(abase + ro * p.ldaux) = make_uint4(pack2bf(dg[0], dg[1]), pack2bf(dg[2], dg[3]), pack2bf(dg[4], dg[5]), pack2bf(dg[6], dg[7]));
+        }
+        if (EPI == UDM_EPI_DGELU) {
+          const uint32_t w[4] = {au[q].x, au[q].y, au[q].z, au[q].w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            x[2 * e] *= __uint_as_float(w[e] << 16);
+            x[2 * e + 1] *= __uint_as_float(w[e] & 0xffff0000u);
+          }
+          // (summed whether or not `colsum` is wanted: a block-uniform branch here costs more than the operations it would skip)
+          if (OUT_F32) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) csum8[e] += x[e];
+          }
+        }
+        if (OUT_F32) {
+          float* cp = reinterpret_cast<float*>(cbase) + ro * p.ldc;
+          if (S == 1 && p.beta != 0.f) {
+            const float4 c0 = *reinterpret_cast<const float4*>(cp), c1 = *reinterpret_cast<const float4*>(cp + 4);
+            x[0] += p.beta * c0.x; x[1] += p.beta * c0.y; x[2] += p.beta * c0.z; x[3] += p.beta * c0.w;
+            x[4] += p.beta * c1.x; x[5] += p.beta * c1.y; x[6] += p.beta * c1.z; x[7] += p.beta * c1.w;
+          }
+          *reinterpret_cast<float4*>(cp) = make_float4(x[0], x[1], x[2], x[3]);
+          *reinterpret_cast<float4*>(cp + 4) = make_float4(x[4], x[5], x[6], x[7]);
+        } else {
+          const uint32_t pk[4] = {pack2bf(x[0], x[1]), pack2bf(x[2], x[3]), pack2bf(x[4], x[5]), pack2bf(x[6], x[7])};
+          if (EPI == UDM_EPI_DGELU) {   // column sums of the ROUNDED values (what the bias gradient of the bf16 tensor is), from the words about to be stored
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              csum8[2 * e] += __uint_as_float(pk[e] << 16);
+              csum8[2 * e + 1] += __uint_as_float(pk[e] & 0xffff0000u);
+            }
+          }
+          *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(cbase) + ro * p.ldc) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+        }
+      }
+    }
+    if (EPI == UDM_EPI_DGELU && colsum) {
+      // column totals of the wave's 32 x FM rows: after the three exchanges every lane of a column group holds its group's eight totals; lane L then takes
+      // column L of the wave's 64 (element L & 7 of group L >> 3) so that ONE atomic instruction per wave and tile adds 256 contiguous bytes (one instruction
+      // per element covered 8 x 4 bytes at a 32-byte stride: eight times the instructions and four times the cache-line operations on addresses that every
+      // row tile of the column contends for)
+      float mine = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float v = csum8[e];
+        v += __shfl_xor(v, 8, 64);
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        mine = (er == e) ? v : mine;
+      }
+      const float tot = __shfl(mine, (lane >> 3) | ((lane & 7) << 3), 64);
+      atomicAdd(colsum + col0 + wn * WN + lane, tot);
+    }
+  } else {
   float bias4[FN][4];
 #pragma unroll
   for (int j = 0; j < FN; ++j)
@@ -584,9 +691,6 @@ __global__ __launch_bounds__(512) void gemm_nt_stagger_kernel(GemmArgs p) {
       const int gn = col0 + wn * WN + j * 32 + ec + e;
       bias4[j][e] = ((EPI == UDM_EPI_BIAS || EPI == UDM_EPI_BIAS_GELU) && gn < p.N) ? p.bias[gn] : 0.f;
     }
-  // EPI_DGELU + non-null `bias`: the pointer is an fp32 [N] OUTPUT that receives the column sums of the (bf16-rounded) result,
-  // i.e. the bias gradient of the Linear whose dgrad this is — saves a separate pass over the [M, 4d] gradient.
-  float* colsum = (EPI == UDM_EPI_DGELU) ? const_cast<float*>(p.bias) : nullptr;
   float csum[FN][4];
 #pragma unroll
   for (int j = 0; j < FN; ++j)
@@ -690,6 +794,7 @@ __global__ __launch_bounds__(512) void gemm_nt_stagger_kernel(GemmArgs p) {
         if (er == 0) atomicAdd(colsum + col0 + wn * WN + j * 32 + ec + e, v);
       }
   }
+  }  // narrow form
   if (!PERSIST || !has_next) break;
   par = (nk + par) & 1;   // where the last K iteration put the next tile's first K tile
   primed = true;
@@ -726,7 +831,8 @@ int launch_big_t(const GemmArgs& a0, hipStream_t stream) {
       return true;
     }();
     (void)env_once;
-    if (g_gemm_persist && a.splitk <= 1 && a.tiles_m * a.tiles_n > 256 && a.M % BMX == 0 && a.N % 256 == 0 && a.K / BK >= 2) {
+    if (g_gemm_persist && a.splitk <= 1 && a.tiles_m * a.tiles_n > 256 && a.M % BMX == 0 && a.N % 256 == 0 && a.K / BK >= 2 &&
+        (!UDM_EPI_WIDE || ((OUT_F32 ? a.ldc % 4 == 0 : a.ldc % 8 == 0) && (EPI < UDM_EPI_BIAS_GELU || a.ldaux % 8 == 0)))) {
       auto kp = gemm_nt_stagger_kernel<BMX, EPI, OUT_F32, false, 1, true>;
       static bool attr_p = false;
       if (!attr_p) {
