@@ -120,6 +120,7 @@ def test_gemm_persistent_blocks_every_epilogue(K, M, N, K_):
     (gp,) = torch.autograd.grad(y.sum(), u)
     assert rel_err(g.float().cpu(), y.detach()) < 6e-3 and rel_err(aux.float().cpu(), gp) < 6e-3
     assert rel_err(dg.float().cpu(), acc * gp) < 8e-3
+    assert torch.allclose(dbias.cpu(), dg.float().cpu().sum(0), atol=2e-2, rtol=2e-3)   # one coalesced atomic per wave: lane L carries column L of the wave's 64
 
 
 @pytest.mark.parametrize("Kc,M,N", [(256, 192, 256), (1280, 2048, 2048), (128, 64, 200), (640, 1001, 328), (2560, 6144, 2048), (192, 320, 8192), (10240, 512, 512), (4096, 300, 260)])
