@@ -8,7 +8,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from unidisc_amd import kernels as K
 
-M, N, Kd, R = 10240, 8192, 2048, 3
+M, N, Kd, R = int(os.environ.get("M", 10240)), int(os.environ.get("N", 8192)), int(os.environ.get("KD", 2048)), 3
 g = torch.Generator(device="cuda").manual_seed(0)
 A = [(torch.rand(M, Kd, device="cuda", generator=g) - 0.5).to(torch.bfloat16) for _ in range(R)]
 B = (torch.rand(N, Kd, device="cuda", generator=g) - 0.5).to(torch.bfloat16)

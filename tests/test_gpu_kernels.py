@@ -266,7 +266,8 @@ def test_gemm_nn_dgrad_from_forward_shadow(K, M, N, K_):
     side.  K-tile counts 2 / 3 / 4 / 7 / 16 / 32 / 96 / 128, every tile height, padded strides; against fp32, and bit-equal to the NT kernel fed
     the explicitly transposed weight (same products, same k order)."""
     assert K.gemm_nn_ok(M, N, K_)
-    assert not K.gemm_nn_ok(M + 8, N, K_) and not K.gemm_nn_ok(M, N + 128, K_) and not K.gemm_nn_ok(M, N, K_ + 32)
+    ragged_fills = (M + 8 > 320) and -(-(M + 8) // 320) * (N // 256) >= 128   # (a ragged last tile row is taken when 320-row tiles fill the chip)
+    assert (K.gemm_nn_ok(M + 8, N, K_) == ragged_fills) and not K.gemm_nn_ok(M, N + 128, K_) and not K.gemm_nn_ok(M, N, K_ + 32)
     lda, ldb, ldc = K_ + 8, N + 16, N + 8
     a, w = torch.zeros(M, lda, dtype=torch.bfloat16), torch.zeros(K_, ldb, dtype=torch.bfloat16)
     a[:, :K_], w[:, :N] = bf(rnd(M, K_, seed=290, scale=0.5)), bf(rnd(K_, N, seed=291, scale=0.5))
@@ -283,6 +284,22 @@ def test_gemm_nn_dgrad_from_forward_shadow(K, M, N, K_):
         assert torch.equal(nt, out[:, :N])
     finally:
         K.gemm_set_quad(1)
+
+
+@pytest.mark.parametrize("M,N,K_", [(9216, 2048, 2048), (9216, 2048, 6144), (5000, 2048, 512), (4100, 2560, 256), (10248, 2048, 128)])
+def test_gemm_nn_ragged_last_tile_row(K, M, N, K_):
+    """NN form with a row count no whole tile height divides into one round (config E: M = 9216): 320-row tiles, the last tile row hangs over M - its operand
+    rows are clamped at the source, its output rows are not stored (the rows behind M keep their sentinel).  Against fp32 and bit-equal to the NT kernels."""
+    assert K.gemm_nn_ok(M, N, K_)
+    a, w = bf(rnd(M, K_, seed=292, scale=0.5)), bf(rnd(K_, N, seed=293, scale=0.5))
+    ref = a.float() @ w.float()
+    ad, wd = a.to(DEV), w.to(DEV)
+    buf = torch.full((M + 320, N), 7.0, dtype=torch.bfloat16, device=DEV)
+    K.gemm_nn(ad, wd, out=buf[:M])
+    assert rel_err(buf[:M].float().cpu(), ref) < 3e-3
+    assert torch.all(buf[M:] == 7.0)
+    nt = K.gemm_nt(ad, w.t().contiguous().to(DEV), N=N)
+    assert torch.equal(nt, buf[:M])
 
 
 @pytest.mark.parametrize("M,N,K_", [(5120, 2048, 48512), (5056, 2048, 4096), (704, 512, 8192), (100, 300, 640), (5120, 2048, 192)])

@@ -879,6 +879,11 @@ int choose_tile(long M, long N, long K, long lda, long ldb) {
     // (scripts/bench_gemm_s.py): N = 3072 + GELU 162 us persistent 256 vs 178 (192) / 194 (320, ragged); + GELU' 166 vs 187 / 228; N = 2304 plain 111 vs 120 / 114.
     const bool persistent = c >= 2 && M % bms[c] == 0 && N % 256 == 0 && tm * tn > 256;
     if (K <= 1024 && !persistent) t *= 1.15;
+    // ... and at any K the persistent form (next tile's first loads under the epilogue, wide epilogue) is worth ~10 % of a launch: M = 9216 (config E), K = 2048,
+    // N = 8192 + GELU: 293 us as 5 rounds of persistent 256-row tiles against 313 us as 6 rounds of 192-row tiles (GELU' + column sums 290 vs 316); N = 6144 plain:
+    // 207 us (4 rounds of 256) against 217 (3 rounds of ragged 320) - scripts/bench_gemm_epi.py with M / N / TILE from the environment
+    static const int env_pb = [] { const char* e = getenv("UDM_GEMM_PERSIST_BONUS"); return e ? atoi(e) : 1; }();   // diagnostics: 0 = the round-2 cost model
+    if (persistent && env_pb) t *= 0.90;
     if (t < best || (t == best && c > 0)) { best = t; pick = c == 0 ? 0 : bms[c]; }  // ties go to the larger tile (fewer operand re-reads)
   }
   return pick;
@@ -1133,7 +1138,7 @@ extern "C" int udm_cast_transpose_multi_f32_bf16(const void* jobs, int64_t njobs
 }
 
 // C[M, N] bf16 = A[M, K] B[K, N] (A row-major with K contiguous, B row-major with N contiguous): the dgrad dX = dY W read from the forward's own
-// bf16 shadow of W [out, in], so that no transposed shadow has to be produced by the per-step weight cast.  Whole tiles only (udm_gemm_nn_ok).
+// bf16 shadow of W [out, in], so that no transposed shadow has to be produced by the per-step weight cast.  Whole tiles, or 320-row tiles with a ragged last tile row (udm_gemm_nn_ok).
 extern "C" int udm_gemm_nn_ok(int64_t M, int64_t N, int64_t K) {
   int fm = 0;
   return (M > 0 && udm_quad_nn_ok(M, N, K, &fm)) ? 1 : 0;
@@ -1141,7 +1146,7 @@ extern "C" int udm_gemm_nn_ok(int64_t M, int64_t N, int64_t K) {
 extern "C" int udm_gemm_nn_bf16(const void* A, const void* B, void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, hipStream_t stream) {
   UDM_CHECK_ARG(A && B && C, "udm_gemm_nn_bf16: null pointer");
   int fm = 0;
-  UDM_CHECK_ARG(M > 0 && udm_quad_nn_ok(M, N, K, &fm), "udm_gemm_nn_bf16: shape %ld x %ld x %ld is not whole tiles (M %% 192/256/320, N %% 256, K %% 64; see udm_gemm_nn_ok)",
+  UDM_CHECK_ARG(M > 0 && udm_quad_nn_ok(M, N, K, &fm), "udm_gemm_nn_bf16: shape %ld x %ld x %ld does not fit the NN kernel (N %% 256, K %% 64, M %% 192/256/320 or enough 320-row tiles to fill the chip; see udm_gemm_nn_ok)",
                 (long)M, (long)N, (long)K);
   UDM_CHECK_ARG(lda >= K && ldb >= N && ldc >= N && lda % 8 == 0 && ldb % 8 == 0 && ldc % 4 == 0, "udm_gemm_nn_bf16: bad leading dimensions");
   QuadArgs q{};

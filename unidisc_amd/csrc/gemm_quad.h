@@ -35,6 +35,6 @@ int udm_quad_launch_tn_pair(const QuadArgs& a, long M2, hipStream_t stream);
 // NT (forward / dgrad) form
 bool udm_quad_nt_ok(long M, long N, long K, int* fm);
 int udm_quad_launch_nt(const QuadArgs& a, int fm, int epilogue, int out_f32, hipStream_t stream);
-// NN (dgrad from the forward's W shadow) form: C[M, N] bf16 = A[M, K] B[K, N], plain epilogue
+// NN (dgrad from the forward's W shadow) form: C[M, N] bf16 = A[M, K] B[K, N], plain epilogue.  *fm = 3 / 4 / 5 (whole tiles) or -5 (320-row tiles, ragged last tile row)
 bool udm_quad_nn_ok(long M, long N, long K, int* fm);
 int udm_quad_launch_nn(const QuadArgs& a, int fm, hipStream_t stream);

@@ -47,7 +47,9 @@ __device__ __forceinline__ const char* uniform_ptr(const char* ptr) {   // pin a
 // MODE: 0 = NT (C = A B^T: both operands K-contiguous), 1 = TN (C = A^T B: both operands K-major, rows = contraction index: the wgrad form),
 // 2 = NN (C = A B: A K-contiguous, B K-major - the dgrad form dX = dY W read from the forward's own W shadow, so no W^T shadow has to be cast).
 // Every operand is staged and gathered by its own layout (TA / TB): NN is the NT kernel's A side next to the TN kernel's B side.
-template <int FM, int MODE, int EPI, bool OUT_F32, int DMA_GAP, int ABL = 0>
+// RAGGED (NT / NN forms): the last tile row may hang over M - its operand rows are clamped to M - 1 at the LDS-DMA source and its output rows are not stored.  A row count
+// that no whole tile height divides into one round (config E: M = 9216 = 48 x 192 -> 384 tiles, 1.5 rounds) then still runs as ONE round of 320-row tiles (29 x 8 = 232).
+template <int FM, int MODE, int EPI, bool OUT_F32, int DMA_GAP, int ABL = 0, bool RAGGED = false>
 __global__ __launch_bounds__(256, 1) void gemm_quad_kernel(QuadArgs p0) {
   QuadArgs p = p0;   // (the paired launch redirects the operand fields of the blocks that belong to the second problem, once, before anything reads them)
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -93,7 +95,8 @@ __global__ __launch_bounds__(256, 1) void gemm_quad_kernel(QuadArgs p0) {
     for (int j = 0; j < A_PW; ++j) {
       if (!TA) {
         const int r = (wave * A_PW + j) * 8 + lrow;
-        offa[j] = (uint32_t)(((long)r * p.lda + ((lslot ^ ((r >> 1) & 7)) << 3)) * 2);
+        const int rs = RAGGED ? min(r, p.M - 1 - row0) : r;   // source row (the swizzle follows the LDS row r)
+        offa[j] = (uint32_t)(((long)rs * p.lda + ((lslot ^ ((r >> 1) & 7)) << 3)) * 2);
       } else {
         const int off = (wave * A_PW + j) * 1024 + lane * 16;
         const int row = off / RB_A, within = off % RB_A;
@@ -307,16 +310,17 @@ __global__ __launch_bounds__(256, 1) void gemm_quad_kernel(QuadArgs p0) {
       float4 cold[4];
       if (EPI == UDM_EPI_DGELU) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) au[q] = *reinterpret_cast<const uint2*>(p.aux + (long)(gm0 + q * 8) * p.ldaux + gn);
+        for (int q = 0; q < 4; ++q) au[q] = *reinterpret_cast<const uint2*>(p.aux + (long)(RAGGED ? min(gm0 + q * 8, p.M - 1) : gm0 + q * 8) * p.ldaux + gn);
       }
       if (OUT_F32 && p.beta != 0.f && S == 1) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) cold[q] = *reinterpret_cast<const float4*>(reinterpret_cast<float*>(p.C) + (long)(gm0 + q * 8) * p.ldc + gn);
+        for (int q = 0; q < 4; ++q) cold[q] = *reinterpret_cast<const float4*>(reinterpret_cast<float*>(p.C) + (long)(RAGGED ? min(gm0 + q * 8, p.M - 1) : gm0 + q * 8) * p.ldc + gn);
       }
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         float x[4] = {v[q].x + bias4[j][0], v[q].y + bias4[j][1], v[q].z + bias4[j][2], v[q].w + bias4[j][3]};
         const long gm = gm0 + q * 8;
+        if (RAGGED && gm >= p.M) continue;
         if (EPI == UDM_EPI_BIAS_GELU) {
           bf16_t pre[4];
 #pragma unroll
@@ -355,18 +359,18 @@ __global__ __launch_bounds__(256, 1) void gemm_quad_kernel(QuadArgs p0) {
   }
 }
 
-template <int FM, int MODE, int EPI, bool OUT_F32>
+template <int FM, int MODE, int EPI, bool OUT_F32, bool RAGGED = false>
 int launch_quad_t(const QuadArgs& a0, hipStream_t stream) {
   QuadArgs a = a0;
   constexpr int BM = 64 * FM;
-  a.tiles_m = a.M / BM;
+  a.tiles_m = RAGGED ? (a.M + BM - 1) / BM : a.M / BM;
   a.tiles_n = a.N / 256;
   static const int env_gm = [] { const char* e = getenv("UDM_GEMM_GROUP_M"); return e ? atoi(e) : 0; }();
   a.group_m = env_gm;
   const size_t lds = (size_t)2 * (BM + 256) * BK * 2;
   constexpr int GAP = 2;
-  auto kern = gemm_quad_kernel<FM, MODE, EPI, OUT_F32, GAP>;
-  if constexpr (EPI == UDM_EPI_NONE && FM >= 4) {   // timing-only ablations of the plain kernels (scripts/bench_gemm_quad.py)
+  auto kern = gemm_quad_kernel<FM, MODE, EPI, OUT_F32, GAP, 0, RAGGED>;
+  if constexpr (EPI == UDM_EPI_NONE && FM >= 4 && !RAGGED) {   // timing-only ablations of the plain kernels (scripts/bench_gemm_quad.py)
     static const int abl = [] { const char* e = getenv("UDM_QUAD_ABL"); return e ? atoi(e) : 0; }();
     if (abl == 1) kern = gemm_quad_kernel<FM, MODE, EPI, OUT_F32, GAP, 1>;
     if (abl == 2) kern = gemm_quad_kernel<FM, MODE, EPI, OUT_F32, GAP, 2>;
@@ -467,9 +471,23 @@ int udm_quad_launch_nt(const QuadArgs& a, int fm, int epilogue, int out_f32, hip
 }
 
 // NN (dgrad) form: C[M, N] bf16 = A[M, K] B[K, N]; whole tiles, plain epilogue
-bool udm_quad_nn_ok(long M, long N, long K, int* fm) { return udm_quad_nt_ok(M, N, K, fm); }
+// fm = 3 / 4 / 5: whole tiles of that height; fm = -5: 320-row tiles with a ragged last tile row, where that is fewer rounds x rows than any whole-tile height
+bool udm_quad_nn_ok(long M, long N, long K, int* fm) {
+  int whole = 0;
+  const bool ok = udm_quad_nt_ok(M, N, K, &whole);
+  double best = ok ? (double)(((M / (64 * whole)) * (N / 256) + 255) / 256) * 64 * whole : 1e30;
+  static const int env_ragged = [] { const char* e = getenv("UDM_QUAD_RAGGED"); return e ? atoi(e) : 1; }();   // diagnostics: 0 = whole tiles only
+  if (env_ragged && udm_quad_mode() && K % 64 == 0 && K >= 128 && N % 256 == 0 && M > 320 && M % 320 != 0) {
+    const long tiles = ((M + 319) / 320) * (N / 256);
+    const double t = (double)((tiles + 255) / 256) * 320 * 1.03;
+    if (tiles >= 128 && t < best) { *fm = -5; return true; }
+  }
+  if (ok) *fm = whole;
+  return ok;
+}
 int udm_quad_launch_nn(const QuadArgs& a, int fm, hipStream_t stream) {
   switch (fm) {
+    case -5: return launch_quad_t<5, 2, UDM_EPI_NONE, false, true>(a, stream);
     case 3: return launch_quad_t<3, 2, UDM_EPI_NONE, false>(a, stream);
     case 4: return launch_quad_t<4, 2, UDM_EPI_NONE, false>(a, stream);
     case 5: return launch_quad_t<5, 2, UDM_EPI_NONE, false>(a, stream);
