@@ -298,8 +298,19 @@ def test_gemm_nn_ragged_last_tile_row(K, M, N, K_):
     K.gemm_nn(ad, wd, out=buf[:M])
     assert rel_err(buf[:M].float().cpu(), ref) < 3e-3
     assert torch.all(buf[M:] == 7.0)
-    nt = K.gemm_nt(ad, w.t().contiguous().to(DEV), N=N)
+    wt = w.t().contiguous().to(DEV)
+    nt = K.gemm_nt(ad, wt, N=N)               # (one round of ragged 320-row tiles goes to the one-wave-per-SIMD kernel's ragged NT form as well)
     assert torch.equal(nt, buf[:M])
+    bias = rnd(N, seed=294).to(DEV)
+    ntb = torch.full((M + 320, N), 7.0, dtype=torch.bfloat16, device=DEV)
+    K.gemm_nt(ad, wt, out=ntb[:M], N=N, epilogue=K.EPI_BIAS, bias=bias)
+    assert torch.all(ntb[M:] == 7.0)
+    try:
+        K.gemm_set_quad(0)                    # the 8-wave kernels: same products, same k order
+        assert torch.equal(K.gemm_nt(ad, wt, N=N), nt)
+        assert torch.equal(K.gemm_nt(ad, wt, N=N, epilogue=K.EPI_BIAS, bias=bias), ntb[:M])
+    finally:
+        K.gemm_set_quad(1)
 
 
 @pytest.mark.parametrize("M,N,K_", [(5120, 2048, 48512), (5056, 2048, 4096), (704, 512, 8192), (100, 300, 640), (5120, 2048, 192)])

@@ -942,6 +942,17 @@ extern "C" int udm_gemm_nt_bf16(const void* A, const void* B, void* C, int64_t M
       }
     }
   }
+  {  // one round of 320-row tiles with a ragged last tile row (config E: M = 9216, N = 2048): the one-wave-per-SIMD kernel's ragged form instead of the 8-wave one
+    int fm = 0;
+    const long rt = ((M + 319) / 320) * ((N + 255) / 256);
+    if (g_force_tile < 0 && beta == 0.f && !out_f32 && epilogue <= UDM_EPI_BIAS && M % 320 != 0 && N % 256 == 0 && rt >= 128 && rt <= 256 && ldc % 4 == 0 &&
+        choose_tile(M, N, K, lda, ldb) == 320 && udm_quad_nn_ok(M, N, K, &fm) && fm == -5) {
+      QuadArgs q{};
+      q.A = a.A; q.B = a.B; q.C = C; q.bias = bias; q.lda = lda; q.ldb = ldb; q.ldc = ldc;
+      q.M = a.M; q.N = a.N; q.K = a.K; q.beta = 0.f; q.splitk = 1;
+      return udm_quad_launch_nt(q, -5, epilogue, 0, stream);
+    }
+  }
   switch (choose_tile(M, N, K, lda, ldb)) {
     case 192: return launch_big<192>(a, epilogue, out_f32, stream);
     case 256: return launch_big<256>(a, epilogue, out_f32, stream);

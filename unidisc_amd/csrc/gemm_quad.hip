@@ -462,6 +462,10 @@ static int launch_quad_nt_fm(const QuadArgs& a, int epilogue, int out_f32, hipSt
 }
 
 int udm_quad_launch_nt(const QuadArgs& a, int fm, int epilogue, int out_f32, hipStream_t stream) {
+  if (fm == -5) {   // 320-row tiles, ragged last tile row: plain / bias epilogue, bf16 output
+    if (out_f32 || epilogue > UDM_EPI_BIAS) { udm_set_error("udm_quad_launch_nt: the ragged form has the plain and the bias epilogue only"); return 2; }
+    return epilogue == UDM_EPI_BIAS ? launch_quad_t<5, false, UDM_EPI_BIAS, false, true>(a, stream) : launch_quad_t<5, false, UDM_EPI_NONE, false, true>(a, stream);
+  }
   switch (fm) {
     case 3: return launch_quad_nt_fm<3>(a, epilogue, out_f32, stream);
     case 4: return launch_quad_nt_fm<4>(a, epilogue, out_f32, stream);
