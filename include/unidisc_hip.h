@@ -54,7 +54,8 @@ int udm_gemm_nt_bf16(const void* A, const void* B, void* C, int64_t M, int64_t N
                      int epilogue, const float* bias, void* aux, int64_t ldaux, float beta, hipStream_t stream);
 /* wgrad form read straight from row-major activations: C[M,N] (fp32) = beta*C + A[K,M]ᵀ · B[K,N]  (K % 64 == 0). */
 /* dgrad without a transposed weight shadow: C[M,N] bf16 = A[M,K] B[K,N] (A = dY with K = out features contiguous, B = the forward's bf16 W [out, in]);
- * replaces the dX = dY W half of nn.Linear's backward (models/dit.py:642,877,917-919).  Whole tiles only: udm_gemm_nn_ok(M, N, K) != 0. */
+ * replaces the dX = dY W half of nn.Linear's backward (models/dit.py:642,877,917-919).  Shapes must pass udm_gemm_nn_ok(M, N, K) != 0:
+ * N % 256 == 0, K % 64 == 0, K >= 128 and either M a multiple of 192 / 256 / 320 or enough 320-row tiles (>= 128, the last tile row may be ragged) to fill the chip. */
 int udm_gemm_nn_bf16(const void* A, const void* B, void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, hipStream_t stream);
 int udm_gemm_nn_ok(int64_t M, int64_t N, int64_t K);
 int udm_gemm_tn_bf16(const void* A, const void* B, void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, float beta,
