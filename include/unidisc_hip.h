@@ -74,8 +74,13 @@ int udm_gemm_tn_pair_bf16(const void* A0, const void* B0, void* C0, int64_t M0, 
  * (>= slices*M*N), reduce pass rounds to bf16; falls back to udm_gemm_nt_bf16 when splitting does not apply. */
 int udm_gemm_nt_splitk_bf16(const void* A, const void* B, void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, float* ws,
                             int64_t ws_elems, hipStream_t stream);
-/* data-parallel runs: cap the persistent NT grid at `cus` blocks (multiple of 8 in [8, 256]; 0 = all 256 CUs) so RCCL's channel kernels of the
- * gradient all-reduce overlapped with backward (main.py:641-656) find free CUs; also env UDM_GEMM_CUS */
+/* NN form of the same idea (bf16 result, whole tiles: udm_gemm_nn_ok): the leftover tile rows of a dgrad when a collective holds CUs (below). */
+int udm_gemm_nn_splitk_bf16(const void* A, const void* B, void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, float* ws,
+                            int64_t ws_elems, hipStream_t stream);
+/* data-parallel runs: the GEMMs plan for `cus` CUs (multiple of 8 in [8, 256]; 0 = all 256) so that RCCL's channel kernels of the gradient all-reduce
+ * overlapped with backward (main.py:641-656) find free CUs: the persistent NT grid is capped at `cus` blocks, the split-K forms cut K for `cus` blocks, and
+ * the host side (kernels.py) runs a single-round GEMM of more than `cus` tiles as whole tile rows that fit + a split-K launch of the leftover rows; also env
+ * UDM_GEMM_CUS */
 int udm_gemm_set_cus(int cus);
 /* out[C,R] = in[R,C]ᵀ (bf16); optional colsum[c] += Σ_r in[r,c] (bias gradient).  Feeds the wgrad GEMMs. */
 int udm_transpose_bf16(const void* in, void* out, int64_t R, int64_t C, int64_t ld_in, int64_t ld_out, float* colsum, hipStream_t stream);

@@ -313,6 +313,45 @@ def test_gemm_nn_ragged_last_tile_row(K, M, N, K_):
         K.gemm_set_quad(1)
 
 
+@pytest.mark.parametrize("cus", [248, 240, 224])
+def test_gemm_single_round_shapes_split_by_rows_when_cus_are_held(K, cus):
+    """gemm_set_cus(n) (data-parallel runs: a collective's kernels hold CUs): a GEMM of exactly one round of 256 one-workgroup tiles would run two rounds, so the host
+    side runs the whole tile rows that fit n CUs and sends the leftover rows through a split-K launch (NN, TN) or small tiles (NT).  Same results: the rows of the
+    main part and the NT remainder bit for bit, the split-K remainders to fp32 summation order."""
+    M, d, dff = 10240, 2048, 8192
+    dy, w = bf(rnd(M, dff, seed=400, scale=0.5)).to(DEV), bf(rnd(dff, d, seed=401, scale=0.3)).to(DEV)     # fc1 dgrad: dX[M, d] = dY[M, 4d] W[4d, d]
+    x = bf(rnd(M, d, seed=402, scale=0.5)).to(DEV)
+    wt, bias = bf(rnd(d, dff, seed=403, scale=0.3)).to(DEV), rnd(d, seed=404).to(DEV)                       # fc2 forward: [M, 4d] x [d, 4d]^T + bias
+    ref_nn = K.gemm_nn(dy, w)
+    ref_tn = K.gemm_tn(dy, x, torch.zeros(dff, d, dtype=torch.float32, device=DEV))                         # fc1 wgrad [4d, d] (32 x 8 tiles)
+    ref_tn2 = K.gemm_tn(x, dy, torch.zeros(d, dff, dtype=torch.float32, device=DEV))                        # fc2-shaped wgrad [d, 4d] (8 x 32 tiles)
+    ref_nt = K.gemm_nt(dy, wt, epilogue=K.EPI_BIAS, bias=bias)
+    try:
+        K.gemm_set_cus(cus)
+        assert not K.gemm_tn_pair_ok(6144, 2048, 2048, M)                                                   # 192 + 64 tiles no longer fit one round
+        main = (cus // 8) * 320
+        nn = K.gemm_nn(dy, w)
+        assert torch.equal(nn[:main], ref_nn[:main]) and rel_err(nn.float().cpu(), ref_nn.float().cpu()) < 2e-3
+        tn = K.gemm_tn(dy, x, torch.zeros(dff, d, dtype=torch.float32, device=DEV))
+        main_t = (cus // 8) * 256
+        assert torch.equal(tn[:main_t], ref_tn[:main_t]) and rel_err(tn.cpu(), ref_tn.cpu()) < 1e-5
+        c0 = torch.full((d, dff), 0.5, dtype=torch.float32, device=DEV)
+        tn2 = K.gemm_tn(x, dy, c0, beta=1.0)                                                               # beta reaches the split-K remainder too
+        assert rel_err(tn2.cpu(), ref_tn2.cpu() + 0.5) < 1e-5
+        nt = K.gemm_nt(dy, wt, epilogue=K.EPI_BIAS, bias=bias)
+        assert torch.equal(nt, ref_nt)
+        # qkv-shaped wgrad [6144, 2048]: 256 tiles of 192 rows -> the leftover rows are a COLUMN SLICE of dY that ends the allocation (192-row tiles in the split-K launch)
+        dq = bf(rnd(M, 6144, seed=405, scale=0.5)).to(DEV)
+        K.gemm_set_cus(0)
+        ref_q = K.gemm_tn(dq, x, torch.zeros(6144, d, dtype=torch.float32, device=DEV))
+        K.gemm_set_cus(cus)
+        tq = K.gemm_tn(dq, x, torch.zeros(6144, d, dtype=torch.float32, device=DEV))
+        assert rel_err(tq.cpu(), ref_q.cpu()) < 1e-5
+    finally:
+        K.gemm_set_cus(0)
+    assert K.gemm_tn_pair_ok(6144, 2048, 2048, M)
+
+
 @pytest.mark.parametrize("M,N,K_", [(5120, 2048, 48512), (5056, 2048, 4096), (704, 512, 8192), (100, 300, 640), (5120, 2048, 192)])
 def test_gemm_nt_splitk_bf16_output(K, M, N, K_):
     """NT split-K with a bf16 result (the head dgrad on the compacted rows): ragged row counts, shapes where it must fall back, long K."""

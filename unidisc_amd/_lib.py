@@ -25,6 +25,7 @@ PROTOTYPES = {
     "udm_gemm_nn_bf16": [_P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _P],
     "udm_gemm_nn_ok": [_I64, _I64, _I64],
     "udm_gemm_nt_splitk_bf16": [_P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _P, _I64, _P],
+    "udm_gemm_nn_splitk_bf16": [_P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _P, _I64, _P],
     "udm_gemm_tn_splitk_bf16": [_P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _F, _P, _I64, _P],
     "udm_gemm_tn_pair_bf16": [_P, _P, _P, _I64, _I64, _I64, _I64, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _F, _P, _I64, _P],
     "udm_gemm_set_cus": [_I],

@@ -450,7 +450,8 @@ __global__ __launch_bounds__(512) void gemm_nt_stagger_kernel(GemmArgs p) {
       const int off = (wave * A_PW + j) * 1024 + lane * 16;
       const int row = off / RB_A, within = off % RB_A;
       const int gran = (within / 64 + NG_A - ROT_A(row & 3)) % NG_A;
-      const long col = min((long)row0 + (gran * 64 + within % 64) / 2, p.lda - 8);
+      // (ragged tiles: clamp to the last 8-column group that holds valid data - NOT to the row's end: A may be a column slice of a wider matrix, whose last k-row ends the allocation)
+      const long col = min((long)row0 + (gran * 64 + within % 64) / 2, (long)((p.M - 1) / 8 * 8));
       src[j] = p.A + (long)row * p.lda + col;
       dst[j] = (wave * A_PW + j) * 1024;
     }
@@ -459,7 +460,7 @@ __global__ __launch_bounds__(512) void gemm_nt_stagger_kernel(GemmArgs p) {
       const int off = (wave * B_PW + j) * 1024 + lane * 16;
       const int row = off / RB_B, within = off % RB_B;
       const int gran = (within / 64 + NG_B - ROT_B(row & 3)) % NG_B;
-      const long col = min((long)col0 + (gran * 64 + within % 64) / 2, p.ldb - 8);
+      const long col = min((long)col0 + (gran * 64 + within % 64) / 2, (long)((p.N - 1) / 8 * 8));
       src[A_PW + j] = p.B + (long)row * p.ldb + col;
       dst[A_PW + j] = A_BYTES + (wave * B_PW + j) * 1024;
     }
@@ -808,6 +809,14 @@ int g_gemm_persist = 1;   // diagnostics (UDM_GEMM_PERSIST=0): 0 = one block per
 // gradient all-reduce overlapped with backward) then only get CUs between launches.  UDM_GEMM_CUS = n (or udm_gemm_set_cus) caps the
 // persistent grid at n blocks (a multiple of 8: one block per CU, XCD round-robin), leaving 256 - n CUs to the collective.  0 = all 256.
 int g_gemm_cus = 0;
+int gemm_cus_available() {   // (also reached from gemm_quad.hip through udm_gemm_cus_available below)
+  static const bool env_once = [] {
+    if (const char* e = getenv("UDM_GEMM_CUS")) { const int n = atoi(e); if (n >= 8 && n <= 256) g_gemm_cus = n / 8 * 8; }
+    return true;
+  }();
+  (void)env_once;
+  return g_gemm_cus ? g_gemm_cus : 256;
+}
 
 template <int BMX, int EPI, bool OUT_F32, bool TN = false>
 int launch_big_t(const GemmArgs& a0, hipStream_t stream) {
@@ -1054,7 +1063,7 @@ extern "C" int udm_gemm_nt_splitk_bf16(const void* A, const void* B, void* C, in
   UDM_CHECK_ARG(M > 0 && N > 0 && K > 0, "udm_gemm_nt_splitk_bf16: empty problem");
   const long tiles = ((M + 319) / 320) * ((N + 255) / 256);
   const long nkt = K / 64;
-  long skl = 256 / tiles;
+  long skl = gemm_cus_available() / tiles;
   if (skl > nkt / 8) skl = nkt / 8;
   if (skl > 32) skl = 32;
   const int sk = skl < 2 ? 1 : (int)skl;
@@ -1084,10 +1093,12 @@ extern "C" int udm_gemm_tn_splitk_bf16(const void* A, const void* B, void* C, in
                                        float beta, float* ws, int64_t ws_elems, hipStream_t stream) {
   UDM_CHECK_ARG(A && B && C, "udm_gemm_tn_splitk_bf16: null operand");
   UDM_CHECK_ARG(M > 0 && N > 0 && K > 0 && K % 64 == 0, "udm_gemm_tn_splitk_bf16: K must be a positive multiple of 64 (got M=%ld N=%ld K=%ld)", (long)M, (long)N, (long)K);
-  const long tiles = ((M + 255) / 256) * ((N + 255) / 256);
+  int fm = 0;
+  const bool quad = g_force_tile < 0 && udm_quad_tn_ok(M, N, K, &fm);   // whole 256- or 192-row tiles of the one-wave-per-SIMD kernel
+  const long tiles = quad ? (M / (64 * fm)) * (N / 256) : ((M + 255) / 256) * ((N + 255) / 256);
   const long nkt = K / 64;
-  // as many slices as fill the 256 CUs once (any count: slices may be uneven), each at least 8 K tiles deep, at most 32
-  long skl = 256 / tiles;
+  // as many slices as fill the CUs once (256, or the cap of udm_gemm_set_cus; any count: slices may be uneven), each at least 8 K tiles deep, at most 32
+  long skl = gemm_cus_available() / tiles;
   if (skl > nkt / 8) skl = nkt / 8;
   if (skl > 32) skl = 32;
   const int sk = skl < 2 ? 1 : (int)skl;
@@ -1101,12 +1112,11 @@ extern "C" int udm_gemm_tn_splitk_bf16(const void* A, const void* B, void* C, in
   a.M = (int)M; a.N = (int)N; a.K = (int)K; a.beta = 0.f;
   a.splitk = sk;
   a.slice_stride = (long)M * N;
-  int fm = 0;
-  if (g_force_tile < 0 && M % 256 == 0 && udm_quad_tn_ok(M, N, K, &fm)) {   // same slices, 256 x 256 one-wave-per-SIMD tiles
+  if (quad) {   // same slices, one-wave-per-SIMD tiles
     QuadArgs q{};
     q.A = a.A; q.B = a.B; q.C = ws; q.lda = lda; q.ldb = ldb; q.ldc = N; q.M = a.M; q.N = a.N; q.K = a.K; q.beta = 0.f; q.splitk = sk;
     q.slice_stride = (long)M * N;
-    if (int rc = udm_quad_launch_tn(q, 4, stream)) return rc;
+    if (int rc = udm_quad_launch_tn(q, fm, stream)) return rc;
   } else if (int rc = launch_big_t<256, UDM_EPI_NONE, true, true>(a, stream)) return rc;
   const long n4 = (long)M * N / 4;
   const int grid = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
@@ -1166,6 +1176,34 @@ extern "C" int udm_gemm_nn_bf16(const void* A, const void* B, void* C, int64_t M
   return udm_quad_launch_nn(q, fm, stream);
 }
 
+// udm_gemm_nn_bf16 for FEW output tiles: the K range cut into slices so that tiles x slices fill the available CUs once, fp32 partial tiles in `ws`
+// (>= slices * M * N), a reduce pass that rounds to bf16.  Its use: the leftover tile rows of a dgrad whose 256 tiles no longer fit one round because a
+// collective holds CUs (udm_gemm_set_cus / UDM_GEMM_CUS; kernels.py splits the rows).  Whole tiles only; falls back to udm_gemm_nn_bf16 when splitting does not apply.
+extern "C" int udm_gemm_nn_splitk_bf16(const void* A, const void* B, void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc,
+                                       float* ws, int64_t ws_elems, hipStream_t stream) {
+  UDM_CHECK_ARG(A && B && C, "udm_gemm_nn_splitk_bf16: null pointer");
+  int fm = 0;
+  UDM_CHECK_ARG(M > 0 && udm_quad_nn_ok(M, N, K, &fm), "udm_gemm_nn_splitk_bf16: shape %ld x %ld x %ld does not fit the NN kernel (see udm_gemm_nn_ok)", (long)M, (long)N, (long)K);
+  const long tiles = fm > 0 ? (M / (64 * fm)) * (N / 256) : 0;
+  const long nkt = K / 64;
+  long skl = tiles ? gemm_cus_available() / tiles : 1;
+  if (skl > nkt / 4) skl = nkt / 4;
+  if (skl > 32) skl = 32;
+  const int sk = skl < 2 ? 1 : (int)skl;
+  if (fm <= 0 || sk == 1 || !ws || ws_elems < (int64_t)sk * M * N || ldc % 4 != 0) return udm_gemm_nn_bf16(A, B, C, M, N, K, lda, ldb, ldc, stream);
+  UDM_CHECK_ARG(lda >= K && ldb >= N && ldc >= N && lda % 8 == 0 && ldb % 8 == 0, "udm_gemm_nn_splitk_bf16: bad leading dimensions");
+  UDM_CHECK_ARG(((uintptr_t)ws % 16 == 0) && ((uintptr_t)C % 8 == 0), "udm_gemm_nn_splitk_bf16: operand alignment");
+  QuadArgs q{};
+  q.A = (const bf16_t*)A; q.B = (const bf16_t*)B; q.C = ws; q.lda = lda; q.ldb = ldb; q.ldc = N;
+  q.M = (int)M; q.N = (int)N; q.K = (int)K; q.beta = 0.f; q.splitk = sk; q.slice_stride = (long)M * N;
+  if (int rc = udm_quad_launch_nn_f32(q, fm, stream)) return rc;
+  const long n4 = (long)M * N / 4;
+  const int grid = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
+  hipLaunchKernelGGL(splitk_reduce_bf16_kernel, dim3(grid), dim3(256), 0, stream, (const float*)ws, (bf16_t*)C, (long)M, (int)N, (long)ldc, sk, (long)M * N);
+  UDM_CHECK_LAUNCH("udm_gemm_nn_splitk_bf16(reduce)");
+  return 0;
+}
+
 // Two weight gradients of one backward step in ONE launch: C0[M0, N] (+)= A0[K, M0]^T B0[K, N] and C1[M1, N] (+)= A1[K, M1]^T B1[K, N] (fp32, beta as
 // udm_gemm_tn_bf16), same N and K, M0 / M1 / N multiples of 256, K a multiple of 64: the 256 x 256 one-wave-per-SIMD tiles of both problems share a grid, so
 // that e.g. the qkv (6144 x 2048: 192 tiles) and the out-proj (2048 x 2048: 64 tiles) weight gradients of a DiT block fill the 256 CUs exactly once.
@@ -1204,6 +1242,7 @@ extern "C" int udm_gemm_tn_pair_bf16(const void* A0, const void* B0, void* C0, i
   return udm_quad_launch_tn_pair(q, M1, stream);
 }
 
+int udm_gemm_cus_available() { return gemm_cus_available(); }
 extern "C" int udm_gemm_set_cus(int cus) {   // 0 = all CUs; otherwise the persistent NT grid (a multiple of 8 in [8, 256])
   UDM_CHECK_ARG(cus == 0 || (cus >= 8 && cus <= 256 && cus % 8 == 0), "udm_gemm_set_cus: 0 or a multiple of 8 in [8, 256]");
   g_gemm_cus = cus;

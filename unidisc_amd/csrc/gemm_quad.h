@@ -26,6 +26,7 @@ struct QuadArgs {
 };
 
 extern int g_quad_mode;
+int udm_gemm_cus_available();   // 256, or the cap of udm_gemm_set_cus / UDM_GEMM_CUS: rounds are counted against it
 int udm_quad_mode();   // 0 off, 1 auto (shapes that fill the chip), 2 force wherever the shape fits
 // TN (wgrad) form: does a quad tile fit (whole tiles, K % 64 == 0)?  *fm receives the tile height / 64 (3, 4 or 5).
 bool udm_quad_tn_ok(long M, long N, long K, int* fm);
@@ -38,3 +39,4 @@ int udm_quad_launch_nt(const QuadArgs& a, int fm, int epilogue, int out_f32, hip
 // NN (dgrad from the forward's W shadow) form: C[M, N] bf16 = A[M, K] B[K, N], plain epilogue.  *fm = 3 / 4 / 5 (whole tiles) or -5 (320-row tiles, ragged last tile row)
 bool udm_quad_nn_ok(long M, long N, long K, int* fm);
 int udm_quad_launch_nn(const QuadArgs& a, int fm, hipStream_t stream);
+int udm_quad_launch_nn_f32(const QuadArgs& a, int fm, hipStream_t stream);   // whole tiles (fm = 3 / 4 / 5), fp32 output, a.splitk slices

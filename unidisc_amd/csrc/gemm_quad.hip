@@ -397,7 +397,8 @@ int udm_quad_mode() {
 
 bool udm_quad_tn_ok(long M, long N, long K, int* fm) {
   if (!udm_quad_mode() || K % 64 != 0 || K < 128 || N % 256 != 0) return false;
-  // the tile height that fills whole rounds of the 256 CUs best (ties: the larger wave tile)
+  // the tile height that fills whole rounds of the CUs (256, or what udm_gemm_set_cus leaves) best (ties: the larger wave tile)
+  const long G = udm_gemm_cus_available();
   const int cands[2] = {4, 3};   // (FM = 5 spills in the TN form: 2 x 9 fragment halves beside 320 accumulators)
   double best = 1e30;
   int pick = 0;
@@ -405,7 +406,7 @@ bool udm_quad_tn_ok(long M, long N, long K, int* fm) {
     const int bm = 64 * cands[c];
     if (M % bm != 0) continue;
     const long tiles = (M / bm) * (N / 256);
-    const long rounds = (tiles + 255) / 256;
+    const long rounds = (tiles + G - 1) / G;
     const double t = (double)rounds * bm;
     if (t < best) { best = t; pick = cands[c]; }
   }
@@ -431,6 +432,7 @@ int udm_quad_launch_tn(const QuadArgs& a, int fm, hipStream_t stream) {
 
 bool udm_quad_nt_ok(long M, long N, long K, int* fm) {
   if (!udm_quad_mode() || K % 64 != 0 || K < 128 || N % 256 != 0) return false;
+  const long G = udm_gemm_cus_available();
   const int cands[3] = {5, 4, 3};
   double best = 1e30;
   int pick = 0;
@@ -438,7 +440,7 @@ bool udm_quad_nt_ok(long M, long N, long K, int* fm) {
     const int bm = 64 * cands[c];
     if (M % bm != 0) continue;
     const long tiles = (M / bm) * (N / 256);
-    const long rounds = (tiles + 255) / 256;
+    const long rounds = (tiles + G - 1) / G;
     const double t = (double)rounds * bm;
     if (t < best) { best = t; pick = cands[c]; }
   }
@@ -479,15 +481,24 @@ int udm_quad_launch_nt(const QuadArgs& a, int fm, int epilogue, int out_f32, hip
 bool udm_quad_nn_ok(long M, long N, long K, int* fm) {
   int whole = 0;
   const bool ok = udm_quad_nt_ok(M, N, K, &whole);
-  double best = ok ? (double)(((M / (64 * whole)) * (N / 256) + 255) / 256) * 64 * whole : 1e30;
+  const long G = udm_gemm_cus_available();
+  double best = ok ? (double)(((M / (64 * whole)) * (N / 256) + G - 1) / G) * 64 * whole : 1e30;
   static const int env_ragged = [] { const char* e = getenv("UDM_QUAD_RAGGED"); return e ? atoi(e) : 1; }();   // diagnostics: 0 = whole tiles only
   if (env_ragged && udm_quad_mode() && K % 64 == 0 && K >= 128 && N % 256 == 0 && M > 320 && M % 320 != 0) {
     const long tiles = ((M + 319) / 320) * (N / 256);
-    const double t = (double)((tiles + 255) / 256) * 320 * 1.03;
+    const double t = (double)((tiles + G - 1) / G) * 320 * 1.03;
     if (tiles >= 128 && t < best) { *fm = -5; return true; }
   }
   if (ok) *fm = whole;
   return ok;
+}
+int udm_quad_launch_nn_f32(const QuadArgs& a, int fm, hipStream_t stream) {   // fp32 output (split-K partial tiles)
+  switch (fm) {
+    case 3: return launch_quad_t<3, 2, UDM_EPI_NONE, true>(a, stream);
+    case 4: return launch_quad_t<4, 2, UDM_EPI_NONE, true>(a, stream);
+    case 5: return launch_quad_t<5, 2, UDM_EPI_NONE, true>(a, stream);
+    default: udm_set_error("udm_quad_launch_nn_f32: bad tile"); return 2;
+  }
 }
 int udm_quad_launch_nn(const QuadArgs& a, int fm, hipStream_t stream) {
   switch (fm) {

@@ -54,6 +54,34 @@ def _scratch(n: int, device) -> torch.Tensor:
     return buf
 
 
+# CUs the GEMMs may plan for (0 = all 256): set by gemm_set_cus / UDM_GEMM_CUS when a collective's kernels hold CUs during the backward (DDP).  A GEMM of
+# exactly one round of one-workgroup tiles (every wgrad / dgrad and the single-round forward GEMMs of the 1.4 B step: 256 tiles) otherwise runs TWO rounds as soon as
+# one CU is taken (+40 % on the step with 8 CUs held): `_row_split` cuts it into the whole tile rows that still fit one round and the leftover rows,
+# which go through a split-K launch (or small tiles) and cost a fraction of a round.
+_CUS = [int(os.environ.get("UDM_GEMM_CUS", "0") or 0) // 8 * 8]
+
+
+def _row_split(rows, cols, tile_rows_options):
+    """rows of the main part (a multiple of the chosen tile height), or None: `rows` x `cols` outputs in (tile height) x 256 tiles, whole tiles only."""
+    G = _CUS[0]
+    if not G or G >= 256 or cols % 256:
+        return None
+    best = None
+    for bm in tile_rows_options:
+        if rows % bm == 0:
+            tiles = (rows // bm) * (cols // 256)
+            cost = -(-tiles // 256) * bm
+            if best is None or cost < best[0]:
+                best = (cost, bm, tiles)
+    if best is None:
+        return None
+    _, bm, tiles = best
+    if not (G < tiles <= 256):
+        return None
+    main = (G // (cols // 256)) * bm
+    return main if 0 < main < rows else None
+
+
 def norm_id(norm_type: str) -> int:
     return NORM_RMS if norm_type == "rms" else NORM_LN
 
@@ -77,6 +105,12 @@ def gemm_nt(a, b, out=None, *, out_dtype=BF16, M=None, N=None, K=None, lda=None,
     ldc = out.stride(0) if ldc is None else ldc
     if aux is not None and ldaux is None:
         ldaux = aux.stride(0)
+    if _CUS[0] and epilogue in (EPI_NONE, EPI_BIAS) and out.dtype == BF16 and beta == 0.0 and K % 64 == 0 and K >= 128:
+        main = _row_split(M, N, (320, 256, 192))   # a single round of whole tiles that no longer fits the CUs a collective leaves: rows that fit + the rest on small tiles
+        if main is not None:
+            _lib.call("udm_gemm_nt_bf16", _p(a), _p(b), _p(out), main, N, K, lda, ldb, ldc, 0, epilogue, _p(bias), None, 0, 0.0, _s())
+            _lib.call("udm_gemm_nt_bf16", _p(a[main:]), _p(b), _p(out[main:]), M - main, N, K, lda, ldb, ldc, 0, epilogue, _p(bias), None, 0, 0.0, _s())
+            return out
     _lib.call("udm_gemm_nt_bf16", _p(a), _p(b), _p(out), M, N, K, lda, ldb, ldc, 1 if out.dtype == F32 else 0, epilogue, _p(bias), _p(aux),
               ldaux or 0, float(beta), _s())
     return out
@@ -95,7 +129,22 @@ def gemm_nn(a, b, out=None, *, N=None):
     N = b.shape[1] if N is None else N
     if out is None:
         out = torch.empty((M, N), dtype=BF16, device=a.device)
+    main = _row_split(M, N, (320, 256, 192))
+    if main is not None and gemm_nn_ok(main, N, Kd) and gemm_nn_ok(M - main, N, Kd):
+        _lib.call("udm_gemm_nn_bf16", _p(a), _p(b), _p(out), main, N, Kd, a.stride(0), b.stride(0), out.stride(0), _s())
+        gemm_nn_splitk(a[main:], b, out[main:], N=N)
+        return out
     _lib.call("udm_gemm_nn_bf16", _p(a), _p(b), _p(out), M, N, Kd, a.stride(0), b.stride(0), out.stride(0), _s())
+    return out
+
+
+def gemm_nn_splitk(a, b, out, *, N=None):
+    """gemm_nn for few output tiles (the leftover tile rows of a row-split dgrad): K split across the available CUs through an fp32 workspace."""
+    _chk(a, BF16, "gemm_nn_splitk a"), _chk(b, BF16, "gemm_nn_splitk b")
+    M, Kd = a.shape
+    N = b.shape[1] if N is None else N
+    ws = _scratch(32 * M * N, a.device) if M * N <= (1 << 22) else None   # (at most 32 slices; big problems do not split)
+    _lib.call("udm_gemm_nn_splitk_bf16", _p(a), _p(b), _p(out), M, N, Kd, a.stride(0), b.stride(0), out.stride(0), _p(ws), ws.numel() if ws is not None else 0, _s())
     return out
 
 
@@ -105,12 +154,19 @@ def gemm_tn(a, b, out, *, M=None, N=None, beta=0.0):
     K = a.shape[0]
     M = a.shape[1] if M is None else M
     N = b.shape[1] if N is None else N
+    main = _row_split(M, N, (256, 192)) if out.stride(0) == N else None   # (the tile heights of the K-major one-wave-per-SIMD kernel, its cost rule)
+    if main is not None:
+        _lib.call("udm_gemm_tn_bf16", _p(a), _p(b), _p(out), main, N, K, a.stride(0), b.stride(0), out.stride(0), float(beta), _s())
+        gemm_tn_splitk(a[:, main:], b, out[main:], M=M - main, N=N, beta=beta)
+        return out
     _lib.call("udm_gemm_tn_bf16", _p(a), _p(b), _p(out), M, N, K, a.stride(0), b.stride(0), out.stride(0), float(beta), _s())
     return out
 
 
 def gemm_tn_pair_ok(M0, M1, N, K):
     """Can two wgrads share one launch of 256 x 256 tiles (gemm_tn_pair)?"""
+    if _CUS[0] and _CUS[0] < 256 and (M0 + M1) // 256 * (N // 256) > _CUS[0]:   # CUs are held: the shared grid would no longer fit one round (the two launches each plan for what is left)
+        return False
     return M0 > 0 and M1 > 0 and M0 % 256 == 0 and M1 % 256 == 0 and N % 256 == 0 and K % 64 == 0 and K >= 128
 
 
@@ -303,8 +359,10 @@ def gemm_set_quad(mode: int):
 
 
 def gemm_set_cus(cus: int):
-    """Cap the persistent NT GEMM grid at `cus` blocks (multiple of 8; 0 = all 256 CUs): leaves CUs to RCCL's kernels in data-parallel runs."""
+    """The GEMMs plan for `cus` CUs (multiple of 8; 0 = all 256): persistent grids are capped, split-K cuts for `cus` blocks, single-round GEMMs of more tiles are
+    split by rows (`_row_split`) - leaves CUs to RCCL's kernels in data-parallel runs."""
     _lib.call("udm_gemm_set_cus", int(cus))
+    _CUS[0] = int(cus)
 
 
 def gemm_set_tile(tile: int):
