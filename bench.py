@@ -354,9 +354,12 @@ def self_launch(n_gpus, argv):
     relay their output, exit with the launcher's code."""
     import subprocess
 
+    from unidisc_amd.ddp import rccl_channel_env
+
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", "8")
+    rccl_channel_env(env)     # bound RCCL's CU footprint (NCCL_MAX_NCHANNELS, default 32) unless the caller chose otherwise
     proc = subprocess.run(launcher_command(n_gpus, argv), env=env)
     raise SystemExit(proc.returncode)
 
@@ -375,6 +378,8 @@ def main():
     ap.add_argument("--time-every", type=int, default=16, help="bracket 1 GEMM launch in this many with HIP events inside the timed region (1 = all: costs ~1.7 ms/step)")
     ap.add_argument("--hog-cus", type=int, default=0, help="diagnostics: hold this many CUs with a spinning kernel for the whole run (stand-in for RCCL's channel kernels; "
                     "combine with UDM_GEMM_CUS = 256 - n so the GEMMs plan for the remaining CUs)")
+    ap.add_argument("--ddp-mode", default=None, choices=["auto", "overlap", "overlap_planned", "serialized"],
+                    help="gradient all-reduce schedule for --gpus > 1 (default: UDM_DDP_MODE or auto = timed in warm-up on all ranks, fastest kept)")
     ap.add_argument("--table-steps", type=int, default=2, help="extra untimed steps after the timed region with every launch event-timed (roofline_table); 0 = off")
     args = ap.parse_args()
 
@@ -392,8 +397,14 @@ def main():
     device = torch.device("cuda", local_rank)
     import torch.distributed as dist
 
+    if args.hog_cus > 0 and world > 1:
+        raise SystemExit("--hog-cus is a single-GPU diagnostic (it cannot be fenced by a collective barrier)")
+    rccl_channels = 0
     if world > 1:
+        from unidisc_amd.ddp import rccl_channel_env
+
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        rccl_channels = rccl_channel_env()     # before the communicator exists (the driver launches torch.distributed.run itself: self_launch is not on that path)
         backend = os.environ.get("UDM_DIST_BACKEND", "nccl")  # "nccl" is RCCL on ROCm; "gloo" only to rehearse the N > 1 path with two ranks on one GPU
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
@@ -416,7 +427,7 @@ def main():
         from unidisc_amd import ddp
 
         ddp.broadcast_parameters(diff.backbone)
-        sync = ddp.wrap(diff.backbone)
+        sync = ddp.wrap(diff.backbone, mode=args.ddp_mode)
     batch = {k: v.to(device) for k, v in synthetic_batch(args.workload, B, seed).items()}
     timer = KernelTimer(sample=args.time_every)
     if not args.no_kernel_timing:
@@ -441,29 +452,36 @@ def main():
         hog_stream = torch.cuda.Stream(device=device)
         _lib.call("udm_debug_cu_hog", int(args.hog_cus), hog_flag.data_ptr(), hog_stream.cuda_stream)
         hog = (hog_flag, hog_stream)
-    for i in range(args.warmup):
-        out = step(i)
-    if hog is None:
-        fence()
-    else:   # (a device-wide synchronise would wait for the spinning kernel)
-        torch.cuda.current_stream().synchronize()
-    if sync is not None:
-        sync.measure_exposed = True
-    timer.enabled = True
-    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]   # one event per step boundary (median beside the mean)
-    t0 = time.perf_counter()
-    marks[0].record()
-    for i in range(args.steps):
-        out = step(args.warmup + i)
-        marks[i + 1].record()
-    if hog is None:
-        fence()
-    else:
-        torch.cuda.current_stream().synchronize()
-    dt = time.perf_counter() - t0
-    if hog is not None:
-        hog[0][0] = 1          # release the held CUs
-        hog[1].synchronize()
+    try:
+        for i in range(args.warmup):
+            out = step(i)
+        if sync is not None:
+            # comm policy: with "auto" every schedule is timed for a few EXTRA untimed steps on all ranks and the fastest kept (ddp.py)
+            fence()
+            sync.autotune(lambda: step(0), steps=2, settle=1, sync_device=device)
+        if hog is None:
+            fence()
+        else:   # (a device-wide synchronise would wait for the spinning kernel)
+            torch.cuda.current_stream().synchronize()
+        if sync is not None:
+            sync.measure_exposed = True
+            wire0 = sync.bytes_on_wire
+        timer.enabled = True
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]   # one event per step boundary (median beside the mean)
+        t0 = time.perf_counter()
+        marks[0].record()
+        for i in range(args.steps):
+            out = step(args.warmup + i)
+            marks[i + 1].record()
+        if hog is None:
+            fence()
+        else:
+            torch.cuda.current_stream().synchronize()
+        dt = time.perf_counter() - t0
+    finally:
+        if hog is not None:    # also on an exception / interrupt: a kernel still polling a freed flag hangs or faults the teardown
+            hog[0][0] = 1      # release the held CUs
+            hog[1].synchronize()
     timer.enabled = False
     per_step_ms = sorted(a.elapsed_time(b) for a, b in zip(marks[:-1], marks[1:]))
     median_ms = per_step_ms[len(per_step_ms) // 2] if len(per_step_ms) % 2 else 0.5 * (per_step_ms[len(per_step_ms) // 2 - 1] + per_step_ms[len(per_step_ms) // 2])
@@ -501,7 +519,12 @@ def main():
                               "share_of_step_time": gs["total_ms"] * (gs["launches_seen"] / gs["launches"]) * 1e-3 / dt}
     result["rccl_world"] = world if (world > 1 and os.environ.get("UDM_DIST_BACKEND", "nccl") == "nccl") else (1 if world == 1 else 0)   # ranks joined over RCCL (0: gloo rehearsal)
     if sync is not None:
-        result["allreduce_bytes_per_step"] = sync.bytes_on_wire // (args.steps + args.warmup)
+        result["allreduce_bytes_per_step"] = (sync.bytes_on_wire - wire0) // args.steps
+        result["ddp_mode"] = sync.mode
+        result["ddp_mode_requested"] = sync.requested_mode
+        result["ddp_mode_warmup_ms"] = sync.mode_timings_ms       # {mode: ms per step, max over ranks} from the auto-selection, else null
+        result["ddp_reserved_cus"] = sync.reserved_cus            # what overlap_planned leaves to the collective
+        result["rccl_max_nchannels"] = rccl_channels              # NCCL_MAX_NCHANNELS in force (0 = RCCL's default)
         # time the compute stream spent waiting for the comm stream at the end of backward (events around BucketedGradSync.finish)
         result["exposed_comm_ms_per_step"] = sync.exposed_ms() / args.steps
     if not args.no_kernel_timing and args.table_steps > 0:

@@ -28,7 +28,7 @@ extern "C" {
 typedef struct ihipStream_t* hipStream_t;
 #endif
 
-#define UDM_ABI_VERSION 1
+#define UDM_ABI_VERSION 2
 
 /* GEMM epilogues */
 #define UDM_EPI_NONE 0      /* C = A·Bᵀ                                                   */

@@ -26,9 +26,11 @@ def main():
     os.environ.setdefault("MASTER_PORT", "29517")
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     from product_utils import product_config
     from unidisc_amd import Diffusion, ddp
+
+    ddp.rccl_channel_env()      # NCCL_MAX_NCHANNELS before the communicator exists, as bench.py does
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
 
     case = dict(hidden_size=768, n_heads=12, cond_dim=128, n_blocks=3, batch_size=4, txt_length=128, img_length=256, text_vocab_size=32001,
                 vocab_size=40193, norm_type="rms", qk_norm=True, sandwich_normalization=True, modality_embed=True, rope_2d=False,
@@ -79,6 +81,25 @@ def main():
                                          exposed_ms=sync.exposed_ms())
         if not repr_ok or err > 1e-2 or sync.bytes_on_wire == 0:
             fails.append(("sync", min_bucket, repr_ok, err))
+    # comm policy (round 4): every schedule under real RCCL - same wire-format gradients; the planned one switches the GEMM CU plan on at the first
+    # bucket and off at the end of the backward; autotune times the three and keeps one
+    if getattr(diff.backbone, "_grad_sync", None) is not None:
+        del diff.backbone._grad_sync
+    sync = ddp.wrap(diff.backbone, min_bucket_elems=4 * 1024 * 1024, force_single_rank=True, mode="auto")
+    from unidisc_amd import kernels as K
+    for mode in ddp.MODES:
+        sync.set_mode(mode)
+        w0 = sync.bytes_on_wire
+        got = grads(1)
+        repr_ok = all(torch.equal(got[k], bf16(got[k])) for k in got)
+        err = worst(got, {k: bf16(v) for k, v in local.items()})
+        res[f"mode_{mode}"] = dict(bf16_representable=repr_ok, worst_rel_vs_bf16_local=err, bytes_on_wire=sync.bytes_on_wire - w0, gemm_cus_after=K._CUS[0])
+        if not repr_ok or err > 1e-2 or sync.bytes_on_wire == w0 or K._CUS[0] != 0:
+            fails.append(("mode", mode, repr_ok, err, K._CUS[0]))
+    table = sync.autotune(lambda: grads(1), steps=2, settle=1, sync_device=dev)
+    res["autotune"] = dict(table_ms=table, chosen=sync.mode, reserved_cus=sync.reserved_cus, nccl_max_nchannels=os.environ.get("NCCL_MAX_NCHANNELS"))
+    if table is None or set(table) != set(ddp.MODES) or sync.mode not in ddp.MODES:
+        fails.append(("autotune", table, sync.mode))
     # no_sync keeps gradients local (NOT bf16-rounded), then accumulate-then-sync reduces the accumulated sum
     sync.enabled = False
     g1 = grads(1)
@@ -95,7 +116,6 @@ def main():
     if not acc_repr or acc_err > 1e-2:
         fails.append(("accumulate", acc_repr, acc_err))
     # persistent GEMM grid with CUs left free for RCCL's channels: same results
-    from unidisc_amd import kernels as K
     K.gemm_set_cus(224)
     red = grads(1)
     K.gemm_set_cus(0)

@@ -444,6 +444,17 @@ def subs_logprobs(logits, xt, modality, V, Vt, mask_id, restrict, out_dtype=BF16
     return out.to(out_dtype)
 
 
+CUS_CALLS = []   # gemm_set_cus history (the DDP comm-policy tests read it)
+
+
+def gemm_set_cus(cus):
+    CUS_CALLS.append(int(cus))
+
+
+def gemm_tn_wants_splitk(M, N, K=None):
+    return ((M + 255) // 256) * ((N + 255) // 256) <= 128 and M * N >= 1 << 16
+
+
 def gemm_tn_pair_ok(M0, M1, N, K):
     return False   # (CPU doubles: the two wgrads stay separate calls)
 

@@ -50,6 +50,7 @@ def test_gpus_n_self_launches_children_before_touching_the_gpu(monkeypatch):
     assert e.value.code == 0
     assert "--nproc-per-node=4" in started["cmd"] and started["cmd"][-6:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"]
     assert started["env"].get("HSA_ENABLE_IPC_MODE_LEGACY") == "0"
+    assert started["env"].get("NCCL_MAX_NCHANNELS") == "32"     # RCCL's CU footprint is bounded in the children's environment (ddp.rccl_channel_env)
 
 
 def test_mismatched_world_size_is_an_error(monkeypatch):

@@ -92,7 +92,39 @@ def _worker(rank, world, port, min_bucket, q):
         acc_same = torch.equal(flat, ref)
         after = _grads(diff, golden, seed=rank)                  # and the next plain step takes the overlapped in-backward path again
         again_ok = all(torch.equal(after[k], synced[k]) for k in synced)
-        q.put((rank, ok, same, local_ok, worst, sync.bytes_on_wire, acc_ok, acc_same, acc_worst, again_ok))
+        # comm policy (round 4): every schedule ends with the SAME synchronised gradients; the planned one brackets the rest of the backward with a GEMM CU plan;
+        # the serialized one sends nothing from inside the backward and coalesces ranges; autotune makes the same decision on every rank
+        modes_ok, plan_calls = True, None
+        for mode in ddp_mod.MODES:
+            sync.set_mode(mode)
+            fake_kernels.CUS_CALLS.clear()
+            launched_inside = []
+            orig_finish = sync.finish
+            def spy_finish(orig=orig_finish, seen=launched_inside):
+                seen.append(sync.bytes_on_wire)
+                return orig()
+            diff.backbone.grad_sync_finish = spy_finish
+            w0 = sync.bytes_on_wire
+            got = _grads(diff, golden, seed=rank)
+            diff.backbone.grad_sync_finish = orig_finish
+            modes_ok = modes_ok and all(torch.equal(got[k], synced[k]) for k in synced)
+            if mode == "overlap_planned":
+                plan_calls = list(fake_kernels.CUS_CALLS)
+            if mode == "serialized":
+                modes_ok = modes_ok and launched_inside == [w0] and sync.bytes_on_wire > w0     # nothing on the wire before the end of the backward
+            else:
+                modes_ok = modes_ok and (min_bucket > 1 or launched_inside[0] > w0)                # small buckets leave from inside the backward
+        sync.requested_mode = "auto"
+        import time
+        def slow_unless_serialized():
+            if sync.mode != "serialized":
+                time.sleep(0.05 if rank == 1 else 0.0)     # only ONE rank is slow: the MAX over ranks must decide
+            _grads(diff, golden, seed=rank)
+        table = sync.autotune(slow_unless_serialized, steps=1, settle=0)
+        tables = [None] * world
+        dist.all_gather_object(tables, (table, sync.mode))
+        auto_ok = sync.mode == "serialized" and all(t == tables[0] for t in tables) and set(table) == set(ddp_mod.MODES)
+        q.put((rank, ok, same, local_ok, worst, sync.bytes_on_wire, acc_ok, acc_same, acc_worst, again_ok, modes_ok, plan_calls, auto_ok, sync.reserved_cus))
     finally:
         dist.destroy_process_group()
 
@@ -109,7 +141,10 @@ def test_bucketed_allreduce_world2(min_bucket):
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    for rank, ok, same, local_ok, worst, nbytes, acc_ok, acc_same, acc_worst, again_ok in res:
+    for rank, ok, same, local_ok, worst, nbytes, acc_ok, acc_same, acc_worst, again_ok, modes_ok, plan_calls, auto_ok, reserved in res:
+        assert modes_ok, rank                 # overlap / overlap_planned / serialized: bit-identical synchronised gradients
+        assert plan_calls == [256 - reserved, 0] and reserved == 32, (rank, plan_calls)   # plan on at the first bucket, off at the end of the backward
+        assert auto_ok, rank                  # autotune: same table and same choice on every rank, decided by the slowest rank
         assert ok, (rank, worst)
         assert same, rank
         assert local_ok, rank
@@ -117,3 +152,17 @@ def test_bucketed_allreduce_world2(min_bucket):
         assert acc_ok, (rank, acc_worst)      # accumulate-then-sync reduces the accumulated gradients
         assert acc_same, rank                 # ... identically on every rank
         assert again_ok, rank
+
+
+def test_rccl_channel_env_defaults_and_overrides():
+    """NCCL_MAX_NCHANNELS bounds the CUs RCCL's channel kernels hold; bench.py sets it before the communicator exists (and in its children's environment)."""
+    from unidisc_amd.ddp import DEFAULT_RCCL_CHANNELS, rccl_channel_env
+
+    env = {}
+    assert rccl_channel_env(env) == DEFAULT_RCCL_CHANNELS == 32 and env["NCCL_MAX_NCHANNELS"] == "32"
+    env = {"NCCL_MAX_NCHANNELS": "8"}                       # the caller's choice wins
+    assert rccl_channel_env(env) == 8 and env["NCCL_MAX_NCHANNELS"] == "8"
+    env = {"UDM_RCCL_CHANNELS": "16", "NCCL_MIN_NCHANNELS": "64"}
+    assert rccl_channel_env(env) == 16 and env["NCCL_MIN_NCHANNELS"] == "16"   # a MIN above the cap would defeat it
+    env = {"UDM_RCCL_CHANNELS": "0"}                        # 0: leave RCCL alone
+    assert rccl_channel_env(env) == 0 and "NCCL_MAX_NCHANNELS" not in env

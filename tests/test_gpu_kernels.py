@@ -186,6 +186,26 @@ def test_gemm_tn_pair_equals_two_launches(K, M0, M1, N, Kc, beta):
         K.gemm_tn_pair(ga0[:, :200], gb0, o0[:200], ga1, gb1, o1)
 
 
+@pytest.mark.parametrize("M0,M1,N,Kc", [(768, 256, 512, 1024), (6144, 2048, 2048, 2560)])
+def test_gemm_tn_pair_falls_back_when_quad_kernels_are_off(K, M0, M1, N, Kc):
+    """udm_gemm_tn_pair_bf16 answers rc = 3 ("not applicable, nothing launched") when the one-wave-per-SIMD kernels are switched off (`gemm_set_quad(0)`, a documented
+    A/B switch) or a pointer is off its 16-byte alignment: K.gemm_tn_pair then issues the two plain problems instead of raising (round-3 advisor finding)."""
+    a0, b0 = bf(rnd(Kc, M0, seed=590, scale=0.5)), bf(rnd(Kc, N, seed=591, scale=0.5))
+    a1, b1 = bf(rnd(Kc, M1, seed=592, scale=0.5)), bf(rnd(Kc, N, seed=593, scale=0.5))
+    ref0, ref1 = a0.float().t() @ b0.float(), a1.float().t() @ b1.float()
+    o0, o1 = torch.zeros(M0, N, device=DEV), torch.zeros(M1, N, device=DEV)
+    try:
+        K.gemm_set_quad(0)
+        K.gemm_tn_pair(a0.to(DEV), b0.to(DEV), o0, a1.to(DEV), b1.to(DEV), o1)
+    finally:
+        K.gemm_set_quad(1)
+    assert rel_err(o0.cpu(), ref0) < 1e-5 and rel_err(o1.cpu(), ref1) < 1e-5
+    # a misaligned operand takes the same route and ends in the plain kernel's own loud alignment error (not a stale message)
+    a0m = torch.empty(Kc * M0 + 4, dtype=torch.bfloat16, device=DEV)[4:].view(Kc, M0).copy_(a0)
+    with pytest.raises(RuntimeError, match="16-byte aligned"):
+        K.gemm_tn_pair(a0m, b0.to(DEV), o0, a1.to(DEV), b1.to(DEV), o1)
+
+
 @pytest.mark.parametrize("M,N,K_", [(512, 512, 128), (512, 256, 192), (768, 512, 448), (384, 256, 256), (1024, 768, 1024), (640, 512, 320), (2560, 2048, 2048)])
 def test_gemm_nt_quad_one_wave_per_simd_every_epilogue(K, M, N, K_):
     """The one-wave-per-SIMD NT kernel (gemm_quad.hip) forced on every shape it fits (192-, 256- and 320-row tiles - the last with its fifth accumulator row in arch VGPRs -, K-tile counts 2 / 3 / 4 / 5 / 7 / 16 / 32):

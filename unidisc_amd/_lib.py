@@ -73,6 +73,7 @@ PROTOTYPES = {
     "udm_silu_bwd": [_P, _P, _P, _I64, _P],
 }
 EXTRA_SYMBOLS = ["udm_last_error", "udm_abi_version"]
+ABI_VERSION = 2   # the UDM_ABI_VERSION of include/unidisc_hip.h that PROTOTYPES was written for (bumped whenever a signature changes)
 
 _lib = None
 
@@ -103,6 +104,11 @@ def load():
             "or `make -C unidisc_amd/csrc`).  unidisc_amd has no CPU fallback."
         )
     lib = ctypes.CDLL(LIB_PATH)
+    lib.udm_abi_version.restype = c_int
+    lib.udm_abi_version.argtypes = []
+    have = lib.udm_abi_version()
+    if have != ABI_VERSION:   # a stale build would be called with shifted arguments (silent UB): refuse it
+        raise HipLibraryMissing(f"{LIB_PATH} reports C-ABI version {have}, these bindings are written for {ABI_VERSION}: rebuild it (`make -C unidisc_amd/csrc`)")
     for name, args in PROTOTYPES.items():
         fn = getattr(lib, name)
         fn.argtypes = args

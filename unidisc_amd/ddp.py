@@ -16,6 +16,20 @@ passes must reduce the ACCUMULATED gradients, which only exist once autograd has
 compresses, all-reduces and decompresses ``p.grad`` bucket by bucket (``allreduce_accumulated``).  Without
 accumulation every pass takes the overlapped in-backward path.
 
+Communication policy (``mode`` / ``UDM_DDP_MODE``; round 4).  A collective's channel kernels HOLD CUs while they run, and every
+backward GEMM of the 1.4 B model is exactly 256 one-workgroup tiles - with k >= 1 CUs held it runs two rounds (measured with a spinning
+kernel: +40 % per step while CUs are held).  Which schedule is fastest therefore depends on the fabric, and is decided by
+MEASUREMENT at start-up rather than assumed:
+  * ``overlap``          buckets all-reduced on the comm stream while the backward continues (the reference DDP's schedule);
+  * ``overlap_planned``  the same, and from the first bucket of a backward until its end the GEMMs plan for ``256 - reserved_cus`` CUs
+                         (`kernels.gemm_set_cus`): single-round grids are cut to what fits beside the collective, leftovers split in K;
+  * ``serialized``       nothing is launched inside the backward; at its end the finished ranges go out as a few large all-reduces (coalesced
+                         up to ``serial_bucket_elems``) and the compute stream waits: no CU contention, communication fully exposed;
+  * ``auto`` (default)   ``autotune(step_fn)`` times each of the three for a few steps on all ranks, takes all_reduce(MAX) of the times and
+                         keeps the fastest; until it has run, ``auto`` behaves as ``overlap``.
+RCCL's CU footprint is bounded by ``rccl_channel_env()`` (NCCL_MAX_NCHANNELS, default 32 = ``reserved_cus``; must be in the environment
+before the communicator is created).
+
 One process per GPU; ``torch.distributed`` backend "nccl" is RCCL on ROCm.  On CPU tensors (gloo, used by the
 world_size-2 tests of this file) the same code path runs with torch casts instead of the HIP cast kernels.
 """
@@ -30,8 +44,27 @@ import torch.distributed as dist
 from . import kernels as K
 
 
+MODES = ("overlap", "overlap_planned", "serialized")
+DEFAULT_RCCL_CHANNELS = 32     # one channel = one workgroup = one CU; 32 is what `overlap_planned` reserves (a whole multiple of the 8 XCDs x 4 shader engines)
+
+
+def rccl_channel_env(env=None, channels=None):
+    """Bound RCCL's CU footprint: NCCL_MAX_NCHANNELS (and a MIN that does not exceed it) in `env` (default os.environ) unless the caller already
+    set them.  Must run BEFORE `init_process_group` / the first collective - RCCL reads them when it creates the communicator.
+    `UDM_RCCL_CHANNELS` overrides the default of 32; 0 leaves RCCL's own choice alone.  Returns the channel cap in force (0 = RCCL's default)."""
+    env = os.environ if env is None else env
+    if channels is None:
+        channels = int(env.get("UDM_RCCL_CHANNELS", DEFAULT_RCCL_CHANNELS) or 0)
+    if channels > 0:
+        env.setdefault("NCCL_MAX_NCHANNELS", str(channels))
+        if "NCCL_MIN_NCHANNELS" in env and int(env["NCCL_MIN_NCHANNELS"]) > int(env["NCCL_MAX_NCHANNELS"]):
+            env["NCCL_MIN_NCHANNELS"] = env["NCCL_MAX_NCHANNELS"]
+    return int(env.get("NCCL_MAX_NCHANNELS", "0") or 0)
+
+
 class BucketedGradSync:
-    def __init__(self, module, process_group=None, min_bucket_elems: int = 32 * 1024 * 1024, wire_dtype=torch.bfloat16, force_single_rank=None):
+    def __init__(self, module, process_group=None, min_bucket_elems: int = 32 * 1024 * 1024, wire_dtype=torch.bfloat16, force_single_rank=None,
+                 mode=None, reserved_cus=None, serial_bucket_elems: int = 256 * 1024 * 1024):
         if not dist.is_initialized():
             raise RuntimeError("BucketedGradSync needs an initialised torch.distributed process group")
         self.module, self.pg = module, process_group
@@ -48,6 +81,18 @@ class BucketedGradSync:
         self.bytes_on_wire = 0
         self.measure_exposed = False   # bench: time the compute stream spends waiting for the comm stream at the end of backward
         self._exposed: List[Tuple[torch.cuda.Event, torch.cuda.Event]] = []
+        mode = os.environ.get("UDM_DDP_MODE", "auto") if mode is None else mode
+        if mode != "auto" and mode not in MODES:
+            raise ValueError(f"BucketedGradSync: unknown mode {mode!r} (one of {MODES + ('auto',)})")
+        self.requested_mode = mode
+        self.mode = "overlap" if mode == "auto" else mode     # what runs now; `autotune` replaces an "auto" request by the measured winner
+        self.mode_timings_ms = None                            # {mode: ms per step, max over ranks} once autotune has run
+        if reserved_cus is None:
+            reserved_cus = int(os.environ.get("UDM_DDP_RESERVED_CUS", "0") or 0) or (int(os.environ.get("NCCL_MAX_NCHANNELS", "0") or 0) or DEFAULT_RCCL_CHANNELS)
+        self.reserved_cus = (int(reserved_cus) + 31) // 32 * 32     # whole shader-engine multiples: an exact fit only works when the held CUs spread one per engine (DESIGN §5 v)
+        self.serial_bucket = int(serial_bucket_elems)
+        self._deferred: List[Tuple[torch.Tensor, int, int]] = []  # serialized mode: ranges finished inside the backward, reduced at its end
+        self._planned = False                                      # overlap_planned: the GEMM plan is in force for the rest of this backward
         module.grad_ready_callback = self._on_ready
         module.grad_sync_finish = self.finish
 
@@ -59,6 +104,12 @@ class BucketedGradSync:
     def _on_ready(self, flat: torch.Tensor, lo: int, hi: int):
         if not self.active or not self.enabled or self._unsynced_passes:
             return   # local pass, or accumulated gradients: reduced after autograd has summed them (finish)
+        if self.mode == "serialized":   # nothing leaves inside the backward; adjacent ranges coalesce into few large messages
+            if self._deferred and self._deferred[-1][0] is flat and self._deferred[-1][2] == lo and hi - self._deferred[-1][1] <= self.serial_bucket:
+                self._deferred[-1] = (flat, self._deferred[-1][1], hi)
+            else:
+                self._deferred.append((flat, lo, hi))
+            return
         if self._pending is not None and self._pending[0] is flat and self._pending[2] == lo:
             lo = self._pending[1]
         elif self._pending is not None:
@@ -101,6 +152,15 @@ class BucketedGradSync:
 
     def _launch(self, flat: torch.Tensor, lo: int, hi: int):
         self._reduce_segment(flat[lo:hi], ("flat", lo))
+        if self.mode == "overlap_planned" and not self._planned:
+            # from here to the end of this backward a collective may be in flight: the GEMMs launched from now on plan for the CUs it leaves
+            K.gemm_set_cus(256 - self.reserved_cus)
+            self._planned = True
+
+    def _unplan(self):
+        if self._planned:
+            K.gemm_set_cus(0)
+            self._planned = False
 
     def _join(self):
         if self.comm_stream is not None:
@@ -128,6 +188,10 @@ class BucketedGradSync:
         if self._pending is not None:
             self._launch(*self._pending)
             self._pending = None
+        for job in self._deferred:
+            self._launch(*job)
+        self._deferred = []
+        self._unplan()     # (the next forward's GEMMs start after the join below: nothing overlaps them)
         self._join()
 
     def allreduce_accumulated(self):
@@ -171,6 +235,51 @@ class BucketedGradSync:
         for g in grads:
             g.copy_(cat[off:off + g.numel()].view_as(g))
             off += g.numel()
+
+    def set_mode(self, mode: str):
+        if mode not in MODES:
+            raise ValueError(f"BucketedGradSync: unknown mode {mode!r} (one of {MODES})")
+        if self._pending is not None or self._deferred:
+            raise RuntimeError("BucketedGradSync.set_mode inside a backward")
+        self._unplan()
+        self.mode = mode
+
+    def autotune(self, step_fn, steps: int = 2, settle: int = 1, modes=MODES, sync_device=None):
+        """Measure `settle + steps` calls of `step_fn()` (one full training step: zero_grad, forward, backward) in every mode, the same sequence on all
+        ranks; the time of a mode is the MAX over ranks of its mean step; the fastest is kept (ties: the earlier of `modes`).  Returns the table
+        {mode: ms}.  No-op unless the mode was requested as "auto" and gradient synchronisation is active."""
+        import time
+
+        if self.requested_mode != "auto" or not self.active:
+            return self.mode_timings_ms
+
+        def fence():
+            if sync_device is not None:
+                torch.cuda.synchronize(sync_device)
+            if self.world > 1:
+                dist.barrier(group=self.pg)
+            if sync_device is not None:
+                torch.cuda.synchronize(sync_device)
+
+        table = {}
+        for m in modes:
+            self.set_mode(m)
+            for _ in range(settle):
+                step_fn()
+            fence()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                step_fn()
+            fence()
+            table[m] = 1e3 * (time.perf_counter() - t0) / max(steps, 1)
+        ms = torch.tensor([table[m] for m in modes], dtype=torch.float64, device=sync_device if sync_device is not None else "cpu")
+        if self.world > 1:
+            dist.all_reduce(ms, op=dist.ReduceOp.MAX, group=self.pg)     # every rank sees the same table -> the same decision
+        ms = ms.tolist()
+        best = min(range(len(modes)), key=lambda i: (ms[i], i))
+        self.mode_timings_ms = {m: ms[i] for i, m in enumerate(modes)}
+        self.set_mode(modes[best])
+        return self.mode_timings_ms
 
     def exposed_ms(self, reset=True) -> float:
         """Sum over recorded backward passes of the time the compute stream waited for the comm stream (needs ``measure_exposed`` and a device sync)."""

@@ -929,7 +929,7 @@ class DIT(nn.Module, _HubMixin):
         db = None
         if lin.bias is not None and not bias_done:
             db = G[id(lin.bias)] if outp == lin.out else torch.zeros(outp, dtype=F32, device=dY.device)
-        few_tiles = ((lin.out + 255) // 256) * ((lin.inp + 255) // 256) <= 128 and lin.out * lin.inp >= 1 << 16
+        few_tiles = K.gemm_tn_wants_splitk(lin.out, lin.inp)
         if Mrows % 64 == 0:  # K-major GEMM reads dY and X in place (transposing LDS reads); bias grad = column sums
             if db is not None:
                 K.colsum(dY, db)

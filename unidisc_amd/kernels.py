@@ -163,6 +163,11 @@ def gemm_tn(a, b, out, *, M=None, N=None, beta=0.0):
     return out
 
 
+def gemm_tn_wants_splitk(M, N, K=None):
+    """Few output tiles (<= half the chip) of a weight-gradient GEMM over the long row contraction: split K (the rule DIT._wgrad dispatches on)."""
+    return ((M + 255) // 256) * ((N + 255) // 256) <= 128 and M * N >= 1 << 16
+
+
 def gemm_tn_pair_ok(M0, M1, N, K):
     """Can two wgrads share one launch of 256 x 256 tiles (gemm_tn_pair)?"""
     if _CUS[0] and _CUS[0] < 256 and (M0 + M1) // 256 * (N // 256) > _CUS[0]:   # CUs are held: the shared grid would no longer fit one round (the two launches each plan for what is left)
@@ -184,8 +189,14 @@ def gemm_tn_pair(a0, b0, out0, a1, b1, out1, *, beta=0.0):
     tiles = ((M0 + M1) // 256) * (N // 256)
     sk = max(1, min(256 // tiles, (K // 64) // 8, 32))   # the rule of udm_gemm_tn_pair_bf16 (sizes the workspace): few tiles over a long K are split in K
     ws = _scratch(sk * (M0 + M1) * N, a0.device) if sk > 1 else None
-    _lib.call("udm_gemm_tn_pair_bf16", _p(a0), _p(b0), _p(out0), M0, a0.stride(0), b0.stride(0), out0.stride(0), _p(a1), _p(b1), _p(out1), M1, a1.stride(0),
-              b1.stride(0), out1.stride(0), N, K, float(beta), _p(ws), ws.numel() if ws is not None else 0, _s())
+    lib = _lib.load()
+    rc = lib.udm_gemm_tn_pair_bf16(_p(a0), _p(b0), _p(out0), M0, a0.stride(0), b0.stride(0), out0.stride(0), _p(a1), _p(b1), _p(out1), M1, a1.stride(0),
+                                   b1.stride(0), out1.stride(0), N, K, float(beta), _p(ws), ws.numel() if ws is not None else 0, _s())
+    if rc == 3:   # "not applicable" (one-wave-per-SIMD kernels switched off, or a pointer off its 16-byte alignment): nothing was launched, issue the two plain problems
+        for a, b, out in ((a0, b0, out0), (a1, b1, out1)):
+            (gemm_tn_splitk if gemm_tn_wants_splitk(out.shape[0], N, K) else gemm_tn)(a, b, out, beta=beta)
+    elif rc != 0:
+        raise RuntimeError(f"udm_gemm_tn_pair_bf16 failed (rc={rc}): {lib.udm_last_error().decode(errors='replace')}")
 
 
 def gemm_tn_splitk(a, b, out, *, M=None, N=None, beta=0.0):

@@ -31,6 +31,7 @@ from .optim import FusedAdamW
 
 class ShardedGradSync(BucketedGradSync):
     def __init__(self, module, **kw):
+        kw.setdefault("mode", "overlap")    # reductions to owners always leave from inside the backward (ddp.py's comm policy covers the replicated path)
         super().__init__(module, **kw)
         self.rank = dist.get_rank(self.pg)
         self.owners: Dict[int, int] = {}                     # bucket start (element offset in the flat buffer) -> owner rank
@@ -185,7 +186,7 @@ class ShardedAdamW(FusedAdamW):
         self.sync = sync
         self._owner: Optional[Dict[int, int]] = None
         self._groups: Optional[List[Tuple[int, List[torch.nn.Parameter]]]] = None   # (owner, parameters of one bucket) in bucket order
-        self._bcast_bufs: Dict[int, torch.Tensor] = {}
+        self._bcast_bufs: dict = {}   # {"ring": [staging buffers]}
         self.ema_decay = float(ema_decay) if ema_decay else None
         self.ema = {} if self.ema_decay else None     # EMA shadows of the OWNED parameters (models/ema.py; stepped with the optimizer, model.py:1541-1545)
         if self.ema is not None and not sync.active:
@@ -214,25 +215,44 @@ class ShardedAdamW(FusedAdamW):
                 if self.ema is not None and id(p) not in self.ema:
                     self.ema[id(p)] = p.detach().clone()
 
+    _BCAST_RING = 3
+
     def _broadcast_from_owners(self, tensors_of):
-        """One broadcast per bucket: the owner packs `tensors_of(p)` of the bucket's parameters into a persistent flat buffer, the others unpack into
-        their parameters (a 1.4 B model has ~600 parameters but ~26 buckets)."""
+        """One broadcast per bucket (a 1.4 B model has ~600 parameters but ~26 buckets): the owner packs `tensors_of(p)` of the bucket's parameters into a
+        flat staging buffer, the others unpack into their parameters.  Staging is a RING of three buffers sized to the largest bucket (~0.6 GB at 1.4 B,
+        not a second fp32 copy of the model): a slot is reused only after the broadcast that last used it has completed and been unpacked."""
         sync = self.sync
-        works = []
-        for gi, (owner, ps) in enumerate(self._groups):
-            n = sum(p.numel() for p in ps)
-            buf = self._bcast_bufs.get(gi)
-            if buf is None or buf.numel() != n or buf.device != ps[0].device:
-                buf = torch.empty(n, dtype=torch.float32, device=ps[0].device)
-                self._bcast_bufs[gi] = buf
-            if owner == sync.rank:
-                torch.cat([tensors_of(p).reshape(-1) for p in ps], out=buf)
-            src = dist.get_global_rank(sync.pg, owner) if sync.pg is not None else owner
-            works.append((dist.broadcast(buf, src=src, group=sync.pg, async_op=True), owner, ps, buf))
-        for w, owner, ps, buf in works:
+        sizes = [sum(p.numel() for p in ps) for _, ps in self._groups]
+        if not sizes:
+            return
+        dev = self._groups[0][1][0].device
+        ring = self._bcast_bufs.get("ring")
+        if ring is None or ring[0].numel() < max(sizes) or ring[0].device != dev:
+            ring = [torch.empty(max(sizes), dtype=torch.float32, device=dev) for _ in range(self._BCAST_RING)]
+            self._bcast_bufs.clear()
+            self._bcast_bufs["ring"] = ring
+        pending = [None] * len(ring)
+
+        def finish(slot):
+            job = pending[slot]
+            if job is None:
+                return
+            w, owner, ps, buf = job
             w.wait()
             if owner != sync.rank:
                 torch._foreach_copy_([p.data.view(-1) for p in ps], list(buf.split([p.numel() for p in ps])))
+            pending[slot] = None
+
+        for gi, (owner, ps) in enumerate(self._groups):
+            slot = gi % len(ring)
+            finish(slot)
+            buf = ring[slot][: sizes[gi]]
+            if owner == sync.rank:
+                torch.cat([tensors_of(p).reshape(-1) for p in ps], out=buf)
+            src = dist.get_global_rank(sync.pg, owner) if sync.pg is not None else owner
+            pending[slot] = (dist.broadcast(buf, src=src, group=sync.pg, async_op=True), owner, ps, buf)
+        for slot in range(len(ring)):
+            finish(slot)
 
     @torch.no_grad()
     def step(self):
