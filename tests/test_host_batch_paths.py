@@ -1,0 +1,124 @@
+"""The host-side batch logic of `unidisc_amd.diffusion.Diffusion` (update_batch / _sample_t / q_xt, written in this repository's own structure) is BIT-EXACT
+against what the imported reference produced for every golden batch (tests/golden/*.npz were recorded from /root/reference by oracle/make_golden*.py):
+joint ids, attention mask, modality, the diffusion times, the per-token and whole-modality masks and x_t - through the fused-launch route (kernel doubles on
+CPU) AND through the generic tensor route, with and without a caller's `allow_move_mask`."""
+import pytest
+import torch
+
+import fake_kernels
+from golden_utils import CASE_NAMES, Golden
+from oracle.cases import INTERLEAVED_CASES
+from product_utils import build_product
+
+ALL = CASE_NAMES + sorted(INTERLEAVED_CASES)
+
+
+@pytest.fixture()
+def fake_k(monkeypatch):
+    import unidisc_amd.dit as dit_mod
+    import unidisc_amd.diffusion as diff_mod
+
+    monkeypatch.setattr(dit_mod, "K", fake_kernels)
+    monkeypatch.setattr(diff_mod, "K", fake_kernels)
+    return fake_kernels
+
+
+def _product(name):
+    g = Golden(name)
+    diff = build_product(g, device="cpu")
+    diff.rng_device = "cpu"
+    return g, diff
+
+
+@pytest.mark.parametrize("name", ALL)
+def test_update_batch_fields_equal_the_reference(name, fake_k):
+    g, diff = _product(name)
+    src = g.batch()
+    keep = {k: v.clone() for k, v in src.items()}
+    b = diff.update_batch(src)
+    assert torch.equal(b["input_ids"], g.t("fp32/input_ids")) and b["input_ids"].dtype == torch.int64
+    assert torch.equal(b["attention_mask"], g.t("fp32/attention_mask").bool()) and b["attention_mask"].dtype == torch.bool
+    if g.has("fp32/modality"):
+        mod = g.t("fp32/modality").long()
+        assert torch.equal(b["modality"], mod)
+        assert torch.equal(b["modality_mask"], torch.nn.functional.one_hot(mod, 2).bool())
+        assert torch.equal(b["batch_contains_img"], (mod == 1).any(-1))
+        assert torch.equal(b["txt_sl"], mod == 0) and torch.equal(b["img_sl"], mod == 1)
+    if "sample_ids" in b and g.has("fp32/sample_ids"):
+        assert torch.equal(b["sample_ids"], g.t("fp32/sample_ids").long())
+    for k, v in keep.items():   # the caller's tensors are not edited in place
+        assert torch.equal(src[k], v), k
+    # lists of per-sample tensors (a collate that did not stack) give the same batch
+    if "img_input_ids" in keep:
+        lst = dict(keep)
+        lst["img_input_ids"] = list(keep["img_input_ids"])
+        b2 = diff.update_batch(lst)
+        assert torch.equal(b2["input_ids"], b["input_ids"])
+
+
+@pytest.mark.parametrize("generic", [False, True])
+@pytest.mark.parametrize("name", ALL)
+def test_sample_t_and_qxt_bit_exact_on_both_routes(name, generic, fake_k):
+    g, diff = _product(name)
+    diff._generic_qxt = generic
+    b = diff.update_batch(g.batch())
+    torch.manual_seed(g.case["step_seed"])
+    t = diff._sample_t(b["input_ids"].shape[0], b["input_ids"].device)
+    assert torch.equal(t, g.t("fp32/t")) and t.dtype == torch.float32
+    sigma, dsigma = diff.noise(t)
+    move_chance = 1 - torch.exp(-sigma[:, None])
+    assert torch.equal(move_chance, g.t("fp32/move_chance").reshape(move_chance.shape))
+    xt, ignore, _, smt, smi, move = diff.q_xt(b["input_ids"], move_chance, return_ignore_batch_mask_for_metrics=True, batch=b)
+    assert torch.equal(xt, g.t("fp32/xt")) and torch.equal(move, g.t("fp32/move_indices"))
+    if g.has("fp32/should_mask_txt") and smt is not None:
+        assert torch.equal(smt.reshape(-1), g.t("fp32/should_mask_txt").reshape(-1).bool())
+        assert torch.equal(smi.reshape(-1), g.t("fp32/should_mask_img").reshape(-1).bool())
+    if g.has("fp32/ignore_batch_mask") and ignore is not None:
+        assert torch.equal(ignore.reshape(-1), g.t("fp32/ignore_batch_mask").reshape(-1).bool())
+
+
+@pytest.mark.parametrize("generic", [False, True])
+@pytest.mark.parametrize("name", CASE_NAMES)
+def test_allow_move_mask_protects_positions_after_the_lottery(name, generic, fake_k):
+    """`allow_move_mask` (model.py:564-566): AND-ed onto the final move mask; the two routes agree and equal the golden mask & allow."""
+    g, diff = _product(name)
+    diff._generic_qxt = generic
+    b = diff.update_batch(g.batch())
+    torch.manual_seed(g.case["step_seed"])
+    t = diff._sample_t(b["input_ids"].shape[0], b["input_ids"].device)
+    move_chance = 1 - torch.exp(-diff.noise(t)[0][:, None])
+    allow = torch.rand(b["input_ids"].shape, generator=torch.Generator().manual_seed(3)) < 0.6
+    xt, _, _, _, _, move = diff.q_xt(b["input_ids"], move_chance, allow_move_mask=allow, return_ignore_batch_mask_for_metrics=True, batch=b)
+    want = g.t("fp32/move_indices") & allow
+    assert torch.equal(move, want)
+    assert torch.equal(xt, torch.where(want, diff.mask_index, b["input_ids"]))
+
+
+def test_static_layout_masks_a_side_on_top_of_the_token_mask(fake_k):
+    """Without `multimodal_batches` the whole-modality lottery ORs the side's static slice onto the per-token mask (model.py:533-539) and never masks the image
+    side of a text-only sample; checked against a literal per-row evaluation."""
+    g, diff = _product("c_large")
+    diff.config.trainer.multimodal_batches = False
+    diff.config.trainer.mask_entire_modality = 0.9     # (so that the six seeds hit text-only, image-only and both-drawn rows)
+    b = diff.update_batch(g.batch())
+    B, L = b["input_ids"].shape
+    Lt = g.case["txt_length"]
+    for seed in range(6):
+        torch.manual_seed(seed)
+        mc = torch.full((B, 1), 0.3)
+        xt, ignore, _, smt, smi, move = diff.q_xt(b["input_ids"], mc, return_ignore_batch_mask_for_metrics=True, batch=b)
+        torch.manual_seed(seed)
+        r = torch.rand(B, L)
+        r_t, r_i = torch.rand(B, 1), torch.rand(B, 1)
+        p = diff.config.trainer.mask_entire_modality / 2
+        for i in range(B):
+            mt, mi = bool(r_t[i] < p), bool(r_i[i] < p)
+            if mt and mi:
+                mt = mi = False
+            row = r[i] < 0.3
+            if mt:
+                row[:Lt] = True
+            if mi:
+                row[Lt:] = True
+            assert torch.equal(move[i], row) and bool(smt[i]) == mt and bool(smi[i]) == mi and bool(ignore[i]) == (mt or mi)
+        assert torch.equal(xt, torch.where(move, diff.mask_index, b["input_ids"]))

@@ -123,6 +123,7 @@ class Diffusion:
         self.neg_infinity = -1000000.0  # model_setup.py:269
 
     rng_device = None  # set to "cpu" to draw t / masks from the CPU generator (bit-reproducible across devices)
+    _generic_qxt = False   # tests: route q_xt through the tensor statements even where the fused launch applies
 
     def _rand(self, *shape, device):
         if self.rng_device is None:
@@ -143,83 +144,107 @@ class Diffusion:
     def img_sl(self, batch=None):
         return batch["modality_mask"][..., 1]
 
-    # ---- model.py:157-395
+    # ---- the batch contract of model.py:157-395 (token-dataset and pre-tokenised branches), in this module's own structure
     def update_batch(self, batch):
-        cfg, tr, m = self.config, cfg_get(self.config, "trainer"), cfg_get(self.config, "model")
+        """Dataset batch -> model batch.  Output keys and values are the reference's (`input_ids`, `attention_mask`, `modality`, `modality_mask`,
+        `batch_contains_img`, `txt_sl`, `img_sl`, `sample_ids`), produced in three stages:
+          1. everything onto the device in the DATASET's dtypes (80 KiB per step at 1.4 B), so that
+          2. the joint sequence comes from ONE gather launch (`_assemble_on_device`, tokens.hip) wherever the batch has the token-dataset shape, and from
+             `_joint_sequence_generic` (slice writes into preallocated tensors) for the shapes the kernel does not cover;
+          3. modality / attention-mask / sample-id fields derived without in-place edits of the caller's tensors."""
         if batch is None:
             return batch
-        batch = dict(batch.items()) if not isinstance(batch, dict) else dict(batch)
+        cfg, tr, m = self.config, cfg_get(self.config, "trainer"), cfg_get(self.config, "model")
+        data = cfg_get(cfg, "data")
+        out = {}
+        for key, val in (batch.items() if not isinstance(batch, dict) else dict(batch).items()):
+            if isinstance(val, (list, tuple)) and val and all(isinstance(v, torch.Tensor) for v in val) and key in ("img_input_ids", "txt_input_ids", "sample_ids"):
+                val = torch.stack(list(val), dim=0)
+            out[key] = val.to(self.device) if isinstance(val, torch.Tensor) else val
         fused = False
-        if self.image_model or cfg_get(cfg_get(cfg, "data"), "force_image_dataset", False):
-            fused = self._assemble_on_device(batch, tr, m)
-            if fused:
-                pass
-            elif "txt_input_ids" in batch or "img_input_ids" in batch:  # :183-212
-                for key in ("img_input_ids", "txt_input_ids", "sample_ids"):
-                    if key in batch:
-                        if isinstance(batch[key], list):
-                            batch[key] = torch.stack(batch[key], dim=0)
-                        batch[key] = batch[key].to(torch.int64)
-                img_input_ids = batch.pop("img_input_ids")
-                batch["input_ids"] = img_input_ids
-                batch["attention_mask"] = torch.ones_like(img_input_ids).to(torch.bool)
-                if "txt_input_ids" in batch:
-                    batch["input_ids"] = torch.cat([batch["txt_input_ids"], batch["input_ids"] + self.text_vocab_size], dim=-1)
-                    batch["attention_mask"] = torch.cat([batch["txt_attention_mask"], batch["attention_mask"]], dim=-1)
-                batch["input_ids"] = batch["input_ids"].to(torch.int64)
-                if "modality" not in batch:
-                    if cfg_get(tr, "ignore_text_in_unified", False):
-                        modality = torch.ones_like(batch["input_ids"], dtype=torch.int64)
-                    else:
-                        assert cfg_get(m, "txt_length") > 0 and cfg_get(m, "img_length") > 0
-                        modality = torch.zeros_like(batch["input_ids"], dtype=torch.int64)
-                        modality[:, -img_input_ids.shape[-1]:] = 1
-                    batch["modality"] = modality
-            elif cfg_get(tr, "multimodal_batches", False) or ("input_ids" in batch and "modality" in batch and "img" not in batch):
-                # :214-250 (pre-tokenised multimodal batches); also batches already assembled on the device by token_data.TokenBatcher
-                if "img" in batch:
-                    raise NotImplementedError("unidisc_amd: raw-image batches need the VQ tokenizer, which is outside the denoising hot path")
-                batch["input_ids"] = batch["input_ids"].to(torch.int64)
-                if "sample_ids" in batch:
-                    batch["sample_ids"] = batch["sample_ids"].to(torch.int64)
+        if self.image_model or cfg_get(data, "force_image_dataset", False):
+            has_token_fields = "txt_input_ids" in out or "img_input_ids" in out
+            assembled = "input_ids" in out and "modality" in out
+            if "img" in out and not has_token_fields:
+                raise NotImplementedError("unidisc_amd: raw-image batches need the VQ tokenizer, which is outside the denoising hot path")
+            if has_token_fields:
+                fused = self._assemble_on_device(out, tr, m)
+                if not fused:
+                    self._joint_sequence_generic(out, tr, m)
+            elif cfg_get(tr, "multimodal_batches", False) or assembled:
+                # pre-tokenised multimodal batches, and batches token_data.TokenBatcher assembled on the device already
+                out["input_ids"] = out["input_ids"].long()
                 if cfg_get(tr, "force_shift_image_batches", False):
-                    batch["input_ids"] = torch.where(batch["modality"] == 1, batch["input_ids"] + self.text_vocab_size, batch["input_ids"])
+                    out["input_ids"] = out["input_ids"] + (out["modality"] == 1).long() * self.text_vocab_size
             else:
                 raise NotImplementedError("unidisc_amd: raw-image batches need the VQ tokenizer, which is outside the denoising hot path")
-            if batch["input_ids"].shape[1] != cfg_get(m, "length") and not cfg_get(tr, "ar_inpainting", False):
-                assert False, f"input ids are not the correct length input ids shape: {batch['input_ids'].shape}, model length: {cfg_get(m, 'length')}"
-        if "modality" in batch:  # :296-304
-            batch["modality"] = batch["modality"].to(torch.int64)
-            if cfg_get(tr, "multimodal_batches", False) and batch["modality"].ndim == 2 and batch["modality"].shape[-1] == 1:
-                batch["modality"] = batch["modality"].repeat(1, cfg_get(m, "length"))
-        else:
-            if self.image_model and not cfg_get(tr, "multimodal_batches", False):
-                modality = torch.zeros_like(batch["input_ids"], dtype=torch.int64)
-                modality[:, self.static_img_sl] = 1
-                batch["modality"] = modality
-            elif cfg_get(cfg_get(cfg, "data"), "txt_only", False):
-                batch["modality"] = torch.zeros_like(batch["input_ids"], dtype=torch.int64)
-        if "modality" in batch:  # :309-315
-            if not fused:   # (the assembly kernel writes 0 on the text positions and 1 on the image positions of a batch that has both: nothing to fix or to check)
-                batch["modality"][batch["modality"] == -1] = 0
-                self._check_modality_range(batch["modality"])
-            batch["modality_mask"] = F.one_hot(batch["modality"], num_classes=2).to(torch.bool)
-            batch["batch_contains_img"] = (batch["modality"] == 1).any(dim=-1)
-            batch["txt_sl"] = self.txt_sl(batch)
-            batch["img_sl"] = self.img_sl(batch)
-        for key in list(batch.keys()):  # :337-343
-            if isinstance(batch[key], torch.Tensor):
-                batch[key] = batch[key].to(self.device)
-        if cfg_get(tr, "force_full_attention_mask", False):
-            batch["attention_mask"] = torch.ones_like(batch["attention_mask"], dtype=torch.bool)
-        batch["attention_mask"] = batch["attention_mask"].to(torch.bool)
-        if cfg_get(cfg_get(cfg, "data"), "require_sample_ids", False):  # :349-353
-            assert "sample_ids" in batch
-            batch["sample_ids"][~(batch["attention_mask"].bool())] = -1
-            batch["attention_mask"][batch["sample_ids"] == -1] = False
-        if cfg_get(tr, "interleaved", False) and "sample_ids" not in batch:
-            batch["sample_ids"] = torch.zeros_like(batch["modality"], dtype=torch.int64)
-        return batch
+            if out["input_ids"].shape[1] != cfg_get(m, "length") and not cfg_get(tr, "ar_inpainting", False):
+                raise AssertionError(f"input ids are not the correct length input ids shape: {out['input_ids'].shape}, model length: {cfg_get(m, 'length')}")
+        if "sample_ids" in out:
+            out["sample_ids"] = out["sample_ids"].long()
+        self._modality_fields(out, tr, m, data, checked=fused)
+        self._attention_fields(out, tr, data)
+        return out
+
+    def _joint_sequence_generic(self, b, tr, m):
+        """`input_ids` / `attention_mask` / `modality` of a token batch the gather kernel does not take (host-dtype surprises, text-less or user-supplied
+        modality, CPU tests): [text | image + Vt] written into preallocated [B, Lt + Li] tensors."""
+        img = b.pop("img_input_ids")
+        txt = b.get("txt_input_ids")
+        B, Li = img.shape[0], img.shape[-1]
+        Lt = txt.shape[-1] if txt is not None else 0
+        ids = torch.empty((B, Lt + Li), dtype=torch.int64, device=img.device)
+        keep = torch.ones((B, Lt + Li), dtype=torch.bool, device=img.device)
+        ids[:, Lt:] = img
+        if txt is not None:   # image ids live behind the text vocabulary only in a joint sequence
+            b["txt_input_ids"] = txt.long()
+            ids[:, Lt:] += self.text_vocab_size
+            ids[:, :Lt] = txt
+            keep[:, :Lt] = b["txt_attention_mask"]
+        b["input_ids"], b["attention_mask"] = ids, keep
+        if "modality" not in b:
+            if cfg_get(tr, "ignore_text_in_unified", False):
+                b["modality"] = torch.ones_like(ids)
+            else:
+                if not (cfg_get(m, "txt_length") > 0 and cfg_get(m, "img_length") > 0):
+                    raise AssertionError("a token batch without `modality` needs model.txt_length > 0 and model.img_length > 0")
+                b["modality"] = (torch.arange(Lt + Li, device=ids.device) >= Lt).long().expand(B, -1).contiguous()
+
+    def _modality_fields(self, b, tr, m, data, checked=False):
+        mm = cfg_get(tr, "multimodal_batches", False)
+        mod = b.get("modality")
+        if mod is not None:
+            mod = mod.long()
+            if mm and mod.ndim == 2 and mod.shape[-1] == 1:    # one modality per sample -> per token
+                mod = mod.expand(-1, cfg_get(m, "length")).contiguous()
+        elif self.image_model and not mm:                     # static layout: the image occupies the last img_length positions
+            mod = torch.zeros_like(b["input_ids"], dtype=torch.int64)
+            mod[:, self.static_img_sl] = 1
+        elif cfg_get(data, "txt_only", False):
+            mod = torch.zeros_like(b["input_ids"], dtype=torch.int64)
+        if mod is None:
+            return
+        if not checked:   # (the gather kernel writes 0 / 1 by construction)
+            mod = mod.clamp_min(0)          # padding (-1, PackingCollate) counts as text
+            self._check_modality_range(mod)
+        b["modality"] = mod
+        is_img = mod == 1
+        b["modality_mask"] = torch.stack((~is_img, is_img), dim=-1)     # == one_hot(modality, 2).bool() once the range check holds
+        b["batch_contains_img"] = is_img.any(dim=-1)
+        b["txt_sl"], b["img_sl"] = self.txt_sl(b), self.img_sl(b)
+
+    def _attention_fields(self, b, tr, data):
+        am = b["attention_mask"]
+        am = torch.ones_like(am, dtype=torch.bool) if cfg_get(tr, "force_full_attention_mask", False) else am.to(torch.bool)
+        if cfg_get(data, "require_sample_ids", False):
+            if "sample_ids" not in b:
+                raise AssertionError("data.require_sample_ids: the batch has no `sample_ids`")
+            sid = torch.where(am, b["sample_ids"], torch.full_like(b["sample_ids"], -1))     # padding belongs to no sample ...
+            am = am & (sid != -1)                                                             # ... and a position without a sample is padding
+            b["sample_ids"] = sid
+        b["attention_mask"] = am
+        if cfg_get(tr, "interleaved", False) and "sample_ids" not in b:
+            b["sample_ids"] = torch.zeros_like(b["modality"], dtype=torch.int64)
 
     def _assemble_on_device(self, batch, tr, m):
         """model.py:183-212 for a token batch that is already on the device in the dataset's own dtypes (int32 text, int16 image ids, bool text mask): joint ids
@@ -280,130 +305,133 @@ class Diffusion:
         batch = self.update_batch(batch)
         return self.compute_loss(batch, prefix="train", batch_idx=batch_idx)
 
-    # ---- model.py:424-587 (absorbing state, non-interleaved)
+    # ---- forward corruption q(x_t | x_0), absorbing state (contract of model.py:424-587)
     def q_xt(self, x, move_chance, allow_move_mask=None, return_ignore_batch_mask_for_metrics=False, mask_image_square=False, mask_text_region=False,
              batch=None):
+        """x_t = [MASK] where a position "moves", x_0 elsewhere.  A position moves when its uniform falls below the sample's move chance; in training a
+        sample's whole text (or image) side may be masked instead (`trainer.mask_entire_modality`).  Draw order - rand(B, L), then the per-sample draws, then
+        (interleaved) one draw per block - is the reference's, so masks are bit-exact for a given generator state.
+        Returns x_t, or (x_t, ignore_batch_mask_for_metrics, None, should_mask_txt, should_mask_img, move_indices)."""
         tr = cfg_get(self.config, "trainer")
         if mask_image_square or mask_text_region:
             raise NotImplementedError("unidisc_amd: square / region masking are evaluation-time options outside the hot path")
-        r_move = self._rand(*x.shape, device=x.device)
-        mask_prob = cfg_get(tr, "mask_entire_modality", None)
-        whole = mask_prob is not None and self.backbone.training
-        if (allow_move_mask is None and cfg_get(tr, "discrete_diffusion_mode", "absorbing") == "absorbing" and x.dim() == 2 and x.dtype == torch.int64
-                and move_chance.numel() == x.shape[0] and cfg_get(tr, "joint_ar_nar_prob", None) is None and cfg_get(tr, "first_token_dropout", None) is None
-                and (not whole or (cfg_get(tr, "multimodal_batches", False) and not cfg_get(tr, "interleaved", False)))):
-            # the statements below (comparisons and selects on [B, L] / [B, 1]) as ONE launch; the random draws stay here, in the reference's order
-            r_txt = r_img = None
-            p_txt = p_img = 0.0
-            if whole:
-                assert batch is not None
-                if cfg_get(tr, "mask_txt_only", False):
-                    r_txt, p_txt = self._rand(x.shape[0], 1, device=x.device), mask_prob
-                else:
-                    r_txt, p_txt = self._rand(x.shape[0], 1, device=x.device), mask_prob / 2
-                    r_img, p_img = self._rand(x.shape[0], 1, device=x.device), mask_prob / 2
-            xt, move_indices, should_mask_txt, should_mask_img, ignore = K.qxt_absorbing(
-                x.contiguous(), r_move.float().contiguous(), move_chance.float(), self.mask_index, r_txt=r_txt, r_img=r_img, p_txt=p_txt, p_img=p_img,
-                modality_mask=batch["modality_mask"].contiguous() if whole else None)
-            if return_ignore_batch_mask_for_metrics:
-                return xt, ignore, None, should_mask_txt, should_mask_img, move_indices
-            return xt
-        move_indices = r_move < move_chance
-        ignore_batch_mask_for_metrics = None
-        should_mask_txt, should_mask_img = None, None
-        if mask_prob is not None and self.backbone.training:
-            assert batch is not None
-            batch_size, seq_len = x.shape
-            if cfg_get(tr, "mask_txt_only", False):
-                should_mask_txt = self._rand(batch_size, 1, device=x.device) < mask_prob
-                should_mask_img = torch.zeros_like(should_mask_txt, device=x.device)
-            else:
-                should_mask_txt = self._rand(batch_size, 1, device=x.device) < mask_prob / 2
-                should_mask_img = self._rand(batch_size, 1, device=x.device) < mask_prob / 2
-            if cfg_get(tr, "multimodal_batches", False):
-                if cfg_get(tr, "interleaved", False):
-                    # model.py:483-522: every (modality, packed sample) block of more than 4 tokens is masked as a whole with probability
-                    # 2 p (k + 1) / n  (k: index of the block inside its sample, n: blocks of that sample); one uniform per block, drawn after
-                    # the two per-row draws above (same call order as the reference).
-                    # Everything stays on the device; the ONE host read is the number of candidate blocks (it sizes the uniform draw - the reference
-                    # reads every block boundary back).  Blocks are numbered in (row, position) order, the order of the reference's draws.
-                    mod, sid = batch["modality"], batch["sample_ids"]
-                    dev, N = x.device, batch_size * seq_len
-                    chg = torch.ones((batch_size, seq_len), dtype=torch.bool, device=dev)
-                    chg[:, 1:] = (mod[:, 1:] != mod[:, :-1]) | (sid[:, 1:] != sid[:, :-1])
-                    gid = chg.reshape(-1).cumsum(0) - 1                                          # block of every position
-                    one = torch.ones(N, dtype=torch.int64, device=dev)
-                    ar = torch.arange(N, device=dev)
-                    blen = torch.zeros(N, dtype=torch.int64, device=dev).scatter_add_(0, gid, one)
-                    bsid = torch.full((N,), -1, dtype=torch.int64, device=dev).scatter_(0, gid, sid.reshape(-1))
-                    brow = torch.zeros(N, dtype=torch.int64, device=dev).scatter_(0, gid, ar // seq_len)
-                    cand = (bsid >= 0) & (blen > 4)
-                    n_cand = int(cand.sum())
-                    accum = torch.zeros_like(move_indices)
-                    ignore_batch_mask_for_metrics = torch.zeros((batch_size,), device=dev, dtype=torch.bool)
-                    if n_cand:
-                        # k = index of the block among the candidate blocks of its (row, sample id), n = their number: stable sort by that key
-                        key = torch.where(cand, brow * (seq_len + 1) + bsid, torch.full_like(brow, (batch_size + 1) * (seq_len + 1)))
-                        order = torch.argsort(key, stable=True)
-                        skey = key[order]
-                        newg = torch.ones(N, dtype=torch.bool, device=dev)
-                        newg[1:] = skey[1:] != skey[:-1]
-                        g_first = torch.cummax(torch.where(newg, ar, torch.zeros_like(ar)), 0).values
-                        g_id = newg.cumsum(0) - 1
-                        g_size = torch.zeros(N, dtype=torch.int64, device=dev).scatter_add_(0, g_id, one)
-                        k = torch.empty_like(ar).scatter_(0, order, ar - g_first)
-                        n = torch.empty_like(ar).scatter_(0, order, g_size[g_id])
-                        r = self._rand(n_cand, 1, device=dev).reshape(-1)
-                        r_blk = r[(cand.cumsum(0) - 1).clamp(min=0)]
-                        thr = mask_prob * ((k + 1) / n) * 2                                      # fp32, in the reference's order of operations
-                        hit = cand & (r_blk < thr)
-                        accum = hit[gid].reshape(batch_size, seq_len)
-                        ignore_batch_mask_for_metrics = torch.zeros(batch_size, dtype=torch.int64, device=dev).scatter_add_(0, brow, hit.long()) > 0
-                    move_indices = move_indices | accum
-                    xt = torch.where(move_indices, self.mask_index, x)
-                    if allow_move_mask is not None:
-                        raise NotImplementedError("unidisc_amd: allow_move_mask with interleaved batches")
-                    if return_ignore_batch_mask_for_metrics:
-                        return xt, ignore_batch_mask_for_metrics, None, should_mask_txt, should_mask_img, move_indices
-                    return xt
-                both_mask = should_mask_txt & should_mask_img
-                should_mask_txt = torch.where(both_mask, False, should_mask_txt)
-                should_mask_img = torch.where(both_mask, False, should_mask_img)
-                move_indices = torch.where(should_mask_txt, batch["modality_mask"][..., 0], move_indices)
-                move_indices = torch.where(should_mask_img, batch["modality_mask"][..., 1], move_indices)
-                ignore_batch_mask_for_metrics = should_mask_img | should_mask_txt
-            else:
-                both_mask = should_mask_txt & should_mask_img
-                should_mask_txt[both_mask] = False
-                should_mask_img[both_mask] = False
-                should_mask_img[batch["txt_sl"].all(dim=-1)] = False
-                move_indices[:, self.static_txt_sl] = torch.where(should_mask_txt, True, move_indices[:, self.static_txt_sl])
-                move_indices[:, self.static_img_sl] = torch.where(should_mask_img, True, move_indices[:, self.static_img_sl])
-                ignore_batch_mask_for_metrics = should_mask_img | should_mask_txt
         for flag in ("joint_ar_nar_prob", "first_token_dropout"):
             if cfg_get(tr, flag, None) is not None:
                 raise NotImplementedError(f"unidisc_amd: trainer.{flag} is not on the denoising hot path")
-        if allow_move_mask is not None:
-            move_indices = move_indices & allow_move_mask
         if cfg_get(tr, "discrete_diffusion_mode", "absorbing") != "absorbing":
             raise NotImplementedError("unidisc_amd: only absorbing-state diffusion is implemented")
-        xt = torch.where(move_indices, self.mask_index, x)
-        if return_ignore_batch_mask_for_metrics:
-            return xt, ignore_batch_mask_for_metrics, None, should_mask_txt, should_mask_img, move_indices
-        return xt
+        r_move = self._rand(*x.shape, device=x.device)
+        mask_prob = cfg_get(tr, "mask_entire_modality", None)
+        whole = mask_prob is not None and self.backbone.training
+        multimodal, interleaved = cfg_get(tr, "multimodal_batches", False), cfg_get(tr, "interleaved", False)
+        if whole and batch is None:
+            raise AssertionError("q_xt: trainer.mask_entire_modality needs the batch (modality masks)")
+        # per-sample uniforms of the whole-modality lottery: text first, image second (none for the image side under mask_txt_only)
+        r_txt = r_img = None
+        p_txt = p_img = 0.0
+        if whole:
+            r_txt = self._rand(x.shape[0], 1, device=x.device)
+            if cfg_get(tr, "mask_txt_only", False):
+                p_txt = mask_prob
+            else:
+                r_img = self._rand(x.shape[0], 1, device=x.device)
+                p_txt = p_img = mask_prob / 2
 
-    def _sample_t(self, n, device):  # model.py:589-619
+        kernel_ok = (not self._generic_qxt and x.dim() == 2 and x.dtype == torch.int64 and move_chance.numel() == x.shape[0] and not (whole and (interleaved or not multimodal)))
+        if kernel_ok:
+            # comparisons and selects on [B, L] / [B, 1] as ONE launch (udm_qxt_absorbing): per-token move, the lottery with its both-sides-drawn rule,
+            # the row REPLACEMENT by the modality mask, x_t
+            xt, move, smt, smi, ignore = K.qxt_absorbing(x.contiguous(), r_move.float().contiguous(), move_chance.float(), self.mask_index, r_txt=r_txt, r_img=r_img,
+                                                         p_txt=p_txt, p_img=p_img, modality_mask=batch["modality_mask"].contiguous() if whole else None)
+            if allow_move_mask is not None:    # positions the caller protects never move (applied after the lottery)
+                move = move & allow_move_mask
+                xt = torch.where(move, self.mask_index, x)
+            return (xt, ignore, None, smt, smi, move) if return_ignore_batch_mask_for_metrics else xt
+
+        move = r_move < move_chance
+        smt = smi = ignore = None
+        if whole:
+            smt = r_txt < p_txt
+            smi = (r_img < p_img) if r_img is not None else torch.zeros_like(smt)
+            if interleaved and multimodal:
+                if allow_move_mask is not None:
+                    raise NotImplementedError("unidisc_amd: allow_move_mask with interleaved batches")
+                block_move, ignore = self._interleaved_block_lottery(batch, mask_prob, x.shape, x.device)
+                move = move | block_move
+                xt = torch.where(move, self.mask_index, x)
+                return (xt, ignore, None, smt, smi, move) if return_ignore_batch_mask_for_metrics else xt
+            # a sample that drew BOTH sides keeps its per-token mask
+            both = smt & smi
+            smt, smi = smt & ~both, smi & ~both
+            if multimodal:    # the row's mask is REPLACED: "all text masked, all image clean" (or the reverse)
+                txt_cols, img_cols = batch["modality_mask"][..., 0], batch["modality_mask"][..., 1]
+                move = torch.where(smt, txt_cols, torch.where(smi, img_cols, move))
+            else:             # static layout: the side is masked ON TOP of the per-token mask; a text-only sample has no image side to mask
+                smi = smi & ~batch["txt_sl"].all(dim=-1, keepdim=True)
+                cols = torch.arange(x.shape[1], device=x.device)
+                txt_cols = torch.zeros(x.shape[1], dtype=torch.bool, device=x.device)
+                img_cols = torch.zeros_like(txt_cols)
+                txt_cols[cols[self.static_txt_sl]] = True
+                img_cols[cols[self.static_img_sl]] = True
+                move = move | (smt & txt_cols) | (smi & img_cols)
+            ignore = smt | smi
+        if allow_move_mask is not None:
+            move = move & allow_move_mask
+        xt = torch.where(move, self.mask_index, x)
+        return (xt, ignore, None, smt, smi, move) if return_ignore_batch_mask_for_metrics else xt
+
+    def _interleaved_block_lottery(self, batch, mask_prob, shape, dev):
+        """Packed / interleaved rows (model.py:483-522): every (modality, packed sample) block of more than 4 tokens is masked as a whole with probability
+        2 p (k + 1) / n  (k: index of the block inside its sample, n: blocks of that sample); one uniform per block, drawn after the two per-row draws
+        (the reference's call order).  Everything stays on the device; the ONE host read is the number of candidate blocks (it sizes the uniform draw - the
+        reference reads every block boundary back).  Blocks are numbered in (row, position) order, the order of the reference's draws.
+        Returns (block mask [B, L], rows that had a block masked [B])."""
+        batch_size, seq_len = shape
+        mod, sid = batch["modality"], batch["sample_ids"]
+        N = batch_size * seq_len
+        chg = torch.ones((batch_size, seq_len), dtype=torch.bool, device=dev)
+        chg[:, 1:] = (mod[:, 1:] != mod[:, :-1]) | (sid[:, 1:] != sid[:, :-1])
+        gid = chg.reshape(-1).cumsum(0) - 1                                          # block of every position
+        one = torch.ones(N, dtype=torch.int64, device=dev)
+        ar = torch.arange(N, device=dev)
+        blen = torch.zeros(N, dtype=torch.int64, device=dev).scatter_add_(0, gid, one)
+        bsid = torch.full((N,), -1, dtype=torch.int64, device=dev).scatter_(0, gid, sid.reshape(-1))
+        brow = torch.zeros(N, dtype=torch.int64, device=dev).scatter_(0, gid, ar // seq_len)
+        cand = (bsid >= 0) & (blen > 4)
+        n_cand = int(cand.sum())
+        if not n_cand:
+            return torch.zeros((batch_size, seq_len), dtype=torch.bool, device=dev), torch.zeros((batch_size,), device=dev, dtype=torch.bool)
+        # k = index of the block among the candidate blocks of its (row, sample id), n = their number: stable sort by that key
+        key = torch.where(cand, brow * (seq_len + 1) + bsid, torch.full_like(brow, (batch_size + 1) * (seq_len + 1)))
+        order = torch.argsort(key, stable=True)
+        skey = key[order]
+        newg = torch.ones(N, dtype=torch.bool, device=dev)
+        newg[1:] = skey[1:] != skey[:-1]
+        g_first = torch.cummax(torch.where(newg, ar, torch.zeros_like(ar)), 0).values
+        g_id = newg.cumsum(0) - 1
+        g_size = torch.zeros(N, dtype=torch.int64, device=dev).scatter_add_(0, g_id, one)
+        k = torch.empty_like(ar).scatter_(0, order, ar - g_first)
+        n = torch.empty_like(ar).scatter_(0, order, g_size[g_id])
+        r = self._rand(n_cand, 1, device=dev).reshape(-1)
+        r_blk = r[(cand.cumsum(0) - 1).clamp(min=0)]
+        thr = mask_prob * ((k + 1) / n) * 2                                      # fp32, in the reference's order of operations
+        hit = cand & (r_blk < thr)
+        rows_hit = torch.zeros(batch_size, dtype=torch.int64, device=dev).scatter_add_(0, brow, hit.long()) > 0
+        return hit[gid].reshape(batch_size, seq_len), rows_hit
+
+    def _sample_t(self, n, device):
+        """Diffusion times of a batch (contract of model.py:589-619): t = eps_s + (1 - eps_s) u with u ~ U[0, 1), stratified over the batch when
+        `antithetic_sampling` (sample i owns the i-th of n equal strata).  The GPU step gets the same values from `udm_sample_t_noise`."""
         tr = cfg_get(self.config, "trainer")
-        _eps_t = self._rand(n, device=device)
         if cfg_get(tr, "joint_ar_nar_timestep_warmup_steps", None) is not None:
             raise NotImplementedError("unidisc_amd: joint AR/NAR timestep warm-up is not on the denoising hot path")
+        u = self._rand(n, device=device)
         if self.antithetic_sampling:
-            offset = torch.arange(n, device=device) / n
-            _eps_t = (_eps_t / n + offset) % 1
-        if cfg_get(tr, "force_timestep", None) is not None:
-            _eps_t[:] = cfg_get(tr, "force_timestep")
-        t = (1 - self.sampling_eps) * _eps_t + self.sampling_eps
-        return t.to(torch.float32)
+            u = torch.remainder(u / n + torch.arange(n, device=device) / n, 1)
+        forced = cfg_get(tr, "force_timestep", None)
+        if forced is not None:
+            u = torch.full_like(u, forced)
+        return (self.sampling_eps + (1 - self.sampling_eps) * u).to(torch.float32)
 
     def _restrict(self):
         return bool(cfg_get(cfg_get(self.config, "model"), "force_argmax_valid_indices", False))

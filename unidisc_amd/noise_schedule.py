@@ -1,36 +1,46 @@
-"""Noise schedules on the hot path (reference models/noise_schedule.py)."""
+"""The noise schedule of the hot path: log-linear total noise (reference models/noise_schedule.py:128-150, `get_noise` :13-28).
+
+With total noise sigma(t) = -log(1 - (1 - eps) t) the absorbing-state move chance 1 - exp(-sigma) is simply (1 - eps) t, and the loss
+weight sigma'(t) / expm1(sigma(t)) is 1 / t up to eps.  On the GPU step both values come out of `udm_sample_t_noise` together with t itself
+(kernels.sample_t_noise); the functions below are the same two formulas for the callers that hold a `t` already (sampler loops, CPU tests).
+"""
 from __future__ import annotations
 
 import torch
 
+DEFAULT_EPS = 1e-3
 
-class LogLinearNoise(torch.nn.Module):
-    """models/noise_schedule.py:128-157: total noise -log1p(-(1-eps) t), so the move chance is (1-eps) t."""
 
-    def __init__(self, eps=1e-3):
-        super().__init__()
-        self.eps = eps
-        self.sigma_max = self.total_noise(torch.tensor(1.0, dtype=torch.float32))
-        self.sigma_min = self.eps + self.total_noise(torch.tensor(0.0, dtype=torch.float32))
+def loglinear_total_noise(t: torch.Tensor, eps: float = DEFAULT_EPS) -> torch.Tensor:
+    """sigma(t) = -log1p(-(1 - eps) t)   (noise_schedule.py:145-146)"""
+    return torch.log1p(t * -(1 - eps)).neg()
 
-    def rate_noise(self, t):
-        return (1 - self.eps) / (1 - (1 - self.eps) * t)
+
+def loglinear_rate_noise(t: torch.Tensor, eps: float = DEFAULT_EPS) -> torch.Tensor:
+    """sigma'(t) = (1 - eps) / (1 - (1 - eps) t)   (noise_schedule.py:142-143)"""
+    keep = 1 - eps
+    return keep / (1 - keep * t)
+
+
+class LogLinearNoise:
+    """Callable holder of `eps`: `noise(t) -> (sigma, sigma')` like the reference module (it has no parameters or buffers, so it is not an nn.Module here
+    and does not show up in a state dict - the reference's does not either)."""
+
+    def __init__(self, eps: float = DEFAULT_EPS):
+        self.eps = float(eps)
 
     def total_noise(self, t):
-        return -torch.log1p(-(1 - self.eps) * t)
+        return loglinear_total_noise(t, self.eps)
 
-    def forward(self, t):  # noise_schedule.py:37-43
-        return self.total_noise(t), self.rate_noise(t)
+    def rate_noise(self, t):
+        return loglinear_rate_noise(t, self.eps)
 
-    def importance_sampling_transformation(self, t):
-        f_T = torch.log1p(-torch.exp(-self.sigma_max))
-        f_0 = torch.log1p(-torch.exp(-self.sigma_min))
-        sigma_t = -torch.log1p(-torch.exp(t * f_T + (1 - t) * f_0))
-        return -torch.expm1(-sigma_t) / (1 - self.eps)
+    def __call__(self, t):
+        return loglinear_total_noise(t, self.eps), loglinear_rate_noise(t, self.eps)
 
 
 def get_noise(config, dtype=torch.float32):
-    """models/noise_schedule.py:13-28 — only the default log-linear schedule is on the hot path."""
+    """Every shipped configuration uses `noise.type: loglinear`; other schedules are not on the denoising hot path."""
     from .dit import cfg_get
 
     kind = cfg_get(cfg_get(config, "noise"), "type", "loglinear")
