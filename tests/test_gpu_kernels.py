@@ -739,42 +739,6 @@ def test_attention_d128_wave_specialised_backward_ragged_lengths(K, L, B, H):
     assert rel_err(dk.float().cpu(), dk_r) < 1.5e-2
 
 
-@pytest.mark.parametrize("B,H,L", [(1, 1, 128), (2, 3, 256), (1, 2, 384), (3, 1, 1152), (2, 2, 1280)])
-@pytest.mark.parametrize("engine_layout", [False, True])
-def test_attention_one_wave_per_simd_kernels_are_bit_identical(K, B, H, L, engine_layout):
-    """The opt-in one-wave-per-SIMD forward / dQ kernels (attention_w64.hip, attention_dq_w64.hip; UDM_ATTN_W64=1): same k order, same lazy-rescale
-    decisions per 32-query block, same summation order as the default 8-wave kernels - O, LSE (same log2 / fma), dQ, dK, dV bit for bit, with
-    separate q / k / v buffers and in the engine's strided layout (q, k from the roped [M, 2d] buffer, v from qkv [M, 3d]); a spiked key forces the
-    rescale branch late in the sequence."""
-    D = 128
-    d, M = H * D, B * L
-    qkr, qkv, do = bf(rnd(M, 2 * d, seed=330)), bf(rnd(M, 3 * d, seed=331)), bf(rnd(M, d, seed=332))
-    if L > 200:
-        qkr[L - 100, d:] = qkr[L - 100, d:] * 12                       # k of one position
-        qkr[7, :d] = bf(qkr[L - 100, d:].float() / 4)                  # a query that matches it
-    g = lambda t: t.to(DEV)
-    res = []
-    try:
-        for mode in (False, True):
-            K.set_attention_w64(mode)
-            if engine_layout:
-                a, b_ = g(qkr), g(qkv)
-                o, lse = K.attention_fwd(a, b_, B, L, H, D)
-                dqkr, dqkv = torch.zeros(M, 2 * d, dtype=torch.bfloat16, device=DEV), torch.zeros(M, 3 * d, dtype=torch.bfloat16, device=DEV)
-                K.attention_bwd(a, b_, o, g(do), lse, dqkr, dqkv, B, L, H, D)
-                res.append((o, lse, dqkr, dqkv))
-            else:
-                q, k, v = g(qkr[:, :d].contiguous()), g(qkr[:, d:].contiguous()), g(qkv[:, 2 * d:].contiguous())
-                o, lse = K.attention_fwd_generic(q, k, v, B, L, H, D)
-                res.append((o, lse) + tuple(K.attention_bwd_generic(q, k, v, o, g(do), lse, B, L, H, D)))
-    finally:
-        K.set_attention_w64(False)
-    for x, y in zip(*res):
-        assert torch.equal(x, y)
-    o_r, dq_r, dk_r, dv_r = _attn_ref(qkr[:, :d], qkr[:, d:], qkv[:, 2 * d:], B, L, H, D, None, do)
-    assert rel_err(res[1][0].float().cpu(), o_r) < 1e-2
-
-
 def _doc_layouts(B, L):
     """Packed-sample id layouts: contiguous documents with a padding tail, one document, non-contiguous ids, a row of padding only, padding inside."""
     g = torch.Generator().manual_seed(L)

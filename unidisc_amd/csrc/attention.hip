@@ -593,7 +593,6 @@ void launch_fwd(const AttnArgs& a, hipStream_t s) {
   auto kern = attn_fwd_kernel<D, SID, TR>;
   static bool once = false;
   if (!once) { set_lds(kern, lds); once = true; }
-  if (D == 128 && !SID && TR && a.out_stride % 8 == 0 && a.L % 128 == 0 && udm_launch_attn_fwd_w64(&a, s)) return;
   if (D == 128 && !SID && TR) {   // UDM_ATTN_ABL=1|2: timing-only ablations of the forward kernel (scripts/bench_attn.py)
     static const int abl = [] { const char* e = getenv("UDM_ATTN_ABL"); return e ? atoi(e) : 0; }();
     if (abl == 1) { auto k1 = attn_fwd_kernel<128, false, true, 1>; set_lds(k1, lds); hipLaunchKernelGGL(k1, grid, dim3(256), lds, s, a); return; }
@@ -616,10 +615,7 @@ void launch_bwd(const AttnArgs& a, hipStream_t s) {
   auto kk = attn_bwd_dkv_kernel<D, SID, TR, 3, W>;
   static bool once = false;
   if (!once) { set_lds(kq, lds_q); set_lds(kk, lds_k); once = true; }
-  static const int dq_w64 = [] { const char* e = getenv("UDM_ATTN_DQ_W64"); return e ? atoi(e) : 1; }();
-  if (D == 128 && !SID && TR && dq_w64 && udm_attn_w64_mode() && a.L % 128 == 0 && a.out_stride % 8 == 0)
-    udm_launch_attn_bwd_dq_w64(&a, s, udm_attn_w64_timeline());
-  else hipLaunchKernelGGL(kq, gq, dim3(256), lds_q, s, a);
+  hipLaunchKernelGGL(kq, gq, dim3(256), lds_q, s, a);
   if (D == 128 && !SID && TR && g_dkv_ws) udm_launch_attn_bwd_dkv_ws(&a, s);
   else if (D == 128 && SID && TR && g_dkv_ws && a.doc_ranges) {
     // packed documents: key blocks that lie inside one document and whose query span is exactly that document go to the wave-specialised
@@ -669,6 +665,7 @@ extern "C" int udm_attention_fwd(const void* q, const void* k, const void* v, vo
   UDM_CHECK_ARG(o_stride % 4 == 0, "udm_attention_fwd: o_stride must be a multiple of 4");
   UDM_CHECK_ARG(sample_ids || !doc_ranges, "udm_attention_fwd: doc_ranges without sample_ids");
   AttnArgs a{};
+  a.exp = udm_exp_flags();
   a.doc_ranges = doc_ranges;
   a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.out = (bf16_t*)o; a.lse = lse; a.sample_ids = sample_ids;
   a.q_stride = q_stride; a.k_stride = k_stride; a.v_stride = v_stride; a.out_stride = o_stride;
@@ -689,6 +686,7 @@ extern "C" int udm_attention_bwd(const void* q, const void* k, const void* v, co
   UDM_CHECK_ARG(o_stride % 8 == 0 && do_stride % 8 == 0 && dq_stride % 4 == 0 && dk_stride % 4 == 0 && dv_stride % 4 == 0, "udm_attention_bwd: bad strides");
   UDM_CHECK_ARG(sample_ids || !doc_ranges, "udm_attention_bwd: doc_ranges without sample_ids");
   AttnArgs a{};
+  a.exp = udm_exp_flags();
   a.doc_ranges = doc_ranges;
   a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.o = (const bf16_t*)o; a.dout = (const bf16_t*)dout;
   a.out = (bf16_t*)dq; a.out2 = (bf16_t*)dk; a.out3 = (bf16_t*)dv; a.lse = const_cast<float*>(lse); a.delta = delta; a.sample_ids = sample_ids;

@@ -74,7 +74,8 @@ struct AttnArgs {
   int B, H, L;
   float scale_log2;     // log2(e) / sqrt(D)
   float scale;          // 1 / sqrt(D)
-  unsigned long long* timeline;   // diagnostics (attention_w64.hip): cycle stamps of a few blocks, or null
+  unsigned long long* timeline;   // diagnostics (experiments library): cycle stamps of a few blocks, or null
+  int exp;                        // experiment bits (udm_exp_flags), 0 in production
 };
 
 // Attention mask codes.  `sample_ids` holds one int64 per position:  bits 0-31 = sample id (signed; < 0 = padding), bits 32-39 = the KEY classes this
@@ -246,10 +247,4 @@ __device__ __forceinline__ void store_rows_via_lds_d128(char* wave_lds, const f3
 
 // dK/dV kernel for head dim 128 without a document mask (attention_dkv_ws.hip); grid = ceil(L / 128) * B * H blocks of 512 threads
 void udm_launch_attn_bwd_dkv_ws(const void* args, hipStream_t stream);
-// forward kernel for head dim 128 without a document mask, one wave per SIMD / 64 queries per wave (attention_w64.hip); false = switched off (UDM_ATTN_W64=0)
-bool udm_launch_attn_fwd_w64(const void* args, hipStream_t stream);
-// dQ kernel of the same family (attention_dq_w64.hip): head dim 128, no document mask, L % 128 == 0, k_stride == v_stride, dq_stride % 8 == 0
-void udm_launch_attn_bwd_dq_w64(const void* args, hipStream_t stream, unsigned long long* timeline);
-int udm_attn_w64_mode();   // 0 off, 1 = the one-wave-per-SIMD forward / dQ kernels (attention_w64.hip, attention_dq_w64.hip)
-unsigned long long* udm_attn_w64_timeline();
 void udm_launch_attn_fwd_ws64(const void* args, hipStream_t stream);   // wave-specialised variant (attention_ws64.hip: experiments library only)

@@ -4,6 +4,7 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
+#include <stdlib.h>
 
 namespace {
 thread_local char g_err[512] = "";
@@ -24,18 +25,18 @@ extern "C" int udm_gemm_set_tile(int tile);      // gemm.hip: force the tile fam
 extern "C" int udm_gemm_set_quad(int mode);      // gemm.hip: one-wave-per-SIMD kernels 0 = off, 1 = auto (default; env UDM_GEMM_QUAD), 2 = wherever the shape fits
 extern "C" int udm_gemm_set_persist(int enable); // gemm.hip: 0 = one block per output tile (default 1: persistent blocks for multi-round NT shapes)
 extern "C" int udm_attention_set_tr_read(int enable);        // attention.hip: 0 = gather V^T fragments with scalar LDS reads
-extern "C" int udm_attention_set_w64(int enable);            // attention_w64.hip: the one-wave-per-SIMD forward / dQ kernels (default off; env UDM_ATTN_W64)
-extern "C" int udm_attention_w64_timeline(uint64_t* buf);    // attention_w64.hip: device buffer of 512 cycle stamps written by the next forward launches; null = off
+
+namespace { int g_exp = [] { const char* e = getenv("UDM_EXP"); return e ? atoi(e) : 0; }(); }
+int udm_exp_flags() { return g_exp; }
 
 extern "C" int udm_debug_set(const char* key, int64_t value) {
   if (!key) { udm_set_error("udm_debug_set: null key"); return 2; }
   const auto is = [&](const char* k) { return strcmp(key, k) == 0; };
+  if (is("exp")) { g_exp = (int)value; return 0; }
   if (is("gemm_tile")) return udm_gemm_set_tile((int)value);
   if (is("gemm_quad")) return udm_gemm_set_quad((int)value);
   if (is("gemm_persist")) return udm_gemm_set_persist((int)value);
   if (is("attention_tr_read")) return udm_attention_set_tr_read((int)value);
-  if (is("attention_w64")) return udm_attention_set_w64((int)value);
-  if (is("attention_w64_timeline")) return udm_attention_w64_timeline(reinterpret_cast<uint64_t*>((uintptr_t)value));
   udm_set_error("udm_debug_set: unknown key '%s'", key);
   return 2;
 }

@@ -99,6 +99,9 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 
 }  // namespace udm
 
+// Experiment switches for in-process A/B runs (udm_debug_set("exp", bits) or env UDM_EXP at load; 0 in production).  Bit meanings live next to the code they switch.
+int udm_exp_flags();
+
 // ---- host-side error plumbing (no exceptions cross the C ABI) -----------------------------------
 void udm_set_error(const char* fmt, ...);
 #define UDM_CHECK_ARG(cond, ...)            \

@@ -35,6 +35,7 @@ struct GemmArgs {
   int splitk;  // > 1: the K range is cut into `splitk` slices per tile and partial tiles are atomically added into an fp32 C
   long slice_stride;  // split-K with a workspace: slice s stores its partial tile (no atomics) at C + s * slice_stride; 0 = atomic form
   int group_m;        // big-tile kernels: row tiles per group of the tile order (0 = GROUP_M); diagnostics knob UDM_GEMM_GROUP_M
+  int exp;            // experiment bits (udm_exp_flags), 0 in production
 };
 
 template <int EPI, bool OUT_F32>
@@ -825,6 +826,7 @@ int launch_big_t(const GemmArgs& a0, hipStream_t stream) {
   a.tiles_n = (a.N + 255) / 256;
   static const int env_gm = [] { const char* e = getenv("UDM_GEMM_GROUP_M"); return e ? atoi(e) : 0; }();
   a.group_m = env_gm;
+  a.exp = udm_exp_flags();
   const size_t lds = (size_t)2 * (BMX + 256) * BK * 2;
   auto kern = gemm_nt_stagger_kernel<BMX, EPI, OUT_F32, TN>;
   static bool attr_set = false;

@@ -171,13 +171,22 @@ class _Lin:
         self.alloc()
         K.cast_transpose(self.weight.detach(), self.w16, self.w16t)
 
-    def dgrad(self, dY, M_rows):
-        """dX [M, in] = dY [M, out] W: from W's forward shadow where the shape allows (no transposed shadow), else from the transposed one"""
-        if self.w16t is None:
-            if not K.gemm_nn_ok(M_rows, self.inp, self.out):
-                raise RuntimeError(f"unidisc_amd: dgrad of a {self.out}x{self.inp} Linear over {M_rows} rows has no transposed weight shadow and the shape is outside gemm_nn")
-            return K.gemm_nn(dY, self.w16, N=self.inp)
-        return K.gemm_nt(dY, self.w16t, N=self.inp)
+    def dgrad_form(self):
+        """Which operand the dgrad of a forward that runs NOW will read, decided at FORWARD time and carried to the backward in the forward's saved state:
+        "nt" = the transposed shadow (it exists for this forward and, being sticky, for every later one), "nn" = W's forward shadow (no transposed one is kept)."""
+        return "nt" if self.w16t is not None else "nn"
+
+    def dgrad(self, dY, M_rows, form=None):
+        """dX [M, in] = dY [M, out] W in the form the forward recorded (`dgrad_form`); a transposed shadow that appeared since (another forward with a row
+        count outside gemm_nn made it sticky) is current and takes over an "nn" record whose shape no longer fits - never the other way round."""
+        form = self.dgrad_form() if form is None else form
+        if form == "nt" or (self.w16t is not None and not K.gemm_nn_ok(M_rows, self.inp, self.out)):
+            if self.w16t is None:
+                raise RuntimeError(f"unidisc_amd: the forward of this {self.out}x{self.inp} Linear recorded an NT dgrad but its transposed weight shadow is gone")
+            return K.gemm_nt(dY, self.w16t, N=self.inp)
+        if not K.gemm_nn_ok(M_rows, self.inp, self.out):
+            raise RuntimeError(f"unidisc_amd: dgrad of a {self.out}x{self.inp} Linear over {M_rows} rows has no transposed weight shadow and the shape is outside gemm_nn")
+        return K.gemm_nn(dY, self.w16, N=self.inp)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -605,6 +614,7 @@ class DIT(nn.Module, _HubMixin):
             doc_ranges = None
         S = dict(B=B, L=L, ids=ids, modality=mod_flat, emb_mod=emb_mod, sid=sid, p_drop=p_drop, seed0=seed0, blocks=[])
         S["doc_ranges"] = doc_ranges
+        S["dgrad_form"] = {name: lin.dgrad_form() for name, lin in self._lins.items()}   # NN vs NT per Linear, fixed by THIS forward's shadows (not re-derived at backward time)
         # SUBS: only [MASK] rows have a non-zero log-probability (model.py:621-658), so in "logp" mode the vocabulary head (GEMM fwd,
         # dgrad, wgrad and the cross-entropy) runs on the masked rows only.  Their number is data dependent: it is counted on a side
         # stream NOW and only read back right before the head, when the host has already queued every block of this forward -- the
@@ -1089,7 +1099,7 @@ class DIT(nn.Module, _HubMixin):
             # dgrad through mlp.2 with the GELU' multiply and the mlp.0 bias gradient (column sums of du1) fused into the epilogue
             du1 = K.gemm_nt(du2, f2.w16t, N=4 * d, epilogue=K.EPI_DGELU, aux=R["u1"], bias=G[id(f1.bias)])
             self._wgrad(du2, R["g"], f2, G, bias_done=not tc)
-            dh2 = f1.dgrad(du1, du1.shape[0])
+            dh2 = f1.dgrad(du1, du1.shape[0], S["dgrad_form"].get(f"{i}.fc1"))
             self._wgrad(du1, R["h2"], f1, G, bias_done=True)
             del du1, du2
             # norm2 backward + attention branch
@@ -1111,7 +1121,7 @@ class DIT(nn.Module, _HubMixin):
                     da = branch_bwd(p2, R["a_out"], p_drop=p_drop, seed=seed0 + 4 * i + 1)
             lo, lq = lin[f"{i}.out"], lin[f"{i}.qkv"]
             pair_out = None
-            do = lo.dgrad(da, da.shape[0])
+            do = lo.dgrad(da, da.shape[0], S["dgrad_form"].get(f"{i}.out"))
             if R.get("rows_c") is not None:
                 # back to all rows: the rows left out have a zero gradient in both the attention output and the residual stream
                 self._wgrad(da, R["o_c"], lo, G)
@@ -1136,7 +1146,7 @@ class DIT(nn.Module, _HubMixin):
                               gk=at.k_norm.weight.detach() if qn else None, stats=R["qstats"], dgq=G[id(at.q_norm.weight)] if qn else None,
                               dbq=G[id(at.q_norm.bias)] if qn else None, dgk=G[id(at.k_norm.weight)] if qn else None,
                               dbk=G[id(at.k_norm.bias)] if qn else None)
-            dh1 = lq.dgrad(dqkv, dqkv.shape[0])
+            dh1 = lq.dgrad(dqkv, dqkv.shape[0], S["dgrad_form"].get(f"{i}.qkv"))
             if pair_out is not None:
                 K.gemm_tn_pair(dqkv, R["h1"], G[id(lq.weight)], pair_out[0], pair_out[1], G[id(lo.weight)])
                 pair_out = None

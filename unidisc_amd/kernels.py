@@ -660,11 +660,6 @@ def set_tr_read(enable: bool):
     debug_set("attention_tr_read", 1 if enable else 0)
 
 
-def set_attention_w64(enable: bool):
-    """A/B switch: the one-wave-per-SIMD forward kernel (head dim 128, no document mask) on / off."""
-    debug_set("attention_w64", 1 if enable else 0)
-
-
 # ------------------------------------------------------------------------------------------------ embedding / CE / adaLN helpers
 def embedding_fwd(ids, E, modality=None, Em=None):
     M = ids.numel()
