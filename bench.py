@@ -258,12 +258,12 @@ def cpu_baseline(workload, cfg, diff, seed):
         bufs = O.make_buffers(ocfg, lumina_rope_2d)
         batch = O.update_batch(ocfg, synthetic_batch(workload, 1, seed))
         t0 = time.perf_counter()
-        out = O.compute_loss(ocfg, P, bufs, batch, torch.Generator().manual_seed(seed))
+        out = O.compute_loss(ocfg, P, bufs, batch, torch.Generator().manual_seed(seed), bf16=True)   # the reference's bf16-autocast numerics
         out.loss.backward()
         return time.perf_counter() - t0
 
     t1 = run(1)
-    what = f"oracle (fp32 torch CPU) fwd+bwd of 1 sequence (B=1, L={L}, d={m.hidden_size}, V={diff.vocab_size})"
+    what = f"oracle (torch CPU, the reference's bf16-autocast rounding points emulated) fwd+bwd of 1 sequence (B=1, L={L}, d={m.hidden_size}, V={diff.vocab_size})"
     if t1 * (1 + 0.6 * (m.n_blocks - 1)) <= 150:
         total = run(m.n_blocks)
         sample = f"{what} through all {m.n_blocks} blocks: {total:.1f} s MEASURED (1-block probe {t1:.1f} s; {threads} threads of {cores} available cores)"

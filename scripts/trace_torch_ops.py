@@ -39,3 +39,6 @@ torch.cuda.synchronize()
 for k, v in sorted(cnt.items(), key=lambda kv: -byt[kv[0]])[:40]:
     print(f"{v:4d} x {k[0]:44s} {k[1]:24s} {byt[k] / 1e6:10.2f} MB")
 print("total ops", sum(cnt.values()))
+print("---- by count")
+for k, v in sorted(cnt.items(), key=lambda kv: -kv[1])[:60]:
+    print(f"{v:4d} x {k[0]:44s} {k[1]:24s} {byt[k] / 1e6:10.2f} MB")

@@ -145,6 +145,9 @@ def test_packed_rows_equal_separate_rows_at_full_size(bench):
     assert float(packed[masked].abs().sum()) > 0
 
 
+QK_ALL_BOUND, QK_MED_BOUND = 1.0, 1.0   # provisional until the first recorded run (round 4)
+
+
 def test_config_e_fp8_attention_full_depth_against_bf16_attention(bench):
     """BASELINE configs[4] at full size (24 blocks, d = 2048, one row of 4 packed samples = 4608 tokens): the same seeded training step with the attention
     forward in fp8 (block-scaled e4m3 MFMA) and in bf16.  Masks bit-exact; stated tolerances of the fp8 path against this repository's bf16 path:
@@ -177,6 +180,13 @@ def test_config_e_fp8_attention_full_depth_against_bf16_attention(bench):
     check(T, "grad_relrms_median_param", errs[len(errs) // 2][0], 3e-2)
     nonqk = [e for e in errs if "q_norm" not in e[1] and "k_norm" not in e[1]]
     check(T, "grad_relrms_worst_param_outside_qk_norm", nonqk[0][0], 5e-2, note=nonqk[0][1])
-    # qk-norm vectors (column sums of dq / dk with heavy cancellation): at 24 blocks the bf16 path itself is 1.5e-1 away from fp32 there (and the reference's own
-    # bf16 flow just as far: ledger rows config_c_24blocks_*), so this row is recorded against a loose bound rather than asserted tightly
-    check(T, "grad_relrms_worst_param", errs[0][0], 2.0, note=errs[0][1])
+    # qk-norm vectors (column sums of dq / dk with heavy cancellation, |g| ~ 2e-5).  At 24 blocks the bf16 path itself is 1.5e-1 away from fp32 on its worst vector (and
+    # the reference's own bf16 flow just as far: ledger rows config_c_24blocks_*), and the fp8 path's WORST vector differs from the bf16 path's by its own magnitude
+    # (achieved 1.07 in round 3).  That single number is RECORDED, not asserted - no bound on it would say anything; what is asserted is the set of qk-norm gradients as a
+    # whole (all 96 vectors concatenated: the direction an optimizer step takes in that subspace) and their median, at <= 3x the recorded values.
+    from ledger import record
+    record(T, "grad_relrms_worst_param", errs[0][0], note=errs[0][1] + " (recorded, not asserted: fp8 attention is an opt-in at break-even, DESIGN.md §6)")
+    qk = sorted(k for k in g0 if "q_norm" in k or "k_norm" in k)
+    check(T, "grad_relrms_all_qk_norm_params_concatenated", rel_err(torch.cat([g1[k].reshape(-1) for k in qk]), torch.cat([g0[k].reshape(-1) for k in qk])), QK_ALL_BOUND)
+    qk_errs = sorted(rel_err(g1[k], g0[k]) for k in qk)
+    check(T, "grad_relrms_median_qk_norm_param", qk_errs[len(qk_errs) // 2], QK_MED_BOUND)

@@ -13,6 +13,19 @@ from product_utils import build_product
 
 DEV = "cuda"
 
+# Token agreement of a product sampling loop with the recorded reference run (bf16 backbone / kernel doubles vs the fp32 reference: a near-tie draw may flip and
+# the flip propagates).  Recorded in the parity ledger; the bound per test is the disagreement achieved (profiles/r04_parity_ledger.json) x 3 + 1 %, never above 10 %.
+AGREE_BOUNDS = {}
+
+
+def _agree(test, case, x, ref):
+    from ledger import check
+
+    key = test if case is None else f"{test}[{case}]"
+    dis = 1.0 - (x.cpu() == ref.cpu()).float().mean().item()
+    check(key, "token_disagreement_vs_reference_run", dis, AGREE_BOUNDS.get(key, 0.10))
+
+
 
 def load_sampler(name):
     z = np.load(os.path.join(GOLDEN_DIR, f"sampler_{name}.npz"))
@@ -46,8 +59,7 @@ def test_sampler_loop_host_logic_replays_reference_run(name, monkeypatch):
     x0, x0_unmask = (s["x0"], s["x0_unmask"].bool()) if "x0" in s else (None, None)
     B, L = s["x_init"].shape
     x, nfe = diff.sample(num_steps=steps, eps=float(s["eps"]), x0=x0, x0_unmask=x0_unmask, batch_size=B, modality=modality, noise=noise, return_nfe=True)
-    agree = (x == s["x_final"]).float().mean().item()
-    assert agree >= 0.9, agree      # bf16 backbone vs the fp32 reference: a few near-tie draws may differ
+    _agree("test_sampler_loop_host_logic_replays_reference_run", locals().get("name"), x, s["x_final"])
     assert nfe == int(s["nfe"]) + 1  # + the noise-removal forward
     assert not (x == diff.mask_index).any()
     if x0 is not None:
@@ -127,7 +139,7 @@ def test_sampler_loop_on_gpu(name):
     B, L = s["x_init"].shape
     x, nfe = diff.sample(num_steps=steps, eps=float(s["eps"]), x0=x0, x0_unmask=x0_unmask, batch_size=B, modality=modality, noise=noise, return_nfe=True)
     x = x.cpu()
-    assert (x == s["x_final"]).float().mean().item() >= 0.9
+    _agree("test_sampler_loop_on_gpu", locals().get("name"), x, s["x_final"])
     assert not (x == diff.mask_index).any() and nfe == int(s["nfe"]) + 1
     if x0 is not None:
         assert torch.equal(x[s["x0_unmask"].bool()], s["x0"][s["x0_unmask"].bool()])
@@ -161,7 +173,7 @@ def test_guided_sampler_host_logic_replays_reference_run(monkeypatch):
     x0, x0_unmask = s["x0"], s["x0_unmask"].bool()
     x, nfe = diff.sample(num_steps=steps, eps=float(s["eps"]), x0=x0, x0_unmask=x0_unmask, batch_size=x0.shape[0], modality=s["modality"], noise=noise,
                          return_nfe=True)
-    assert (x == s["x_final"]).float().mean().item() >= 0.9
+    _agree("test_guided_sampler_host_logic_replays_reference_run", locals().get("name"), x, s["x_final"])
     assert nfe == int(s["nfe"]) + 1 and not (x == diff.mask_index).any() and torch.equal(x[x0_unmask], x0[x0_unmask])
     # the guidance weight is the reference's
     t = s["timesteps"][2] * torch.ones(x0.shape[0])
@@ -252,7 +264,8 @@ def test_guided_sampler_loop_on_gpu():
     x, nfe = diff.sample(num_steps=steps, eps=float(s["eps"]), x0=x0, x0_unmask=x0_unmask, batch_size=x0.shape[0], modality=s["modality"].to(DEV), noise=noise,
                          return_nfe=True)
     x = x.cpu()
-    assert (x == s["x_final"]).float().mean().item() >= 0.9 and nfe == int(s["nfe"]) + 1 and not (x == diff.mask_index).any()
+    _agree("test_guided_sampler_loop_on_gpu", locals().get("name"), x, s["x_final"])
+    assert nfe == int(s["nfe"]) + 1 and not (x == diff.mask_index).any()
     assert torch.equal(x[s["x0_unmask"].bool()], s["x0"][s["x0_unmask"].bool()])
 
 
@@ -286,7 +299,7 @@ def test_maskgit_host_logic_replays_reference_run(name, monkeypatch):
     diff.backbone.eval()
     assert torch.equal(diff.adap_sche(s["x_init"], int(s["steps"]), diff.mask_index), s["schedule"].to(torch.int32))
     x, nfe = _maskgit_run(diff, s, "cpu")
-    assert (x == s["x_final"]).float().mean().item() >= 0.9     # bf16 backbone vs fp32 reference: a near-tie in the top-k may flip
+    _agree("test_maskgit_host_logic_replays_reference_run", locals().get("name"), x, s["x_final"])
     assert nfe == int(s["nfe"]) + 1 and not (x == diff.mask_index).any()
     if "x0" in s:
         assert torch.equal(x[s["x0_unmask"].bool()], s["x0"][s["x0_unmask"].bool()])
@@ -343,7 +356,8 @@ def test_maskgit_nucleus_host_logic_replays_reference_run(monkeypatch):
     x0, x0_unmask = s["x0"], s["x0_unmask"].bool()
     x, nfe = diff.sample(num_steps=steps, eps=float(s["eps"]), x0=x0, x0_unmask=x0_unmask, batch_size=1, modality=s["modality"], predictor="maskgit_nucleus",
                          replay=replay, return_nfe=True)
-    assert (x == s["x_final"]).float().mean().item() >= 0.9 and nfe == int(s["nfe"]) + 1 and not (x == diff.mask_index).any()
+    _agree("test_maskgit_nucleus_host_logic_replays_reference_run", locals().get("name"), x, s["x_final"])
+    assert nfe == int(s["nfe"]) + 1 and not (x == diff.mask_index).any()
     assert torch.equal(x[x0_unmask], x0[x0_unmask])
     # free draw of one step: tokens come from the nucleus of the step's own distribution
     xs, t = s["step1/x"], s["timesteps"][1] * torch.ones(1, 1)
@@ -415,7 +429,8 @@ def test_maskgit_loop_on_gpu(name):
     diff.backbone.eval()
     x, nfe = _maskgit_run(diff, s, DEV)
     x = x.cpu()
-    assert (x == s["x_final"]).float().mean().item() >= 0.9 and nfe == int(s["nfe"]) + 1 and not (x == diff.mask_index).any()
+    _agree("test_maskgit_loop_on_gpu", locals().get("name"), x, s["x_final"])
+    assert nfe == int(s["nfe"]) + 1 and not (x == diff.mask_index).any()
     # free-running (Philox draws + device Gumbel noise): complete, reproducible for a seed
     modality = s["modality"].to(DEV) if "modality" in s else None
     B = s["x_init"].shape[0]
@@ -438,7 +453,8 @@ def test_maskgit_nucleus_loop_on_gpu():
     x0, x0_unmask, mod = s["x0"].to(DEV), s["x0_unmask"].bool().to(DEV), s["modality"].to(DEV)
     x, nfe = diff.sample(num_steps=steps, eps=float(s["eps"]), x0=x0, x0_unmask=x0_unmask, batch_size=1, modality=mod, predictor="maskgit_nucleus",
                          replay=replay, return_nfe=True)
-    assert (x.cpu() == s["x_final"]).float().mean().item() >= 0.9 and nfe == int(s["nfe"]) + 1 and not (x == diff.mask_index).any()
+    _agree("test_maskgit_nucleus_loop_on_gpu", locals().get("name"), x.cpu(), s["x_final"])
+    assert nfe == int(s["nfe"]) + 1 and not (x == diff.mask_index).any()
     # free-running on a batch (the generalisation `all(num_unmask <= 0)` of the reference's batch-1 early exit): complete, reproducible per seed
     B = 4
     mod4 = mod.expand(B, -1).contiguous()
@@ -471,7 +487,8 @@ def test_first_hitting_host_logic_replays_reference_run(name, monkeypatch):
     diff.backbone.eval()
     s, (x, nfe) = _fh_run(diff, name, "cpu")
     assert torch.equal(diff.adap_sche(s["x_init"], int(s["steps"]), diff.mask_index, "linear"), s["schedule"].to(torch.int32))
-    assert (x == s["x_final"]).float().mean().item() >= 0.9 and nfe == int(s["nfe"]) + 1 and not (x == diff.mask_index).any()
+    _agree("test_first_hitting_host_logic_replays_reference_run", locals().get("name"), x, s["x_final"])
+    assert nfe == int(s["nfe"]) + 1 and not (x == diff.mask_index).any()
     # the revealed POSITIONS are exact at every step (integer lottery); only near-tie token draws may differ under bf16
     if "x0" in s:
         assert torch.equal(x[s["x0_unmask"].bool()], s["x0"][s["x0_unmask"].bool()])
@@ -484,7 +501,8 @@ def test_first_hitting_loop_on_gpu(name):
     diff.backbone.eval()
     s, (x, nfe) = _fh_run(diff, name, DEV)
     x = x.cpu()
-    assert (x == s["x_final"]).float().mean().item() >= 0.9 and nfe == int(s["nfe"]) + 1 and not (x == diff.mask_index).any()
+    _agree("test_first_hitting_loop_on_gpu", locals().get("name"), x, s["x_final"])
+    assert nfe == int(s["nfe"]) + 1 and not (x == diff.mask_index).any()
     modality = s["modality"].to(DEV) if "modality" in s else None
     B = s["x_init"].shape[0]
     a = diff.sample(num_steps=int(s["steps"]), batch_size=B, modality=modality, predictor="first_hitting", seed=3)
@@ -561,8 +579,7 @@ def test_attention_caching_sampler_host_logic_replays_reference_run(monkeypatch)
     assert diff.sample_step_modes == modes and {"full", "build", "text"} <= set(modes)
     for i in range(steps):   # every step ran in the reference's view (full sequence or the text slice) and mostly drew the reference's tokens
         assert seen[i][0] == tuple(s[f"step{i}/x"].shape), i
-    agree = (x == s["x_final"]).float().mean().item()
-    assert agree >= 0.9, agree
+    _agree("test_attention_caching_sampler_host_logic_replays_reference_run", locals().get("name"), x, s["x_final"])
     assert nfe == int(s["nfe"]) + 1 and not (x == diff.mask_index).any()
     assert x.shape == (B, L)
 
@@ -592,7 +609,7 @@ def test_attention_caching_sampler_loop_on_gpu():
                          return_nfe=True)
     assert diff.sample_step_modes == modes
     x = x.cpu()
-    assert (x == s["x_final"]).float().mean().item() >= 0.9
+    _agree("test_attention_caching_sampler_loop_on_gpu", locals().get("name"), x, s["x_final"])
     assert not (x == diff.mask_index).any() and nfe == int(s["nfe"]) + 1
     a = diff.sample(num_steps=steps, batch_size=B, modality=s["modality"].to(DEV), seed=5)
     b = diff.sample(num_steps=steps, batch_size=B, modality=s["modality"].to(DEV), seed=5)
