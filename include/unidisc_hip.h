@@ -52,10 +52,6 @@ int udm_abi_version(void);
  * C[M,N] = A[M,K] · B[N,K]ᵀ, A/B bf16 K-contiguous; C bf16 or fp32; beta accumulates into an fp32 C.   */
 int udm_gemm_nt_bf16(const void* A, const void* B, void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int out_f32,
                      int epilogue, const float* bias, void* aux, int64_t ldaux, float beta, hipStream_t stream);
-/* Tile-order layout of `aux` (the saved GELU derivative is private to the mlp.0-forward / mlp.2-dgrad pair, models/dit.py:917-919): returns the tile height (256 / 320)
- * with which udm_gemm_nt_bf16 runs this UDM_EPI_BIAS_GELU / UDM_EPI_DGELU problem in its persistent form, or 0.  When BOTH GEMMs of the pair (same M, N) answer the
- * same non-zero height h, both may be called with ldaux = -h: aux (still M x N elements) is then written and read as contiguous per-wave blocks instead of row-major. */
-int udm_gemm_aux_tile(int64_t M, int64_t N, int64_t K, int epilogue);
 /* wgrad form read straight from row-major activations: C[M,N] (fp32) = beta*C + A[K,M]ᵀ · B[K,N]  (K % 64 == 0). */
 /* dgrad without a transposed weight shadow: C[M,N] bf16 = A[M,K] B[K,N] (A = dY with K = out features contiguous, B = the forward's bf16 W [out, in]);
  * replaces the dX = dY W half of nn.Linear's backward (models/dit.py:642,877,917-919).  Shapes must pass udm_gemm_nn_ok(M, N, K) != 0:

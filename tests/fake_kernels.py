@@ -451,10 +451,6 @@ def gemm_set_cus(cus):
     CUS_CALLS.append(int(cus))
 
 
-def gelu_aux_tile(M, N, K_fwd, K_bwd):
-    return 0   # (CPU doubles keep the saved GELU derivative row-major)
-
-
 def gemm_tn_wants_splitk(M, N, K=None):
     return ((M + 255) // 256) * ((N + 255) // 256) <= 128 and M * N >= 1 << 16
 

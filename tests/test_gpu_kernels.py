@@ -186,35 +186,6 @@ def test_gemm_tn_pair_equals_two_launches(K, M0, M1, N, Kc, beta):
         K.gemm_tn_pair(ga0[:, :200], gb0, o0[:200], ga1, gb1, o1)
 
 
-@pytest.mark.parametrize("M,N,Kf,Kb", [(5120, 4352, 256, 128), (6400, 4096, 128, 192), (10240, 8192, 256, 128), (24576, 3072, 768, 768)])
-def test_gemm_gelu_aux_in_tile_order_is_the_same_computation(K, M, N, Kf, Kb):
-    """The saved GELU derivative in TILE ORDER (ldaux = -tile height, round 4): the mlp.0-forward / mlp.2-dgrad pair produces bit-identical outputs (C of both GEMMs,
-    the fused bias-gradient column sums up to fp32 atomic order) and the same derivative values, merely stored per-wave-block contiguous: un-permuting the
-    tile-order buffer gives the row-major one.  Shapes: two rounds of 256- / 320-row tiles, the 1.4 B MLP, UniDisc-S's MLP."""
-    h = K.gelu_aux_tile(M, N, Kf, Kb)
-    assert h in (256, 320), (M, N, Kf, Kb, h)      # these shapes run the persistent form in both directions
-    a, w, bias = bf(rnd(M, Kf, seed=610, scale=0.5)), bf(rnd(N, Kf, seed=611, scale=0.3)), rnd(N, seed=612)
-    dy, w2t = bf(rnd(M, Kb, seed=613, scale=0.5)), bf(rnd(N, Kb, seed=614, scale=0.3))
-    ga, gw, gbias, gdy, gw2t = a.to(DEV), w.to(DEV), bias.to(DEV), dy.to(DEV), w2t.to(DEV)
-    res = {}
-    for name, ld in (("rows", None), ("tiles", -h)):
-        aux = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
-        g = K.gemm_nt(ga, gw, N=N, epilogue=K.EPI_BIAS_GELU, bias=gbias, aux=aux, ldaux=ld)
-        db = torch.zeros(N, device=DEV)
-        du = K.gemm_nt(gdy, gw2t, N=N, epilogue=K.EPI_DGELU, aux=aux, ldaux=ld, bias=db)
-        res[name] = (g, du, db, aux)
-    assert torch.equal(res["rows"][0], res["tiles"][0]) and torch.equal(res["rows"][1], res["tiles"][1])
-    assert rel_err(res["tiles"][2].cpu(), res["rows"][2].cpu()) < 1e-5
-    # tile order: tiles in (tm, tn) order, inside a tile the 8 waves (2 x 4) each own WM = h / 2 rows x 64 columns, rows of 64 back to back
-    t = res["tiles"][3].view(M // h, N // 256, 2, 4, h // 2, 64)          # [tm, tn, wm, wn, row, col]
-    unperm = t.permute(0, 2, 4, 1, 3, 5).reshape(M, N)                     # -> [tm, wm, row | tn, wn, col]
-    assert torch.equal(unperm, res["rows"][3])
-    # a launch that is not the persistent form refuses the layout instead of writing garbage
-    with pytest.raises(RuntimeError, match="tile-order aux"):
-        K.gemm_nt(ga[:192], gw, N=N, epilogue=K.EPI_BIAS_GELU, bias=gbias, aux=torch.zeros(192, N, dtype=torch.bfloat16, device=DEV), ldaux=-h)
-    assert K.gelu_aux_tile(192, N, Kf, Kb) == 0
-
-
 @pytest.mark.parametrize("M0,M1,N,Kc", [(768, 256, 512, 1024), (6144, 2048, 2048, 2560)])
 def test_gemm_tn_pair_falls_back_when_quad_kernels_are_off(K, M0, M1, N, Kc):
     """udm_gemm_tn_pair_bf16 answers rc = 3 ("not applicable, nothing launched") when the one-wave-per-SIMD kernels are switched off (`gemm_set_quad(0)`, a documented

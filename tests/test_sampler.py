@@ -14,8 +14,13 @@ from product_utils import build_product
 DEV = "cuda"
 
 # Token agreement of a product sampling loop with the recorded reference run (bf16 backbone / kernel doubles vs the fp32 reference: a near-tie draw may flip and
-# the flip propagates).  Recorded in the parity ledger; the bound per test is the disagreement achieved (profiles/r04_parity_ledger.json) x 3 + 1 %, never above 10 %.
-AGREE_BOUNDS = {}
+# the flip propagates).  Recorded in the parity ledger; the bound per test is the disagreement achieved (profiles/r04_parity_ledger.json) x 3 + 2 % (was a flat 10 %).
+AGREE_BOUNDS = {   # achieved 0.0078 (one token of 128) on CPU doubles and on the GPU; every other loop: 0.0 -> the default of 2 % (two tokens of the small cases)
+    "test_first_hitting_host_logic_replays_reference_run[b_small]": 0.045,
+    "test_first_hitting_loop_on_gpu[b_small]": 0.045,
+    "test_attention_caching_sampler_host_logic_replays_reference_run": 0.045,
+    "test_attention_caching_sampler_loop_on_gpu": 0.045,
+}
 
 
 def _agree(test, case, x, ref):
@@ -23,7 +28,7 @@ def _agree(test, case, x, ref):
 
     key = test if case is None else f"{test}[{case}]"
     dis = 1.0 - (x.cpu() == ref.cpu()).float().mean().item()
-    check(key, "token_disagreement_vs_reference_run", dis, AGREE_BOUNDS.get(key, 0.10))
+    check(key, "token_disagreement_vs_reference_run", dis, AGREE_BOUNDS.get(key, 0.02))
 
 
 

@@ -24,7 +24,6 @@ PROTOTYPES = {
     "udm_gemm_tn_bf16": [_P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _F, _P],
     "udm_gemm_nn_bf16": [_P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _P],
     "udm_gemm_nn_ok": [_I64, _I64, _I64],
-    "udm_gemm_aux_tile": [_I64, _I64, _I64, _I],
     "udm_gemm_nt_splitk_bf16": [_P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _P, _I64, _P],
     "udm_gemm_nn_splitk_bf16": [_P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _P, _I64, _P],
     "udm_gemm_tn_splitk_bf16": [_P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _F, _P, _I64, _P],

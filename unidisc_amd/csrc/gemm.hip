@@ -599,13 +599,7 @@ __global__ __launch_bounds__(512) void gemm_nt_stagger_kernel(GemmArgs p) {
     // access (with the row index per lane the compiler multiplied in 64 bits for every store: three quarter-rate integer multiplies per 8 elements and stream)
     const long lrow = (long)(row0 + wm * WM + er);
     char* cbase = reinterpret_cast<char*>(p.C) + ((S > 1 ? slice * p.slice_stride : 0) + lrow * p.ldc + gn) * (OUT_F32 ? 4 : 2);
-    // aux (the saved GELU derivative, private to the fc1-forward / fc2-dgrad pair whose tile grids are identical): row-major [M, N] with leading dimension ldaux,
-    // or - ldaux < 0 - in TILE ORDER: the 64-column x WM-row block of every wave contiguous (rows of 128 bytes back to back), blocks in (tile, wave) order.  A wave's
-    // access of 8 rows x 8 lanes x 16 bytes is then ONE contiguous KiB instead of eight 128-byte lines 2 * N bytes apart
-    const long ldaux = p.ldaux < 0 ? 64 : p.ldaux;
-    bf16_t* abase = (EPI >= UDM_EPI_BIAS_GELU)
-                        ? (p.ldaux < 0 ? p.aux + ((((long)tm * p.tiles_n + tn) * NWAVES + wave) * WM + er) * 64 + s8 * 8 : p.aux + lrow * p.ldaux + gn)
-                        : nullptr;
+    bf16_t* abase = (EPI >= UDM_EPI_BIAS_GELU) ? p.aux + lrow * p.ldaux + gn : nullptr;
     float bias8[8], csum8[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -621,7 +615,7 @@ __global__ __launch_bounds__(512) void gemm_nt_stagger_kernel(GemmArgs p) {
       uint4 au[4];
       if (EPI == UDM_EPI_DGELU) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) au[q] = *reinterpret_cast<const uint4*>(abase + (long)(i * 32 + q * 8) * ldaux);
+        for (int q = 0; q < 4; ++q) au[q] = *reinterpret_cast<const uint4*>(abase + (long)(i * 32 + q * 8) * p.ldaux);
       }
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -636,7 +630,7 @@ __global__ __launch_bounds__(512) void gemm_nt_stagger_kernel(GemmArgs p) {
           float dg[8];
 #pragma unroll
           for (int e = 0; e < 8; ++e) gelu_tanh_both(bf2f(f2bf(x[e])), x[e], dg[e]);
-          *reinterpret_cast<uint4*>(abase + ro * ldaux) = make_uint4(pack2bf(dg[0], dg[1]), pack2bf(dg[2], dg[3]), pack2bf(dg[4], dg[5]), pack2bf(dg[6], dg[7]));
+          *reinterpret_cast<uint4*>(abase + ro * p.ldaux) = make_uint4(pack2bf(dg[0], dg[1]), pack2bf(dg[2], dg[3]), pack2bf(dg[4], dg[5]), pack2bf(dg[6], dg[7]));
         }
         if (EPI == UDM_EPI_DGELU) {
           const uint32_t w[4] = {au[q].x, au[q].y, au[q].z, au[q].w};
@@ -833,15 +827,13 @@ int g_gemm_persist_fwd() {   // the persistent-form switch with its environment 
   (void)env_once;
   return g_gemm_persist;
 }
-// Does this launch take the persistent wide form (256 blocks walking whole tiles, 16-byte epilogue accesses)?  The one place that decides it: the launcher and
-// udm_gemm_aux_tile (which tells a caller whether the tile-order aux layout is available) must agree.
+// Does this launch take the persistent wide form (256 blocks walking whole tiles, 16-byte epilogue accesses)?
 template <int BMX, int EPI, bool OUT_F32>
 bool persistent_wide_ok(const GemmArgs& a) {
   if (BMX < 256) return false;
-  const bool aux_ok = EPI < UDM_EPI_BIAS_GELU || a.ldaux % 8 == 0;    // (tile order: ldaux = -BMX, a multiple of 8 as well)
-  const bool aux_tile_ok = !(EPI >= UDM_EPI_BIAS_GELU && a.ldaux < 0) || a.ldaux == -BMX;
+  const bool aux_ok = EPI < UDM_EPI_BIAS_GELU || a.ldaux % 8 == 0;
   return g_gemm_persist_fwd() && a.splitk <= 1 && (long)((a.M + BMX - 1) / BMX) * ((a.N + 255) / 256) > 256 && a.M % BMX == 0 && a.N % 256 == 0 && a.K / BK >= 2 &&
-         (!UDM_EPI_WIDE || ((OUT_F32 ? a.ldc % 4 == 0 : a.ldc % 8 == 0) && aux_ok)) && aux_tile_ok;
+         (!UDM_EPI_WIDE || ((OUT_F32 ? a.ldc % 4 == 0 : a.ldc % 8 == 0) && aux_ok));
 }
 
 template <int BMX, int EPI, bool OUT_F32, bool TN = false>
@@ -873,11 +865,6 @@ int launch_big_t(const GemmArgs& a0, hipStream_t stream) {
       UDM_CHECK_LAUNCH("udm_gemm_nt_bf16(big, persistent)");
       return 0;
     }
-  }
-  if (EPI >= UDM_EPI_BIAS_GELU && a.ldaux < 0) {
-    udm_set_error("udm_gemm_nt_bf16: tile-order aux (ldaux = %ld) needs the persistent wide form with %d-row tiles; this launch (M=%d N=%d K=%d) is not one - ask udm_gemm_aux_tile first",
-                  a.ldaux, BMX, a.M, a.N, a.K);
-    return 2;
   }
   hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n * (a.splitk > 1 ? a.splitk : 1)), dim3(512), lds, stream, a);
   UDM_CHECK_LAUNCH("udm_gemm_nt_bf16(big)");
@@ -968,7 +955,7 @@ extern "C" int udm_gemm_nt_bf16(const void* A, const void* B, void* C, int64_t M
       // measured (scripts/bench_gemm_quad.py, 1.4 B shapes, random operands): the quad kernel wins 1-3 % on single-round shapes with a plain or
       // bias epilogue and loses 3 % where the GELU / GELU' epilogue runs (one wave per SIMD has nothing to overlap its VALU with);
       // multi-round shapes stay with the persistent 8-wave blocks
-      if ((udm_quad_mode() == 2 && ldaux >= 0) || (qt >= 128 && qt <= 256 && q_cost <= o_cost && epilogue <= UDM_EPI_BIAS)) {
+      if (udm_quad_mode() == 2 || (qt >= 128 && qt <= 256 && q_cost <= o_cost && epilogue <= UDM_EPI_BIAS)) {
         QuadArgs q{};
         q.A = a.A; q.B = a.B; q.C = C; q.bias = bias; q.aux = (bf16_t*)aux; q.lda = lda; q.ldb = ldb; q.ldc = ldc; q.ldaux = ldaux;
         q.M = a.M; q.N = a.N; q.K = a.K; q.beta = 0.f; q.splitk = 1;
@@ -994,7 +981,6 @@ extern "C" int udm_gemm_nt_bf16(const void* A, const void* B, void* C, int64_t M
     case 320: return launch_big<320>(a, epilogue, out_f32, stream);
     default: break;
   }
-  UDM_CHECK_ARG(!(epilogue >= UDM_EPI_BIAS_GELU && ldaux < 0), "udm_gemm_nt_bf16: tile-order aux (ldaux < 0) needs the persistent wide form - ask udm_gemm_aux_tile first");
   switch (epilogue) {
     case UDM_EPI_NONE: return launch_gemm<UDM_EPI_NONE>(a, out_f32, stream);
     case UDM_EPI_BIAS:
@@ -1008,21 +994,6 @@ extern "C" int udm_gemm_nt_bf16(const void* A, const void* B, void* C, int64_t M
       return launch_gemm<UDM_EPI_DGELU>(a, out_f32, stream);
     default: udm_set_error("udm_gemm_nt_bf16: unknown epilogue %d", epilogue); return 2;
   }
-}
-
-// Tile height (256 / 320) with which udm_gemm_nt_bf16 would run this GELU / GELU' problem in its persistent wide form (bf16 output, 16-byte aligned rows), or 0 when it
-// would not: the caller may then pass ldaux = -height to BOTH GEMMs of an fc1-forward / fc2-dgrad pair (same M and N) - the saved derivative lives in tile order.
-extern "C" int udm_gemm_aux_tile(int64_t M, int64_t N, int64_t K, int epilogue) {
-  if (epilogue != UDM_EPI_BIAS_GELU && epilogue != UDM_EPI_DGELU) return 0;
-  if (M <= 0 || N <= 0 || K <= 0 || K % 8 || M >= (1 << 30) || N >= (1 << 30) || udm_quad_mode() == 2 || g_force_tile >= 0) return 0;
-  const int t = choose_tile(M, N, K, K, K);
-  GemmArgs a{};
-  a.M = (int)M; a.N = (int)N; a.K = (int)K; a.ldc = N; a.splitk = 1;
-  a.ldaux = -t;
-  bool ok = false;
-  if (t == 256) ok = epilogue == UDM_EPI_BIAS_GELU ? persistent_wide_ok<256, UDM_EPI_BIAS_GELU, false>(a) : persistent_wide_ok<256, UDM_EPI_DGELU, false>(a);
-  if (t == 320) ok = epilogue == UDM_EPI_BIAS_GELU ? persistent_wide_ok<320, UDM_EPI_BIAS_GELU, false>(a) : persistent_wide_ok<320, UDM_EPI_DGELU, false>(a);
-  return ok ? t : 0;
 }
 
 extern "C" int udm_gemm_tn_bf16(const void* A, const void* B, void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, float beta,

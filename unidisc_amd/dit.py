@@ -716,9 +716,7 @@ class DIT(nn.Module, _HubMixin):
                 h2, rstd2, mean2 = K.norm_fwd(x_mid, blk.norm2.weight.detach(), nt, L, mod=mod, mod_idx=(3, 4), modality=mod_flat, any_img=any_img)
             f1, f2 = lin[f"{i}.fc1"], lin[f"{i}.fc2"]
             u1 = torch.empty((Mb, 4 * d), dtype=BF16, device=dev)
-            # the saved GELU derivative is private to this GEMM and the mlp.2 dgrad (same M x 4d tile grid): in TILE ORDER where both run the persistent form
-            u1_ld = -K.gelu_aux_tile(Mb, 4 * d, d, d) or None
-            g = K.gemm_nt(h2, f1.w16, N=4 * d, epilogue=K.EPI_BIAS_GELU, bias=f1.bias.detach(), aux=u1, ldaux=u1_ld)
+            g = K.gemm_nt(h2, f1.w16, N=4 * d, epilogue=K.EPI_BIAS_GELU, bias=f1.bias.detach(), aux=u1)
             u2 = K.gemm_nt(g, f2.w16, N=d, epilogue=K.EPI_BIAS, bias=f2.bias.detach())
             nxt_w = None
             if not tc:  # the consumer of x_out: norm1 of the next block, or norm_final
@@ -732,7 +730,7 @@ class DIT(nn.Module, _HubMixin):
                     R = dict(x_in=x_full, rows_c=rows_c, ckpt=True)
                 else:
                     R.update(x_in=x_full, h1=h1, rstd1=rstd1, mean1=mean1, qkv=qkv, qkr=qkr, qstats=qstats, o=o_full, lse=lse, a_out=a_out, rstd_a=rstd_a,
-                             mean_a=mean_a, x_mid=x_mid, h2=h2, rstd2=rstd2, mean2=mean2, u1=u1, u1_ld=u1_ld, g=g, u2=u2, rstd_m=rstd_m, mean_m=mean_m, rows_c=rows_c,
+                             mean_a=mean_a, x_mid=x_mid, h2=h2, rstd2=rstd2, mean2=mean2, u1=u1, g=g, u2=u2, rstd_m=rstd_m, mean_m=mean_m, rows_c=rows_c,
                              o_c=o if rows_c is not None else None)
             return x_out, pre, R
 
@@ -1099,7 +1097,7 @@ class DIT(nn.Module, _HubMixin):
                                  dw_b=G[id(blk.post_ff_norm.weight)] if sw else None, p_drop=p_drop, seed=seed0 + 4 * i + 2, dbias=G[id(f2.bias)])
                 pend = None
             # dgrad through mlp.2 with the GELU' multiply and the mlp.0 bias gradient (column sums of du1) fused into the epilogue
-            du1 = K.gemm_nt(du2, f2.w16t, N=4 * d, epilogue=K.EPI_DGELU, aux=R["u1"], ldaux=R.get("u1_ld"), bias=G[id(f1.bias)])
+            du1 = K.gemm_nt(du2, f2.w16t, N=4 * d, epilogue=K.EPI_DGELU, aux=R["u1"], bias=G[id(f1.bias)])
             self._wgrad(du2, R["g"], f2, G, bias_done=not tc)
             dh2 = f1.dgrad(du1, du1.shape[0], S["dgrad_form"].get(f"{i}.fc1"))
             self._wgrad(du1, R["h2"], f1, G, bias_done=True)

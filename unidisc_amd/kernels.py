@@ -116,16 +116,6 @@ def gemm_nt(a, b, out=None, *, out_dtype=BF16, M=None, N=None, K=None, lda=None,
     return out
 
 
-def gelu_aux_tile(M, N, K_fwd, K_bwd):
-    """Tile height for the TILE-ORDER layout of the saved GELU derivative (pass `ldaux=-height` to the mlp.0 forward [M, N] = a[M, K_fwd] W^T + bias -> GELU and to the
-    mlp.2 dgrad [M, N] = dY[M, K_bwd] W ⊙ aux), or 0 when the two launches would not both run the persistent form with the same tile height."""
-    if os.environ.get("UDM_AUX_TILE_ORDER", "1") == "0":
-        return 0
-    lib = _lib.load()
-    h = lib.udm_gemm_aux_tile(int(M), int(N), int(K_fwd), EPI_BIAS_GELU)
-    return h if h > 0 and h == lib.udm_gemm_aux_tile(int(M), int(N), int(K_bwd), EPI_DGELU) else 0
-
-
 def gemm_nn_ok(M, N, K):
     """Does the dgrad-from-W form (gemm_nn) cover this shape?  (whole tiles of the one-wave-per-SIMD kernel)"""
     return bool(_lib.load().udm_gemm_nn_ok(int(M), int(N), int(K)))
