@@ -37,6 +37,10 @@ def test_logits_match_golden(name):
     e, budget = rel_err(logits.float().cpu(), truth), rel_err(ref16, truth)
     record(f"golden_logits[{name}]", "ref_bf16_vs_fp32_logits_relrms", budget, note="the reference's own bf16 run against its fp32 run")
     check(f"golden_logits[{name}]", "logits_relrms_vs_fp32_reference", e, LOGITS_BOUND)
+    # ... and directly against the reference's OWN bf16 run (CPU bf16 autocast): two bf16 evaluations of the same network differ by about sqrt(2) x the distance of
+    # either from fp32 (independent roundings), so the claim "these are the reference's bf16 numerics" is this row staying at that level - asserted at
+    # 2 x the reference's own bf16-vs-fp32 deviation + 2e-3 (the SURVEY F9 budget)
+    check(f"golden_logits[{name}]", "logits_relrms_vs_bf16_reference", rel_err(logits.float().cpu(), ref16), 2 * budget + 2e-3)
 
 
 @pytest.mark.parametrize("name", CASE_NAMES)
