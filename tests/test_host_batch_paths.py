@@ -78,9 +78,10 @@ def test_sample_t_and_qxt_bit_exact_on_both_routes(name, generic, fake_k):
 
 
 @pytest.mark.parametrize("generic", [False, True])
-@pytest.mark.parametrize("name", CASE_NAMES)
+@pytest.mark.parametrize("name", ALL)
 def test_allow_move_mask_protects_positions_after_the_lottery(name, generic, fake_k):
-    """`allow_move_mask` (model.py:564-566): AND-ed onto the final move mask; the two routes agree and equal the golden mask & allow."""
+    """`allow_move_mask` (model.py:564-566): AND-ed onto the final move mask - behind the whole-modality lottery and, for packed / interleaved batches, behind the
+    per-block lottery as well; the two routes agree and equal the golden mask & allow."""
     g, diff = _product(name)
     diff._generic_qxt = generic
     b = diff.update_batch(g.batch())

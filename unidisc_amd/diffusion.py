@@ -354,10 +354,10 @@ class Diffusion:
             smt = r_txt < p_txt
             smi = (r_img < p_img) if r_img is not None else torch.zeros_like(smt)
             if interleaved and multimodal:
-                if allow_move_mask is not None:
-                    raise NotImplementedError("unidisc_amd: allow_move_mask with interleaved batches")
                 block_move, ignore = self._interleaved_block_lottery(batch, mask_prob, x.shape, x.device)
                 move = move | block_move
+                if allow_move_mask is not None:    # protected positions never move, whole-block masks included (model.py:564-565 sits behind every branch)
+                    move = move & allow_move_mask
                 xt = torch.where(move, self.mask_index, x)
                 return (xt, ignore, None, smt, smi, move) if return_ignore_batch_mask_for_metrics else xt
             # a sample that drew BOTH sides keeps its per-token mask
