@@ -107,7 +107,8 @@ def synthetic_batch(workload, B, seed):
 # fraction of the L x L query/key pairs a query may attend to (document masks of packed rows: sum_doc len^2 / L^2); set per workload in main()
 ATTN_PAIR_FRACTION = 1.0
 
-GEMM_ENTRY_POINTS = ("udm_gemm_nt_bf16", "udm_gemm_tn_bf16", "udm_gemm_nn_bf16", "udm_gemm_nt_splitk_bf16", "udm_gemm_tn_splitk_bf16", "udm_gemm_tn_pair_bf16")   # (A, B, C, M, N, K, ...)
+GEMM_ENTRY_POINTS = ("udm_gemm_nt_bf16", "udm_gemm_tn_bf16", "udm_gemm_nn_bf16", "udm_gemm_nt_splitk_bf16", "udm_gemm_tn_splitk_bf16", "udm_gemm_tn_pair_bf16",
+                     "udm_gemm_tn_multi_bf16")   # (A, B, C, M, N, K, ...)
 
 
 def _work(name, a):
@@ -115,6 +116,8 @@ def _work(name, a):
     figures of the HBM-bound kernels: what the op must read and write once), flops count what the MFMA pipe is asked to do."""
     if name == "udm_gemm_tn_pair_bf16":   # (A0, B0, C0, M0, lda0, ldb0, ldc0, A1, B1, C1, M1, lda1, ldb1, ldc1, N, K, beta, ws, ws_elems)
         return "flop", 2.0 * (a[3] + a[10]) * a[14] * a[15]
+    if name == "udm_gemm_tn_multi_bf16":  # (nprob, A[], B[], C[], M[], N[], lda[], ldb[], K, ...)
+        return "flop", 2.0 * a[8] * sum(float(a[4][i]) * float(a[5][i]) for i in range(a[0]))
     if name in GEMM_ENTRY_POINTS:
         return "flop", 2.0 * a[3] * a[4] * a[5]
     if name == "udm_attention_fwd":           # only the pairs inside a document count (a packed row of 4 x 1152 is a quarter of 4608^2)

@@ -69,6 +69,12 @@ int udm_gemm_tn_splitk_bf16(const void* A, const void* B, void* C, int64_t M, in
  * out-proj (64 tiles) weight gradients of a DiT block fill the 256 CUs exactly once.  Returns 3 without doing anything when the shapes do not qualify. */
 int udm_gemm_tn_pair_bf16(const void* A0, const void* B0, void* C0, int64_t M0, int64_t lda0, int64_t ldb0, int64_t ldc0, const void* A1, const void* B1, void* C1,
                           int64_t M1, int64_t lda1, int64_t ldb1, int64_t ldc1, int64_t N, int64_t K, float beta, float* ws, int64_t ws_elems, hipStream_t stream);
+/* up to four wgrads of one backward step over the SAME contraction in ONE split-K launch + ONE reduce pass (the few-tile weight gradients of a small DiT block:
+ * UniDisc-S's qkv / out-proj / mlp.0 / mlp.2 weights over K = B*L): C_i[M_i, N_i] (fp32, contiguous) = beta * C_i + A_i[K, M_i]^T B_i[K, N_i]; M_i, N_i multiples of
+ * 256, K of 64, at most 128 tiles in total, ws >= slices * sum(M_i * N_i) floats with slices = min(CUs / tiles, K / 512, 32) >= 2.  Returns 3 without doing
+ * anything when the shapes do not qualify. */
+int udm_gemm_tn_multi_bf16(int nprob, const void* const* A, const void* const* B, void* const* C, const int64_t* M, const int64_t* N, const int64_t* lda,
+                           const int64_t* ldb, int64_t K, float beta, float* ws, int64_t ws_elems, hipStream_t stream);
 /* (few tiles over a long K: split in K through `ws` - fp32, >= slices * (M0 + M1) * N elements, slices = min(256 / tiles, K / 512, 32); NULL = never split) */
 /* NT form of the same idea with a bf16 result (head dgrad on the compacted [MASK] rows: few 320 x 256 tiles over K = V): fp32 partial tiles in ws
  * (>= slices*M*N), reduce pass rounds to bf16; falls back to udm_gemm_nt_bf16 when splitting does not apply. */

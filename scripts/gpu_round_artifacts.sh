@@ -3,7 +3,7 @@
 # RCCL world-1 check), the bench workloads (headline with the CPU baseline; config E with bf16 and fp8 attention; UniDisc-S), the rocprofv3 kernel-trace
 # summaries of all three workloads and the two PMC passes (HBM traffic, MFMA utilisation) of the headline command, the CU-reservation measurement.
 # Usage: bash scripts/gpu_round_artifacts.sh r03     (outputs under gpurun_out/, copied to profiles/ by scripts/collect_profiles.sh)
-TAG=${1:-r03}; R=${GRAFT_REPO_ROOT:-$(pwd)}; mkdir -p $R/gpurun_out; export TMPDIR=/tmp
+TAG=${1:-r04}; R=${GRAFT_REPO_ROOT:-$(pwd)}; mkdir -p $R/gpurun_out; export TMPDIR=/tmp
 cd $R
 [ -n "$SKIP_TESTS" ] || UDM_DUMP_GRAD_ERRS=gpurun_out/graderrs_$TAG UDM_LEDGER=gpurun_out/parity_ledger_$TAG.json timeout 2400 python -m pytest tests -m gpu -q -p no:cacheprovider --timeout 1500 2>&1 | tail -15 > gpurun_out/gputests_$TAG.log
 timeout 900 python bench.py --steps 25 --warmup 5 > gpurun_out/bench_1.4b_b8_$TAG.json 2> gpurun_out/bench_1.4b_b8_$TAG.err
@@ -22,7 +22,7 @@ rm -rf gpurun_out/pmcb gpurun_out/pmcm gpurun_out/prof_$TAG gpurun_out/prof_${TA
 tail -4 gpurun_out/gputests_$TAG.log; cut -c1-400 gpurun_out/bench_1.4b_b8_$TAG.json; tail -3 gpurun_out/prof_summary_$TAG.log; tail -16 gpurun_out/pmc_traffic_summary_$TAG.log; tail -16 gpurun_out/pmc_mfma_summary_$TAG.log
 python3 - <<'PY'
 import json,glob
-for f in sorted(glob.glob('gpurun_out/bench_*_r03.json')):
+for f in sorted(glob.glob('gpurun_out/bench_*_'"$TAG"'.json')):
     try:
         s=open(f).read(); j=json.loads(s[s.index('{'):])
         print(f, round(j['ms_per_step'],2), round(j['ms_per_step_median'],2), round(j['step_mfu'],4), round(j['roofline']['frac'],4))

@@ -186,6 +186,34 @@ def test_gemm_tn_pair_equals_two_launches(K, M0, M1, N, Kc, beta):
         K.gemm_tn_pair(ga0[:, :200], gb0, o0[:200], ga1, gb1, o1)
 
 
+@pytest.mark.parametrize("beta", [0.0, 1.0])
+@pytest.mark.parametrize("shapes,Kc", [([(2304, 768), (768, 768), (3072, 768), (768, 3072)], 24576), ([(512, 256), (256, 768)], 2048), ([(256, 256)], 1024)])
+def test_gemm_tn_multi_equals_separate_launches(K, shapes, Kc, beta):
+    """Up to four wgrads over the same K in ONE split-K launch + ONE reduce (udm_gemm_tn_multi_bf16: UniDisc-S's qkv / out-proj / mlp.0 / mlp.2 weight gradients):
+    every output equals the fp32 product and the single-problem launches (to fp32 summation order: the K split differs), different leading dimensions per operand,
+    beta on every output; shapes that do not qualify are refused without touching anything."""
+    probs, refs = [], []
+    for i, (M, N) in enumerate(shapes):
+        a, b = bf(rnd(Kc, M + 8 * i, seed=700 + i, scale=0.5)), bf(rnd(Kc, N + 16, seed=720 + i, scale=0.5))
+        c = rnd(M, N, seed=740 + i)
+        probs.append((a.to(DEV)[:, :M], b.to(DEV)[:, :N], c.clone().to(DEV)))
+        refs.append((a[:, :M], b[:, :N], c))
+    assert K.gemm_tn_multi(probs, beta=beta)
+    for (ga, gb, out), (a, b, c) in zip(probs, refs):
+        M, N = c.shape
+        if Kc * M * N <= 2 ** 31:
+            ref = a.float().t() @ b.float() + beta * c
+            assert rel_err(out.cpu(), ref) < 1e-5
+        single = c.clone().to(DEV)
+        K.gemm_tn_splitk(ga, gb, single, M=M, N=N, beta=beta)
+        assert rel_err(out, single) < 3e-6
+    # not multiples of 256 / too many tiles / different K: refused, outputs untouched
+    o = torch.full((192, 256), 3.0, device=DEV)
+    assert not K.gemm_tn_multi([(probs[0][0][:, :192], probs[0][1][:, :256], o)]) and torch.all(o == 3.0)
+    big = torch.zeros(4096, 4096, device=DEV)
+    assert not K.gemm_tn_multi([(bf(rnd(1024, 4096, seed=1)).to(DEV), bf(rnd(1024, 4096, seed=2)).to(DEV), big)])
+
+
 @pytest.mark.parametrize("M0,M1,N,Kc", [(768, 256, 512, 1024), (6144, 2048, 2048, 2560)])
 def test_gemm_tn_pair_falls_back_when_quad_kernels_are_off(K, M0, M1, N, Kc):
     """udm_gemm_tn_pair_bf16 answers rc = 3 ("not applicable, nothing launched") when the one-wave-per-SIMD kernels are switched off (`gemm_set_quad(0)`, a documented

@@ -28,6 +28,7 @@ PROTOTYPES = {
     "udm_gemm_nn_splitk_bf16": [_P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _P, _I64, _P],
     "udm_gemm_tn_splitk_bf16": [_P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _F, _P, _I64, _P],
     "udm_gemm_tn_pair_bf16": [_P, _P, _P, _I64, _I64, _I64, _I64, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _F, _P, _I64, _P],
+    "udm_gemm_tn_multi_bf16": [_I, _P, _P, _P, _P, _P, _P, _P, _I64, _F, _P, _I64, _P],
     "udm_gemm_set_cus": [_I],
     "udm_debug_set": [ctypes.c_char_p, _I64],
     "udm_debug_cu_hog": [_I64, _P, _P],
@@ -80,6 +81,13 @@ _lib = None
 
 class HipLibraryMissing(RuntimeError):
     pass
+
+
+class NotApplicable(RuntimeError):
+    """An entry point of SOFT_RC3 answered rc = 3: "these shapes are not mine, nothing was launched" - the caller issues the plain calls instead."""
+
+
+SOFT_RC3 = {"udm_gemm_tn_pair_bf16", "udm_gemm_tn_multi_bf16"}
 
 
 def build(verbose: bool = False) -> str:
@@ -138,5 +146,7 @@ def call(name: str, *args):
     """Invoke an entry point; non-zero return raises RuntimeError(udm_last_error())."""
     lib = load()
     rc = getattr(lib, name)(*args)
+    if rc == 3 and name in SOFT_RC3:
+        raise NotApplicable(name)
     if rc != 0:
         raise RuntimeError(f"{name} failed (rc={rc}): {lib.udm_last_error().decode(errors='replace')}")

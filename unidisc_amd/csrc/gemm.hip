@@ -1256,6 +1256,68 @@ extern "C" int udm_gemm_tn_pair_bf16(const void* A0, const void* B0, void* C0, i
   return udm_quad_launch_tn_pair(q, M1, stream);
 }
 
+namespace {
+struct ReduceSegs { long start4[5]; float* out[4]; int n; };   // segment i = float4 indices [start4[i], start4[i + 1]) of the concatenated partial matrices
+// out_i = beta * out_i + sum_s ws[s] over up to four contiguous outputs laid out back to back in every workspace slice
+__global__ __launch_bounds__(256) void splitk_reduce_multi_kernel(const float* __restrict__ ws, ReduceSegs sg, int S, long stride, float beta) {
+  const long n4 = sg.start4[sg.n];
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    float4 acc = reinterpret_cast<const float4*>(ws)[i];
+    for (int s = 1; s < S; ++s) {
+      const float4 v = reinterpret_cast<const float4*>(ws + s * stride)[i];
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    int k = 0;
+    while (k + 1 < sg.n && i >= sg.start4[k + 1]) ++k;
+    float4* o = reinterpret_cast<float4*>(sg.out[k]) + (i - sg.start4[k]);
+    if (beta != 0.f) { const float4 c = *o; acc.x += beta * c.x; acc.y += beta * c.y; acc.z += beta * c.z; acc.w += beta * c.w; }
+    *o = acc;
+  }
+}
+}  // namespace
+
+// Up to four weight gradients of one backward step over the SAME contraction (the rows of a small DiT block: UniDisc-S's qkv 2304 x 768, out-proj 768 x 768,
+// mlp.0 3072 x 768 and mlp.2 768 x 3072 over K = B*L = 24 576) in ONE split-K launch + ONE reduce pass: C_i[M_i, N_i] (fp32, contiguous) = beta * C_i +
+// A_i[K, M_i]^T B_i[K, N_i].  All tiles (256 x 256) of all problems share the grid and the K split (as many slices as fill the CUs once), so the partial-tile
+// traffic and the launch count are those of one problem of the combined size (separately: three launches at 7 slices each + four reduce passes).
+// M_i, N_i multiples of 256, K of 64, at most 128 tiles in total, ws >= slices * sum(M_i N_i) floats.  Returns 3 (and does nothing) when the shapes do not
+// qualify: the caller then issues the plain calls.
+extern "C" int udm_gemm_tn_multi_bf16(int nprob, const void* const* A, const void* const* B, void* const* C, const int64_t* M, const int64_t* N, const int64_t* lda,
+                                      const int64_t* ldb, int64_t K, float beta, float* ws, int64_t ws_elems, hipStream_t stream) {
+  UDM_CHECK_ARG(A && B && C && M && N && lda && ldb && nprob >= 1 && nprob <= 4, "udm_gemm_tn_multi_bf16: one to four problems");
+  if (!udm_quad_mode() || K < 128 || K % 64 || !ws || ((uintptr_t)ws % 16)) return 3;
+  QuadArgs q{};
+  long tiles = 0, area = 0;
+  for (int i = 0; i < nprob; ++i) {
+    if (!A[i] || !B[i] || !C[i] || M[i] <= 0 || N[i] <= 0 || M[i] % 256 || N[i] % 256 || lda[i] % 8 || ldb[i] % 8 || lda[i] < M[i] || ldb[i] < N[i]) return 3;
+    if (((uintptr_t)A[i] | (uintptr_t)B[i] | (uintptr_t)C[i]) % 16) return 3;
+    q.m_tile_start[i] = (int)tiles;
+    q.m_tiles_n[i] = (int)(N[i] / 256);
+    q.mA[i] = (const bf16_t*)A[i]; q.mB[i] = (const bf16_t*)B[i];
+    q.mC[i] = ws + area; q.mlda[i] = lda[i]; q.mldb[i] = ldb[i]; q.mldc[i] = N[i];   // every slice writes its partial tile; slice s at + s * total area
+    tiles += (M[i] / 256) * (N[i] / 256);
+    area += M[i] * N[i];
+  }
+  q.m_tile_start[nprob] = (int)tiles;
+  q.nprob = nprob;
+  const long nkt = K / 64;
+  long skl = gemm_cus_available() / tiles;
+  if (skl > nkt / 8) skl = nkt / 8;
+  if (skl > 32) skl = 32;
+  if (tiles > 128 || skl < 2 || ws_elems < skl * area) return 3;
+  q.A = q.mA[0]; q.B = q.mB[0]; q.C = q.mC[0]; q.lda = q.mlda[0]; q.ldb = q.mldb[0]; q.ldc = q.mldc[0];
+  q.K = (int)K; q.beta = 0.f; q.splitk = (int)skl; q.slice_stride = area;
+  if (int rc = udm_quad_launch_tn_multi(q, stream)) return rc;
+  ReduceSegs sg{};
+  sg.n = nprob;
+  long at = 0;
+  for (int i = 0; i < nprob; ++i) { sg.start4[i] = at / 4; sg.out[i] = (float*)C[i]; at += M[i] * N[i]; }
+  sg.start4[nprob] = at / 4;
+  hipLaunchKernelGGL(splitk_reduce_multi_kernel, dim3((unsigned)std::min<long>((at / 4 + 255) / 256, 2048)), dim3(256), 0, stream, (const float*)ws, sg, (int)skl, area, beta);
+  UDM_CHECK_LAUNCH("udm_gemm_tn_multi_bf16(reduce)");
+  return 0;
+}
+
 int udm_gemm_cus_available() { return gemm_cus_available(); }
 extern "C" int udm_gemm_set_cus(int cus) {   // 0 = all CUs; otherwise the persistent NT grid (a multiple of 8 in [8, 256])
   UDM_CHECK_ARG(cus == 0 || (cus >= 8 && cus <= 256 && cus % 8 == 0), "udm_gemm_set_cus: 0 or a multiple of 8 in [8, 256]");

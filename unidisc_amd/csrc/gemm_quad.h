@@ -19,6 +19,16 @@ struct QuadArgs {
   // problem one, the rest problem two (its own operands and output).  One launch of exactly 256 tiles instead of a 256-tile launch of 192-row tiles plus a
   // split-K launch + reduce (qkv and out-proj weight gradients: 192 + 64 tiles of 256 x 256).  0 = single problem.
   int tiles_m_split = 0;
+  // multi-problem launch (TN wgrad form, 256 x 256 tiles): up to four problems C_i[M_i, N_i] = A_i[K, M_i]^T B_i[K, N_i] over the SAME K share one grid (and one
+  // K split) - the four few-tile weight gradients of a small DiT block (UniDisc-S: 27 + 9 + 36 + 36 tiles over K = 24 576).  Tiles of problem i are
+  // [m_tile_start[i], m_tile_start[i + 1]); 0 = off.
+  int nprob = 0;
+  int m_tile_start[5] = {0, 0, 0, 0, 0};
+  int m_tiles_n[4] = {0, 0, 0, 0};
+  const bf16_t* mA[4] = {nullptr, nullptr, nullptr, nullptr};
+  const bf16_t* mB[4] = {nullptr, nullptr, nullptr, nullptr};
+  void* mC[4] = {nullptr, nullptr, nullptr, nullptr};
+  long mlda[4] = {0, 0, 0, 0}, mldb[4] = {0, 0, 0, 0}, mldc[4] = {0, 0, 0, 0};
   const bf16_t* A2 = nullptr;
   const bf16_t* B2 = nullptr;
   void* C2 = nullptr;
@@ -33,6 +43,8 @@ bool udm_quad_tn_ok(long M, long N, long K, int* fm);
 int udm_quad_launch_tn(const QuadArgs& a, int fm, hipStream_t stream);
 // two wgrads C = A^T B, C2 = A2^T B2 with the same N and K in one launch of 256 x 256 tiles (a.M / a.tiles_m_split describe problem one, M2 rows problem two)
 int udm_quad_launch_tn_pair(const QuadArgs& a, long M2, hipStream_t stream);
+// up to four wgrads over the same K in one launch of 256 x 256 tiles (a.nprob, a.m*: filled by the caller; a.splitk slices per tile)
+int udm_quad_launch_tn_multi(const QuadArgs& a, hipStream_t stream);
 // NT (forward / dgrad) form
 bool udm_quad_nt_ok(long M, long N, long K, int* fm);
 int udm_quad_launch_nt(const QuadArgs& a, int fm, int epilogue, int out_f32, hipStream_t stream);

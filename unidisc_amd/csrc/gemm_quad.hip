@@ -74,10 +74,24 @@ __global__ __launch_bounds__(256, 1) void gemm_quad_kernel(QuadArgs p0) {
   const int grp = pid / per_group, first_m = grp * grp_rows;
   const int gsz = min(p.tiles_m - first_m, grp_rows);
   int tm = first_m + (pid % per_group) % gsz;
-  const int tn = (pid % per_group) / gsz;
+  int tn = (pid % per_group) / gsz;
   if (p.tiles_m_split > 0 && tm >= p.tiles_m_split) {   // block-uniform
     tm -= p.tiles_m_split;
     p.A = p.A2; p.B = p.B2; p.C = p.C2; p.lda = p.lda2; p.ldb = p.ldb2; p.ldc = p.ldc2;
+  }
+  if (MODE == 1 && p0.nprob > 0) {   // multi-problem launch (block-uniform, scalar): which problem does tile `pid` belong to, and where inside it
+    // (selected by an unrolled compare chain on the kernel ARGUMENT: indexing a local copy with a run-time index would send the whole struct to private memory)
+    int start = 0, end = p0.m_tile_start[1], tnn = p0.m_tiles_n[0];
+#pragma unroll
+    for (int i = 1; i < 4; ++i) {
+      if (i < p0.nprob && pid >= p0.m_tile_start[i]) {
+        start = p0.m_tile_start[i]; end = p0.m_tile_start[i + 1]; tnn = p0.m_tiles_n[i];
+        p.A = p0.mA[i]; p.B = p0.mB[i]; p.C = p0.mC[i]; p.lda = p0.mlda[i]; p.ldb = p0.mldb[i]; p.ldc = p0.mldc[i];
+      }
+    }
+    const int local = pid - start, rows_i = (end - start) / tnn;
+    tm = local % rows_i;   // column-major inside a problem: neighbouring blocks share the B panel
+    tn = local / rows_i;
   }
   const int row0 = tm * BM, col0 = tn * BN;
 
@@ -419,6 +433,14 @@ int udm_quad_launch_tn_pair(const QuadArgs& a0, long M2, hipStream_t stream) {
   QuadArgs a = a0;
   a.tiles_m_split = a.M / 256;
   a.M = a.M + (int)M2;        // launch_quad_t derives the tile rows of BOTH problems from M
+  return launch_quad_t<4, true, UDM_EPI_NONE, true>(a, stream);
+}
+
+int udm_quad_launch_tn_multi(const QuadArgs& a0, hipStream_t stream) {
+  QuadArgs a = a0;
+  a.M = a.m_tile_start[a.nprob] * 256;   // launch_quad_t derives the grid from M / 256 x N / 256: all tiles of all problems
+  a.N = 256;
+  a.tiles_m_split = 0;
   return launch_quad_t<4, true, UDM_EPI_NONE, true>(a, stream);
 }
 

@@ -290,6 +290,8 @@ class DIT(nn.Module, _HubMixin):
         # forward and has a zero gradient) - the head (forward, dgrad, wgrad) then runs as (text rows x text ids) + (image rows x image ids) instead of rows x all ids
         self.split_head = os.environ.get("UDM_SPLIT_HEAD", "1") != "0"
         self.pair_wgrads = os.environ.get("UDM_PAIR_WGRADS", "1") != "0"   # qkv + out-proj weight gradients in one 256-tile launch (K.gemm_tn_pair)
+        # the four weight gradients of a block in ONE split-K launch + ONE reduce where each of them is a few tiles over the long row contraction (UniDisc-S)
+        self.multi_wgrads = os.environ.get("UDM_MULTI_WGRADS", "1") != "0"
         self.dgrad_from_w = os.environ.get("UDM_DGRAD_NN", "1") != "0"   # dgrads from the forward's W shadow where the shape allows (see refresh_weight_shadows)
         self.grad_ready_callback = None   # fn(flat_grads, lo, hi): elements [lo, hi) of this backward's flat fp32 gradient buffer are final
         self.grad_sync_finish = None      # fn(): called at the end of backward (e.g. make the compute stream wait for the all-reduces)
@@ -1098,9 +1100,18 @@ class DIT(nn.Module, _HubMixin):
                 pend = None
             # dgrad through mlp.2 with the GELU' multiply and the mlp.0 bias gradient (column sums of du1) fused into the epilogue
             du1 = K.gemm_nt(du2, f2.w16t, N=4 * d, epilogue=K.EPI_DGELU, aux=R["u1"], bias=G[id(f1.bias)])
-            self._wgrad(du2, R["g"], f2, G, bias_done=not tc)
+            lo, lq = lin[f"{i}.out"], lin[f"{i}.qkv"]
+            # few-tile regime (every weight of the block is at most half a round of tiles: UniDisc-S): the four weight gradients wait for the end of the block's
+            # backward and share ONE split-K launch + ONE reduce (K.gemm_tn_multi) instead of three split-K launches + four reduce passes
+            multi = None
+            if (self.multi_wgrads and du2.is_cuda and not tc and R.get("rows_c") is None and M % 64 == 0 and lo.bias is None and lq.bias is None
+                    and all(K.gemm_tn_wants_splitk(l_.out, l_.inp) and l_.out % 256 == 0 and l_.inp % 256 == 0 for l_ in (f1, f2, lo, lq))):
+                multi = [(du2, R["g"], f2), (du1, R["h2"], f1)]
+            if multi is None:
+                self._wgrad(du2, R["g"], f2, G, bias_done=not tc)
             dh2 = f1.dgrad(du1, du1.shape[0], S["dgrad_form"].get(f"{i}.fc1"))
-            self._wgrad(du1, R["h2"], f1, G, bias_done=True)
+            if multi is None:
+                self._wgrad(du1, R["h2"], f1, G, bias_done=True)
             del du1, du2
             # norm2 backward + attention branch
             if tc:
@@ -1119,7 +1130,6 @@ class DIT(nn.Module, _HubMixin):
                                     dw_b=G[id(blk.pre_residual_norm.weight)])
                 else:
                     da = branch_bwd(p2, R["a_out"], p_drop=p_drop, seed=seed0 + 4 * i + 1)
-            lo, lq = lin[f"{i}.out"], lin[f"{i}.qkv"]
             pair_out = None
             do = lo.dgrad(da, da.shape[0], S["dgrad_form"].get(f"{i}.out"))
             if R.get("rows_c") is not None:
@@ -1132,7 +1142,9 @@ class DIT(nn.Module, _HubMixin):
                 # The out-proj weight gradient (2048 x 2048: 64 tiles) waits for the qkv one (6144 x 2048: 192 tiles of 256 rows) where the two fill the chip
                 # exactly once TOGETHER (K.gemm_tn_pair): one launch instead of 256 tiles of 192 rows + a split-K launch + its reduce pass; few tiles over a long
                 # contraction (UniDisc-S: 27 + 9) share ONE split-K launch
-                if (self.pair_wgrads and da.is_cuda and lo.bias is None and lq.bias is None and lo.inp == lq.inp
+                if multi is not None:
+                    multi.append((da, R["o"], lo))
+                elif (self.pair_wgrads and da.is_cuda and lo.bias is None and lq.bias is None and lo.inp == lq.inp
                         and K.gemm_tn_pair_ok(lq.out, lo.out, lq.inp, M)
                         and ((lq.out // 256 + lo.out // 256) * (lq.inp // 256) % 256 == 0 or (lq.out // 256 + lo.out // 256) * (lq.inp // 256) <= 128)):
                     pair_out = (da, R["o"])
@@ -1147,7 +1159,13 @@ class DIT(nn.Module, _HubMixin):
                               dbq=G[id(at.q_norm.bias)] if qn else None, dgk=G[id(at.k_norm.weight)] if qn else None,
                               dbk=G[id(at.k_norm.bias)] if qn else None)
             dh1 = lq.dgrad(dqkv, dqkv.shape[0], S["dgrad_form"].get(f"{i}.qkv"))
-            if pair_out is not None:
+            if multi is not None:
+                multi.append((dqkv, R["h1"], lq))
+                if not K.gemm_tn_multi([(dy_, x_, G[id(l_.weight)]) for dy_, x_, l_ in multi]):
+                    for dy_, x_, l_ in multi:    # (shapes outside the shared launch: the plain calls)
+                        self._wgrad(dy_, x_, l_, G, bias_done=True)
+                multi = None
+            elif pair_out is not None:
                 K.gemm_tn_pair(dqkv, R["h1"], G[id(lq.weight)], pair_out[0], pair_out[1], G[id(lo.weight)])
                 pair_out = None
             else:

@@ -189,14 +189,45 @@ def gemm_tn_pair(a0, b0, out0, a1, b1, out1, *, beta=0.0):
     tiles = ((M0 + M1) // 256) * (N // 256)
     sk = max(1, min(256 // tiles, (K // 64) // 8, 32))   # the rule of udm_gemm_tn_pair_bf16 (sizes the workspace): few tiles over a long K are split in K
     ws = _scratch(sk * (M0 + M1) * N, a0.device) if sk > 1 else None
-    lib = _lib.load()
-    rc = lib.udm_gemm_tn_pair_bf16(_p(a0), _p(b0), _p(out0), M0, a0.stride(0), b0.stride(0), out0.stride(0), _p(a1), _p(b1), _p(out1), M1, a1.stride(0),
-                                   b1.stride(0), out1.stride(0), N, K, float(beta), _p(ws), ws.numel() if ws is not None else 0, _s())
-    if rc == 3:   # "not applicable" (one-wave-per-SIMD kernels switched off, or a pointer off its 16-byte alignment): nothing was launched, issue the two plain problems
+    try:   # (through _lib.call like every launch: the bench's per-entry-point timer hooks it)
+        _lib.call("udm_gemm_tn_pair_bf16", _p(a0), _p(b0), _p(out0), M0, a0.stride(0), b0.stride(0), out0.stride(0), _p(a1), _p(b1), _p(out1), M1, a1.stride(0),
+                  b1.stride(0), out1.stride(0), N, K, float(beta), _p(ws), ws.numel() if ws is not None else 0, _s())
+    except _lib.NotApplicable:
+        # rc = 3 (one-wave-per-SIMD kernels switched off, or a pointer off its 16-byte alignment): nothing was launched, issue the two plain problems
         for a, b, out in ((a0, b0, out0), (a1, b1, out1)):
             (gemm_tn_splitk if gemm_tn_wants_splitk(out.shape[0], N, K) else gemm_tn)(a, b, out, beta=beta)
-    elif rc != 0:
-        raise RuntimeError(f"udm_gemm_tn_pair_bf16 failed (rc={rc}): {lib.udm_last_error().decode(errors='replace')}")
+
+
+def gemm_tn_multi(problems, *, beta=0.0):
+    """[(a_i [K, M_i], b_i [K, N_i], out_i [M_i, N_i] fp32 contiguous)] -> out_i = beta * out_i + a_i^T b_i for up to four problems over the SAME K in ONE split-K launch
+    + ONE reduce pass (the few-tile weight gradients of a small DiT block).  Returns False (nothing launched) when the shapes do not qualify."""
+    import ctypes
+
+    n = len(problems)
+    if not (1 <= n <= 4):
+        return False
+    K = problems[0][0].shape[0]
+    tiles = 0
+    for a, b, out in problems:
+        _chk(a, BF16, "gemm_tn_multi a"), _chk(b, BF16, "gemm_tn_multi b"), _chk(out, F32, "gemm_tn_multi out")
+        M, N = out.shape
+        if a.shape[0] != K or b.shape[0] != K or M % 256 or N % 256 or out.stride(0) != N or a.stride(1) != 1 or b.stride(1) != 1:
+            return False
+        tiles += (M // 256) * (N // 256)
+    cus = _CUS[0] or 256
+    sk = min(cus // max(tiles, 1), (K // 64) // 8, 32)
+    if tiles > 128 or sk < 2 or K % 64:
+        return False
+    area = sum(o.numel() for _, _, o in problems)
+    ws = _scratch(sk * area, problems[0][0].device)
+    P, I64 = ctypes.c_void_p * n, ctypes.c_int64 * n
+    try:
+        _lib.call("udm_gemm_tn_multi_bf16", n, P(*[a.data_ptr() for a, _, _ in problems]), P(*[b.data_ptr() for _, b, _ in problems]),
+                  P(*[o.data_ptr() for _, _, o in problems]), I64(*[o.shape[0] for _, _, o in problems]), I64(*[o.shape[1] for _, _, o in problems]),
+                  I64(*[a.stride(0) for a, _, _ in problems]), I64(*[b.stride(0) for _, b, _ in problems]), K, float(beta), _p(ws), ws.numel(), _s())
+    except _lib.NotApplicable:
+        return False
+    return True
 
 
 def gemm_tn_splitk(a, b, out, *, M=None, N=None, beta=0.0):
