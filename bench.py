@@ -381,7 +381,7 @@ def main():
     ap.add_argument("--time-every", type=int, default=16, help="bracket 1 GEMM launch in this many with HIP events inside the timed region (1 = all: costs ~1.7 ms/step)")
     ap.add_argument("--hog-cus", type=int, default=0, help="diagnostics: hold this many CUs with a spinning kernel for the whole run (stand-in for RCCL's channel kernels; "
                     "combine with UDM_GEMM_CUS = 256 - n so the GEMMs plan for the remaining CUs)")
-    ap.add_argument("--ddp-mode", default=None, choices=["auto", "overlap", "overlap_planned", "serialized"],
+    ap.add_argument("--ddp-mode", default=None, choices=["auto", "overlap", "overlap_planned", "serialized", "copy_engine"],
                     help="gradient all-reduce schedule for --gpus > 1 (default: UDM_DDP_MODE or auto = timed in warm-up on all ranks, fastest kept)")
     ap.add_argument("--table-steps", type=int, default=2, help="extra untimed steps after the timed region with every launch event-timed (roofline_table); 0 = off")
     args = ap.parse_args()
@@ -527,6 +527,10 @@ def main():
         result["ddp_mode_requested"] = sync.requested_mode
         result["ddp_mode_warmup_ms"] = sync.mode_timings_ms       # {mode: ms per step, max over ranks} from the auto-selection, else null
         result["ddp_reserved_cus"] = sync.reserved_cus            # what overlap_planned leaves to the collective
+        if getattr(sync, "_cx", None) is not None:                # copy_engine: host-side wait for the helper thread, bytes pushed to peers by this rank
+            # (the join at the end of a backward; it includes the part of the backward the host had run ahead of: not "exposed communication")
+            result["copy_engine_host_join_ms_per_step"] = 1e3 * sync._cx.host_wait_s / (args.steps + args.warmup)
+            result["copy_engine_bytes_pushed_per_step"] = sync._cx.bytes_copied // (args.steps + args.warmup)
         result["rccl_max_nchannels"] = rccl_channels              # NCCL_MAX_NCHANNELS in force (0 = RCCL's default)
         # time the compute stream spent waiting for the comm stream at the end of backward (events around BucketedGradSync.finish)
         result["exposed_comm_ms_per_step"] = sync.exposed_ms() / args.steps

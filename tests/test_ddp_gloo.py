@@ -118,7 +118,7 @@ def _worker(rank, world, port, min_bucket, q):
         import time
         def slow_unless_serialized():
             if sync.mode != "serialized":
-                time.sleep(0.05 if rank == 1 else 0.0)     # only ONE rank is slow: the MAX over ranks must decide
+                time.sleep(0.6 if rank == 1 else 0.0)      # only ONE rank is slow: the MAX over ranks must decide
             _grads(diff, golden, seed=rank)
         table = sync.autotune(slow_unless_serialized, steps=1, settle=0)
         tables = [None] * world

@@ -25,6 +25,8 @@ MEASUREMENT at start-up rather than assumed:
                          (`kernels.gemm_set_cus`): single-round grids are cut to what fits beside the collective, leftovers split in K;
   * ``serialized``       nothing is launched inside the backward; at its end the finished ranges go out as a few large all-reduces (coalesced
                          up to ``serial_bucket_elems``) and the compute stream waits: no CU contention, communication fully exposed;
+  * ``copy_engine``      opt-in, not timed by ``auto``: the overlapped schedule with every bucket exchanged as peer-to-peer copies + one small sum kernel
+                         (``ddp_copy.py``: no CUs held); rehearsed with two ranks on one GPU only, falls back to ``overlap`` when the node cannot set it up;
   * ``auto`` (default)   ``autotune(step_fn)`` times each of the three for a few steps on all ranks, takes all_reduce(MAX) of the times and
                          keeps the fastest; until it has run, ``auto`` behaves as ``overlap``.
 RCCL's CU footprint is bounded by ``rccl_channel_env()`` (NCCL_MAX_NCHANNELS, default 32 = ``reserved_cus``; must be in the environment
@@ -44,7 +46,8 @@ import torch.distributed as dist
 from . import kernels as K
 
 
-MODES = ("overlap", "overlap_planned", "serialized")
+MODES = ("overlap", "overlap_planned", "serialized")      # the schedules `auto` times
+EXTRA_MODES = ("copy_engine",)                             # opt-in: buckets exchanged by peer-to-peer copies on the copy engines (ddp_copy.py), never picked by `auto`
 DEFAULT_RCCL_CHANNELS = 32     # one channel = one workgroup = one CU; 32 is what `overlap_planned` reserves (a whole multiple of the 8 XCDs x 4 shader engines)
 
 
@@ -82,10 +85,12 @@ class BucketedGradSync:
         self.measure_exposed = False   # bench: time the compute stream spends waiting for the comm stream at the end of backward
         self._exposed: List[Tuple[torch.cuda.Event, torch.cuda.Event]] = []
         mode = os.environ.get("UDM_DDP_MODE", "auto") if mode is None else mode
-        if mode != "auto" and mode not in MODES:
-            raise ValueError(f"BucketedGradSync: unknown mode {mode!r} (one of {MODES + ('auto',)})")
+        if mode != "auto" and mode not in MODES + EXTRA_MODES:
+            raise ValueError(f"BucketedGradSync: unknown mode {mode!r} (one of {MODES + EXTRA_MODES + ('auto',)})")
         self.requested_mode = mode
         self.mode = "overlap" if mode == "auto" else mode     # what runs now; `autotune` replaces an "auto" request by the measured winner
+        self._cx = None                                        # copy_engine: the peer-buffer exchange (created on first use; None after a failed setup = RCCL path)
+        self._cx_tried = False
         self.mode_timings_ms = None                            # {mode: ms per step, max over ranks} once autotune has run
         if reserved_cus is None:
             reserved_cus = int(os.environ.get("UDM_DDP_RESERVED_CUS", "0") or 0) or (int(os.environ.get("NCCL_MAX_NCHANNELS", "0") or 0) or DEFAULT_RCCL_CHANNELS)
@@ -133,6 +138,9 @@ class BucketedGradSync:
         """bf16-compress `seg` (fp32, contiguous), all-reduce, decompress in place.  GPU: on the comm stream, after what the current stream queued."""
         n = seg.numel()
         self.bytes_on_wire += n * 2
+        if seg.is_cuda and self.mode == "copy_engine" and self._copy_engine(seg.device) is not None:
+            self._cx.submit(seg)         # exchanged by the helper thread on the copy stream; joined in _join
+            return
         if seg.is_cuda:
             if self.comm_stream is None:
                 self.comm_stream = torch.cuda.Stream(device=seg.device)
@@ -150,6 +158,17 @@ class BucketedGradSync:
             dist.all_reduce(wire, op=dist.ReduceOp.SUM, group=self.pg)
             seg.copy_(wire.float())
 
+    def _copy_engine(self, device):
+        """The copy-engine exchange, set up collectively on first use; a node that cannot (no IPC, no peer access) drops every rank back to the RCCL path."""
+        if not self._cx_tried:
+            self._cx_tried = True
+            from . import ddp_copy
+
+            self._cx = ddp_copy.setup(dist.get_rank(self.pg), self.world, device, self.pg)
+            if self._cx is None:
+                self.mode = "overlap"
+        return self._cx
+
     def _launch(self, flat: torch.Tensor, lo: int, hi: int):
         self._reduce_segment(flat[lo:hi], ("flat", lo))
         if self.mode == "overlap_planned" and not self._planned:
@@ -163,6 +182,15 @@ class BucketedGradSync:
             self._planned = False
 
     def _join(self):
+        if self._cx is not None:
+            if self.measure_exposed:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(torch.cuda.current_stream())
+                self._cx.drain()
+                e1.record(torch.cuda.current_stream())
+                self._exposed.append((e0, e1))
+            else:
+                self._cx.drain()
         if self.comm_stream is not None:
             cur = torch.cuda.current_stream()
             if self.measure_exposed:
@@ -237,8 +265,8 @@ class BucketedGradSync:
             off += g.numel()
 
     def set_mode(self, mode: str):
-        if mode not in MODES:
-            raise ValueError(f"BucketedGradSync: unknown mode {mode!r} (one of {MODES})")
+        if mode not in MODES + EXTRA_MODES:
+            raise ValueError(f"BucketedGradSync: unknown mode {mode!r} (one of {MODES + EXTRA_MODES})")
         if self._pending is not None or self._deferred:
             raise RuntimeError("BucketedGradSync.set_mode inside a backward")
         self._unplan()
