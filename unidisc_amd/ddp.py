@@ -165,8 +165,8 @@ class BucketedGradSync:
             from . import ddp_copy
 
             self._cx = ddp_copy.setup(dist.get_rank(self.pg), self.world, device, self.pg)
-            if self._cx is None:
-                self.mode = "overlap"
+        if self._cx is None:
+            self.mode = "overlap"      # (every rank: `setup` answers collectively)
         return self._cx
 
     def _launch(self, flat: torch.Tensor, lo: int, hi: int):
@@ -289,6 +289,8 @@ class BucketedGradSync:
             if sync_device is not None:
                 torch.cuda.synchronize(sync_device)
 
+        if os.environ.get("UDM_DDP_AUTO_COPY_ENGINE") == "1" and "copy_engine" not in modes:
+            modes = tuple(modes) + ("copy_engine",)     # opt-in: let the measurement decide about the copy-engine exchange too (a failed set-up times the RCCL path again)
         table = {}
         for m in modes:
             self.set_mode(m)
