@@ -235,3 +235,23 @@ def test_gradient_checkpointing_recomputes_blocks_bit_identically(name, fake_k):
     assert set(res[0][1]) == set(res[1][1])
     for k in res[0][1]:
         assert torch.equal(res[0][1][k], res[1][1][k]), k
+
+
+def test_low_precision_loss_is_accepted_and_changes_nothing(fake_k):
+    """`trainer.low_precision_loss` (model.py:747, :924): under bf16 autocast the reference's loss is the SAME number with the flag on or off (checked against the
+    imported reference on the c_large case when this test was written: loss 3.809645652770996 and the NLL sum identical to the last bit) - the product accepts the flag
+    instead of raising, and computes the same loss."""
+    g = Golden("c_large")
+    vals = []
+    for flag in (False, True):
+        diff = build_product(g, device="cpu")
+        diff.config.trainer.low_precision_loss = flag
+        diff.rng_device = "cpu"
+        from unidisc_amd import Diffusion
+
+        diff2 = Diffusion(diff.config, None, "cpu", backbone=diff.backbone)   # (init re-reads the trainer flags: must not raise)
+        diff2.rng_device = "cpu"
+        torch.manual_seed(g.case["step_seed"])
+        out = diff2.training_step(g.batch(), 1)
+        vals.append((float(out.loss.detach()), out.nlls.detach().clone()))
+    assert vals[0][0] == vals[1][0] and torch.equal(vals[0][1], vals[1][1])

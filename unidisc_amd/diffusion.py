@@ -73,10 +73,12 @@ class Diffusion:
         # trainer options that change the loss / the batch and are not built: refuse them instead of training silently with another objective
         for flag, why in (("ar_llm_loss", "the extra auto-regressive LLM loss term (model.py:1076-1136)"),
                           ("force_remove_img_tokens", "dropping image tokens from the batch (model.py:316-319, :1054)"),
-                          ("add_label", "the class-label token written by update_batch (model.py:321-334)"),
-                          ("low_precision_loss", "the bf16 loss reduction (this path reduces in fp32)")):
+                          ("add_label", "the class-label token written by update_batch (model.py:321-334)")):
             if cfg_get(tr, flag, False):
                 raise NotImplementedError(f"unidisc_amd: trainer.{flag} — {why} — is not on the denoising hot path (SURVEY.md §8)")
+        # trainer.low_precision_loss (model.py:747, :924) keeps the SUBS log-probabilities in the autocast dtype instead of widening them to fp32 before the gather.  Under
+        # bf16 autocast they ARE bf16 values either way (widening is exact) and every later product meets an fp32 weight, so the reference's loss is the same number with
+        # the flag on or off; this path takes log p from an fp32 log-sum-exp in both cases.  Accepted, nothing to switch.
         self.image_model = bool(cfg_get(m, "image_model", False))
         self.unified_model = bool(cfg_get(m, "unified_model", False))
         self.antithetic_sampling = cfg_get(tr, "antithetic_sampling", True)
