@@ -228,6 +228,21 @@ int udm_categorical_sample_rows(const void* logits, const void* logits_uncond, c
  * int64 (0 text / 1 image).  The caller guarantees 0 <= idx[b] < n. */
 int udm_assemble_joint_tokens(const int32_t* txt, const uint8_t* txt_mask, const int16_t* img, const int64_t* idx, int64_t B, int64_t Lt, int64_t Li,
                               int64_t Vt, int64_t* ids, uint8_t* mask, int64_t* modality, hipStream_t stream);
+
+/* ---- interleaved / packed rows: the per-position layout work of a packed batch as kernels (static shapes, no host reads)
+ * udm_interleaved_rope: models/dit.py:1421-1444 with add_img_data_to_blocks / add_txt_data_to_blocks (:122-191).  modality / sid int64 [B, L]; img_cos / img_sin the 2-D
+ *   tables of the supported image block sizes concatenated in the order of `sizes` (a HOST array of nsizes <= 8 ints), [sum sizes, half] fp32; txt_cos / txt_sin
+ *   [txt_rows, half].  Writes cos, sin fp32 [B, L, half] and count_idx int64 [B, L] (row of img_count_embedding to add, -1: none).  scratch: B * 5 * L ints.
+ * udm_interleaved_block_lottery: model.py:483-522 after its draws - candidate block i of the batch (row-major order) reads r[i] (r fp32 [n_r]; ranks >= n_r never hit).
+ *   Writes accum bool bytes [B, L] (positions of the blocks masked as a whole), rows_hit bool bytes [B], n_cand int64 [1] (number of candidate blocks).
+ *   scratch: B * 4 * L ints, row_cands: B ints.
+ * udm_rowgroup_sum_f32: out[g, :] += sum of the rows r of x [M, d] with group[r] == g (0 <= g < G <= 32; other rows are skipped): the image-count embedding's gradient. */
+int udm_interleaved_rope(const int64_t* modality, const int64_t* sid, const float* img_cos, const float* img_sin, const int32_t* sizes, int64_t nsizes, const float* txt_cos,
+                         const float* txt_sin, int64_t txt_rows, int64_t B, int64_t L, int64_t half, float* cos, float* sin, int64_t* count_idx, int32_t* scratch,
+                         hipStream_t stream);
+int udm_interleaved_block_lottery(const int64_t* modality, const int64_t* sid, const float* r, int64_t n_r, float mask_prob, int64_t B, int64_t L, uint8_t* accum,
+                                  uint8_t* rows_hit, int64_t* n_cand, int32_t* scratch, int32_t* row_cands, hipStream_t stream);
+int udm_rowgroup_sum_f32(const float* x, const int64_t* group, float* out, int64_t M, int64_t d, int64_t G, hipStream_t stream);
 /* q_xt model.py:424-587 for multimodal (non-interleaved) batches after its random draws: move = r_move < move_chance[b], whole-modality masking (a row drawn for both
  * modalities masks neither), xt = move ? mask_id : x; outputs bool [B, L] move_indices and bool [B] rows (text masked, image masked, either).  r_txt / r_img NULL: no draw. */
 int udm_qxt_absorbing(const int64_t* x, const float* r_move, const float* move_chance, const float* r_txt, const float* r_img, float thr_txt, float thr_img,

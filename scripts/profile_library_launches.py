@@ -6,8 +6,9 @@ from torch.profiler import ProfilerActivity, profile
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 dev = torch.device("cuda", 0)
-cfg, diff = bench.build("unidisc-1.4b-l1280", dev, 0.1)
-batch = {k: v.to(dev) for k, v in bench.synthetic_batch("unidisc-1.4b-l1280", 8, 42).items()}
+WL = os.environ.get("WORKLOAD", "unidisc-1.4b-l1280")
+cfg, diff = bench.build(WL, dev, 0.1)
+batch = {k: v.to(dev) for k, v in bench.synthetic_batch(WL, bench.WORKLOADS[WL]["batch"], 42).items()}
 def step(i):
     diff.backbone.zero_grad(set_to_none=True)
     out = diff.training_step(batch, i); out.loss.backward(); return out

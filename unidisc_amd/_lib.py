@@ -53,6 +53,9 @@ PROTOTYPES = {
     "udm_attention_quantize_v_fp8": [_P, _I64, _P, _P, _I64, _I64, _I64, _I64, _P],
     "udm_attention_fwd_fp8": [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _P],
     "udm_assemble_joint_tokens": [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _P, _P, _P, _P],
+    "udm_interleaved_rope": [_P, _P, _P, _P, _P, _I64, _P, _P, _I64, _I64, _I64, _I64, _P, _P, _P, _P, _P],
+    "udm_interleaved_block_lottery": [_P, _P, _P, _I64, _F, _I64, _I64, _P, _P, _P, _P, _P, _P],
+    "udm_rowgroup_sum_f32": [_P, _P, _P, _I64, _I64, _I64, _P],
     "udm_sample_t_noise": [_P, _I64, _I, _F, _F, _F, _P, _P, _P, _P, _P],
     "udm_qxt_absorbing": [_P, _P, _P, _P, _P, _F, _F, _P, _I64, _I64, _I64, _P, _P, _P, _P, _P, _P],
     "udm_categorical_sample_rows": [_P, _P, _P, _I64, _P, _P, _I64, _U64, _P, _P, _P, _I64, _I64, _I64, _I64, _I, _P],

@@ -390,6 +390,21 @@ class Diffusion:
         Returns (block mask [B, L], rows that had a block masked [B])."""
         batch_size, seq_len = shape
         mod, sid = batch["modality"], batch["sample_ids"]
+        x_is_cuda = mod.is_cuda
+        if x_is_cuda and os.environ.get("UDM_INTERLEAVED_KERNELS", "1") != "0":
+            # two launches (udm_interleaved_block_lottery, tokens.hip) instead of ~40 tensor statements with a sort and three contended scatter_adds; bit-identical to the
+            # statements below (tests/test_gpu_kernels.py).  Device generator: one uniform per POSSIBLE candidate (a candidate block is longer than 4 tokens: at most
+            # seq_len // 5 per row), no host read.  Replay (rng_device = "cpu"): the reference draws exactly n_cand uniforms, so the count is read back first.
+            if self.rng_device is None:
+                r = self._rand(batch_size * (seq_len // 5 + 1), 1, device=dev)
+            else:
+                _, _, n_dev = K.interleaved_block_lottery(mod, sid, torch.empty(0, device=dev), mask_prob)
+                n_cand = int(n_dev)
+                if not n_cand:
+                    return torch.zeros((batch_size, seq_len), dtype=torch.bool, device=dev), torch.zeros((batch_size,), device=dev, dtype=torch.bool)
+                r = self._rand(n_cand, 1, device=dev)
+            accum, rows_hit, _ = K.interleaved_block_lottery(mod, sid, r, mask_prob)
+            return accum, rows_hit
         N = batch_size * seq_len
         chg = torch.ones((batch_size, seq_len), dtype=torch.bool, device=dev)
         chg[:, 1:] = (mod[:, 1:] != mod[:, :-1]) | (sid[:, 1:] != sid[:, :-1])
@@ -400,9 +415,16 @@ class Diffusion:
         bsid = torch.full((N,), -1, dtype=torch.int64, device=dev).scatter_(0, gid, sid.reshape(-1))
         brow = torch.zeros(N, dtype=torch.int64, device=dev).scatter_(0, gid, ar // seq_len)
         cand = (bsid >= 0) & (blen > 4)
-        n_cand = int(cand.sum())
-        if not n_cand:
-            return torch.zeros((batch_size, seq_len), dtype=torch.bool, device=dev), torch.zeros((batch_size,), device=dev, dtype=torch.bool)
+        if self.rng_device is None and x_is_cuda:
+            # device generator (production): one uniform per POSSIBLE candidate block - at most seq_len // 5 per row, blocks being longer than 4 - indexed by the
+            # candidate's rank, so the host never reads the count back (that read stalled the launch queue at the top of every step: 2.7 ms of idle GPU per 81 ms
+            # step of the packed 4608-token workload).  The draws of a block do not depend on how many follow it; the stream position after the step differs from a
+            # draw of exactly n_cand values, which only a bit-exact REPLAY needs - and replays run with rng_device = "cpu" (below: the exact count).
+            n_cand = batch_size * (seq_len // 5 + 1)
+        else:
+            n_cand = int(cand.sum())
+            if not n_cand:
+                return torch.zeros((batch_size, seq_len), dtype=torch.bool, device=dev), torch.zeros((batch_size,), device=dev, dtype=torch.bool)
         # k = index of the block among the candidate blocks of its (row, sample id), n = their number: stable sort by that key
         key = torch.where(cand, brow * (seq_len + 1) + bsid, torch.full_like(brow, (batch_size + 1) * (seq_len + 1)))
         order = torch.argsort(key, stable=True)

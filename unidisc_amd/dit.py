@@ -501,6 +501,18 @@ class DIT(nn.Module, _HubMixin):
 
     # -------------------------------------------------------------------------------------------- engine: forward
     def _rotary_interleaved(self, modality, sample_ids):
+        """Rotary rows and image-count indices of packed rows: ONE launch on the GPU (`udm_interleaved_rope`, tokens.hip), the tensor-statement form below elsewhere
+        (CPU tests) - bit-identical (tests/test_gpu_kernels.py)."""
+        if modality.is_cuda and os.environ.get("UDM_INTERLEAVED_KERNELS", "1") != "0":
+            dev = modality.device
+            if getattr(self, "_img_tab_cos", None) is None or self._img_tab_cos.device != dev:
+                self._img_tab_cos = torch.cat([getattr(self, f"rotary_cos_emb_img_{n}") for n, _ in self.IMG_BLOCKS], 0).to(dev).contiguous()
+                self._img_tab_sin = torch.cat([getattr(self, f"rotary_sin_emb_img_{n}") for n, _ in self.IMG_BLOCKS], 0).to(dev).contiguous()
+            return K.interleaved_rope(modality, sample_ids, self._img_tab_cos, self._img_tab_sin, [n for n, _ in self.IMG_BLOCKS],
+                                      self.rotary_cos_emb_txt, self.rotary_sin_emb_txt)
+        return self._rotary_interleaved_torch(modality, sample_ids)
+
+    def _rotary_interleaved_torch(self, modality, sample_ids):
         """models/dit.py:1421-1444 with `add_img_data_to_blocks` / `add_txt_data_to_blocks` (:122-191), as tensor operations on the device (the
         reference loops over blocks on the host): cos, sin fp32 [B, L, D/2] and, per position, the row of `img_count_embedding` to add (-1: none).
         Image runs whose length is a supported block size get that size's 2-D table and count embedding j = number of earlier image runs of the row
@@ -515,7 +527,8 @@ class DIT(nn.Module, _HubMixin):
         run_start = torch.cummax(torch.where(start, ar, torch.full_like(ar, -1)), dim=1).values
         rows = torch.arange(B, device=dev)[:, None].expand(B, L)
         key = (rows * L + run_start.clamp(min=0))
-        counts = torch.bincount(key[is_img], minlength=B * L)
+        # (static shapes only - no boolean-mask indexing, no host reads: the host must be able to run ahead of the device across this preamble)
+        counts = torch.bincount(torch.where(is_img, key, torch.full_like(key, B * L)).reshape(-1), minlength=B * L + 1)[: B * L]
         run_len = torch.where(is_img, counts[key], torch.zeros_like(key))
         pos_in_run = ar - run_start
         if getattr(self, "_img_tab_cos", None) is None or self._img_tab_cos.device != dev:
@@ -531,10 +544,19 @@ class DIT(nn.Module, _HubMixin):
         cos_img, sin_img = self._img_tab_cos[idx], self._img_tab_sin[idx]
         # image index inside its packed sample: running count of image-run starts per (row, sample id)
         sid = sample_ids
-        nsid = int(sid.max().item()) + 1 if sid.numel() else 1
-        onehot = start[:, None, :] & (sid[:, None, :] == torch.arange(max(nsid, 1), device=dev)[None, :, None])
-        cum = onehot.cumsum(2)                                                   # [B, nsid, L] starts with that id up to and including l (scan over the contiguous dim)
-        j_at = (cum.gather(1, sid.clamp(min=0)[:, None, :]).squeeze(1) - 1)      # at a run start: earlier runs with the same id
+        # rank of every image-run start among the starts of its (row, sample id), in position order: stable sort of the flattened positions by group key (non-starts
+        # sort behind every group), rank = index in the sorted order - index of the group's first element.  No one-hot over the number of sample ids (which would need it
+        # on the host), any layout of ids inside a row.
+        N = B * L
+        flat_start = start.reshape(-1)
+        gkey = torch.where(flat_start, (rows * (L + 2) + sid.clamp(min=-1) + 1).reshape(-1), torch.full((N,), B * (L + 2) + 1, dtype=torch.int64, device=dev))
+        order = torch.argsort(gkey, stable=True)
+        skey = gkey[order]
+        arn = torch.arange(N, device=dev)
+        newg = torch.ones(N, dtype=torch.bool, device=dev)
+        newg[1:] = skey[1:] != skey[:-1]
+        g_first = torch.cummax(torch.where(newg, arn, torch.zeros_like(arn)), 0).values
+        j_at = torch.empty(N, dtype=torch.int64, device=dev).scatter_(0, order, arn - g_first).reshape(B, L)   # valid at run starts (read only there)
         j_run = j_at.gather(1, run_start.clamp(min=0))
         count_idx = torch.where(valid_img, j_run, torch.full_like(j_run, -1))
         # text: positions restart at every run of one sample id
@@ -633,11 +655,13 @@ class DIT(nn.Module, _HubMixin):
             if raw_sid is None:
                 raise ValueError("unidisc_amd.DIT: data.require_sample_ids needs sample_ids")
             cos, sin, count_idx = self._rotary_interleaved(modality.to(torch.int64), raw_sid)
-            cnt_rows = (count_idx.view(-1) >= 0).nonzero().view(-1)
-            cnt_j = count_idx.view(-1).index_select(0, cnt_rows)
-            if cnt_rows.numel():  # x[b, l] += img_count_embedding[j] on the positions of supported image blocks
-                x.index_add_(0, cnt_rows, self.img_count_embedding.detach().to(x.dtype).index_select(0, cnt_j))
-            S["cnt_rows"], S["cnt_j"] = cnt_rows, cnt_j
+            # x[b, l] += img_count_embedding[j] on the positions of supported image blocks.  Static shapes (no nonzero(): that is a host read in the step's preamble):
+            # every position gathers a row of the table extended by one zero row, positions without an image index take that row
+            n_cnt = self.img_count_embedding.shape[0]
+            cnt_j = torch.where(count_idx.view(-1) >= 0, count_idx.view(-1), torch.full_like(count_idx.view(-1), n_cnt))
+            tab = torch.cat([self.img_count_embedding.detach().to(x.dtype), torch.zeros((1, x.shape[1]), dtype=x.dtype, device=x.device)], 0)
+            x.add_(tab.index_select(0, cnt_j))
+            S["cnt_j"] = cnt_j
         else:
             cos, sin = self._rotary(modality, L)
         S["cos"], S["sin"] = cos, sin
@@ -1186,8 +1210,13 @@ class DIT(nn.Module, _HubMixin):
             pend["done"]()
 
         # ---- embeddings
-        if S.get("cnt_rows") is not None and S["cnt_rows"].numel():
-            G[id(self.img_count_embedding)].index_add_(0, S["cnt_j"], dx.index_select(0, S["cnt_rows"]))
+        if S.get("cnt_j") is not None:
+            n_cnt = self.img_count_embedding.shape[0]
+            if dx.is_cuda and dx.dtype == F32:   # sums formed in LDS per run of equal indices (an index_add_ here is 19 M contended atomics: 225 us)
+                K.rowgroup_sum(dx, S["cnt_j"], G[id(self.img_count_embedding)])
+            else:
+                gext = torch.zeros((n_cnt + 1, dx.shape[1]), dtype=dx.dtype, device=dx.device).index_add_(0, S["cnt_j"], dx)   # (row n_cnt collects the positions without an image index)
+                G[id(self.img_count_embedding)].add_(gext[:n_cnt])
         K.embedding_bwd(S["ids"], dx, G[id(self.vocab_embed.embedding)], self.mask_index,
                         modality=S["emb_mod"] if self.modality_embed is not None else None,
                         dEm=G[id(self.modality_embed.embedding)] if self.modality_embed is not None else None)

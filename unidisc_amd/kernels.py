@@ -296,6 +296,47 @@ def assemble_joint_tokens(txt, txt_mask, img, Vt, idx=None):
     return ids, mask, modality
 
 
+def interleaved_rope(modality, sid, img_cos, img_sin, sizes, txt_cos, txt_sin):
+    """Rotary rows and image-count indices of packed rows (udm_interleaved_rope): modality / sid int64 [B, L] -> (cos, sin fp32 [B, L, half], count_idx int64 [B, L])."""
+    import ctypes
+
+    _chk(modality, torch.int64, "interleaved_rope modality"), _chk(sid, torch.int64, "interleaved_rope sid")
+    B, L = modality.shape
+    half = img_cos.shape[1]
+    dev = modality.device
+    cos = torch.empty((B, L, half), dtype=F32, device=dev)
+    sin = torch.empty((B, L, half), dtype=F32, device=dev)
+    cidx = torch.empty((B, L), dtype=torch.int64, device=dev)
+    scratch = torch.empty(B * 5 * L, dtype=torch.int32, device=dev)
+    hs = (ctypes.c_int32 * len(sizes))(*[int(n) for n in sizes])
+    _lib.call("udm_interleaved_rope", _p(modality.contiguous()), _p(sid.contiguous()), _p(img_cos.contiguous()), _p(img_sin.contiguous()), hs, len(sizes),
+              _p(txt_cos.contiguous()), _p(txt_sin.contiguous()), txt_cos.shape[0], B, L, half, _p(cos), _p(sin), _p(cidx), _p(scratch), _s())
+    return cos, sin, cidx
+
+
+def interleaved_block_lottery(modality, sid, r, mask_prob):
+    """Whole-block masking of packed rows after its draws (udm_interleaved_block_lottery): -> (accum bool [B, L], rows_hit bool [B], n_cand int64 [1] on the device)."""
+    _chk(modality, torch.int64, "interleaved_block_lottery modality"), _chk(sid, torch.int64, "interleaved_block_lottery sid")
+    B, L = modality.shape
+    dev = modality.device
+    accum = torch.empty((B, L), dtype=torch.bool, device=dev)
+    rows_hit = torch.empty((B,), dtype=torch.bool, device=dev)
+    n_cand = torch.empty(1, dtype=torch.int64, device=dev)
+    scratch = torch.empty(B * 4 * L, dtype=torch.int32, device=dev)
+    row_cands = torch.empty(B, dtype=torch.int32, device=dev)
+    r = r.reshape(-1).float().contiguous()
+    _lib.call("udm_interleaved_block_lottery", _p(modality.contiguous()), _p(sid.contiguous()), _p(r), r.numel(), torch.tensor(mask_prob, dtype=F32).item(), B, L,
+              _p(accum), _p(rows_hit), _p(n_cand), _p(scratch), _p(row_cands), _s())
+    return accum, rows_hit, n_cand
+
+
+def rowgroup_sum(x, group, out):
+    """out[g] += sum of the rows of x [M, d] fp32 whose group index (int64 [M]) is g; rows with an index outside [0, out.shape[0]) are skipped."""
+    _chk(x, F32, "rowgroup_sum x"), _chk(group, torch.int64, "rowgroup_sum group"), _chk(out, F32, "rowgroup_sum out")
+    _lib.call("udm_rowgroup_sum_f32", _p(x.contiguous()), _p(group.contiguous()), _p(out), x.shape[0], x.shape[1], out.shape[0], _s())
+    return out
+
+
 def sample_t_noise(u, *, antithetic, sampling_eps, noise_eps):
     """(t, sigma, dsigma, move_chance), fp32 [n] each, from the uniform draws u [n]: `_sample_t` + the log-linear schedule in one launch, rounded like the statements."""
     _chk(u, F32, "sample_t_noise u")
