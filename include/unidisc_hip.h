@@ -269,6 +269,15 @@ int udm_adamw_step_shadow(float* p, const float* g, float* m, float* v, int64_t 
  * warm-up min(decay, (1 + n) / (10 + n))).  ema NULL: identical to the plain forms. */
 int udm_adamw_step_ema(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay,
                        int64_t step, const float* grad_norm_sq, float max_grad_norm, float* ema, float ema_decay, hipStream_t stream);
+/* the same update for MANY flat tensors in one launch: `jobs` = device array of njobs records {float* p; const float* g; float* m; float* v; float* ema (nullable);
+ * int64 n; int64 chunk0} with chunk0 = sum over the earlier jobs of ceil(n / 1024) and nchunks the total; every pointer 16-byte aligned. */
+int udm_adamw_step_multi(const void* jobs, int64_t njobs, int64_t nchunks, float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step,
+                         const float* grad_norm_sq, float max_grad_norm, float ema_decay, hipStream_t stream);
+/* ... and for MANY 2-D GEMM weights with their bf16 shadows: `jobs` = device array of records {float* p; const float* g; float* m; float* v; float* ema (nullable);
+ * bf16* w16 (nullable); bf16* w16t (nullable); int64 ld16; int64 ldt; int32 R; int32 C; int32 tile0; int32 tiles_c} with tiles_c = ceil(C / 64) and tile0 = sum over
+ * the earlier jobs of ceil(R / 64) * tiles_c; ntiles the total. */
+int udm_adamw_step_shadow_multi(const void* jobs, int64_t njobs, int64_t ntiles, float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step,
+                                const float* grad_norm_sq, float max_grad_norm, float ema_decay, hipStream_t stream);
 int udm_adamw_step_shadow_ema(float* p, const float* g, float* m, float* v, int64_t R, int64_t C, float lr, float beta1, float beta2, float eps,
                               float weight_decay, int64_t step, const float* grad_norm_sq, float max_grad_norm, void* w16, int64_t ld16, void* w16t,
                               int64_t ldt, float* ema, float ema_decay, hipStream_t stream);

@@ -64,6 +64,8 @@ PROTOTYPES = {
     "udm_sumsq_f32": [_P, _I64, _P, _P, _I64, _P],
     "udm_adamw_step_ema": [_P, _P, _P, _P, _I64, _F, _F, _F, _F, _F, _I64, _P, _F, _P, _F, _P],
     "udm_adamw_step_shadow_ema": [_P, _P, _P, _P, _I64, _I64, _F, _F, _F, _F, _F, _I64, _P, _F, _P, _I64, _P, _I64, _P, _F, _P],
+    "udm_adamw_step_shadow_multi": [_P, _I64, _I64, _F, _F, _F, _F, _F, _I64, _P, _F, _F, _P],
+    "udm_adamw_step_multi": [_P, _I64, _I64, _F, _F, _F, _F, _F, _I64, _P, _F, _F, _P],
     "udm_adamw_step": [_P, _P, _P, _P, _I64, _F, _F, _F, _F, _F, _I64, _P, _F, _P],
     "udm_adamw_step_shadow": [_P, _P, _P, _P, _I64, _I64, _F, _F, _F, _F, _F, _I64, _P, _F, _P, _I64, _P, _I64, _P],
     "udm_embedding_fwd": [_P, _P, _P, _P, _P, _I64, _I64, _I64, _P],

@@ -70,12 +70,49 @@ __global__ __launch_bounds__(256) void adamw_kernel(AdamArgs a, long n) {
   }
 }
 
+// every flat parameter of a model in ONE launch (a 1.4 B DiT has ~250 norm / bias / embedding tensors: one launch each is ~250 x (launch + a wave of idle CUs)):
+// device job table, chunk c of 1024 elements belongs to the job with chunk0 <= c < next chunk0 (bisection)
+struct AdamJob { float* p; const float* g; float* m; float* v; float* ema; long n; long chunk0; };
+constexpr int ADAM_CHUNK = 1024;   // elements per block iteration (256 threads x float4)
+__global__ __launch_bounds__(256) void adamw_multi_kernel(AdamArgs a, const AdamJob* __restrict__ jobs, int njobs, long nchunks) {
+  const float clip = clip_coef(a);
+  for (long c = blockIdx.x; c < nchunks; c += gridDim.x) {
+    int lo = 0, hi = njobs - 1;
+    while (lo < hi) {   // last job with chunk0 <= c (block-uniform)
+      const int mid = (lo + hi + 1) >> 1;
+      if (jobs[mid].chunk0 <= c) lo = mid; else hi = mid - 1;
+    }
+    const AdamJob j = jobs[lo];
+    const long i = (c - j.chunk0) * ADAM_CHUNK + threadIdx.x * 4;
+    if (i + 3 < j.n) {
+      float4 p = *reinterpret_cast<float4*>(j.p + i), m = *reinterpret_cast<float4*>(j.m + i), v = *reinterpret_cast<float4*>(j.v + i);
+      const float4 g = *reinterpret_cast<const float4*>(j.g + i);
+      p.x = adam_update(a, p.x, g.x * clip, m.x, v.x);
+      p.y = adam_update(a, p.y, g.y * clip, m.y, v.y);
+      p.z = adam_update(a, p.z, g.z * clip, m.z, v.z);
+      p.w = adam_update(a, p.w, g.w * clip, m.w, v.w);
+      *reinterpret_cast<float4*>(j.p + i) = p; *reinterpret_cast<float4*>(j.m + i) = m; *reinterpret_cast<float4*>(j.v + i) = v;
+      if (j.ema) {
+        float4 e = *reinterpret_cast<float4*>(j.ema + i);
+        e.x -= a.ema_omd * (e.x - p.x); e.y -= a.ema_omd * (e.y - p.y); e.z -= a.ema_omd * (e.z - p.z); e.w -= a.ema_omd * (e.w - p.w);
+        *reinterpret_cast<float4*>(j.ema + i) = e;
+      }
+    } else {
+      for (long k = i; k < j.n && k < i + 4; ++k) {
+        float m = j.m[k], v = j.v[k];
+        const float pn = adam_update(a, j.p[k], j.g[k] * clip, m, v);
+        j.p[k] = pn; j.m[k] = m; j.v[k] = v;
+        if (j.ema) j.ema[k] -= a.ema_omd * (j.ema[k] - pn);
+      }
+    }
+  }
+}
+
 // 2-D GEMM weight [R, C] row-major: update + bf16 shadow [R, ld16] + transposed bf16 shadow [C, ldt] through a 64 x 64 LDS tile
 constexpr int TT = 64, TPAD = 8;
-__global__ __launch_bounds__(256) void adamw_shadow_kernel(AdamArgs a, int R, int C, bf16_t* __restrict__ w16, long ld16, bf16_t* __restrict__ w16t, long ldt) {
-  __shared__ __attribute__((aligned(16))) bf16_t tile[TT][TT + TPAD];
+__device__ __forceinline__ void adamw_shadow_tile(const AdamArgs& a, int R, int C, bf16_t* __restrict__ w16, long ld16, bf16_t* __restrict__ w16t, long ldt, int r0, int c0,
+                                                  bf16_t (*tile)[TT + TPAD]) {
   const float clip = clip_coef(a);
-  const int r0 = blockIdx.y * TT, c0 = blockIdx.x * TT;
   const int tid = threadIdx.x;
   const int cs = (tid & 15) * 4;
   const bool vec = (C % 4 == 0);
@@ -130,6 +167,26 @@ __global__ __launch_bounds__(256) void adamw_shadow_kernel(AdamArgs a, int R, in
         if (r0 + rs + k < R) op[k] = tile[c][rs + k];
     }
   }
+}
+__global__ __launch_bounds__(256) void adamw_shadow_kernel(AdamArgs a, int R, int C, bf16_t* __restrict__ w16, long ld16, bf16_t* __restrict__ w16t, long ldt) {
+  __shared__ __attribute__((aligned(16))) bf16_t tile[TT][TT + TPAD];
+  adamw_shadow_tile(a, R, C, w16, ld16, w16t, ldt, blockIdx.y * TT, blockIdx.x * TT, tile);
+}
+// every GEMM weight of a model in ONE launch (97 at 1.4 B: a launch each ramps up and drains the chip 97 times): device job table, block -> job by bisection on tile0
+struct AdamShadowJob { float* p; const float* g; float* m; float* v; float* ema; bf16_t* w16; bf16_t* w16t; long ld16, ldt; int R, C, tile0, tiles_c; };
+__global__ __launch_bounds__(256) void adamw_shadow_multi_kernel(AdamArgs a0, const AdamShadowJob* __restrict__ jobs, int njobs) {
+  __shared__ __attribute__((aligned(16))) bf16_t tile[TT][TT + TPAD];
+  int lo = 0, hi = njobs - 1;
+  const int t = blockIdx.x;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (jobs[mid].tile0 <= t) lo = mid; else hi = mid - 1;
+  }
+  const AdamShadowJob j = jobs[lo];
+  AdamArgs a = a0;
+  a.p = j.p; a.g = j.g; a.m = j.m; a.v = j.v; a.ema = j.ema;
+  const int lt = t - j.tile0;
+  adamw_shadow_tile(a, j.R, j.C, j.w16, j.ld16, j.w16t, j.ldt, (lt / j.tiles_c) * TT, (lt % j.tiles_c) * TT, tile);
 }
 
 // sum of squares, two phases (no deep atomic chains): per-block partials, then one block folds them
@@ -205,6 +262,37 @@ extern "C" int udm_adamw_step_ema(float* p, const float* g, float* m, float* v, 
   if (grid < 1) grid = 1;
   hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)grid), dim3(256), 0, stream, a, (long)n);
   UDM_CHECK_LAUNCH("udm_adamw_step");
+  return 0;
+}
+
+// jobs: device array of njobs records {p, g, m, v, ema (nullable), n, chunk0} (7 x 8 bytes; chunk0 = sum over the jobs before of ceil(n / 1024)), nchunks = the total
+extern "C" int udm_adamw_step_multi(const void* jobs, int64_t njobs, int64_t nchunks, float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step,
+                                    const float* grad_norm_sq, float max_grad_norm, float ema_decay, hipStream_t stream) {
+  UDM_CHECK_ARG(jobs && njobs > 0 && nchunks > 0, "udm_adamw_step_multi: empty job table");
+  AdamArgs a;
+  float dummy = 0.f;
+  if (int rc = fill_args(a, "udm_adamw_step_multi", &dummy, &dummy, &dummy, &dummy, lr, beta1, beta2, eps, weight_decay, step, grad_norm_sq, max_grad_norm)) return rc;
+  UDM_CHECK_ARG(ema_decay >= 0.f && ema_decay <= 1.f, "udm_adamw_step_multi: EMA decay must be in [0, 1]");
+  a.p = nullptr; a.g = nullptr; a.m = nullptr; a.v = nullptr;
+  a.ema_omd = 1.f - ema_decay;
+  const long grid = nchunks < 4096 ? nchunks : 4096;
+  hipLaunchKernelGGL(adamw_multi_kernel, dim3((unsigned)grid), dim3(256), 0, stream, a, (const AdamJob*)jobs, (int)njobs, (long)nchunks);
+  UDM_CHECK_LAUNCH("udm_adamw_step_multi");
+  return 0;
+}
+
+// jobs: device array of records {p, g, m, v, ema (nullable), w16 (nullable), w16t (nullable), ld16, ldt, R, C, tile0, tiles_c} (see AdamShadowJob), ntiles = total 64 x 64 tiles
+extern "C" int udm_adamw_step_shadow_multi(const void* jobs, int64_t njobs, int64_t ntiles, float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step,
+                                           const float* grad_norm_sq, float max_grad_norm, float ema_decay, hipStream_t stream) {
+  UDM_CHECK_ARG(jobs && njobs > 0 && ntiles > 0 && ntiles < (1ll << 31), "udm_adamw_step_shadow_multi: empty / oversized job table");
+  AdamArgs a;
+  float dummy = 0.f;
+  if (int rc = fill_args(a, "udm_adamw_step_shadow_multi", &dummy, &dummy, &dummy, &dummy, lr, beta1, beta2, eps, weight_decay, step, grad_norm_sq, max_grad_norm)) return rc;
+  UDM_CHECK_ARG(ema_decay >= 0.f && ema_decay <= 1.f, "udm_adamw_step_shadow_multi: EMA decay must be in [0, 1]");
+  a.p = nullptr; a.g = nullptr; a.m = nullptr; a.v = nullptr;
+  a.ema_omd = 1.f - ema_decay;
+  hipLaunchKernelGGL(adamw_shadow_multi_kernel, dim3((unsigned)ntiles), dim3(256), 0, stream, a, (const AdamShadowJob*)jobs, (int)njobs);
+  UDM_CHECK_LAUNCH("udm_adamw_step_shadow_multi");
   return 0;
 }
 

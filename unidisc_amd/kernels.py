@@ -488,6 +488,45 @@ def cast_transpose_jobs(items, device):
     return table, len(items), tile0
 
 
+def adamw_jobs(items, device):
+    """Device job table for `adamw_step_multi`: items = [(p, g, m, v, ema or None)] fp32 contiguous tensors of equal numel per item."""
+    import struct
+
+    buf, chunk0 = bytearray(), 0
+    for p, g, m, v, e in items:
+        n = p.numel()
+        buf += struct.pack("<QQQQQqq", _p(p), _p(g), _p(m), _p(v), _p(e) or 0, n, chunk0)
+        chunk0 += (n + 1023) // 1024
+    return torch.frombuffer(buf, dtype=torch.uint8).to(device), len(items), chunk0
+
+
+def adamw_step_multi(jobs, lr, beta1, beta2, eps, weight_decay, step, grad_norm_sq=None, max_grad_norm=None, ema_decay=0.0):
+    """AdamW (+ clipping coefficient from the device scalar, + EMA) of every tensor of a job table (see `adamw_jobs`) in one launch."""
+    table, n, chunks = jobs
+    _lib.call("udm_adamw_step_multi", _p(table), n, chunks, float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), int(step),
+              _p(grad_norm_sq) if grad_norm_sq is not None else None, float(max_grad_norm if max_grad_norm is not None else 0.0), float(ema_decay), _s())
+
+
+def adamw_shadow_jobs(items, device):
+    """Device job table for `adamw_step_shadow_multi`: items = [(p [R, C], g, m, v, ema or None, w16 or None, w16t or None)]."""
+    import struct
+
+    buf, tile0 = bytearray(), 0
+    for p, g, m, v, e, w16, w16t in items:
+        R, C = p.shape
+        tiles_c = (C + 63) // 64
+        buf += struct.pack("<QQQQQQQqqiiii", _p(p), _p(g), _p(m), _p(v), _p(e) or 0, _p(w16) or 0, _p(w16t) or 0, w16.stride(0) if w16 is not None else 0,
+                           w16t.stride(0) if w16t is not None else 0, R, C, tile0, tiles_c)
+        tile0 += ((R + 63) // 64) * tiles_c
+    return torch.frombuffer(buf, dtype=torch.uint8).to(device), len(items), tile0
+
+
+def adamw_step_shadow_multi(jobs, lr, beta1, beta2, eps, weight_decay, step, grad_norm_sq=None, max_grad_norm=None, ema_decay=0.0):
+    table, n, tiles = jobs
+    _lib.call("udm_adamw_step_shadow_multi", _p(table), n, tiles, float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), int(step),
+              _p(grad_norm_sq) if grad_norm_sq is not None else None, float(max_grad_norm if max_grad_norm is not None else 0.0), float(ema_decay), _s())
+
+
 def cast_transpose_multi(jobs):
     """fp32 -> bf16 (and transposed bf16) for every matrix of a job table (see `cast_transpose_jobs`) in one launch."""
     table, n, tiles = jobs

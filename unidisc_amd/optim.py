@@ -77,15 +77,18 @@ class FusedAdamW:
         dev = grads[0].device
         if self._gsq is None or self._gsq.device != dev:
             self._gsq = torch.zeros(1, dtype=torch.float32, device=dev)
-        ref = getattr(self.backbone, "_last_grad_flat_ref", None)
-        flat = ref() if ref is not None else None
-        if flat is not None and flat.device == dev:
-            lo, hi = flat.data_ptr(), flat.data_ptr() + flat.numel() * 4
-            inside = sum(g.numel() for g in grads if lo <= g.data_ptr() < hi)
-            covered = getattr(self.backbone, "_last_grad_numel", -1)
-            if inside == covered == sum(g.numel() for g in grads):  # the buffer holds exactly these gradients (alignment gaps are zero)
-                K.sumsq(flat, self._gsq)
-                return self._gsq
+        # The engine's backward returns views of ONE flat buffer.  Autograd installs DETACHED copies of the views as p.grad (no `_base`) and the buffer's own Python
+        # wrapper is gone by now (round 4: a weak reference to it was dead at every step, so 341 sum-of-squares launches ran instead of one) - but the gradients
+        # still share its STORAGE.  When every gradient lives in one storage of the expected size, that storage is this backward's buffer (alignment gaps zeroed
+        # by `_alloc_grads`): one pass over all of it.
+        st = grads[0].untyped_storage()
+        covered = getattr(self.backbone, "_last_grad_numel", -1)
+        total = sum(g.numel() for g in grads)
+        if (total == covered and st.nbytes() % 4 == 0 and st.nbytes() // 4 <= total + 64 * len(grads)
+                and all(g.dtype == torch.float32 and g.untyped_storage().data_ptr() == st.data_ptr() for g in grads)):
+            flat = torch.empty(0, dtype=torch.float32, device=dev).set_(st, 0, (st.nbytes() // 4,))
+            K.sumsq(flat, self._gsq)
+            return self._gsq
         self._gsq.zero_()
         for g in grads:  # generic path (accumulated / foreign gradients): one pass per tensor
             part = torch.zeros(1, dtype=torch.float32, device=dev)
@@ -113,15 +116,31 @@ class FusedAdamW:
             lins = {id(l.weight): l for l in self.backbone._lins.values()}
         b1, b2 = self.betas
         ed = self._ema_decay_now() if self.ema is not None else 0.0
+        flat_items, shadow_items = [], []
         for p in todo:
             m, v = self.state[id(p)]
             lin = lins.get(id(p))
             e = self.ema[id(p)] if self.ema is not None else None
             if lin is not None and lin.w16 is not None:
-                K.adamw_step_shadow(p, p.grad, m, v, self.lr, b1, b2, self.eps, self.weight_decay, self.step_count, gsq, self.max_grad_norm, lin.w16, lin.w16t,
-                                    ema=e, ema_decay=ed)
+                if p.is_cuda and p.dim() == 2 and p.is_contiguous() and all(t.data_ptr() % 16 == 0 for t in (p, p.grad, m, v) + ((e,) if e is not None else ())):
+                    shadow_items.append((p, p.grad, m, v, e, lin.w16, lin.w16t))   # every GEMM weight with its bf16 shadows: ONE launch below
+                else:
+                    K.adamw_step_shadow(p, p.grad, m, v, self.lr, b1, b2, self.eps, self.weight_decay, self.step_count, gsq, self.max_grad_norm, lin.w16, lin.w16t,
+                                        ema=e, ema_decay=ed)
+            elif p.is_cuda and p.is_contiguous() and all(t.data_ptr() % 16 == 0 for t in (p, p.grad, m, v) + ((e,) if e is not None else ())):
+                flat_items.append((p, p.grad, m, v, e))     # every norm / bias / embedding tensor: ONE launch below (a 1.4 B DiT has ~250 of them)
             else:
                 K.adamw_step(p, p.grad, m, v, self.lr, b1, b2, self.eps, self.weight_decay, self.step_count, gsq, self.max_grad_norm, ema=e, ema_decay=ed)
+        if shadow_items:
+            key = tuple(t.data_ptr() if t is not None else 0 for it in shadow_items for t in it)
+            if getattr(self, "_smulti_key", None) != key:
+                self._smulti_jobs, self._smulti_key = K.adamw_shadow_jobs(shadow_items, shadow_items[0][0].device), key
+            K.adamw_step_shadow_multi(self._smulti_jobs, self.lr, b1, b2, self.eps, self.weight_decay, self.step_count, gsq, self.max_grad_norm, ema_decay=ed)
+        if flat_items:
+            key = tuple(t.data_ptr() if t is not None else 0 for it in flat_items for t in it)
+            if getattr(self, "_multi_key", None) != key:     # the table holds raw pointers: rebuilt whenever one moves (the flat gradient buffer is re-allocated per backward
+                self._multi_jobs, self._multi_key = K.adamw_jobs(flat_items, flat_items[0][0].device), key   # only if the caching allocator hands out another block)
+            K.adamw_step_multi(self._multi_jobs, self.lr, b1, b2, self.eps, self.weight_decay, self.step_count, gsq, self.max_grad_norm, ema_decay=ed)
         if self.maintain_shadows:
             # the shadows are current: the next forward must not re-cast (kernel writes do not bump tensor versions, so record them)
             self.backbone.recast_every_forward = False
