@@ -280,10 +280,19 @@ class ShardedAdamW(FusedAdamW):
             self.grad_norm = gsq.sqrt()
         b1, b2 = self.betas
         ed = self._ema_decay_now() if self.ema is not None else 0.0
+        items = []
         for p in mine:
             m, v = self.state[id(p)]
             e = self.ema[id(p)] if self.ema is not None else None
-            K.adamw_step(p, p.grad, m, v, self.lr, b1, b2, self.eps, self.weight_decay, self.step_count, gsq, self.max_grad_norm, ema=e, ema_decay=ed)
+            if p.is_cuda and p.is_contiguous() and p.grad.is_contiguous() and all(t.data_ptr() % 16 == 0 for t in (p, p.grad, m, v) + ((e,) if e is not None else ())):
+                items.append((p, p.grad, m, v, e))      # every owned tensor in ONE launch below (optim.hip: udm_adamw_step_multi)
+            else:
+                K.adamw_step(p, p.grad, m, v, self.lr, b1, b2, self.eps, self.weight_decay, self.step_count, gsq, self.max_grad_norm, ema=e, ema_decay=ed)
+        if items:
+            key = tuple(t.data_ptr() if t is not None else 0 for it in items for t in it)
+            if getattr(self, "_multi_key", None) != key:
+                self._multi_jobs, self._multi_key = K.adamw_jobs(items, items[0][0].device), key
+            K.adamw_step_multi(self._multi_jobs, self.lr, b1, b2, self.eps, self.weight_decay, self.step_count, gsq, self.max_grad_norm, ema_decay=ed)
         self._broadcast_from_owners(lambda p: p.data)   # updated masters: every bucket from its owner
         if hasattr(self.backbone, "invalidate_shadows"):   # the bf16 shadows of every rank follow on the next forward
             self.backbone.invalidate_shadows()
