@@ -593,6 +593,8 @@ void launch_fwd(const AttnArgs& a, hipStream_t s) {
   auto kern = attn_fwd_kernel<D, SID, TR>;
   static bool once = false;
   if (!once) { set_lds(kern, lds); once = true; }
+  // head dim 128, no mask, L % 256 == 0 (the headline shape): the one-wave-per-SIMD, 64-queries-per-wave kernel of attention_fwd64.hip
+  if (D == 128 && !SID && TR && udm_launch_attn_fwd64(&a, s)) return;
   if (D == 128 && !SID && TR) {   // UDM_ATTN_ABL=1|2: timing-only ablations of the forward kernel (scripts/bench_attn.py)
     static const int abl = [] { const char* e = getenv("UDM_ATTN_ABL"); return e ? atoi(e) : 0; }();
     if (abl == 1) { auto k1 = attn_fwd_kernel<128, false, true, 1>; set_lds(k1, lds); hipLaunchKernelGGL(k1, grid, dim3(256), lds, s, a); return; }

@@ -25,6 +25,8 @@ extern "C" int udm_gemm_set_tile(int tile);      // gemm.hip: force the tile fam
 extern "C" int udm_gemm_set_quad(int mode);      // gemm.hip: one-wave-per-SIMD kernels 0 = off, 1 = auto (default; env UDM_GEMM_QUAD), 2 = wherever the shape fits
 extern "C" int udm_gemm_set_persist(int enable); // gemm.hip: 0 = one block per output tile (default 1: persistent blocks for multi-round NT shapes)
 extern "C" int udm_attention_set_tr_read(int enable);        // attention.hip: 0 = gather V^T fragments with scalar LDS reads
+extern "C" int udm_attention_set_fwd64_timeline(int64_t device_ptr);   // attention_fwd64.hip diagnostics
+extern "C" int udm_attention_set_fwd64(int enable);          // attention_fwd64.hip: 0 = the 8-wave forward also at D = 128, L % 256 == 0 (default 1; env UDM_ATTN_FWD64)
 
 namespace { int g_exp = [] { const char* e = getenv("UDM_EXP"); return e ? atoi(e) : 0; }(); }
 int udm_exp_flags() { return g_exp; }
@@ -37,6 +39,8 @@ extern "C" int udm_debug_set(const char* key, int64_t value) {
   if (is("gemm_quad")) return udm_gemm_set_quad((int)value);
   if (is("gemm_persist")) return udm_gemm_set_persist((int)value);
   if (is("attention_tr_read")) return udm_attention_set_tr_read((int)value);
+  if (is("attention_fwd64")) return udm_attention_set_fwd64((int)value);
+  if (is("attention_fwd64_timeline")) return udm_attention_set_fwd64_timeline(value);
   udm_set_error("udm_debug_set: unknown key '%s'", key);
   return 2;
 }

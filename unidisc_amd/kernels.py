@@ -771,6 +771,11 @@ def set_tr_read(enable: bool):
     debug_set("attention_tr_read", 1 if enable else 0)
 
 
+def set_attention_fwd64(enable: bool):
+    """A/B switch: the 64-queries-per-wave forward (csrc/attention_fwd64.hip; head dim 128, no mask, L % 256 == 0) on / off."""
+    debug_set("attention_fwd64", 1 if enable else 0)
+
+
 # ------------------------------------------------------------------------------------------------ embedding / CE / adaLN helpers
 def embedding_fwd(ids, E, modality=None, Em=None):
     M = ids.numel()
