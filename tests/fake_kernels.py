@@ -205,26 +205,15 @@ def _qk(qkv, cos, sin, L, D, gq, bq, gk, bk):
     return out.reshape(M, 2 * d)
 
 
-def e4m3_pow2_quant(x, group):
-    """Reference of the product's q / k quantisation: one power-of-two scale per `group` consecutive columns (a head) with amax * 2^-k <= 448, round to
-    e4m3 (nearest even).  Returns (dequantised values, bytes as float8 tensor, E8M0 exponents)."""
-    shp = x.shape
-    g = x.float().reshape(*shp[:-1], shp[-1] // group, group)
-    amax = g.abs().amax(-1, keepdim=True)
-    mant, ex = torch.frexp(amax)                      # amax = mant * 2^ex, mant in [0.5, 1)  ->  amax = (2 mant) * 2^(ex - 1)
-    k = (ex - 1) - 8 + ((2 * mant) > 1.75).to(ex.dtype)
-    k = torch.where(amax > 0, k, torch.zeros_like(k)).clamp(-126, 126)
-    sc = torch.exp2(k.float())
-    q8 = (g / sc).to(torch.float8_e4m3fn)
-    return (q8.float() * sc).reshape(shp), q8.reshape(shp), (k + 127).squeeze(-1)
+def attention_q_scale(D):
+    return 1.4426950408889634 / math.sqrt(D)
 
 
-def qknorm_rope_fwd(qkv, cos, sin, L, D, *, gq=None, bq=None, gk=None, bk=None, fp8=False):
-    out = _qk(qkv.float(), cos, sin, L, D, gq, bq, gk, bk).bfloat16()
+def qknorm_rope_fwd(qkv, cos, sin, L, D, *, gq=None, bq=None, gk=None, bk=None, q_scale=1.0):
+    out = _qk(qkv.float(), cos, sin, L, D, gq, bq, gk, bk)
+    d = out.shape[1] // 2
+    out = torch.cat([out[:, :d] * q_scale, out[:, d:]], 1).bfloat16()
     stats = torch.zeros(qkv.shape[0], 4) if gq is not None else None
-    if fp8:
-        deq, q8, e8 = e4m3_pow2_quant(out, D)
-        return deq.bfloat16(), stats, (q8, e8)
     return out, stats
 
 
@@ -232,8 +221,10 @@ _saved_qk = {}
 
 
 @torch.enable_grad()
-def qknorm_rope_bwd(dqkr, qkv, dqkv, cos, sin, L, D, *, gq=None, gk=None, stats=None, dgq=None, dbq=None, dgk=None, dbk=None, bq=None, bk=None):
+def qknorm_rope_bwd(dqkr, qkv, dqkv, cos, sin, L, D, *, gq=None, gk=None, stats=None, dgq=None, dbq=None, dgk=None, dbk=None, bq=None, bk=None, q_scale=1.0):
     d = qkv.shape[1] // 3
+    if q_scale != 1.0:   # the incoming dq is the gradient wrt q * q_scale
+        dqkr = torch.cat([dqkr[:, :d].float() * q_scale, dqkr[:, d:].float()], 1)
     x = qkv.float().clone().requires_grad_()
     p = [t.clone().requires_grad_() if t is not None else None for t in (gq, gk)]
     zeros = torch.zeros(d)
@@ -295,32 +286,19 @@ def attention_doc_ranges(sample_ids):
     return r
 
 
-def attention_fwd(qkr, qkv, B, L, H, D, sample_ids=None, doc_ranges=None):
+def attention_fwd(qkr, qkv, B, L, H, D, sample_ids=None, doc_ranges=None, q_prescaled=False):
     d = H * D
-    o = _attn(qkr[:, :d].float(), qkr[:, d:].float(), qkv[:, 2 * d:].float(), B, L, H, D, sample_ids)
-    return o.bfloat16(), torch.zeros(B, H, L)
-
-
-def attention_fwd_fp8(qk8, qk_e8, qkv, B, L, H, D, sample_ids=None, doc_ranges=None):
-    """Stand-in for the fp8 forward: q, k as quantised by qknorm_rope_fwd(fp8=True), v with one power-of-two scale per (head, 64-key tile), fp32 attention
-    (P is not quantised here)."""
-    d = H * D
-    qk = qk8.float() * torch.exp2(qk_e8.float() - 127).repeat_interleave(D, dim=-1)
-    v = qkv[:, 2 * d:].float().reshape(B, L, H, D)
-    Lp = (L + 63) // 64 * 64
-    vp = torch.zeros(B, Lp, H, D)
-    vp[:, :L] = v
-    vt = vp.reshape(B, Lp // 64, 64, H, D).permute(0, 1, 3, 2, 4).reshape(B, Lp // 64, H, 64 * D)   # one scale per (b, tile, head)
-    vq = e4m3_pow2_quant(vt, 64 * D)[0].reshape(B, Lp // 64, H, 64, D).permute(0, 1, 3, 2, 4).reshape(B, Lp, H, D)[:, :L].reshape(B * L, d)
-    o = _attn(qk[:, :d], qk[:, d:], vq, B, L, H, D, sample_ids)
+    qs = attention_q_scale(D) if q_prescaled else 1.0
+    o = _attn(qkr[:, :d].float() / qs, qkr[:, d:].float(), qkv[:, 2 * d:].float(), B, L, H, D, sample_ids)
     return o.bfloat16(), torch.zeros(B, H, L)
 
 
 @torch.enable_grad()
-def attention_bwd(qkr, qkv, o, do, lse, dqkr, dqkv, B, L, H, D, sample_ids=None, doc_ranges=None):
+def attention_bwd(qkr, qkv, o, do, lse, dqkr, dqkv, B, L, H, D, sample_ids=None, doc_ranges=None, q_prescaled=False):
     d = H * D
+    qs = attention_q_scale(D) if q_prescaled else 1.0
     q, k, v = (t.float().clone().requires_grad_() for t in (qkr[:, :d], qkr[:, d:], qkv[:, 2 * d:]))
-    _attn(q, k, v, B, L, H, D, sample_ids).backward(do.float())
+    _attn(q / qs, k, v, B, L, H, D, sample_ids).backward(do.float())   # (q.grad is then the gradient wrt the stored, scaled q)
     dqkr[:, :d], dqkr[:, d:], dqkv[:, 2 * d:] = q.grad.bfloat16(), k.grad.bfloat16(), v.grad.bfloat16()
 
 

@@ -27,7 +27,7 @@ def test_header_symbols_exported(lib):
     assert declared == bound, (declared - bound, bound - declared)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.udm_abi_version() == _lib.ABI_VERSION == 2
+    assert lib.udm_abi_version() == _lib.ABI_VERSION == 3
 
 
 def test_prototype_arity_matches_header(lib):

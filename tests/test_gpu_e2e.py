@@ -155,57 +155,6 @@ def test_subs_logprobs_forward_contract():
     assert torch.allclose(lp.float().cpu()[finite], ref[finite], atol=0.12, rtol=0.02)
 
 
-@pytest.mark.parametrize("heads", [12, 6])
-def test_fp8_attention_forward_training_step(heads):
-    """model.fp8_attention (BASELINE config E; no reference counterpart): the same step with the attention forward in fp8, at width 768 with head
-    dim 64 / 128 (the fp8 kernel's head dims), 2 blocks.  Stated tolerances against this repository's bf16 path on the same inputs: masks
-    bit-exact, loss 5e-3 relative, per-token nll 3e-2 rel-RMS, worst-parameter gradient 3e-2 rel-RMS (forward e4m3 noise on q, k, v and P; the bf16
-    backward runs on the DEQUANTISED q, k the forward saw, with the forward's log-sum-exp - round 2 paired the fp8 forward with the unquantised q, k and
-    sat at 7-14 %)."""
-    case = dict(hidden_size=768, n_heads=heads, cond_dim=128, n_blocks=2, batch_size=2, txt_length=64, img_length=64, text_vocab_size=32001,
-                vocab_size=40193, norm_type="rms", qk_norm=True, sandwich_normalization=True, modality_embed=True, rope_2d=False,
-                time_conditioning=False, multimodal_batches=True, force_argmax_valid_indices=True, mask_entire_modality=0.1, softmin_snr=5,
-                text_loss_weight=1.0, img_loss_weight=None, force_full_attention_mask_loss_only=True)
-    from unidisc_amd import Diffusion
-
-    gen = torch.Generator().manual_seed(5)
-    B, Lt, Li = 2, 64, 64
-    batch = dict(txt_input_ids=torch.randint(0, 32000, (B, Lt), generator=gen, dtype=torch.int32),
-                 img_input_ids=torch.randint(0, 8192, (B, Li), generator=gen, dtype=torch.int32).to(torch.int16),
-                 txt_attention_mask=torch.ones(B, Lt, dtype=torch.bool))
-    res = []
-    for fp8 in (False, True):
-        torch.manual_seed(0)
-        diff = Diffusion(product_config(case), None, DEV)
-        diff.backbone.train()
-        diff.backbone.fp8_attention = fp8
-        diff.rng_device = "cpu"
-        wg = torch.Generator().manual_seed(7)
-        with torch.no_grad():
-            for n, p in sorted(diff.backbone.named_parameters()):
-                if n.endswith("linear.weight"):
-                    p.copy_((torch.randn(p.shape, generator=wg) / p.shape[-1] ** 0.5).to(DEV))
-        torch.manual_seed(123)
-        out = diff.training_step({k: v.clone() for k, v in batch.items()}, 1)
-        out.loss.backward()
-        torch.cuda.synchronize()
-        res.append((diff._last["xt"].cpu(), float(out.loss), out.nlls.detach().cpu(), {k: p.grad.cpu() for k, p in diff.backbone.named_parameters() if p.grad is not None}))
-    (x0, l0, n0, g0), (x1, l1, n1, g1) = res
-    assert torch.equal(x0, x1)
-    T = f"fp8_attention_step[heads={heads}]"
-    check(T, "loss_rel_vs_bf16_path", abs(l1 - l0) / abs(l0), 5e-3)
-    check(T, "nll_relrms_vs_bf16_path", rel_err(n1, n0), 3e-2)
-    assert l1 != l0                                             # the fp8 kernel really ran
-    errs = sorted(((rel_err(g1[k], g0[k]), k) for k in g0), reverse=True)
-    check(T, "grad_relrms_all_params_vs_bf16_path", rel_err(torch.cat([g1[k].reshape(-1) for k in g0]), torch.cat([g0[k].reshape(-1) for k in g0])), 3e-2)
-    check(T, "grad_relrms_median_param_vs_bf16_path", errs[len(errs) // 2][0], 3e-2)
-    # the worst parameter is a qk-norm vector: a column sum of dq / dk with heavy cancellation, whose bf16-vs-fp32 error is itself 2e-2 .. 1.5e-1 (ledger rows
-    # of test_gpu_fullwidth_oracle.py); the e4m3 rounding of q, k (3 mantissa bits against bf16's 7) scales that noise up
-    check(T, "grad_relrms_worst_param_vs_bf16_path", errs[0][0], 0.25, note=errs[0][1])
-    nonqk = [e for e in errs if "q_norm" not in e[1] and "k_norm" not in e[1]]
-    check(T, "grad_relrms_worst_param_outside_qk_norm_vs_bf16_path", nonqk[0][0], 3e-2, note=nonqk[0][1])
-
-
 @pytest.mark.parametrize("frac", [0.0, 1.0])
 def test_no_masked_rows_and_all_masked_rows(frac):
     """Extremes of the corruption: a batch without a single [MASK] (the compacted vocabulary head has zero real rows: log p = 0 everywhere, loss 0,

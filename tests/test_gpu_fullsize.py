@@ -143,50 +143,3 @@ def test_packed_rows_equal_separate_rows_at_full_size(bench):
     for s in range(4):
         assert rel_err(sep[s, :n], packed[s * n:(s + 1) * n]) < 1e-2, s
     assert float(packed[masked].abs().sum()) > 0
-
-
-QK_ALL_BOUND, QK_MED_BOUND = 0.2, 1.0   # achieved 0.067 / 0.55 (profiles/r04_parity_ledger.json): 3x, and "not beyond its own magnitude" for the median vector
-
-
-def test_config_e_fp8_attention_full_depth_against_bf16_attention(bench):
-    """BASELINE configs[4] at full size (24 blocks, d = 2048, one row of 4 packed samples = 4608 tokens): the same seeded training step with the attention
-    forward in fp8 (block-scaled e4m3 MFMA) and in bf16.  Masks bit-exact; stated tolerances of the fp8 path against this repository's bf16 path:
-    loss 5e-3, per-token NLL 4e-2 rel-RMS, gradients 3e-2 rel-RMS over all parameters together and for the median parameter, 5e-2 for every parameter
-    outside the qk-norm vectors (forward e4m3 noise on q, k, v and P accumulated over 24 blocks; the backward runs on the dequantised q, k the forward saw)."""
-    from ledger import check
-
-    workload = "unidisc-1.4b-interleaved-l4608"
-    res = []
-    for fp8 in (False, True):
-        cfg, diff = _build(bench, workload, dropout=0.0, seed=0)
-        diff.backbone.fp8_attention = fp8
-        diff.rng_device = "cpu"
-        batch = {k: v.to(DEV) for k, v in bench.synthetic_batch(workload, 1, 21).items()}
-        torch.manual_seed(123)
-        out = diff.training_step(batch, 1)
-        out.loss.backward()
-        torch.cuda.synchronize()
-        res.append((diff._last["xt"].cpu(), float(out.loss.detach()), out.nlls.detach().float().cpu(),
-                    {k: p.grad.detach().cpu() for k, p in diff.backbone.named_parameters() if p.grad is not None}))
-        del diff, out
-        torch.cuda.empty_cache()
-    (x0, l0, n0, g0), (x1, l1, n1, g1) = res
-    assert torch.equal(x0, x1) and l0 != l1
-    T = "config_e_24blocks_b1_fp8_vs_bf16_path"
-    check(T, "loss_rel", abs(l1 - l0) / abs(l0), 5e-3)
-    check(T, "nll_relrms", rel_err(n1, n0), 4e-2)
-    errs = sorted(((rel_err(g1[k], g0[k]), k) for k in g0), reverse=True)
-    check(T, "grad_relrms_all_params", rel_err(torch.cat([g1[k].reshape(-1) for k in g0]), torch.cat([g0[k].reshape(-1) for k in g0])), 3e-2)
-    check(T, "grad_relrms_median_param", errs[len(errs) // 2][0], 3e-2)
-    nonqk = [e for e in errs if "q_norm" not in e[1] and "k_norm" not in e[1]]
-    check(T, "grad_relrms_worst_param_outside_qk_norm", nonqk[0][0], 5e-2, note=nonqk[0][1])
-    # qk-norm vectors (column sums of dq / dk with heavy cancellation, |g| ~ 2e-5).  At 24 blocks the bf16 path itself is 1.5e-1 away from fp32 on its worst vector (and
-    # the reference's own bf16 flow just as far: ledger rows config_c_24blocks_*), and the fp8 path's WORST vector differs from the bf16 path's by its own magnitude
-    # (achieved 1.07 in round 3).  That single number is RECORDED, not asserted - no bound on it would say anything; what is asserted is the set of qk-norm gradients as a
-    # whole (all 96 vectors concatenated: the direction an optimizer step takes in that subspace) and their median, at <= 3x the recorded values.
-    from ledger import record
-    record(T, "grad_relrms_worst_param", errs[0][0], note=errs[0][1] + " (recorded, not asserted: fp8 attention is an opt-in at break-even, DESIGN.md §6)")
-    qk = sorted(k for k in g0 if "q_norm" in k or "k_norm" in k)
-    check(T, "grad_relrms_all_qk_norm_params_concatenated", rel_err(torch.cat([g1[k].reshape(-1) for k in qk]), torch.cat([g0[k].reshape(-1) for k in qk])), QK_ALL_BOUND)
-    qk_errs = sorted(rel_err(g1[k], g0[k]) for k in qk)
-    check(T, "grad_relrms_median_qk_norm_param", qk_errs[len(qk_errs) // 2], QK_MED_BOUND)

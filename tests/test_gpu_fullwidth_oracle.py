@@ -165,7 +165,7 @@ def test_training_step_matches_oracle_at_full_width(name):
     check(name, "grad_relrms_all_params", _rel(allg, allo), bound["grad_med"])
 
 
-# ------------------------------------------------------------------------------------------------ BASELINE configs[4]: packed rows, L = 4608, fp8 attention
+# ------------------------------------------------------------------------------------------------ BASELINE configs[4]: packed rows, L = 4608
 _PACKED = dict(_LARGE, txt_length=512, img_length=4096, interleaved=True, img_loss_weight=0.2, mask_entire_modality=0.2)
 
 
@@ -180,11 +180,11 @@ def _packed_batch(case, B, gen, samples=4, txt=128, img=1024):
     return dict(input_ids=ids, modality=torch.cat(mod, 1), sample_ids=torch.cat(sid, 1), attention_mask=torch.ones_like(ids, dtype=torch.bool))
 
 
-def test_config_e_packed_l4608_bf16_and_fp8_attention_match_oracle():
+def test_config_e_packed_l4608_matches_oracle():
     """BASELINE configs[4] at its real width and length (d = 2048, D = 128, rows of 4 packed samples = 4608 tokens, document mask from the sample ids),
-    one block: the same seeded step through the fp32 oracle, the product with bf16 attention and the product with the fp8 attention forward
-    (`model.fp8_attention`: block-scaled e4m3 MFMA forward, bf16 backward on the dequantised q, k).  Masks bit-exact in all three; the fp8 path is held to
-    STATED tolerances against the oracle and against the bf16 path (ledger rows `config_e_1block_b2_*`)."""
+    one block: the same seeded step through the fp32 oracle and the product.  Masks bit-exact; ledger rows `config_e_1block_b2_*`.  (The fp8 attention
+    forward that BASELINE configs[4] names was built in round 2-4, never beat the bf16 kernel inside the step and was 12.8 x noisier on the qk-norm
+    gradients: removed in round 5)"""
     from unidisc_amd import Diffusion
 
     case, B = dict(_PACKED, n_blocks=1), 2   # (B = 1 trips the reference's own `.squeeze(-1)` on the interleaved ignore mask, model.py - the oracle restates it)
@@ -195,11 +195,10 @@ def test_config_e_packed_l4608_bf16_and_fp8_attention_match_oracle():
     bufs = O.make_buffers(ocfg, lumina_rope_2d)
     res = {}
     P = None
-    for mode in ("bf16", "fp8"):
+    for mode in ("bf16",):
         torch.manual_seed(0)
         diff = Diffusion(cfg, None, DEV)
         diff.backbone.train()
-        diff.backbone.fp8_attention = mode == "fp8"
         diff.rng_device = "cpu"
         wg = torch.Generator().manual_seed(5)
         with torch.no_grad():
@@ -221,11 +220,9 @@ def test_config_e_packed_l4608_bf16_and_fp8_attention_match_oracle():
         del diff
         torch.cuda.empty_cache()
     l32 = float(o32.loss.detach())
-    # stated = asserted tolerances against the fp32 oracle.  bf16 attention: as the other full-width rows.  fp8 attention: loss 5e-3, NLL 3e-2, MEDIAN parameter
-    # gradient 4e-2 (achieved 2.5e-2 in profiles/r03_parity_ledger.json), WORST parameter 0.3 - always a qk-norm vector (achieved 0.226: a column sum of dq / dk with
-    # heavy cancellation that e4m3's 3 mantissa bits hit hardest; the bf16 path is at 4e-2 on the same vector); against this repository's own bf16 path: below
-    tol = dict(bf16=dict(loss=5e-5, nll=1.5e-3, grad_max=6e-2, grad_med=2e-2), fp8=dict(loss=5e-3, nll=3e-2, grad_max=0.3, grad_med=4e-2))
-    for mode in ("bf16", "fp8"):
+    # stated = asserted tolerances against the fp32 oracle: as the other full-width rows
+    tol = dict(bf16=dict(loss=5e-5, nll=1.5e-3, grad_max=6e-2, grad_med=2e-2))
+    for mode in ("bf16",):
         l, nll, g = res[mode]
         T = f"{name}_{mode}_attention"
         check(T, "loss_rel_vs_fp32_oracle", abs(l - l32) / abs(l32), tol[mode]["loss"])
@@ -233,22 +230,3 @@ def test_config_e_packed_l4608_bf16_and_fp8_attention_match_oracle():
         errs = sorted(((_rel(g[k], P[k].grad), k) for k in g if P[k].grad is not None), reverse=True)
         check(T, "grad_relrms_worst_param", errs[0][0], tol[mode]["grad_max"], note=errs[0][1])
         check(T, "grad_relrms_median_param", errs[len(errs) // 2][0], tol[mode]["grad_med"])
-    (l0, n0, g0), (l1, n1, g1) = res["bf16"], res["fp8"]
-    assert l1 != l0                                                    # the fp8 kernel really ran
-    T = f"{name}_fp8_vs_bf16_path"
-    check(T, "loss_rel", abs(l1 - l0) / abs(l0), 5e-3)
-    check(T, "nll_relrms", _rel(n1, n0), 3e-2)
-    errs = sorted(((_rel(g1[k], g0[k]), k) for k in g0), reverse=True)
-    check(T, "grad_relrms_all_params", _rel(torch.cat([g1[k].reshape(-1) for k in g0]), torch.cat([g0[k].reshape(-1) for k in g0])), 3e-2)
-    check(T, "grad_relrms_median_param", errs[len(errs) // 2][0], 3e-2)
-    nonqk = [e for e in errs if "q_norm" not in e[1] and "k_norm" not in e[1]]
-    check(T, "grad_relrms_worst_param_outside_qk_norm", nonqk[0][0], 4e-2, note=nonqk[0][1])
-    check(T, "grad_relrms_worst_param", errs[0][0], 0.3, note=errs[0][1])   # a qk-norm vector (see test_fp8_attention_forward_training_step); achieved 0.23
-    # the same vector against the TRUTH: the fp8 path's error is held to a multiple of the bf16 path's own error on it
-    k_w = errs[0][1]
-    e_bf16, e_fp8 = _rel(g0[k_w], P[k_w].grad), _rel(g1[k_w], P[k_w].grad)
-    from ledger import record
-    record(T, "worst_param_err_vs_fp32_oracle_bf16_path", e_bf16, note=k_w)
-    # RECORDED, not asserted: 12.8 in round 4 (0.226 against the bf16 path's 0.0176 on blocks.0.attention.k_norm.bias) - the fp8 forward is an order of magnitude
-    # noisier than bf16 on the qk-norm column sums, which is why it stays an opt-in; the asserted rows above bound everything else
-    record(T, "worst_param_err_vs_fp32_oracle_fp8_over_bf16_path", e_fp8 / max(e_bf16, 1e-12), note=k_w)

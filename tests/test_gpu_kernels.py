@@ -680,7 +680,10 @@ def test_residual_dropout_mask_statistics(K):
 @pytest.mark.parametrize("d,D", [(64, 32), (768, 64), (2048, 128), (256, 64)])
 @pytest.mark.parametrize("qk_norm", [True, False])
 @pytest.mark.parametrize("per_sample", [False, True])
-def test_qknorm_rope(K, d, D, qk_norm, per_sample):
+@pytest.mark.parametrize("q_scale", [1.0, "attention"])
+def test_qknorm_rope(K, d, D, qk_norm, per_sample, q_scale):
+    """q_scale = "attention": the engine's form - the stored q carries log2(e) / sqrt(D) (one rounding), the backward takes the gradient wrt that stored q"""
+    q_scale = K.attention_q_scale(D) if q_scale == "attention" else 1.0
     B, L = 2, 20
     M = B * L
     qkv, dqkr = bf(rnd(M, 3 * d, seed=22)), bf(rnd(M, 2 * d, seed=23))
@@ -691,16 +694,16 @@ def test_qknorm_rope(K, d, D, qk_norm, per_sample):
     cos, sin = ang.cos().contiguous(), ang.sin().contiguous()
     gq, bq, gk, bk = (1 + 0.1 * rnd(d, seed=25), 0.1 * rnd(d, seed=26), 1 + 0.1 * rnd(d, seed=27), 0.1 * rnd(d, seed=28)) if qk_norm else (None,) * 4
     g = lambda t: t.to(DEV) if t is not None else None
-    ref, _ = R.qknorm_rope_fwd(qkv, cos, sin, L, D, gq=gq, bq=bq, gk=gk, bk=bk)
-    out, stats = K.qknorm_rope_fwd(g(qkv), g(cos), g(sin), L, D, gq=g(gq), bq=g(bq), gk=g(gk), bk=g(bk))
-    assert rel_err(out.float().cpu(), ref.float()) < 6e-3
+    ref, _ = R.qknorm_rope_fwd(qkv, cos, sin, L, D, gq=gq, bq=bq, gk=gk, bk=bk, q_scale=q_scale)
+    out, stats = K.qknorm_rope_fwd(g(qkv), g(cos), g(sin), L, D, gq=g(gq), bq=g(bq), gk=g(gk), bk=g(bk), q_scale=q_scale)
+    assert rel_err(out.float().cpu()[:, :d], ref.float()[:, :d]) < 6e-3 and rel_err(out.float().cpu()[:, d:], ref.float()[:, d:]) < 6e-3
     dqkv_r = torch.zeros(M, 3 * d, dtype=torch.bfloat16)
     grads_r = [torch.zeros(d) for _ in range(4)] if qk_norm else [None] * 4
-    R.qknorm_rope_bwd(dqkr, qkv, dqkv_r, cos, sin, L, D, gq=gq, gk=gk, dgq=grads_r[0], dbq=grads_r[1], dgk=grads_r[2], dbk=grads_r[3])
+    R.qknorm_rope_bwd(dqkr, qkv, dqkv_r, cos, sin, L, D, gq=gq, gk=gk, dgq=grads_r[0], dbq=grads_r[1], dgk=grads_r[2], dbk=grads_r[3], q_scale=q_scale)
     dqkv = torch.zeros(M, 3 * d, dtype=torch.bfloat16, device=DEV)
     grads = [torch.zeros(d, device=DEV) for _ in range(4)] if qk_norm else [None] * 4
-    K.qknorm_rope_bwd(g(dqkr), g(qkv), dqkv, g(cos), g(sin), L, D, gq=g(gq), gk=g(gk), stats=stats, dgq=grads[0], dbq=grads[1], dgk=grads[2], dbk=grads[3])
-    assert rel_err(dqkv.float().cpu()[:, :2 * d], dqkv_r.float()[:, :2 * d]) < 8e-3
+    K.qknorm_rope_bwd(g(dqkr), g(qkv), dqkv, g(cos), g(sin), L, D, gq=g(gq), gk=g(gk), stats=stats, dgq=grads[0], dbq=grads[1], dgk=grads[2], dbk=grads[3], q_scale=q_scale)
+    assert rel_err(dqkv.float().cpu()[:, :d], dqkv_r.float()[:, :d]) < 8e-3 and rel_err(dqkv.float().cpu()[:, d:2 * d], dqkv_r.float()[:, d:2 * d]) < 8e-3
     assert torch.all(dqkv.cpu()[:, 2 * d:] == 0)
     if qk_norm:
         for a, b in zip(grads, grads_r):
@@ -747,6 +750,34 @@ def test_attention_fwd_bwd(K, tr, D, H, L, use_sid):
             assert torch.allclose(lse.cpu() * math.log(2.0), torch.logsumexp(s, -1), atol=2e-2, rtol=1e-3)
     finally:
         K.set_tr_read(True)
+
+
+@pytest.mark.parametrize("D,H,L,use_sid", [(32, 2, 100, False), (64, 3, 384, True), (128, 2, 384, False), (128, 8, 512, False), (128, 3, 200, True)])
+def test_attention_fwd_bwd_with_prescaled_q(K, D, H, L, use_sid):
+    """UDM_ATTN_Q_PRESCALED (the engine's form): q holds bf16(q log2(e) / sqrt(D)); O and LSE as for the plain call, dq is the gradient wrt the STORED q
+    (= dq / q_scale), dk and dv unchanged.  (128, 8, 512) takes the persistent 64-queries-per-wave forward, the others the 8-wave kernels."""
+    B = 2
+    d, M = H * D, B * L
+    qs = K.attention_q_scale(D)
+    qf, k, v, do = (rnd(M, d, seed=s_) for s_ in (230, 231, 232, 233))
+    q_st = bf(qf * qs)
+    k, v, do = bf(k), bf(v), bf(do)
+    sid = None
+    if use_sid:
+        sid = torch.zeros(B, L, dtype=torch.int64)
+        sid[:, L // 2:] = 1
+        sid[1, -7:] = -1
+    o_r, dq_r, dk_r, dv_r = _attn_ref(q_st.float() / qs, k, v, B, L, H, D, sid, do)   # the function of the UNSCALED q the stored one stands for
+    g = lambda t: t.to(DEV) if t is not None else None
+    o, lse = K.attention_fwd_generic(g(q_st), g(k), g(v), B, L, H, D, g(sid), q_prescaled=True)
+    assert rel_err(o.float().cpu(), o_r) < 1e-2
+    dq, dk, dv = K.attention_bwd_generic(g(q_st), g(k), g(v), o, g(do), lse, B, L, H, D, g(sid), q_prescaled=True)
+    assert rel_err(dv.float().cpu(), dv_r) < 1.5e-2
+    assert rel_err(dk.float().cpu(), dk_r) < 1.5e-2
+    assert rel_err(dq.float().cpu() * qs, dq_r) < 1.5e-2
+    if not use_sid:
+        s_ = ((q_st.float() / qs).reshape(B, L, H, D).transpose(1, 2) @ k.float().reshape(B, L, H, D).transpose(1, 2).transpose(-1, -2)) / math.sqrt(D)
+        assert torch.allclose(lse.cpu() * math.log(2.0), torch.logsumexp(s_, -1), atol=2e-2, rtol=1e-3)
 
 
 @pytest.mark.parametrize("L", [2, 31, 33, 64, 65, 127, 129, 191, 193, 257, 640, 1000])
@@ -834,130 +865,6 @@ def test_attention_tile_skipping_is_exact(K, D, H, L):
             assert rel_err(a.float().cpu(), b_) < 1.5e-2, (name, nm)
         pad_rows = (sid.reshape(-1) < 0)
         assert (o1.float().cpu()[pad_rows] == 0).all() and all((t.float().cpu()[pad_rows] == 0).all() for t in g1), name   # padding rows: zeros
-
-
-# ------------------------------------------------------------------------------------------------ fp8 attention forward (config E; no reference counterpart)
-def _fp8_key_order():
-    """position of key kappa (0..63) inside a 64-byte V^T row: byte hi*32 + f*16 + r holds key f*32 + (r&3) + 8 (r>>2) + 4 hi"""
-    pos = torch.zeros(64, dtype=torch.long)
-    for hi in range(2):
-        for f in range(2):
-            for r in range(16):
-                pos[f * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi] = hi * 32 + f * 16 + r
-    return pos
-
-
-def _fp8_dequant(quant, B, L, H, D):
-    """(qkr_dequantised, qk8, qk_e8, v8t, v_e8) of the quantise kernels -> fp32 q, k, v [B*L, H*D] (undoing the per-tile transpose and the key order)."""
-    qkr, qk8, qk_e8, v8t, v_e8 = (t.cpu() for t in quant)
-    d = H * D
-    Hp = qk_e8.shape[1] // 2
-    qk_e8 = torch.cat([qk_e8[:, :H], qk_e8[:, Hp:Hp + H]], 1)          # [M, 2 Hp] (heads padded to a multiple of 4) -> [M, 2 H]
-    qk = qk8.view(torch.float8_e4m3fn).float() * torch.exp2(qk_e8.float() - 127).repeat_interleave(D, dim=-1)
-    nt = v8t.shape[1]
-    vt = v8t.view(torch.float8_e4m3fn).float()[..., _fp8_key_order()] * torch.exp2(v_e8.float() - 127)[:, :, None, None]     # [B*H, nt, D, 64] in key order
-    v = vt.permute(0, 1, 3, 2).reshape(B, H, nt * 64, D)
-    tail = v[:, :, L:]
-    v = v[:, :, :L].permute(0, 2, 1, 3).reshape(B * L, d)
-    return qk[:, :d], qk[:, d:], v, tail
-
-
-@pytest.mark.parametrize("D,H", [(64, 3), (128, 2)])
-@pytest.mark.parametrize("L", [100, 640, 1500])
-def test_attention_fp8_quantize(K, D, H, L):
-    """q, k: one power-of-two scale per (row, head), bytes, scales and the dequantised bf16 copy EXACTLY as the reference quantiser (fake_kernels.e4m3_pow2_quant:
-    amax 2^-k <= 448, round to nearest even); v: one scale per (head, 64-key tile), transposed into the forward kernel's operand order, zero past L."""
-    import fake_kernels
-    B = 2
-    M, d = B * L, H * D
-    q, k, v = (bf(rnd(M, d, seed=s)) for s in (330, 331, 332))
-    q[5] = q[5] * 37.0                    # rows of very different magnitude: the scale is per row and head
-    k[7, :D] = k[7, :D] * 1e-3
-    v = bf(v.float() * 3.0)
-    o, lse, quant = K.attention_fwd_fp8_generic(q.to(DEV), k.to(DEV), v.to(DEV), B, L, H, D, return_quantized=True)
-    qd, kd, vd, tail = _fp8_dequant(quant, B, L, H, D)
-    ref_deq, ref_q8, ref_e8 = fake_kernels.e4m3_pow2_quant(torch.cat([q, k], 1), D)
-    Hp = quant[2].shape[1] // 2
-    assert torch.equal(torch.cat([quant[2][:, :H], quant[2][:, Hp:Hp + H]], 1).cpu().long(), ref_e8.long())   # E8M0 scales
-    assert torch.equal(quant[1].cpu(), ref_q8.view(torch.uint8))                                # bytes
-    assert torch.equal(quant[0].float().cpu(), ref_deq) and torch.equal(torch.cat([qd, kd], 1), ref_deq)   # the bf16 copy the backward reads = what the MFMA sees
-    assert rel_err(qd, q.float()) < 4e-2 and rel_err(kd, k.float()) < 4e-2                      # 3 mantissa bits
-    Lp = (L + 63) // 64 * 64
-    vp = torch.zeros(B, Lp, H, D)
-    vp[:, :L] = v.float().reshape(B, L, H, D)
-    vt = vp.reshape(B, Lp // 64, 64, H, D).permute(0, 1, 3, 2, 4).reshape(B, Lp // 64, H, 64 * D)
-    ref_v = fake_kernels.e4m3_pow2_quant(vt, 64 * D)[0].reshape(B, Lp // 64, H, 64, D).permute(0, 1, 3, 2, 4).reshape(B, Lp, H, D)[:, :L].reshape(M, d)
-    assert torch.equal(vd, ref_v)
-    assert (tail == 0).all()                                                                    # keys past L are zero
-
-
-def test_qknorm_rope_fwd_fp8_fused_equals_two_pass(K):
-    """d = 2048: the qk-norm + rope row kernel quantises while the row is in registers; bit-identical to the plain kernel followed by the generic quantiser."""
-    M, d, D, L = 6 * 96, 2048, 128, 96
-    qkv = bf(rnd(M, 3 * d, seed=350))
-    ang = rnd(L, D // 2, seed=355)
-    cos, sin = ang.cos().contiguous(), ang.sin().contiguous()
-    gq, bq, gk, bk = (rnd(d, seed=s) * 0.2 + (1.0 if s % 2 else 0.0) for s in (351, 352, 353, 354))
-    g = lambda t: t.to(DEV)
-    kw = dict(gq=g(gq), bq=g(bq), gk=g(gk), bk=g(bk))
-    qkr_f, st_f, (qk8_f, e8_f) = K.qknorm_rope_fwd(g(qkv), g(cos), g(sin), L, D, fp8=True, **kw)
-    qkr_p, st_p = K.qknorm_rope_fwd(g(qkv), g(cos), g(sin), L, D, **kw)
-    qk8_p, e8_p = K.attention_quantize_qk_fp8(qkr_p, D)
-    assert torch.equal(st_f, st_p) and torch.equal(qk8_f, qk8_p) and torch.equal(e8_f, e8_p) and torch.equal(qkr_f, qkr_p)
-
-
-@pytest.mark.parametrize("D,H", [(64, 3), (128, 2)])
-@pytest.mark.parametrize("L", [100, 640, 1500])
-@pytest.mark.parametrize("use_sid", [False, True])
-def test_attention_fp8_forward(K, D, H, L, use_sid):
-    """Tolerances (stated): against fp32 attention on the SAME quantised operands 3e-2 rel-RMS (what the e4m3 rounding of P
-    costs); against the bf16 kernel 8e-2 (adds the e4m3 rounding of q, k, v); log-sum-exp (log2 units) within 0.25 of the bf16 kernel's and
-    within 5e-3 of the exact one of the quantised operands."""
-    B = 3
-    M, d = B * L, H * D
-    q, k, v = (bf(rnd(M, d, seed=s)) for s in (340, 341, 342))
-    q[11] = q[11] * 3.0     # per-row scales at work (a row of large scores: its log-sum-exp moves with the e4m3 rounding of q, k in proportion)
-    g = lambda t: t.to(DEV) if t is not None else None
-    layouts = _doc_layouts(B, L) if use_sid else {"none": None}
-    if use_sid:   # mask CODES (modality attention dropout): asymmetric text / image visibility, no doc_ranges - the fp8 kernel must apply attn_pair_ok like the bf16 one
-        drop = torch.tensor([True, False, True])
-        layouts["modality_codes"] = K.modality_mask_codes(drop.to(DEV), torch.tensor([False, True, True]).to(DEV), L // 3, L).cpu()
-    for name, sid in layouts.items():
-        r = K.attention_doc_ranges(g(sid)) if (sid is not None and name != "modality_codes") else None
-        o, lse, quant = K.attention_fwd_fp8_generic(g(q), g(k), g(v), B, L, H, D, g(sid), r, return_quantized=True)
-        qd, kd, vd, _ = _fp8_dequant(quant, B, L, H, D)
-        o16, lse16 = K.attention_fwd_generic(g(q), g(k), g(v), B, L, H, D, g(sid), r)
-        assert rel_err(o.float().cpu(), o16.float().cpu()) < 8e-2, name
-        fin = torch.isfinite(lse16)
-        assert torch.equal(torch.isfinite(lse), fin) and torch.allclose(lse[fin], lse16[fin], atol=0.5, rtol=0), name      # log2 units; q, k rounding
-        # the bf16 kernel on the DEQUANTISED q, k, v computes the same scores (exact products) and differs only by the rounding of P: the backward's view of this forward
-        o16q, lse16q = K.attention_fwd_generic(g(qd.bfloat16()), g(kd.bfloat16()), g(vd.bfloat16()), B, L, H, D, g(sid), r)
-        assert rel_err(o.float().cpu(), o16q.float().cpu()) < 3e-2, name
-        assert torch.allclose(lse[fin], lse16q[fin], atol=2e-3, rtol=0), name
-        if name != "modality_codes":
-            o_ref = R._attn(qd, kd, vd, B, L, H, D, sid)
-            assert rel_err(o.float().cpu(), o_ref) < 3e-2, name
-        if sid is None:   # the softmax statistics themselves are fp32: tight against the exact scores of the quantised operands
-            sc = (qd.reshape(B, L, H, D).transpose(1, 2) @ kd.reshape(B, L, H, D).transpose(1, 2).transpose(-1, -2)) / math.sqrt(D)
-            assert torch.allclose(lse.cpu() * math.log(2.0), torch.logsumexp(sc, -1), atol=5e-3, rtol=1e-4), name
-        if sid is not None and r is not None:
-            o_noskip, _ = K.attention_fwd_fp8_generic(g(q), g(k), g(v), B, L, H, D, g(sid), None)
-            assert torch.equal(o, o_noskip), name                       # tile skipping changes nothing
-            assert (o.float().cpu()[sid.reshape(-1) < 0] == 0).all(), name
-
-
-def test_attention_online_softmax_rescale_branch(K):
-    # a key far above the others late in the sequence forces the running max to jump (rule: test the rare branch)
-    B, H, L, D = 1, 1, 256, 64
-    q, k, v, do = (bf(rnd(L, D, seed=s)) for s in (40, 41, 42, 43))
-    k[200] = k[200] * 12
-    q[7] = bf(k[200].float() / 4)
-    o_r, dq_r, dk_r, dv_r = _attn_ref(q, k, v, B, L, H, D, None, do)
-    o, lse = K.attention_fwd_generic(q.to(DEV), k.to(DEV), v.to(DEV), B, L, H, D)
-    assert rel_err(o.float().cpu(), o_r) < 1e-2
-    assert torch.allclose(o.float().cpu()[7], o_r[7], atol=3e-2)
-    dq, dk, dv = K.attention_bwd_generic(q.to(DEV), k.to(DEV), v.to(DEV), o, do.to(DEV), lse, B, L, H, D)
-    assert rel_err(dq.float().cpu(), dq_r) < 2e-2 and rel_err(dk.float().cpu(), dk_r) < 2e-2 and rel_err(dv.float().cpu(), dv_r) < 2e-2
 
 
 # ------------------------------------------------------------------------------------------------ embedding / CE / small ops

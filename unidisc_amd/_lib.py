@@ -43,15 +43,11 @@ PROTOTYPES = {
     "udm_residual_norm_fwd": [_P, _P, _P, _P, _P, _P, _P, _I64, _P, _I64, _I64, _I64, _I, _F, _F, _U64, _P, _P, _P, _P, _P],
     "udm_residual_bwd": [_P, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _P, _I64, _I64, _I64, _I, _F, _U64, _P, _I64, _P],
     "udm_norm_residual_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I, _F, _U64, _P, _I64, _P],
-    "udm_qknorm_rope_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I64, _I64, _I64, _I64, _F, _P],
-    "udm_qknorm_rope_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _P, _I64, _P],
+    "udm_qknorm_rope_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I64, _I64, _I64, _I64, _F, _F, _P],
+    "udm_qknorm_rope_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _F, _P, _I64, _P],
     "udm_attention_doc_ranges": [_P, _I64, _I64, _P, _P],
-    "udm_attention_fwd": [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _P],
-    "udm_attention_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _P],
-    "udm_qknorm_rope_fwd_fp8": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I64, _I64, _I64, _I64, _F, _P],
-    "udm_attention_quantize_qk_fp8": [_P, _P, _P, _I64, _I64, _I64, _P],
-    "udm_attention_quantize_v_fp8": [_P, _I64, _P, _P, _I64, _I64, _I64, _I64, _P],
-    "udm_attention_fwd_fp8": [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _P],
+    "udm_attention_fwd": [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _P],
+    "udm_attention_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _P],
     "udm_assemble_joint_tokens": [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _P, _P, _P, _P],
     "udm_interleaved_rope": [_P, _P, _P, _P, _P, _I64, _P, _P, _I64, _I64, _I64, _I64, _P, _P, _P, _P, _P],
     "udm_interleaved_block_lottery": [_P, _P, _P, _I64, _F, _I64, _I64, _P, _P, _P, _P, _P, _P],
@@ -79,7 +75,7 @@ PROTOTYPES = {
     "udm_silu_bwd": [_P, _P, _P, _I64, _P],
 }
 EXTRA_SYMBOLS = ["udm_last_error", "udm_abi_version"]
-ABI_VERSION = 2   # the UDM_ABI_VERSION of include/unidisc_hip.h that PROTOTYPES was written for (bumped whenever a signature changes)
+ABI_VERSION = 3   # the UDM_ABI_VERSION of include/unidisc_hip.h that PROTOTYPES was written for (bumped whenever a signature changes)
 
 _lib = None
 

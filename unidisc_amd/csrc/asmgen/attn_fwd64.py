@@ -49,11 +49,11 @@ S_ = Alloc("s", 36, 100)
 
 Sbuf = [V("Sa", 64), V("Sb", 64)]
 Vf = V("Vf", 64)
-P = V("P", 32)
+negm = [V("negm0", 16), V("negm1", 16)]   # -mc[q] in all 16 registers: the C operand of a score chain's first MFMA, so the accumulator holds s - mc
 kaddr, vaddr = V("kaddr"), V("vaddr")
 dk, dv = V("dk", 4), V("dv", 4)
-m = [V("m0_"), V("m1_")]
-mc = [V("mc0"), V("mc1")]
+mc = [V("mc0"), V("mc1")]                 # reference exponent per query (base 2; q carries log2(e) / sqrt(D))
+eight = V("eight")
 ls = [[V("l00"), V("l01")], [V("l10"), V("l11")]]
 mx = [V("mx0"), V("mx1")]
 ta = [V("ta0"), V("ta1")]      # cross-half maximum (mloc) of the tile under decision
@@ -67,8 +67,8 @@ Ka = A("K", 64)
 # inputs (copied from the asm statement's operands, in this order)
 s_qb, s_kb, s_vb, s_ob, s_lseb = S_("qb", 2, 2), S_("kb", 2, 2), S_("vb", 2, 2), S_("ob", 2, 2), S_("lseb", 2, 2)
 s_qstr, s_kstr, s_vstr, s_ostr = S_("qstr"), S_("kstr"), S_("vstr"), S_("ostr")
-s_L, s_nkv, s_H, s_nt, s_mg_nt, s_mg_H, s_nblk, s_c, s_lds, s_bid, s_gstride = (S_(n) for n in ("L", "nkv", "H", "nt", "mg_nt", "mg_H", "nblk", "c", "lds", "bid", "gstride"))
-INPUTS = ["qb", "kb", "vb", "ob", "lseb", "qstr", "kstr", "vstr", "ostr", "L", "nkv", "H", "nt", "mg_nt", "mg_H", "nblk", "c", "lds", "bid", "gstride", "tid", "tl"]
+s_L, s_nkv, s_H, s_nt, s_mg_nt, s_mg_H, s_nblk, s_lds, s_bid, s_gstride = (S_(n) for n in ("L", "nkv", "H", "nt", "mg_nt", "mg_H", "nblk", "lds", "bid", "gstride"))
+INPUTS = ["qb", "kb", "vb", "ob", "lseb", "qstr", "kstr", "vstr", "ostr", "L", "nkv", "H", "nt", "mg_nt", "mg_H", "nblk", "lds", "bid", "gstride", "tid", "tl"]
 # working
 s_wave = S_("wave")
 s_kt, s_vt = S_("kt", 2, 2), S_("vt", 2, 2)       # running tile bases of the refills
@@ -103,8 +103,9 @@ def Vfr(cc, i):
     return Vf.sub((cc * 4 + i) * 4, 4)
 
 
-def Pfr(q, cc):
-    return P.sub((q * 4 + cc) * 4, 4)
+def Pfr(buf, q, cc):
+    """packed bf16 P^T of 16 keys: written IN PLACE over the first four of the eight fp32 scores it was made from"""
+    return Sblk(buf, q, cc >> 1).sub(8 * (cc & 1), 4)
 
 
 def Oblk(q, i):
@@ -162,16 +163,16 @@ def score_mfmas(buf):
         for ks in range(KS):
             for q in range(2):
                 d = Sblk(buf, q, f)
-                out.append(v_mfma_f32_32x32x16_bf16(d, Kfr(f, ks), Qfr(q, ks), 0 if ks == 0 else d))
+                out.append(v_mfma_f32_32x32x16_bf16(d, Kfr(f, ks), Qfr(q, ks), negm[q] if ks == 0 else d))
     return out
 
 
-def pv_mfmas():
+def pv_mfmas(buf):
     out = []
     for cc in range(4):
         for i in range(4):
             for q in range(2):
-                out.append(v_mfma_f32_32x32x16_bf16(Oblk(q, i), Vfr(cc, i), Pfr(q, cc), Oblk(q, i)))
+                out.append(v_mfma_f32_32x32x16_bf16(Oblk(q, i), Vfr(cc, i), Pfr(buf, q, cc), Oblk(q, i)))
     return out
 
 
@@ -200,37 +201,43 @@ def max_ops(buf):
 
 
 def decide_ops(tag):
-    """mloc = max over the two half-waves; move the reference exponent of block q iff some lane saw mloc c > m c + 8 (attention.hip)"""
+    """cross-half maximum of the accumulators (= s - mc); the reference exponent moves iff some lane of the wave saw more than 2^8 above it (attention.hip's rule)"""
     out = []
     out += [v_mov_b32(ta[0], mx[0]), v_mov_b32(tb[0], mx[0]), v_mov_b32(ta[1], mx[1]), v_mov_b32(tb[1], mx[1])]
-    out += [v_permlane32_swap_b32(ta[0], tb[0]), v_permlane32_swap_b32(ta[1], tb[1])]
+    out += [s_nop(0), v_permlane32_swap_b32(ta[0], tb[0]), v_permlane32_swap_b32(ta[1], tb[1])]
     out += [v_max_f32(ta[0], ta[0], tb[0]), v_max_f32(ta[1], ta[1], tb[1])]
-    out += [v_mul_f32(tmp[0], s_c, ta[0]), v_add_f32(tmp[1], 8.0, mc[0]), v_mul_f32(tmp[2], s_c, ta[1]), v_add_f32(tmp[3], 8.0, mc[1])]
-    out += [v_cmp_gt_f32(s_dec[0], tmp[0], tmp[1]), v_cmp_gt_f32(s_dec[1], tmp[2], tmp[3])]
-    out += [s_or_b64(s_dec[0], s_dec[0], s_dec[1])]          # SCC = some block moves
+    out += [v_cmp_gt_f32(s_dec[0], ta[0], eight), v_cmp_gt_f32(s_dec[1], ta[1], eight)]
+    out += [s_or_b64(s_dec[0], s_dec[0], s_dec[1])]          # SCC = some lane moves
     out += [s_cbranch_scc1(f"L_move_{tag}"), label(f"L_moved_{tag}")]
     return out
 
 
-def move_block(tag):
-    """out of line: new reference exponents (both blocks: m_new = max(m, mloc) leaves an unmoved lane alone), row sums rescaled now, O^T at the
-    end of the PV phase (P(t), still being accumulated, is relative to the OLD exponent)"""
+def move_block(tag, buf, set_flag=True):
+    """out of line: every lane of both blocks raises its reference exponent by d = max(s_max - mc, 0): the row sums are rescaled now, the scores of the tile
+    under decision (still accumulators: nothing of it is exponentiated yet) drop by d, the C-operand registers follow, O^T is rescaled at the end of the PV
+    phase (P(t), still being accumulated, is relative to the OLD exponent).  set_flag = False: the block's first tile (O^T = 0, l = 0)."""
     out = [label(f"L_move_{tag}"), s_nop(1)]
+    d = [tmp[0], tmp[1]]
     for q in range(2):
-        out += [v_max_f32(tmp[q], m[q], ta[q])]
+        out += [v_max_f32(d[q], 0, ta[q])]
     for q in range(2):
-        out += [v_sub_f32(tmp[2 + q], m[q], tmp[q])]
+        out += [v_sub_f32(tmp[2 + q], 0, d[q])]
     for q in range(2):
-        out += [v_mul_f32(tmp[2 + q], s_c, tmp[2 + q])]
+        out += [v_exp_f32(alpha[q], tmp[2 + q])]
     for q in range(2):
-        out += [v_exp_f32(tmp[2 + q], tmp[2 + q])]
+        out += [v_add_f32(mc[q], mc[q], d[q])]
     for q in range(2):
-        out += [v_mov_b32(m[q], tmp[q])]
+        out += [v_mul_f32(ls[q][0], ls[q][0], alpha[q]), v_mul_f32(ls[q][1], ls[q][1], alpha[q]), v_sub_f32(tmp[2 + q], 0, mc[q])]
     for q in range(2):
-        out += [v_mul_f32(mc[q], s_c, tmp[q])]
-    for q in range(2):   # a second move before the O^T rescale of the first cannot happen (one decision per tile), alpha simply overwrites
-        out += [v_mov_b32(alpha[q], tmp[2 + q]), v_mul_f32(ls[q][0], ls[q][0], tmp[2 + q]), v_mul_f32(ls[q][1], ls[q][1], tmp[2 + q])]
-    out += [s_mov_b32(s_flag[0], 1), s_branch(f"L_moved_{tag}")]
+        for r in range(16):
+            out += [v_mov_b32(negm[q][r], tmp[2 + q])]
+        for f in range(2):
+            blk = Sblk(buf, q, f)
+            for r in range(16):
+                out += [v_sub_f32(blk[r], blk[r], d[q])]
+    if set_flag:
+        out += [s_mov_b32(s_flag[0], 1)]
+    out += [s_branch(f"L_moved_{tag}")]
     return out
 
 
@@ -251,17 +258,13 @@ def rescale_o_block():
 
 
 def softmax_group(buf, q, cc):
-    """8 scores of block q, key chunk cc: p = exp2(s c - mc), row sums (two chains), packed bf16 P"""
+    """8 accumulators (s - mc) of block q, key chunk cc: p = exp2(.), row sums (two chains), bf16 P packed over the first four of them"""
     f, r0 = cc >> 1, 8 * (cc & 1)
     s = Sblk(buf, q, f)
-    out = [v_fma_f32(s[r0 + e], s[r0 + e], s_c, mc[q], neg_c=True) for e in range(8)]
-    out += [v_exp_f32(s[r0 + e], s[r0 + e]) for e in range(8)]
-    tail = []
-    for e in range(8):
-        tail.append(v_add_f32(ls[q][e & 1], ls[q][e & 1], s[r0 + e]))
-        if e & 1:
-            tail.append(v_cvt_pk_bf16_f32(Pfr(q, cc)[e >> 1], s[r0 + e - 1], s[r0 + e]))
-    return out + tail
+    out = [v_exp_f32(s[r0 + e], s[r0 + e]) for e in range(8)]
+    out += [v_add_f32(ls[q][e & 1], ls[q][e & 1], s[r0 + e]) for e in range(8)]
+    out += [v_cvt_pk_bf16_f32(s[r0 + j], s[r0 + 2 * j], s[r0 + 2 * j + 1]) for j in range(4)]
+    return out
 
 
 GROUPS = [(q, cc) for cc in range(4) for q in range(2)]   # in the order the PV MFMAs need P
@@ -390,7 +393,7 @@ def _body(j, variant, tag, vm_wait):
             early += softmax_group(nxt, q, cc)
         streams.append((soft, 3, 14))
         streams.append((early, 16, 30))
-    b, cb = spread(pv_mfmas(), streams, "phase B")
+    b, cb = spread(pv_mfmas(cur), streams, "phase B")
     prog += b
     if not last:
         prog += [s_waitcnt(lgkmcnt=0)] + stamp(10 + 3 * tag)
@@ -426,7 +429,7 @@ def next_block_ptrs():
 def entry():
     p = [comment("---- entry: constants of the wave, first block's loads")]
     raw = lambda t: Inst(t, "raw")
-    regs = [s_qb, s_kb, s_vb, s_ob, s_lseb, s_qstr, s_kstr, s_vstr, s_ostr, s_L, s_nkv, s_H, s_nt, s_mg_nt, s_mg_H, s_nblk, s_c, s_lds, s_bid, s_gstride]
+    regs = [s_qb, s_kb, s_vb, s_ob, s_lseb, s_qstr, s_kstr, s_vstr, s_ostr, s_L, s_nkv, s_H, s_nt, s_mg_nt, s_mg_H, s_nblk, s_lds, s_bid, s_gstride]
     for i, r in enumerate(regs):
         p += [raw(f"s_mov_b{64 if r.n == 2 else 32} {r}, %{i}")]
     tid = tmp[0]
@@ -461,7 +464,7 @@ def entry():
     p += [v_lshlrev_b32(t[3], 10, hi), v_and_b32(t[4], 15, lane_v), v_lshrrev_b32(t[4], 2, t[4]), v_lshlrev_b32(t[4], 6, t[4]), v_add_u32(t[3], t[3], t[4]),
           v_lshrrev_b32(t[4], 4, lane_v), v_and_b32(t[4], 1, t[4]), v_lshlrev_b32(t[4], 5, t[4]), v_add_u32(t[3], t[3], t[4]),
           v_and_b32(t[4], 3, lane_v), v_lshlrev_b32(t[4], 3, t[4]), v_add_u32(t[3], t[3], t[4]), v_add_u32(t[3], s_lds, t[3]), v_add_u32(vaddr, LDS_V0, t[3])]
-    p += [s_mov_b32(s_flag[0], 0), s_mov_b32(s_relax, 0)]
+    p += [s_mov_b32(s_flag[0], 0), s_mov_b32(s_relax, 0), v_mov_b32(eight, 8.0)]
     # ---- first block: its pointers, Q, and the ring as if its tiles -4 .. -1 had run: K0, K1, V0, K2, V1, K3, V2
     p += block_ptrs(s_bid, s_qn, s_kt, s_vt, s_o, s_lse)
     if ABL & 32:   # debug: dump the first block's scalars into the LSE tensor (lane i of wave 0 stores SGPR 36 + i) and stop
@@ -487,6 +490,8 @@ def block_start():
     # the seam's loads have landed - the last Q loads are the youngest of them - only the previous block's 18 stores may still fly; fresh block: nothing does
     p += [s_cmp_eq_u32(s_relax, 1), s_cbranch_scc0("L_bs_fresh"), s_waitcnt(vmcnt=18), label("L_bs_fresh")] + stamp(4) + [s_barrier()]
     p += k_reads(0) + [s_waitcnt(lgkmcnt=0)] + stamp(5)
+    for q in range(2):
+        p += [v_mov_b32(mc[q], 0)] + [v_mov_b32(negm[q][r], 0) for r in range(16)]
     zero = [v_accvgpr_write_b32(Oacc[r], 0) for r in range(128)]
     for q in range(2):
         zero += [v_mov_b32(ls[q][0], 0), v_mov_b32(ls[q][1], 0)]
@@ -494,12 +499,8 @@ def block_start():
     p += sm
     p += k_reads(1)
     p += [s_nop(7)]
-    # first reference exponent = the first tile's maximum itself (nothing to rescale yet)
-    p += max_ops(0)
-    p += [v_mov_b32(ta[0], mx[0]), v_mov_b32(tb[0], mx[0]), v_mov_b32(ta[1], mx[1]), v_mov_b32(tb[1], mx[1])]
-    p += [s_nop(1), v_permlane32_swap_b32(ta[0], tb[0]), v_permlane32_swap_b32(ta[1], tb[1])]
-    p += [v_max_f32(m[0], ta[0], tb[0]), v_max_f32(m[1], ta[1], tb[1]), s_nop(0)]
-    p += [v_mul_f32(mc[0], s_c, m[0]), v_mul_f32(mc[1], s_c, m[1])]
+    # first reference exponent: the common decision with mc = 0 (scores within 2^8 of zero keep it there); nothing to rescale yet
+    p += max_ops(0) + decide_ops(7)
     for (q, cc) in GROUPS[:N_EARLY]:
         p += softmax_group(0, q, cc)
     p += [s_waitcnt(lgkmcnt=0)] + stamp(6)
@@ -521,7 +522,7 @@ def epilogue():
     e += [s_nop(1), v_permlane32_swap_b32(ta[0], tb[0]), v_permlane32_swap_b32(ta[1], tb[1])]
     e += [v_add_f32(ta[0], ta[0], tb[0]), v_add_f32(ta[1], ta[1], tb[1]), s_nop(0)]
     e += [v_rcp_f32(inv[0], ta[0]), v_rcp_f32(inv[1], ta[1]), v_log_f32(tb[0], ta[0]), v_log_f32(tb[1], ta[1]), s_nop(0)]
-    e += [v_fma_f32(tb[0], m[0], s_c, tb[0]), v_fma_f32(tb[1], m[1], s_c, tb[1])]
+    e += [v_add_f32(tb[0], mc[0], tb[0]), v_add_f32(tb[1], mc[1], tb[1])]
     lane_v, l31, hi = mx[0], mx[1], ta[0]
     e += v_mbcnt_lane_id(lane_v)
     e += [v_and_b32(l31, 31, lane_v), v_lshrrev_b32(hi, 5, lane_v)]
@@ -537,7 +538,7 @@ def epilogue():
     e += [v_lshrrev_b32(g8, 3, lane_v), v_and_b32(t[2], 7, lane_v), v_xor_b32(t[3], t[2], g8), v_lshlrev_b32(t[3], 4, t[3]), v_lshlrev_b32(rdaddr, 7, g8), v_add_u32(rdaddr, rdaddr, t[3]),
           v_add_u32(rdaddr, s_t0, rdaddr)]
     # global offsets: (wave * 64 + 8 k + (lane >> 3)) * ostr + (lane & 7) * 16   (+ q * 32 rows, + ch * 128 bytes as immediate)
-    go = [P[0], P[1], P[2], P[3]]      # P is dead after the last PV phase
+    go = [negm[0][0], negm[0][1], negm[0][2], negm[0][3]]      # (the next block start rewrites the C-operand registers)
     e += [s_lshl_b32(s_t1, s_wave, 6), s_nop(0), v_add_u32(t[3], s_t1, g8), v_mul_lo_u32(t[3], t[3], s_ostr), v_lshlrev_b32(t[2], 4, t[2]), v_add_u32(go[0], t[3], t[2])]
     e += [s_lshl_b32(s_t1, s_ostr, 3), s_nop(0)]
     for k in range(1, 4):
@@ -609,8 +610,9 @@ def build():
     # next block (its outputs' pointers were computed at this block's start), or out
     prog += [s_cmp_lt_u32(s_nbid, s_nblk), s_cbranch_scc0("L_done"), s_mov_b32(s_bid, s_nbid), s_mov_b64(s_o, s_on), s_mov_b64(s_lse, s_lsen), s_mov_b32(s_relax, 1),
              s_branch("L_block"), label("L_done"), s_waitcnt(vmcnt=0)] + stamp(42) + timeline_store() + [s_branch("L_end")]
-    for tag in range(7):
-        prog += move_block(tag)
+    for tag in range(7):       # bodies 0-3 decide about tile t+1 in S buffer (j+1) & 1; the three tails 4-6 likewise
+        prog += move_block(tag, (tag + 1) & 1)
+    prog += move_block(7, 0, set_flag=False)
     prog += rescale_o_block()
     prog += [label("L_end"), Inst("s_endpgm", "end", final=True)]
     return prog, counts

@@ -21,12 +21,15 @@ def run(B=1, H=8, L=512, grid=8, wg_id=0, mode="late", seed=0, spike=False, prog
     d = g.D
     M = B * L
     # engine layout: q | k in one [M, 2 H d] buffer, v at column 2 H d of [M, 3 H d]
-    qk = bf16_bits(rng.standard_normal((M, 2 * H * d)) * 1.5)
+    c = np.float32(1.4426950408889634 / np.sqrt(d))
+    qk_f = rng.standard_normal((M, 2 * H * d)) * 1.5
+    qk_f[:, :H * d] *= c                                   # the engine stores q * log2(e) / sqrt(D)
+    qk = bf16_bits(qk_f)
     qkv = bf16_bits(rng.standard_normal((M, 3 * H * d)))
     if spike:
         for (b, h, key, qrow) in [(0, wg_id % H, L - 100, 70), (0, wg_id % H, 3, 300)]:
             qk[b * L + key, H * d + h * d: H * d + (h + 1) * d] = bf16_bits(np.full(d, 6.0))
-            qk[b * L + qrow, h * d:(h + 1) * d] = bf16_bits(np.full(d, 6.0))
+            qk[b * L + qrow, h * d:(h + 1) * d] = bf16_bits(np.full(d, 6.0 * c))
     out = np.zeros((M, H * d), np.uint16)
     lse = np.zeros((B, H, L), np.float32)
     wg = isa.Workgroup(lds_bytes=g.LDS_TOTAL, mode=mode)
@@ -35,11 +38,10 @@ def run(B=1, H=8, L=512, grid=8, wg_id=0, mode="late", seed=0, spike=False, prog
     nblk = B * H * nt
     tl = np.zeros((nblk, 4, 64), np.uint32)
     a_tl = wg.add_buffer(tl)
-    c = np.float32(1.4426950408889634 / np.sqrt(d))
     if prog is None:
         prog, _ = g.build()
     vals = dict(qb=a_qk, kb=a_qk + H * d * 2, vb=a_qkv + 2 * H * d * 2, ob=a_out, lseb=a_lse, qstr=2 * H * d * 2, kstr=2 * H * d * 2, vstr=3 * H * d * 2, ostr=H * d * 2,
-                L=L, nkv=L // 64, H=H, nt=nt, mg_nt=magic(nt), mg_H=magic(H), nblk=nblk, c=int(c.view(np.uint32)), lds=0, bid=wg_id, gstride=grid)
+                L=L, nkv=L // 64, H=H, nt=nt, mg_nt=magic(nt), mg_H=magic(H), nblk=nblk, lds=0, bid=wg_id, gstride=grid)
     waves = []
     for wid in range(4):
         w = isa.Wave(wg, wid)
@@ -63,7 +65,7 @@ def run(B=1, H=8, L=512, grid=8, wg_id=0, mode="late", seed=0, spike=False, prog
         q = bits_f32(qk[rows, h * d:(h + 1) * d]).astype(np.float64)
         k = bits_f32(qk[b * L:(b + 1) * L, H * d + h * d:H * d + (h + 1) * d]).astype(np.float64)
         v = bits_f32(qkv[b * L:(b + 1) * L, 2 * H * d + h * d:2 * H * d + (h + 1) * d]).astype(np.float64)
-        s = (q @ k.T) * float(c)
+        s = q @ k.T                  # base-2 exponents: q is pre-scaled
         mrow = s.max(1, keepdims=True)
         p = np.exp2(s - mrow)
         l = p.sum(1, keepdims=True)

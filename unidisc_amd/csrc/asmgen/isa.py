@@ -138,6 +138,8 @@ class Wave:
             if x.kind in "va":
                 return self.rf(x)[0]
             return np.uint32(self.sget(x))
+        if isinstance(x, float):
+            return np.float32(x).view(np.uint32)
         return np.uint32(int(x) & 0xFFFFFFFF)
 
 

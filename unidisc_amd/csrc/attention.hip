@@ -593,8 +593,8 @@ void launch_fwd(const AttnArgs& a, hipStream_t s) {
   auto kern = attn_fwd_kernel<D, SID, TR>;
   static bool once = false;
   if (!once) { set_lds(kern, lds); once = true; }
-  // head dim 128, no mask, L % 256 == 0 (the headline shape): the one-wave-per-SIMD, 64-queries-per-wave kernel of attention_fwd64.hip
-  if (D == 128 && !SID && TR && udm_launch_attn_fwd64(&a, s)) return;
+  // head dim 128, no mask, L % 256 == 0, q pre-scaled (the headline path): the one-wave-per-SIMD, 64-queries-per-wave kernel of attention_fwd64.hip
+  if (D == 128 && !SID && TR && a.q_prescaled && udm_launch_attn_fwd64(&a, s)) return;
   if (D == 128 && !SID && TR) {   // UDM_ATTN_ABL=1|2: timing-only ablations of the forward kernel (scripts/bench_attn.py)
     static const int abl = [] { const char* e = getenv("UDM_ATTN_ABL"); return e ? atoi(e) : 0; }();
     if (abl == 1) { auto k1 = attn_fwd_kernel<128, false, true, 1>; set_lds(k1, lds); hipLaunchKernelGGL(k1, grid, dim3(256), lds, s, a); return; }
@@ -661,8 +661,9 @@ extern "C" int udm_attention_doc_ranges(const int64_t* sample_ids, int64_t B, in
 }
 
 extern "C" int udm_attention_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const int64_t* sample_ids, const int32_t* doc_ranges, int64_t B, int64_t H, int64_t L,
-                                 int64_t D, int64_t q_stride, int64_t k_stride, int64_t v_stride, int64_t o_stride, hipStream_t stream) {
+                                 int64_t D, int64_t q_stride, int64_t k_stride, int64_t v_stride, int64_t o_stride, int64_t flags, hipStream_t stream) {
   UDM_CHECK_ARG(q && k && v && o && lse, "udm_attention_fwd: null pointer");
+  UDM_CHECK_ARG((flags & ~(int64_t)UDM_ATTN_Q_PRESCALED) == 0, "udm_attention_fwd: unknown flags %ld", (long)flags);
   if (int rc = check_common("udm_attention_fwd", B, H, L, D, q_stride, k_stride, v_stride)) return rc;
   UDM_CHECK_ARG(o_stride % 4 == 0, "udm_attention_fwd: o_stride must be a multiple of 4");
   UDM_CHECK_ARG(sample_ids || !doc_ranges, "udm_attention_fwd: doc_ranges without sample_ids");
@@ -674,6 +675,7 @@ extern "C" int udm_attention_fwd(const void* q, const void* k, const void* v, vo
   a.B = (int)B; a.H = (int)H; a.L = (int)L;
   a.scale = 1.0f / sqrtf((float)D);
   a.scale_log2 = a.scale * 1.4426950408889634f;
+  if (flags & UDM_ATTN_Q_PRESCALED) { a.q_prescaled = 1; a.scale_log2 = 1.0f; }   // q already carries log2(e) / sqrt(D): the scores ARE the base-2 exponents
   ATTN_DISPATCH(launch_fwd, a, D, sample_ids != nullptr, g_use_tr, stream);
   UDM_CHECK_LAUNCH("udm_attention_fwd");
   return 0;
@@ -682,8 +684,9 @@ extern "C" int udm_attention_fwd(const void* q, const void* k, const void* v, vo
 extern "C" int udm_attention_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse, float* delta, void* dq, void* dk,
                                  void* dv, const int64_t* sample_ids, const int32_t* doc_ranges, int64_t B, int64_t H, int64_t L, int64_t D, int64_t q_stride, int64_t k_stride,
                                  int64_t v_stride, int64_t o_stride, int64_t do_stride, int64_t dq_stride, int64_t dk_stride, int64_t dv_stride,
-                                 hipStream_t stream) {
+                                 int64_t flags, hipStream_t stream) {
   UDM_CHECK_ARG(q && k && v && o && dout && lse && delta && dq && dk && dv, "udm_attention_bwd: null pointer");
+  UDM_CHECK_ARG((flags & ~(int64_t)UDM_ATTN_Q_PRESCALED) == 0, "udm_attention_bwd: unknown flags %ld", (long)flags);
   if (int rc = check_common("udm_attention_bwd", B, H, L, D, q_stride, k_stride, v_stride)) return rc;
   UDM_CHECK_ARG(o_stride % 8 == 0 && do_stride % 8 == 0 && dq_stride % 4 == 0 && dk_stride % 4 == 0 && dv_stride % 4 == 0, "udm_attention_bwd: bad strides");
   UDM_CHECK_ARG(sample_ids || !doc_ranges, "udm_attention_bwd: doc_ranges without sample_ids");
@@ -697,6 +700,9 @@ extern "C" int udm_attention_bwd(const void* q, const void* k, const void* v, co
   a.B = (int)B; a.H = (int)H; a.L = (int)L;
   a.scale = 1.0f / sqrtf((float)D);
   a.scale_log2 = a.scale * 1.4426950408889634f;
+  // q~ = q log2(e) / sqrt(D): scores are base-2 exponents as they come; dq~ = ln2 dS K and dk = ln2 dS^T q~ (dS wrt the natural-log scores): the factor
+  // the kernels put on dQ / dK is ln 2 instead of 1 / sqrt(D)
+  if (flags & UDM_ATTN_Q_PRESCALED) { a.q_prescaled = 1; a.scale_log2 = 1.0f; a.scale = 0.6931471805599453f; }
   static const bool env_once = [] { if (const char* e = getenv("UDM_DKV_WS")) g_dkv_ws = atoi(e); return true; }();
   (void)env_once;
   // (delta is computed and stored by the dQ kernel, which launch_bwd runs first)

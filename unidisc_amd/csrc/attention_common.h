@@ -76,6 +76,7 @@ struct AttnArgs {
   float scale;          // 1 / sqrt(D)
   unsigned long long* timeline;   // diagnostics (experiments library): cycle stamps of a few blocks, or null
   int exp;                        // experiment bits (udm_exp_flags), 0 in production
+  int q_prescaled;                // UDM_ATTN_Q_PRESCALED: q carries log2(e) / sqrt(D) (scale_log2 = 1; the backward's `scale` = ln 2)
 };
 
 // Attention mask codes.  `sample_ids` holds one int64 per position:  bits 0-31 = sample id (signed; < 0 = padding), bits 32-39 = the KEY classes this

@@ -1,4 +1,5 @@
-// Attention forward at head dim 128 without a mask, L % 256 == 0: ONE wave per SIMD, 64 queries per wave - the whole workgroup program is the
+// Attention forward at head dim 128 without a mask, L % 256 == 0, q pre-scaled by log2(e) / sqrt(D) (UDM_ATTN_Q_PRESCALED): ONE wave per SIMD, 64 queries
+// per wave, persistent workgroups - the whole workgroup program is the
 // hand-scheduled instruction stream that asmgen/attn_fwd64.py generates (registers, LDS layout, schedule: see that file; it is linted for
 // hazards and executed on a CPU emulator by tests/test_asmgen.py before it ships).  This file only computes the block's scalars and launches.
 // Replaces flash_attn_qkvpacked_func (reference models/dit.py:843) on the headline path; attention.hip keeps every other shape.
@@ -13,12 +14,12 @@ template <int ABLV>
 __global__ __launch_bounds__(256) void attn_fwd64_kernel(AttnArgs a, uint32_t nt, uint32_t mg_nt, uint32_t mg_h, uint32_t nblk) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const uint32_t qstr = (uint32_t)(a.q_stride * 2), kstr = (uint32_t)(a.k_stride * 2), vstr = (uint32_t)(a.v_stride * 2), ostr = (uint32_t)(a.out_stride * 2);
-  const uint32_t L = (uint32_t)a.L, nkv = (uint32_t)(a.L / 64), H = (uint32_t)a.H, c = __float_as_uint(a.scale_log2);
+  const uint32_t L = (uint32_t)a.L, nkv = (uint32_t)(a.L / 64), H = (uint32_t)a.H;
   const uint32_t lds = (uint32_t)(size_t)(UDM_LDS char*)smem;
   const uint32_t bid = blockIdx.x, gstride = gridDim.x, tid = threadIdx.x;
 #define UDM_FWD64_RUN(TEXT)                                                                                                                                  \
   asm volatile(TEXT : : "s"(a.q), "s"(a.k), "s"(a.v), "s"(a.out), "s"(a.lse), "s"(qstr), "s"(kstr), "s"(vstr), "s"(ostr), "s"(L), "s"(nkv), "s"(H), "s"(nt), \
-               "s"(mg_nt), "s"(mg_h), "s"(nblk), "s"(c), "s"(lds), "s"(bid), "s"(gstride), "v"(tid), "s"(a.timeline)                                       \
+               "s"(mg_nt), "s"(mg_h), "s"(nblk), "s"(lds), "s"(bid), "s"(gstride), "v"(tid), "s"(a.timeline)                                               \
                : UDM_FWD64_CLOBBERS)
   if constexpr (ABLV == 0) UDM_FWD64_RUN(UDM_FWD64_ASM);
 #ifdef UDM_FWD64_ASM_ABL1
@@ -70,7 +71,7 @@ bool udm_launch_attn_fwd64(const void* args, hipStream_t stream) {
   a.timeline = g_timeline;
   if (g_fwd64 < 0) { const char* e = getenv("UDM_ATTN_FWD64"); g_fwd64 = e ? atoi(e) : 1; }
   // whole 256-query blocks, at least two trips of the four-tile loop, the XCD-sequential block order of attention.hip (B H a multiple of 8)
-  if (!g_fwd64 || a.L % 256 != 0 || a.L < 512 || a.out_stride % 8 != 0 || (a.B * a.H) % 8 != 0) return false;
+  if (!g_fwd64 || !a.q_prescaled || a.L % 256 != 0 || a.L < 512 || a.out_stride % 8 != 0 || (a.B * a.H) % 8 != 0) return false;
   if (a.q_stride * 2 * 256 >= (1L << 31) || a.k_stride * 2 * 80 >= (1L << 31) || a.v_stride * 2 * 80 >= (1L << 31) || a.out_stride * 2 * 256 >= (1L << 31)) return false;   // 32-bit lane offsets
   const long nt = a.L / 256, nblk = nt * a.B * a.H;
   if ((long)a.B * a.L >= (1L << 30) || nblk >= (1L << 24) || nt > 4096 || a.H > 4096 || (long)a.B * a.H * a.L >= (1L << 29)) return false;   // 32-bit row / lse indices, exact magic divisions

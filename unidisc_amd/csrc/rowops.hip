@@ -7,7 +7,6 @@
 // (bias_dropout_add_scale), :263-304 (modulate_fused), :680-682 (qk LayerNorm), models/standalone_rotary.py:14-31
 // (rotary), :1036-1043 + :1402-1411 (embedding + modality embedding), :415-449 (timestep embedding).
 #include "common.h"
-#include "fp8_common.h"
 #include <stdlib.h>
 #include "../../include/unidisc_hip.h"
 
@@ -520,8 +519,8 @@ struct QkArgs {
   const float* sin_t;
   int M, d, L, D, rope_per_sample;
   float eps;
-  uint8_t* qk8 = nullptr;     // fp8 path (udm_qknorm_rope_fwd_fp8): [M, 2d] e4m3 bytes of the rotated q | k ...
-  uint8_t* qk_e8 = nullptr;   // ... and one E8M0 scale per (row, q head | k head): [M, 2 Hp], Hp = d / D rounded up to 4
+  float q_scale = 1.f;        // the rotated q is stored as bf16(q * q_scale) - ONE rounding, where the reference rounds q and flash-attn scales the fp32 scores: the
+                              // attention kernels then find log2(e) / sqrt(D) already folded into their operand (udm_attention_fwd flag UDM_ATTN_Q_PRESCALED)
 };
 
 __device__ __forceinline__ void load4_bf16(const bf16_t* p, float (&v)[4]) {
@@ -616,13 +615,14 @@ __global__ __launch_bounds__(256) void qknorm_rope_fwd_kernel(QkArgs a) {
         for (int k = 0; k < 8; ++k) { xl[k] = lo[i][k]; xh[k] = hi[i][k]; }
       }
       float cs[8], sn[8], ol[8], oh[8];
+      const float qs = part ? 1.f : a.q_scale;
       const int pc = (r % per_head) * 8;
       load8_f32(a.cos_t + trow * half + pc, cs);
       load8_f32(a.sin_t + trow * half + pc, sn);
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
-        ol[k] = xl[k] * cs[k] - xh[k] * sn[k];
-        oh[k] = xh[k] * cs[k] + xl[k] * sn[k];
+        ol[k] = (xl[k] * cs[k] - xh[k] * sn[k]) * qs;
+        oh[k] = (xh[k] * cs[k] + xl[k] * sn[k]) * qs;
       }
       store8_bf16(a.qkr + row * 2 * a.d + part * a.d + hc, ol);
       store8_bf16(a.qkr + row * 2 * a.d + part * a.d + hc + half, oh);
@@ -640,6 +640,7 @@ struct QkBwdArgs {
   float* dgq; float* dbq; float* dgk; float* dbk;  // [d] atomics
   float* ws;           // optional [gridDim.x, 4, d] partial-sum workspace (block-per-row form)
   int M, d, L, D, rope_per_sample;
+  float q_scale = 1.f;  // the incoming dq is the gradient wrt q * q_scale (see QkArgs)
 };
 
 template <int NIT>
@@ -679,6 +680,10 @@ __global__ __launch_bounds__(256) void qknorm_rope_bwd_kernel(QkBwdArgs a) {
         float dl[8], dh[8], cs[8], sn[8];
         load8_bf16(a.dqkr + row * 2 * a.d + part * a.d + hc, dl);
         load8_bf16(a.dqkr + row * 2 * a.d + part * a.d + hc + half, dh);
+        if (part == 0) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) { dl[k] *= a.q_scale; dh[k] *= a.q_scale; }
+        }
         load8_f32(a.cos_t + trow * half + pc, cs);
         load8_f32(a.sin_t + trow * half + pc, sn);
 #pragma unroll
@@ -1419,13 +1424,14 @@ __global__ __launch_bounds__(256) void qknorm_rope_fwd_brow_kernel(QkArgs a) {
         for (int k = 0; k < 8; ++k) { xl[k] = lo[i][k]; xh[k] = hi[i][k]; }
       }
       float cs[8], sn[8], ol[8], oh[8];
+      const float qs = part ? 1.f : a.q_scale;
       const int pc = (r % per_head) * 8;
       load8_f32(a.cos_t + trow * half + pc, cs);
       load8_f32(a.sin_t + trow * half + pc, sn);
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
-        ol[k] = xl[k] * cs[k] - xh[k] * sn[k];
-        oh[k] = xh[k] * cs[k] + xl[k] * sn[k];
+        ol[k] = (xl[k] * cs[k] - xh[k] * sn[k]) * qs;
+        oh[k] = (xh[k] * cs[k] + xl[k] * sn[k]) * qs;
       }
       store8_bf16(a.qkr + row * 2 * a.d + part * a.d + hc, ol);
       store8_bf16(a.qkr + row * 2 * a.d + part * a.d + hc + half, oh);
@@ -1437,11 +1443,7 @@ __global__ __launch_bounds__(256) void qknorm_rope_fwd_brow_kernel(QkArgs a) {
 // 32 KB of LDS for the affine vectors, 5 blocks per CU hold 5 x 8 KB of loads in flight - at ~3 us of loaded memory latency that is 3.4 TB/s, what was
 // measured.  Here a thread keeps the affine values of its 16 columns in registers (they are the same for every row: no LDS at all), and every iteration
 // loads R rows before the first reduction, so the two block-wide reductions of a row are shared by R rows as well.
-// FP8 (BASELINE config E): the rotated values are additionally quantised to e4m3 with one power-of-two scale per (row, head) - the amax of a head lives in
-// the D / 16 neighbouring lanes that hold it - written as bytes (qk8) + E8M0 scales (qk_e8); `qkr` then holds the DEQUANTISED values, which is what the bf16
-// backward attention kernels must see to differentiate the function the fp8 forward computed.  Bit-identical to the plain kernel followed by
-// udm_attention_quantize_qk_fp8 (the bf16 rounding of the rotated value is kept in front of the quantisation).
-template <int R, bool FP8 = false>
+template <int R>
 __global__ __launch_bounds__(256) void qknorm_rope_fwd_brow_rows_kernel(QkArgs a) {
   __shared__ float sm[4 * 2 * R];
   const int tid = threadIdx.x;
@@ -1513,24 +1515,13 @@ __global__ __launch_bounds__(256) void qknorm_rope_fwd_brow_rows_kernel(QkArgs a
         for (int k = 0; k < 8; ++k) { xl[k] = lo[j][k]; xh[k] = hi[j][k]; }
       }
       float cs[8], sn[8], ol[8], oh[8];
+      const float qs = part ? 1.f : a.q_scale;
       load8_f32(a.cos_t + trow * half + pc, cs);
       load8_f32(a.sin_t + trow * half + pc, sn);
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
-        ol[k] = xl[k] * cs[k] - xh[k] * sn[k];
-        oh[k] = xh[k] * cs[k] + xl[k] * sn[k];
-      }
-      if (FP8) {
-        float amax = 0.f;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) { ol[k] = rbf(ol[k]); oh[k] = rbf(oh[k]); amax = fmaxf(amax, fmaxf(fabsf(ol[k]), fabsf(oh[k]))); }
-        for (int o = per_head >> 1; o >= 1; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
-        const int e8 = udm::e8m0_for_amax(amax);
-        const uint2 l8 = udm::quant8_e4m3(ol, e8), h8 = udm::quant8_e4m3(oh, e8);
-        uint8_t* q8 = a.qk8 + row * 2 * a.d + part * a.d + hc;
-        *reinterpret_cast<uint2*>(q8) = l8;
-        *reinterpret_cast<uint2*>(q8 + half) = h8;
-        if (r % per_head == 0) { const int Hp = (a.d / a.D + 3) & ~3; a.qk_e8[row * 2 * Hp + part * Hp + r / per_head] = (uint8_t)e8; }
+        ol[k] = (xl[k] * cs[k] - xh[k] * sn[k]) * qs;
+        oh[k] = (xh[k] * cs[k] + xl[k] * sn[k]) * qs;
       }
       store8_bf16(a.qkr + row * 2 * a.d + part * a.d + hc, ol);
       store8_bf16(a.qkr + row * 2 * a.d + part * a.d + hc + half, oh);
@@ -1576,6 +1567,10 @@ __global__ __launch_bounds__(256) void qknorm_rope_bwd_brow_kernel(QkBwdArgs a) 
         float dl[8], dh[8], cs[8], sn[8];
         load8_bf16(a.dqkr + row * 2 * a.d + part * a.d + hc, dl);
         load8_bf16(a.dqkr + row * 2 * a.d + part * a.d + hc + half, dh);
+        if (part == 0) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) { dl[k] *= a.q_scale; dh[k] *= a.q_scale; }
+        }
         load8_f32(a.cos_t + trow * half + pc, cs);
         load8_f32(a.sin_t + trow * half + pc, sn);
 #pragma unroll
@@ -1821,35 +1816,13 @@ extern "C" int udm_norm_residual_bwd(const void* dy, const float* x, const float
   return 0;
 }
 
-extern "C" int udm_attention_quantize_qk_fp8(void* qkr, void* qk8, uint8_t* qk_e8, int64_t M, int64_t d, int64_t D, hipStream_t stream);   // attention_fp8.hip
-
-static int qknorm_rope_fwd_impl(const void* qkv, void* qkr, const float* gq, const float* bq, const float* gk, const float* bk, float* stats,
-                                const float* cos_t, const float* sin_t, int rope_per_sample, int64_t M, int64_t d, int64_t L, int64_t D, float eps,
-                                void* qk8, uint8_t* qk_e8, hipStream_t stream);
-
 extern "C" int udm_qknorm_rope_fwd(const void* qkv, void* qkr, const float* gq, const float* bq, const float* gk, const float* bk, float* stats,
                                    const float* cos_t, const float* sin_t, int rope_per_sample, int64_t M, int64_t d, int64_t L, int64_t D, float eps,
-                                   hipStream_t stream) {
-  return qknorm_rope_fwd_impl(qkv, qkr, gq, bq, gk, bk, stats, cos_t, sin_t, rope_per_sample, M, d, L, D, eps, nullptr, nullptr, stream);
-}
-
-// fp8 attention path (BASELINE config E): as udm_qknorm_rope_fwd, plus qk8 [M, 2d] e4m3 bytes and qk_e8 [M, 2 Hp] E8M0 scales (Hp = d / D rounded up to 4) of the rotated q | k; `qkr`
-// receives the dequantised values.  Fused into the row kernel at d = 2048; other widths run the plain kernel followed by udm_attention_quantize_qk_fp8.
-extern "C" int udm_qknorm_rope_fwd_fp8(const void* qkv, void* qkr, void* qk8, uint8_t* qk_e8, const float* gq, const float* bq, const float* gk, const float* bk,
-                                       float* stats, const float* cos_t, const float* sin_t, int rope_per_sample, int64_t M, int64_t d, int64_t L, int64_t D,
-                                       float eps, hipStream_t stream) {
-  UDM_CHECK_ARG(qk8 && qk_e8, "udm_qknorm_rope_fwd_fp8: null pointer");
-  UDM_CHECK_ARG(D == 64 || D == 128, "udm_qknorm_rope_fwd_fp8: head_dim 64 or 128");
-  return qknorm_rope_fwd_impl(qkv, qkr, gq, bq, gk, bk, stats, cos_t, sin_t, rope_per_sample, M, d, L, D, eps, qk8, qk_e8, stream);
-}
-
-static int qknorm_rope_fwd_impl(const void* qkv, void* qkr, const float* gq, const float* bq, const float* gk, const float* bk, float* stats,
-                                const float* cos_t, const float* sin_t, int rope_per_sample, int64_t M, int64_t d, int64_t L, int64_t D, float eps,
-                                void* qk8, uint8_t* qk_e8, hipStream_t stream) {
+                                   float q_scale, hipStream_t stream) {
   UDM_CHECK_ARG(qkv && qkr && cos_t && sin_t, "udm_qknorm_rope_fwd: null pointer");
   UDM_CHECK_ARG(M > 0 && d > 0 && D > 0 && d % D == 0 && D % 16 == 0, "udm_qknorm_rope_fwd: bad shape d=%ld D=%ld", (long)d, (long)D);
   UDM_CHECK_ARG(!gq || (bq && gk && bk && stats), "udm_qknorm_rope_fwd: qk-norm needs all four affine vectors and stats");
-  QkArgs a{(const bf16_t*)qkv, (bf16_t*)qkr, gq, bq, gk, bk, stats, cos_t, sin_t, (int)M, (int)d, (int)L, (int)D, rope_per_sample, eps};
+  QkArgs a{(const bf16_t*)qkv, (bf16_t*)qkr, gq, bq, gk, bk, stats, cos_t, sin_t, (int)M, (int)d, (int)L, (int)D, rope_per_sample, eps, q_scale};
   UDM_CHECK_ARG(D % 16 == 0 && d % 16 == 0, "udm_qknorm_rope_fwd: head_dim and hidden size must be multiples of 16");
   const int nit = (int)((2 * (d / 16) + 63) / 64);
   UDM_CHECK_ARG(nit <= 8, "udm_qknorm_rope_fwd: hidden size too large");
@@ -1858,10 +1831,7 @@ static int qknorm_rope_fwd_impl(const void* qkv, void* qkr, const float* gq, con
   if (d == 2048) {   // two rows per block iteration, 1024 blocks (in the step: 1.08-1.10 ms against 1.22-1.24 for one row per iteration; 3 rows 1.18, 4 rows 1.41)
     const long groups = (M + 1) / 2;
     const int g = (int)(groups < 1024 ? groups : 1024);
-    if (qk8) {
-      a.qk8 = (uint8_t*)qk8; a.qk_e8 = qk_e8;
-      hipLaunchKernelGGL((qknorm_rope_fwd_brow_rows_kernel<2, true>), dim3(g), dim3(256), 0, stream, a);
-    } else hipLaunchKernelGGL((qknorm_rope_fwd_brow_rows_kernel<2>), dim3(g), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL((qknorm_rope_fwd_brow_rows_kernel<2>), dim3(g), dim3(256), 0, stream, a);
     UDM_CHECK_LAUNCH("udm_qknorm_rope_fwd");
     return 0;
   }
@@ -1870,7 +1840,7 @@ static int qknorm_rope_fwd_impl(const void* qkv, void* qkr, const float* gq, con
     if (d <= 2048) hipLaunchKernelGGL((qknorm_rope_fwd_brow_kernel<1>), dim3(g), dim3(256), lds, stream, a);
     else hipLaunchKernelGGL((qknorm_rope_fwd_brow_kernel<2>), dim3(g), dim3(256), lds, stream, a);
     UDM_CHECK_LAUNCH("udm_qknorm_rope_fwd");
-    return qk8 ? udm_attention_quantize_qk_fp8(qkr, qk8, qk_e8, M, d, D, stream) : 0;
+    return 0;
   }
   const int grid = min(grid_rows(M), 1024);
   switch (nch) {
@@ -1881,17 +1851,17 @@ static int qknorm_rope_fwd_impl(const void* qkv, void* qkr, const float* gq, con
     default: hipLaunchKernelGGL((qknorm_rope_fwd_kernel<8>), dim3(grid), dim3(256), lds, stream, a); break;
   }
   UDM_CHECK_LAUNCH("udm_qknorm_rope_fwd");
-  return qk8 ? udm_attention_quantize_qk_fp8(qkr, qk8, qk_e8, M, d, D, stream) : 0;
+  return 0;
 }
 
 extern "C" int udm_qknorm_rope_bwd(const void* dqkr, const void* qkv, void* dqkv, const float* gq, const float* gk, const float* stats, const float* cos_t,
                                    const float* sin_t, int rope_per_sample, float* dgq, float* dbq, float* dgk, float* dbk, int64_t M, int64_t d, int64_t L,
-                                   int64_t D, float* ws, int64_t ws_elems, hipStream_t stream) {
+                                   int64_t D, float q_scale, float* ws, int64_t ws_elems, hipStream_t stream) {
   UDM_CHECK_ARG(dqkr && qkv && dqkv && cos_t && sin_t, "udm_qknorm_rope_bwd: null pointer");
   UDM_CHECK_ARG(M > 0 && d > 0 && D > 0 && d % D == 0 && D % 8 == 0, "udm_qknorm_rope_bwd: bad shape");
   UDM_CHECK_ARG(!gq || (gk && stats && dgq && dbq && dgk && dbk), "udm_qknorm_rope_bwd: qk-norm needs gk, stats and the four gradient vectors");
   QkBwdArgs a{(const bf16_t*)dqkr, (const bf16_t*)qkv, (bf16_t*)dqkv, gq, gk, stats, cos_t, sin_t, dgq, dbq, dgk, dbk, nullptr, (int)M, (int)d, (int)L, (int)D,
-              rope_per_sample};
+              rope_per_sample, q_scale};
   UDM_CHECK_ARG(D % 16 == 0 && d % 16 == 0, "udm_qknorm_rope_bwd: head_dim and hidden size must be multiples of 16");
   const int nit = (int)((2 * (d / 16) + 63) / 64);
   UDM_CHECK_ARG(nit <= 8, "udm_qknorm_rope_bwd: hidden size too large");

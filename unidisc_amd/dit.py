@@ -236,9 +236,10 @@ class DIT(nn.Module, _HubMixin):
         self.txt_length, self.img_length, self.total_length = cfg_get(m, "txt_length"), cfg_get(m, "img_length"), cfg_get(m, "length")
         self.multimodal_batches = bool(cfg_get(tr, "multimodal_batches", False))
         self.rope_2d = bool(cfg_get(m, "rope_2d", False))
-        # BASELINE config E: attention FORWARD through the fp8 (e4m3) block-scaled MFMA kernel (no reference counterpart).  The backward
-        # stays bf16 and runs on the dequantised q, k the forward saw, with the forward's log-sum-exp (tolerances in tests/test_gpu_e2e.py, test_gpu_fullsize.py).
-        self.fp8_attention = bool(cfg_get(m, "fp8_attention", False))
+        # The softmax scale lives in the stored q: the qk-norm + rope kernel writes bf16(q log2(e) / sqrt(D)) - one rounding, where the reference rounds q and
+        # flash-attn scales the fp32 scores - so the attention kernels' scores are base-2 exponents as they leave the matrix pipe (no multiply per score in
+        # the forward or in either backward kernel); the rope backward multiplies the incoming dq by the same factor.
+        self.attn_q_scale = K.attention_q_scale(self.head_dim)
         # model.head_chunk_rows (extension key, 0 = off): fused vocabulary head + SUBS cross-entropy that never materialises [rows, V] logits - the head
         # runs on chunks of this many rows (forward: logits chunk -> log p, dropped; backward: the chunk's logits are recomputed, d logits formed in
         # place and consumed by the dgrad / wgrad).  Trades one extra head GEMM per step for rows * V * 2 bytes of peak memory (SURVEY K11 + K12).
@@ -707,15 +708,8 @@ class DIT(nn.Module, _HubMixin):
             at = blk.attention
             qn_kw = dict(gq=at.q_norm.weight.detach() if self.qk_norm else None, bq=at.q_norm.bias.detach() if self.qk_norm else None,
                          gk=at.k_norm.weight.detach() if self.qk_norm else None, bk=at.k_norm.bias.detach() if self.qk_norm else None)
-            if self.fp8_attention:
-                # config E: the qk-norm + rope kernel also emits the e4m3 bytes + per-(row, head) power-of-two scales and leaves the DEQUANTISED q, k in qkr.
-                # Backward rule: the bf16 backward kernels read that qkr (their recomputed scores are bit-identical to the fp8 forward's: products of e4m3
-                # values are exact in fp32), the forward's log-sum-exp and v; the rounding itself is a straight-through estimator.
-                qkr, qstats, (qk8, qk_e8) = K.qknorm_rope_fwd(qkv, cos, sin, L, D, fp8=True, **qn_kw)
-                o, lse = K.attention_fwd_fp8(qk8, qk_e8, qkv, B, L, H, D, sid, S["doc_ranges"])
-            else:
-                qkr, qstats = K.qknorm_rope_fwd(qkv, cos, sin, L, D, **qn_kw)
-                o, lse = K.attention_fwd(qkr, qkv, B, L, H, D, sid, S["doc_ranges"])
+            qkr, qstats = K.qknorm_rope_fwd(qkv, cos, sin, L, D, q_scale=self.attn_q_scale, **qn_kw)
+            o, lse = K.attention_fwd(qkr, qkv, B, L, H, D, sid, S["doc_ranges"], q_prescaled=True)
             rows_c = last_rows
             if not recompute and i + 1 == self.n_blocks and head_plan is not None and mode == "logp" and self.compact_last_block and not tc:
                 head_rows_c = self._masked_rows(head_plan, M)   # (the count was queued at the top of this forward: the host does not wait for the device here)
@@ -1176,12 +1170,12 @@ class DIT(nn.Module, _HubMixin):
                     self._wgrad(da, R["o"], lo, G)
             dqkr = torch.empty((M, 2 * d), dtype=BF16, device=dev)
             dqkv = torch.empty((M, 3 * d), dtype=BF16, device=dev)
-            K.attention_bwd(R["qkr"], R["qkv"], R["o"], do, R["lse"], dqkr, dqkv, B, L, H, D, S["sid"], S["doc_ranges"])
+            K.attention_bwd(R["qkr"], R["qkv"], R["o"], do, R["lse"], dqkr, dqkv, B, L, H, D, S["sid"], S["doc_ranges"], q_prescaled=True)
             qn = self.qk_norm
             K.qknorm_rope_bwd(dqkr, R["qkv"], dqkv, S["cos"], S["sin"], L, D, gq=at.q_norm.weight.detach() if qn else None,
                               gk=at.k_norm.weight.detach() if qn else None, stats=R["qstats"], dgq=G[id(at.q_norm.weight)] if qn else None,
                               dbq=G[id(at.q_norm.bias)] if qn else None, dgk=G[id(at.k_norm.weight)] if qn else None,
-                              dbk=G[id(at.k_norm.bias)] if qn else None)
+                              dbk=G[id(at.k_norm.bias)] if qn else None, q_scale=self.attn_q_scale)
             dh1 = lq.dgrad(dqkv, dqkv.shape[0], S["dgrad_form"].get(f"{i}.qkv"))
             if multi is not None:
                 multi.append((dqkv, R["h1"], lq))

@@ -9,6 +9,8 @@ from typing import Optional
 
 import os
 
+import math
+
 import torch
 
 from . import _lib
@@ -629,32 +631,31 @@ def norm_residual_bwd(dy, x, rstd, mean, w, norm_type, L, dx, dw, branch, *, acc
 
 
 # ------------------------------------------------------------------------------------------------ attention
-def qknorm_rope_fwd(qkv, cos, sin, L, D, *, gq=None, bq=None, gk=None, bk=None, fp8=False):
-    """qkv bf16 [M, 3d] -> qkr bf16 [M, 2d] (normalised + rotated q | k), LayerNorm statistics.  fp8=True (BASELINE config E): additionally the e4m3 bytes
-    qk8 [M, 2d] and the per-(row, head) E8M0 scales qk_e8 [M, 2 Hp] (Hp = H rounded up to 4) the fp8 attention forward reads; qkr then holds the dequantised values."""
+def attention_q_scale(D):
+    """log2(e) / sqrt(D): folded into the stored q by qknorm_rope_fwd(q_scale=...) on the engine's path, so that the attention kernels' scores are the base-2
+    exponents as they leave the matrix pipe (attention_fwd / attention_bwd with q_prescaled=True)."""
+    return 1.4426950408889634 / math.sqrt(D)
+
+
+def qknorm_rope_fwd(qkv, cos, sin, L, D, *, gq=None, bq=None, gk=None, bk=None, q_scale=1.0):
+    """qkv bf16 [M, 3d] -> qkr bf16 [M, 2d] (normalised + rotated q | k), LayerNorm statistics.  q_scale != 1: the q half holds bf16(q * q_scale) (one rounding)."""
     M, d3 = qkv.shape
     d = d3 // 3
     qkr = torch.empty((M, 2 * d), dtype=BF16, device=qkv.device)
     stats = torch.empty((M, 4), dtype=F32, device=qkv.device) if gq is not None else None
     per_sample = 1 if cos.dim() == 3 else 0
-    if fp8:
-        qk8 = torch.empty((M, 2 * d), dtype=torch.uint8, device=qkv.device)
-        qk_e8 = torch.full((M, 2 * _hp(d // D)), 127, dtype=torch.uint8, device=qkv.device)
-        _lib.call("udm_qknorm_rope_fwd_fp8", _p(qkv), _p(qkr), _p(qk8), _p(qk_e8), _p(gq), _p(bq), _p(gk), _p(bk), _p(stats), _p(cos), _p(sin), per_sample, M, d, L, D,
-                  1e-5, _s())
-        return qkr, stats, (qk8, qk_e8)
-    _lib.call("udm_qknorm_rope_fwd", _p(qkv), _p(qkr), _p(gq), _p(bq), _p(gk), _p(bk), _p(stats), _p(cos), _p(sin), per_sample, M, d, L, D, 1e-5, _s())
+    _lib.call("udm_qknorm_rope_fwd", _p(qkv), _p(qkr), _p(gq), _p(bq), _p(gk), _p(bk), _p(stats), _p(cos), _p(sin), per_sample, M, d, L, D, 1e-5, float(q_scale), _s())
     return qkr, stats
 
 
-def qknorm_rope_bwd(dqkr, qkv, dqkv, cos, sin, L, D, *, gq=None, gk=None, stats=None, dgq=None, dbq=None, dgk=None, dbk=None):
+def qknorm_rope_bwd(dqkr, qkv, dqkv, cos, sin, L, D, *, gq=None, gk=None, stats=None, dgq=None, dbq=None, dgk=None, dbk=None, q_scale=1.0):
     M, d3 = qkv.shape
     d = d3 // 3
     per_sample = 1 if cos.dim() == 3 else 0
     contig = gq is not None and dbq.data_ptr() == dgq.data_ptr() + 4 * d and dgk.data_ptr() == dgq.data_ptr() + 8 * d and dbk.data_ptr() == dgq.data_ptr() + 12 * d
     ws = _scratch(4096 * d, qkv.device) if contig else None
     _lib.call("udm_qknorm_rope_bwd", _p(dqkr), _p(qkv), _p(dqkv), _p(gq), _p(gk), _p(stats), _p(cos), _p(sin), per_sample, _p(dgq), _p(dbq), _p(dgk),
-              _p(dbk), M, d, L, D, _p(ws), ws.numel() if ws is not None else 0, _s())
+              _p(dbk), M, d, L, D, float(q_scale), _p(ws), ws.numel() if ws is not None else 0, _s())
 
 
 def modality_mask_codes(txt_drop, img_drop, txt_length, L):
@@ -681,89 +682,42 @@ def attention_doc_ranges(sample_ids):
     return r
 
 
-def attention_fwd(qkr, qkv, B, L, H, D, sample_ids=None, doc_ranges=None):
-    """q, k from qkr [M,2d] (normalised+rotated), v from qkv [M,3d] columns [2d,3d)."""
+def attention_fwd(qkr, qkv, B, L, H, D, sample_ids=None, doc_ranges=None, q_prescaled=False):
+    """q, k from qkr [M,2d] (normalised+rotated), v from qkv [M,3d] columns [2d,3d).  q_prescaled: q holds q * attention_q_scale(D)."""
     d = H * D
     M = B * L
     o = torch.empty((M, d), dtype=BF16, device=qkr.device)
     lse = torch.empty((B, H, L), dtype=F32, device=qkr.device)
     q_ptr, k_ptr, v_ptr = qkr.data_ptr(), qkr.data_ptr() + 2 * d, qkv.data_ptr() + 4 * d
-    _lib.call("udm_attention_fwd", q_ptr, k_ptr, v_ptr, _p(o), _p(lse), _p(sample_ids), _p(doc_ranges), B, H, L, D, 2 * d, 2 * d, 3 * d, d, _s())
+    _lib.call("udm_attention_fwd", q_ptr, k_ptr, v_ptr, _p(o), _p(lse), _p(sample_ids), _p(doc_ranges), B, H, L, D, 2 * d, 2 * d, 3 * d, d, 1 if q_prescaled else 0, _s())
     return o, lse
 
 
-def _hp(H):
-    return (H + 3) // 4 * 4
-
-
-def attention_quantize_qk_fp8(qkr, D):
-    """In place on qkr bf16 [M, 2d] (normalised + rotated q | k): e4m3 bytes qk8 [M, 2d] + per-(row, head) E8M0 scales qk_e8 [M, 2 Hp] (q heads at [0, H), k heads at [Hp, Hp + H)); qkr <- dequantised values.
-    (The generic form of what udm_qknorm_rope_fwd_fp8 does inside the row kernel at d = 2048.)"""
-    M, d2 = qkr.shape
-    d = d2 // 2
-    qk8 = torch.empty((M, d2), dtype=torch.uint8, device=qkr.device)
-    qk_e8 = torch.full((M, 2 * _hp(d // D)), 127, dtype=torch.uint8, device=qkr.device)
-    _lib.call("udm_attention_quantize_qk_fp8", _p(qkr), _p(qk8), _p(qk_e8), M, d, D, _s())
-    return qk8, qk_e8
-
-
-def attention_quantize_v_fp8(v_ptr, v_stride, B, L, H, D, device):
-    """v (bf16, row stride v_stride elements) -> v8t [B*H, ceil(L/64), D, 64] e4m3 bytes in the forward kernel's operand order + one E8M0 scale per tile."""
-    nt = (L + 63) // 64
-    v8t = torch.empty((B * H, nt, D, 64), dtype=torch.uint8, device=device)
-    v_e8 = torch.empty((B * H, nt), dtype=torch.int32, device=device)
-    _lib.call("udm_attention_quantize_v_fp8", v_ptr, v_stride, _p(v8t), _p(v_e8), B, H, L, D, _s())
-    return v8t, v_e8
-
-
-def attention_fwd_fp8(qk8, qk_e8, qkv, B, L, H, D, sample_ids=None, doc_ranges=None):
-    """fp8 (e4m3) forward through the block-scaled 32x32x64 MFMA (config E; no reference counterpart): q, k bytes + scales from qknorm_rope_fwd(fp8=True),
-    v quantised here from qkv [M, 3d] columns [2d, 3d).  Returns o bf16 [M, d], lse."""
-    d = H * D
-    v8t, v_e8 = attention_quantize_v_fp8(qkv.data_ptr() + 4 * d, 3 * d, B, L, H, D, qkv.device)
-    o = torch.empty((B * L, d), dtype=BF16, device=qkv.device)
-    lse = torch.empty((B, H, L), dtype=F32, device=qkv.device)
-    _lib.call("udm_attention_fwd_fp8", _p(qk8), _p(qk_e8), _p(v8t), _p(v_e8), _p(o), _p(lse), _p(sample_ids), _p(doc_ranges), B, H, L, D, d, _s())
-    return o, lse
-
-
-def attention_fwd_fp8_generic(q, k, v, B, L, H, D, sample_ids=None, doc_ranges=None, return_quantized=False):
-    """q, k, v: separate contiguous bf16 [B*L, H*D] (unit tests).  With return_quantized: also (qkr_dequantised, qk8, qk_e8, v8t, v_e8)."""
-    d = H * D
-    qkr = torch.cat([q, k], 1).contiguous()
-    qk8, qk_e8 = attention_quantize_qk_fp8(qkr, D)
-    v8t, v_e8 = attention_quantize_v_fp8(v.data_ptr(), d, B, L, H, D, q.device)
-    o = torch.empty((B * L, d), dtype=BF16, device=q.device)
-    lse = torch.empty((B, H, L), dtype=F32, device=q.device)
-    _lib.call("udm_attention_fwd_fp8", _p(qk8), _p(qk_e8), _p(v8t), _p(v_e8), _p(o), _p(lse), _p(sample_ids), _p(doc_ranges), B, H, L, D, d, _s())
-    return (o, lse, (qkr, qk8, qk_e8, v8t, v_e8)) if return_quantized else (o, lse)
-
-
-def attention_bwd(qkr, qkv, o, do, lse, dqkr, dqkv, B, L, H, D, sample_ids=None, doc_ranges=None):
-    """Writes dq|dk (wrt rotated q,k) into dqkr [M,2d] and dv into dqkv[:, 2d:3d]."""
+def attention_bwd(qkr, qkv, o, do, lse, dqkr, dqkv, B, L, H, D, sample_ids=None, doc_ranges=None, q_prescaled=False):
+    """Writes dq|dk (wrt the stored rotated q, k) into dqkr [M,2d] and dv into dqkv[:, 2d:3d]."""
     d = H * D
     delta = torch.empty((B, H, L), dtype=F32, device=qkr.device)
     q_ptr, k_ptr, v_ptr = qkr.data_ptr(), qkr.data_ptr() + 2 * d, qkv.data_ptr() + 4 * d
     dq_ptr, dk_ptr, dv_ptr = dqkr.data_ptr(), dqkr.data_ptr() + 2 * d, dqkv.data_ptr() + 4 * d
     _lib.call("udm_attention_bwd", q_ptr, k_ptr, v_ptr, _p(o), _p(do), _p(lse), _p(delta), dq_ptr, dk_ptr, dv_ptr, _p(sample_ids), _p(doc_ranges), B, H, L, D, 2 * d,
-              2 * d, 3 * d, d, do.stride(0), 2 * d, 2 * d, 3 * d, _s())
+              2 * d, 3 * d, d, do.stride(0), 2 * d, 2 * d, 3 * d, 1 if q_prescaled else 0, _s())
 
 
-def attention_fwd_generic(q, k, v, B, L, H, D, sample_ids=None, doc_ranges=None):
+def attention_fwd_generic(q, k, v, B, L, H, D, sample_ids=None, doc_ranges=None, q_prescaled=False):
     """q, k, v: separate contiguous bf16 [B*L, H*D] (unit tests)."""
     d = H * D
     o = torch.empty((B * L, d), dtype=BF16, device=q.device)
     lse = torch.empty((B, H, L), dtype=F32, device=q.device)
-    _lib.call("udm_attention_fwd", _p(q), _p(k), _p(v), _p(o), _p(lse), _p(sample_ids), _p(doc_ranges), B, H, L, D, d, d, d, d, _s())
+    _lib.call("udm_attention_fwd", _p(q), _p(k), _p(v), _p(o), _p(lse), _p(sample_ids), _p(doc_ranges), B, H, L, D, d, d, d, d, 1 if q_prescaled else 0, _s())
     return o, lse
 
 
-def attention_bwd_generic(q, k, v, o, do, lse, B, L, H, D, sample_ids=None, doc_ranges=None):
+def attention_bwd_generic(q, k, v, o, do, lse, B, L, H, D, sample_ids=None, doc_ranges=None, q_prescaled=False):
     d = H * D
     dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
     delta = torch.empty((B, H, L), dtype=F32, device=q.device)
     _lib.call("udm_attention_bwd", _p(q), _p(k), _p(v), _p(o), _p(do), _p(lse), _p(delta), _p(dq), _p(dk), _p(dv), _p(sample_ids), _p(doc_ranges), B, H, L, D, d, d, d, d,
-              d, d, d, d, _s())
+              d, d, d, d, 1 if q_prescaled else 0, _s())
     return dq, dk, dv
 
 
