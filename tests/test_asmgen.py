@@ -30,7 +30,7 @@ def test_hazard_lint_is_clean(gen):
 
 
 @pytest.mark.parametrize("mode", ["late", "early"])
-@pytest.mark.parametrize("kw", [dict(B=1, H=8, L=512, grid=8, wg_id=0), dict(B=1, H=8, L=1024, grid=8, wg_id=3), dict(B=2, H=4, L=512, grid=8, wg_id=5, spike=True)],
+@pytest.mark.parametrize("kw", [dict(B=1, H=8, L=512, grid=8, wg_id=0), dict(B=1, H=8, L=1024, grid=8, wg_id=3), dict(B=2, H=4, L=512, grid=8, wg_id=1, spike=True)],
                          ids=["two_blocks", "four_blocks_three_trips", "rescale_path"])
 def test_emulated_workgroup_matches_float64_attention(gen, kw, mode):
     _, e, prog = gen

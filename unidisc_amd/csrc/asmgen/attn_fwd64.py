@@ -271,28 +271,53 @@ GROUPS = [(q, cc) for cc in range(4) for q in range(2)]   # in the order the PV 
 N_EARLY = 3                                              # groups of softmax(t+1) done in phase B(t); the rest in phase A(t+1)
 
 
-def spread(mfmas, streams, note):
-    """Merge `streams` of filler instructions into the gaps behind `mfmas`.  A stream = (instructions, first gap, last gap): its
-    instructions go out in order, evenly over gaps first..last (gap g = behind MFMA g; gap -1 = ahead of the first MFMA)."""
+CAP = 5.5          # issue budget behind one MFMA (single-issue slots of ~4 cycles under its 32; MI355X_MICROARCH.md: <= 5 hidden per gap)
+COST = {"trans": 1.5, "dma": 1.5, "label": 0.0, "comment": 0.0}
+
+
+def spread(mfmas, streams, note, cap=None):
+    """Merge `streams` of filler instructions into the gaps behind `mfmas` (gap g = behind MFMA g; gap -1 = ahead of the first MFMA).  A stream =
+    (instructions, first gap, last gap): its instructions go out in order, none before `first`, all of them by `last`.  Every gap is filled to the same
+    issue budget (an in-order wave cannot bank the slack of a thin gap for a fat one): the most urgent stream - remaining cost per remaining gap -
+    goes first; a stream past its last gap is flushed whatever the budget."""
+    cap = CAP if cap is None else cap
     n = len(mfmas)
     out = [comment(note)]
     pos = [0] * len(streams)
+    cost = lambda ins: COST.get(ins.kind, 1.0)
+    rem = [sum(cost(i) for i in ins) for ins, _, _ in streams]
     counts = []
     for g in range(-1, n):
         if g >= 0:
             out.append(mfmas[g])
-        c = 0
-        for si, (ins, g0, g1) in enumerate(streams):
-            if g < g0:
-                continue
-            want = len(ins) if g >= g1 else (len(ins) * (g - g0 + 1)) // (g1 - g0 + 1)
-            while pos[si] < want:
-                out.append(ins[pos[si]])
-                pos[si] += 1
-                c += 1
-        counts.append(c)
+        budget, c = cap, 0.0
+        while True:
+            best, bu = None, -1.0
+            for si, (ins, g0, g1) in enumerate(streams):
+                if pos[si] >= len(ins) or g < g0:
+                    continue
+                u = 1e9 if g >= g1 else rem[si] / (g1 - g + 1)
+                if u > bu:
+                    best, bu = si, u
+            if best is None:
+                break
+            nxt = streams[best][0][pos[best]]
+            if bu < 1e9 and budget - cost(nxt) < -0.25:
+                break
+            while True:    # an instruction that reads SCC (s_addc, s_cbranch_scc) stays glued to the one before it: another stream's SALU op in between
+                out.append(nxt)   # would feed it a foreign carry / condition
+                pos[best] += 1
+                rem[best] -= cost(nxt)
+                budget -= cost(nxt)
+                c += cost(nxt)
+                ins_b = streams[best][0]
+                if pos[best] < len(ins_b) and (("scc", 0) in ins_b[pos[best]].reads or ins_b[pos[best]].kind == "label"):
+                    nxt = ins_b[pos[best]]
+                else:
+                    break
+        counts.append(round(c, 1))
     for si, (ins, _, _) in enumerate(streams):
-        assert pos[si] == len(ins)
+        assert pos[si] == len(ins), (note, si, pos[si], len(ins))
     return out, counts
 
 
@@ -367,7 +392,7 @@ def _body(j, variant, tag, vm_wait):
         fin += softmax_group(cur, q, cc)
     vr = v_reads(j)
     if not last:
-        a, ca = spread(score_mfmas(nxt), [(wait_bar, 1, 1), (vr, 2, 27), (fin, -1, 30)], "phase A")
+        a, ca = spread(score_mfmas(nxt), [(wait_bar, 1, 1), (vr, 2, 28), (fin, -1, 31)], "phase A")
     else:
         a, ca = [comment("phase A (last tile: no scores)")] + fin[:16] + wait_bar + vr + fin[16:], []
     prog += a
@@ -375,9 +400,9 @@ def _body(j, variant, tag, vm_wait):
     # ---------------- phase B
     streams = []
     if variant in ("main", "tail0", "tail1"):
-        streams.append((k_reads((j + 2) % 4), 0, 17))
+        streams.append((k_reads((j + 2) % 4), -1, 20))
     dma = dma_k(j) + dma_v((j + 3) % 4)
-    streams.append((dma, 2, 14 if variant == "tail2" else 27))
+    streams.append((dma, 1, 14 if variant == "tail2" else 31))
     # the next block's Q fragments: a load instruction touches 32 rows (64 cache lines) - sixteen of them back to back stalled the issue for 3.2 k cycles
     # (timeline), so they go out one per four MFMAs over the last two PV phases.  Offsets live in two registers of the S buffer whose tile is finished.
     if variant == "tail2":
@@ -391,8 +416,8 @@ def _body(j, variant, tag, vm_wait):
         early = []
         for (q, cc) in GROUPS[:N_EARLY]:
             early += softmax_group(nxt, q, cc)
-        streams.append((soft, 3, 14))
-        streams.append((early, 16, 30))
+        streams.append((soft, 1, 14))       # (the f = 0 halves of S(t+1) were finished half a phase ago; the f = 1 maxima come 16 ops later)
+        streams.append((early, 15, 31))
     b, cb = spread(pv_mfmas(cur), streams, "phase B")
     prog += b
     if not last:

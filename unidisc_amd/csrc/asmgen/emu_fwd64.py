@@ -27,9 +27,12 @@ def run(B=1, H=8, L=512, grid=8, wg_id=0, mode="late", seed=0, spike=False, prog
     qk = bf16_bits(qk_f)
     qkv = bf16_bits(rng.standard_normal((M, 3 * H * d)))
     if spike:
-        for (b, h, key, qrow) in [(0, wg_id % H, L - 100, 70), (0, wg_id % H, 3, 300)]:
-            qk[b * L + key, H * d + h * d: H * d + (h + 1) * d] = bf16_bits(np.full(d, 6.0))
-            qk[b * L + qrow, h * d:(h + 1) * d] = bf16_bits(np.full(d, 6.0 * c))
+        # a key far above the rest in a LATE tile for query 70 (the mid-block rescale) and one in the first tile for query 300; orthogonal sign patterns, so that
+        # each query only sees its own spike
+        alt = np.where(np.arange(d) % 2 == 0, 1.0, -1.0)
+        for (b, h, key, qrow, pat) in [(0, wg_id % H, L - 100, 70, np.ones(d)), (0, wg_id % H, 3, 300, alt)]:
+            qk[b * L + key, H * d + h * d: H * d + (h + 1) * d] = bf16_bits(6.0 * pat)
+            qk[b * L + qrow, h * d:(h + 1) * d] = bf16_bits(6.0 * c * pat)
     out = np.zeros((M, H * d), np.uint16)
     lse = np.zeros((B, H, L), np.float32)
     wg = isa.Workgroup(lds_bytes=g.LDS_TOTAL, mode=mode)

@@ -698,6 +698,10 @@ def lint(prog, window=24):
     s_nop pad).  Returns a list of problem strings."""
     problems = []
     real = [ins for ins in prog if ins.kind not in ("comment", "label")]
+    # SCC is one bit every SALU compare / add / shift overwrites: a reader (s_addc, s_cbranch_scc, s_cselect) must sit directly behind its writer
+    for i, ins in enumerate(real):
+        if ("scc", 0) in ins.reads and (i == 0 or ("scc", 0) not in real[i - 1].writes):
+            problems.append(f"[{i}] {ins.text}: reads SCC but follows {real[i - 1].text if i else 'nothing'}")
     for i, ins in enumerate(real):
         if not ins.reads and not ins.writes:
             continue
