@@ -30,6 +30,10 @@ WORKLOADS = {
     # BASELINE.json configs[2]: large_scale_train + large_scale_train_high_res, data.block_size=256
     "unidisc-1.4b-l1280": dict(preset="extra_large", txt_length=256, img_length=1024, text_vocab=32001, image_vocab=16384, batch=8,
                                desc="UniDisc 1.4B non-interleaved, seq_len=1280 (256 text + 1024 image), bf16"),
+    # SURVEY §8(d) secondary workload: the same model with adaLN-Zero timestep modulation on (`time_conditioning=True`: models/dit.py:922-925, 966-967; no shipped
+    # config sets it, north_star names it).  F_tok as above: the modulation GEMMs are [B, cond_dim] x [cond_dim, 6 d] per block - not counted, like the reference's 6 N D
+    "unidisc-1.4b-l1280-adaln": dict(preset="extra_large", txt_length=256, img_length=1024, text_vocab=32001, image_vocab=16384, batch=8, time_conditioning=True,
+                                     desc="UniDisc 1.4B non-interleaved, seq_len=1280 (256 text + 1024 image), bf16, adaLN-Zero time conditioning ON"),
     # BASELINE.json configs[1]: UniDisc-S
     # BASELINE.json configs[4] with bf16 attention (the fp8 forward of rounds 2-4 never paid inside the step and was removed): large_scale_train_high_res_interleaved with model.length=4608:
     # every row packs 4 samples of 128 text + 1024 image tokens; attention stays inside a sample (document mask from sample_ids)
@@ -70,7 +74,8 @@ def build(workload, device, dropout):
     w = WORKLOADS[workload]
     large = w["preset"] == "extra_large"
     cfg = make_config(**MODEL_PRESETS[w["preset"]], txt_length=w["txt_length"], img_length=w["img_length"], norm_type="rms", qk_norm=True,
-                      sandwich_normalization=True, modality_embed=True, rope_2d=large, linear_factor=2.0 if large else 1.0, time_conditioning=False,
+                      sandwich_normalization=True, modality_embed=True, rope_2d=large, linear_factor=2.0 if large else 1.0,
+                      time_conditioning=bool(w.get("time_conditioning", False)),
                       multimodal_batches=True, force_argmax_valid_indices=True, dropout=dropout, zero_linear_init=False,
                       image_vocab_size=w["image_vocab"], mask_entire_modality=0.1, softmin_snr=5, text_loss_weight=1.0,
                       img_loss_weight=0.5 if large else None, force_full_attention_mask=True if large else None,
@@ -245,26 +250,28 @@ def cpu_baseline(workload, cfg, diff, seed):
     threads = min(cores, 64)
     torch.set_num_threads(threads)
     L = w["txt_length"] + w["img_length"]
+    nseq = 2 if "packed" in w else 1     # (one packed row alone trips the reference's own `.squeeze(-1)` on the interleaved ignore mask, which the oracle restates)
 
     def run(nb):
         case = dict(hidden_size=m.hidden_size, n_heads=m.n_heads, cond_dim=m.cond_dim, n_blocks=nb, txt_length=w["txt_length"],
                     img_length=w["img_length"], vocab_size=diff.vocab_size, text_vocab_size=diff.text_vocab_size, norm_type="rms", qk_norm=True,
-                    sandwich_normalization=True, modality_embed=True, rope_2d=m.rope_2d, linear_factor=m.linear_factor, time_conditioning=False,
-                    multimodal_batches=True, force_argmax_valid_indices=True, mask_entire_modality=0.1, softmin_snr=5, text_loss_weight=1.0,
-                    img_loss_weight=cfg.trainer.get("img_loss_weight"), force_full_attention_mask=cfg.trainer.get("force_full_attention_mask"),
+                    sandwich_normalization=True, modality_embed=True, rope_2d=m.rope_2d, linear_factor=m.linear_factor,
+                    time_conditioning=bool(w.get("time_conditioning", False)), interleaved="packed" in w,
+                    multimodal_batches=True, force_argmax_valid_indices=True, mask_entire_modality=cfg.trainer.get("mask_entire_modality", 0.1), softmin_snr=5,
+                    text_loss_weight=1.0, img_loss_weight=cfg.trainer.get("img_loss_weight"), force_full_attention_mask=cfg.trainer.get("force_full_attention_mask"),
                     force_full_attention_mask_loss_only=cfg.trainer.get("force_full_attention_mask_loss_only"))
         ocfg = O.OracleConfig.from_case(case)
         keep = lambda k: not k.startswith("blocks.") or int(k.split(".")[1]) < nb
         P = {k: v.detach().float().cpu().requires_grad_() for k, v in diff.backbone.named_parameters() if keep(k)}
         bufs = O.make_buffers(ocfg, lumina_rope_2d)
-        batch = O.update_batch(ocfg, synthetic_batch(workload, 1, seed))
+        batch = O.update_batch(ocfg, synthetic_batch(workload, nseq, seed))
         t0 = time.perf_counter()
         out = O.compute_loss(ocfg, P, bufs, batch, torch.Generator().manual_seed(seed), bf16=True)   # the reference's bf16-autocast numerics
         out.loss.backward()
         return time.perf_counter() - t0
 
     t1 = run(1)
-    what = f"oracle (torch CPU, the reference's bf16-autocast rounding points emulated) fwd+bwd of 1 sequence (B=1, L={L}, d={m.hidden_size}, V={diff.vocab_size})"
+    what = f"oracle (torch CPU, the reference's bf16-autocast rounding points emulated) fwd+bwd of {nseq} sequence(s) (B={nseq}, L={L}, d={m.hidden_size}, V={diff.vocab_size})"
     if t1 * (1 + 0.6 * (m.n_blocks - 1)) <= 150:
         total = run(m.n_blocks)
         sample = f"{what} through all {m.n_blocks} blocks: {total:.1f} s MEASURED (1-block probe {t1:.1f} s; {threads} threads of {cores} available cores)"
@@ -273,7 +280,7 @@ def cpu_baseline(workload, cfg, diff, seed):
         total = t1 + (m.n_blocks - 1) * max(t2 - t1, 1e-6)
         sample = (f"{what} through 1 and 2 of the {m.n_blocks} blocks: {t1:.1f} s and {t2:.1f} s; EXTRAPOLATED to {m.n_blocks} blocks = {total:.1f} s "
                   f"(host too slow for the full depth inside the bench's time bound; {threads} threads of {cores} available cores)")
-    return dict(value=L / total, unit="tokens/s", cores=threads, kind="port", sample=sample)
+    return dict(value=nseq * L / total, unit="tokens/s", cores=threads, kind="port", sample=sample)
 
 
 def cpu_baseline_legs(seed):
@@ -378,7 +385,7 @@ def main():
     ap.add_argument("--time-every", type=int, default=16, help="bracket 1 GEMM launch in this many with HIP events inside the timed region (1 = all: costs ~1.7 ms/step)")
     ap.add_argument("--hog-cus", type=int, default=0, help="diagnostics: hold this many CUs with a spinning kernel for the whole run (stand-in for RCCL's channel kernels; "
                     "combine with UDM_GEMM_CUS = 256 - n so the GEMMs plan for the remaining CUs)")
-    ap.add_argument("--ddp-mode", default=None, choices=["auto", "overlap", "overlap_planned", "serialized", "copy_engine"],
+    ap.add_argument("--ddp-mode", default=None, choices=["auto", "overlap", "overlap_planned", "serialized"],
                     help="gradient all-reduce schedule for --gpus > 1 (default: UDM_DDP_MODE or auto = timed in warm-up on all ranks, fastest kept)")
     ap.add_argument("--table-steps", type=int, default=2, help="extra untimed steps after the timed region with every launch event-timed (roofline_table); 0 = off")
     args = ap.parse_args()
@@ -457,7 +464,7 @@ def main():
         if sync is not None:
             # comm policy: with "auto" every schedule is timed for a few EXTRA untimed steps on all ranks and the fastest kept (ddp.py)
             fence()
-            sync.autotune(lambda: step(0), steps=2, settle=1, sync_device=device)
+            sync.autotune(lambda: step(0), steps=4, settle=1, sync_device=device)    # >= 3 % for the slowest rank or "overlap" stays; skipped past 60 s (ddp.py)
         if hog is None:
             fence()
         else:   # (a device-wide synchronise would wait for the spinning kernel)
@@ -523,10 +530,7 @@ def main():
         result["ddp_mode_requested"] = sync.requested_mode
         result["ddp_mode_warmup_ms"] = sync.mode_timings_ms       # {mode: ms per step, max over ranks} from the auto-selection, else null
         result["ddp_reserved_cus"] = sync.reserved_cus            # what overlap_planned leaves to the collective
-        if getattr(sync, "_cx", None) is not None:                # copy_engine: host-side wait for the helper thread, bytes pushed to peers by this rank
-            # (the join at the end of a backward; it includes the part of the backward the host had run ahead of: not "exposed communication")
-            result["copy_engine_host_join_ms_per_step"] = 1e3 * sync._cx.host_wait_s / (args.steps + args.warmup)
-            result["copy_engine_bytes_pushed_per_step"] = sync._cx.bytes_copied // (args.steps + args.warmup)
+        result["ddp_mode_decision"] = sync.autotune_report        # margin of the fastest schedule over "overlap", steps per mode, or why the selection was skipped
         result["rccl_max_nchannels"] = rccl_channels              # NCCL_MAX_NCHANNELS in force (0 = RCCL's default)
         # time the compute stream spent waiting for the comm stream at the end of backward (events around BucketedGradSync.finish)
         result["exposed_comm_ms_per_step"] = sync.exposed_ms() / args.steps
@@ -563,10 +567,13 @@ def main():
         ex = sum(w[1] for _, _, _, w in full.records if w and w[0] == "flop") / args.table_steps   # everything the matrix pipe executed in a step
         result["executed_mfma_flops_per_step"] = ex
         result["executed_mfma_utilization"] = ex / (dt / args.steps) / (PEAK_BF16_DENSE_TFLOPS * 1e12)
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and "packed" not in w:
+    if world > 1:
+        dist.barrier()     # (rank 0 alone times the CPU comparator below: the other ranks are done)
+    if rank == 0 and not args.no_cpu_baseline:     # every world size and every workload: north_star wants the CPU path timed "in the same run"
         try:
             result["cpu_baseline"] = cpu_baseline(args.workload, cfg, diff, seed)
-            result["cpu_baseline"]["legs"] = cpu_baseline_legs(seed)
+            if world == 1 and "packed" not in w:
+                result["cpu_baseline"]["legs"] = cpu_baseline_legs(seed)
         except Exception as e:  # the GPU number stands on its own; say why the comparator is missing
             result["cpu_baseline"] = {"value": None, "unit": "tokens/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {type(e).__name__}: {e}"}
     if rank == 0:

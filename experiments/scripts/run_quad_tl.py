@@ -2,7 +2,7 @@
 import ctypes, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from unidisc_amd import _lib
+from unidisc_amd import _lib  # (exp library: experiments/exp_lib.py)
 lib = _lib.load()
 fn = _lib.load_experiments().udm_gemm_nt_bf16_variant
 fn.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 3 + [ctypes.c_int64] * 6 + [ctypes.c_void_p]

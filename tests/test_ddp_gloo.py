@@ -124,7 +124,38 @@ def _worker(rank, world, port, min_bucket, q):
         tables = [None] * world
         dist.all_gather_object(tables, (table, sync.mode))
         auto_ok = sync.mode == "serialized" and all(t == tables[0] for t in tables) and set(table) == set(ddp_mod.MODES)
-        q.put((rank, ok, same, local_ok, worst, sync.bytes_on_wire, acc_ok, acc_same, acc_worst, again_ok, modes_ok, plan_calls, auto_ok, sync.reserved_cus))
+        auto_ok = auto_ok and sync.autotune_report["decision"] == "serialized" and sync.autotune_report["gain_of_fastest_over_overlap"] > 0.03
+        # hysteresis (round 5): a 1 % "win" of another schedule is noise - "overlap" stays, the report says which one was fastest and by how much
+        sync.requested_mode = "auto"
+        def near_tie():
+            time.sleep({"overlap": 0.300, "overlap_planned": 0.297, "serialized": 0.310}[sync.mode])
+        sync.autotune(near_tie, steps=2, settle=0)
+        rep = sync.autotune_report
+        hyst_ok = sync.mode == "overlap" and rep["decision"] == "overlap" and rep["fastest_measured"] == "overlap_planned" and 0.0 < rep["gain_of_fastest_over_overlap"] < 0.03
+        # a rank that cannot switch leaves EVERY rank in "overlap" (divergent schedules = divergent collective sequences = a hang); the step still works
+        orig_set = sync.set_mode
+        def failing(mode, orig=orig_set):
+            if rank == 1 and mode == "serialized":
+                raise RuntimeError("this rank cannot run that schedule")
+            return orig(mode)
+        sync.set_mode = failing
+        switched = sync._set_mode_everywhere("serialized")
+        fail_ok = switched is False and sync.mode == "overlap"
+        got = _grads(diff, golden, seed=rank)
+        fail_ok = fail_ok and all(torch.equal(got[k], synced[k]) for k in synced)
+        sync.autotune(near_tie, steps=1, settle=0)
+        fail_ok = fail_ok and sync.autotune_report["modes_that_could_not_be_set"] == ["serialized"] and sync.mode in ("overlap", "overlap_planned")
+        sync.set_mode = orig_set
+        modes_now = [None] * world
+        dist.all_gather_object(modes_now, sync.mode)
+        fail_ok = fail_ok and len(set(modes_now)) == 1
+        # bounded in wall time: a selection that would take longer than the budget is skipped, with the reason on record
+        sync._set_mode_everywhere("overlap")
+        sync.autotune(lambda: time.sleep(0.05), steps=4, settle=1, budget_s=0.2)
+        bound_ok = sync.mode == "overlap" and "skipped" in sync.autotune_report
+        policy_ok = hyst_ok and fail_ok and bound_ok
+        q.put((rank, ok, same, local_ok, worst, sync.bytes_on_wire, acc_ok, acc_same, acc_worst, again_ok, modes_ok, plan_calls, auto_ok and policy_ok, sync.reserved_cus,
+               (hyst_ok, fail_ok, bound_ok, rep)))
     finally:
         dist.destroy_process_group()
 
@@ -141,7 +172,8 @@ def test_bucketed_allreduce_world2(min_bucket):
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    for rank, ok, same, local_ok, worst, nbytes, acc_ok, acc_same, acc_worst, again_ok, modes_ok, plan_calls, auto_ok, reserved in res:
+    for rank, ok, same, local_ok, worst, nbytes, acc_ok, acc_same, acc_worst, again_ok, modes_ok, plan_calls, auto_ok, reserved, policy in res:
+        assert all(policy[:3]), (rank, policy)    # hysteresis, a failing rank drags everybody back to "overlap", wall-time bound
         assert modes_ok, rank                 # overlap / overlap_planned / serialized: bit-identical synchronised gradients
         assert plan_calls == [256 - reserved, 0] and reserved == 32, (rank, plan_calls)   # plan on at the first bucket, off at the end of the backward
         assert auto_ok, rank                  # autotune: same table and same choice on every rank, decided by the slowest rank

@@ -1,7 +1,7 @@
 """End-to-end parity on a real MI355X (pytest -m gpu): the HIP path vs the golden vectors of the imported
 reference and vs the CPU oracle on the same seeded inputs.
 
-Tolerances: every comparison is recorded in the parity ledger (tests/ledger.py -> profiles/r03_parity_ledger.json) together with the
+Tolerances: every comparison is recorded in the parity ledger (tests/ledger.py -> profiles/r05_parity_ledger.json) together with the
 reference's own bf16-vs-fp32 deviation (~1e-3 on the loss, ~3e-3 rel-RMS on logits), and asserted against a STATED bound that is
 <= 3x the error achieved there: loss 1e-3 relative (north_star's figure), logits / NLL / gradients as rel-RMS against the reference's fp32 run.
 Mask indices (xt, move_indices, token_mask) must be bit-exact.
@@ -18,9 +18,16 @@ from product_utils import build_product, product_config
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
-# Stated bounds (<= 3x the errors recorded in profiles/r03_parity_ledger.json; d = 64 goldens, so per-parameter gradients of 64-element vectors are
+# Stated bounds (<= 3x the errors recorded in profiles/r05_parity_ledger.json; d = 64 goldens, so per-parameter gradients of 64-element vectors are
 # the noisiest quantity): relative error of the loss, rel-RMS of logits / per-token NLL / per-parameter gradients against the reference's fp32 run.
-LOSS_BOUND, LOGITS_BOUND, NLL_BOUND, GRAD_BOUND = 1e-3, 1e-2, 4.5e-3, 6e-2
+LOSS_BOUND, NLL_BOUND, GRAD_BOUND = 1e-3, 4.5e-3, 6e-2
+
+
+def logits_bound(ref_floor):
+    """bf16 logits against the reference's fp32 run: north_star's literal 1e-3 cannot be met by ANY bf16 evaluation - the reference's own bf16 run sits
+    3.0e-3 .. 6.3e-3 rel-RMS from its fp32 run.  The bound is therefore tied to that floor, case by case: 1.25 x the reference's own bf16
+    deviation + 5e-4 (a flat 1e-2 was 1.6 - 3.3 x what is achieved)."""
+    return 1.25 * ref_floor + 5e-4
 
 
 @pytest.mark.parametrize("name", CASE_NAMES)
@@ -36,7 +43,7 @@ def test_logits_match_golden(name):
     assert logits.dtype == torch.bfloat16 and logits.shape == truth.shape
     e, budget = rel_err(logits.float().cpu(), truth), rel_err(ref16, truth)
     record(f"golden_logits[{name}]", "ref_bf16_vs_fp32_logits_relrms", budget, note="the reference's own bf16 run against its fp32 run")
-    check(f"golden_logits[{name}]", "logits_relrms_vs_fp32_reference", e, LOGITS_BOUND)
+    check(f"golden_logits[{name}]", "logits_relrms_vs_fp32_reference", e, logits_bound(budget))
     # ... and directly against the reference's OWN bf16 run (CPU bf16 autocast): two bf16 evaluations of the same network differ by about sqrt(2) x the distance of
     # either from fp32 (independent roundings), so the claim "these are the reference's bf16 numerics" is this row staying at that level - asserted at
     # 2 x the reference's own bf16-vs-fp32 deviation + 2e-3 (the SURVEY F9 budget)

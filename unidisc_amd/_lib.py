@@ -92,9 +92,8 @@ SOFT_RC3 = {"udm_gemm_tn_pair_bf16", "udm_gemm_tn_multi_bf16"}
 
 
 def build(verbose: bool = False) -> str:
-    """Compile EVERY HIP source for gfx950 in-tree (``make`` in ``csrc/``): the product library and the experiments library scripts/ load
-    (the product never loads the latter).  Cross-compiles without a GPU."""
-    out = subprocess.run(["make", "-C", CSRC, "-j4", "all", "exp"], capture_output=True, text=True)
+    """Compile EVERY HIP source of the product for gfx950 in-tree (``make`` in ``csrc/``).  Cross-compiles without a GPU."""
+    out = subprocess.run(["make", "-C", CSRC, "-j4", "all"], capture_output=True, text=True)
     if verbose or out.returncode != 0:
         print(out.stdout[-4000:])
         print(out.stderr[-4000:])
@@ -128,26 +127,3 @@ def load():
     lib.udm_abi_version.argtypes = []
     _lib = lib
     return lib
-
-
-def load_experiments():
-    """``libunidisc_exp.so``: GEMM variant / micro-benchmark experiments used by scripts/ only (``make -C unidisc_amd/csrc exp``); never
-    loaded by the product."""
-    path = os.path.join(_HERE, "libunidisc_exp.so")
-    if not os.path.exists(path):
-        out = subprocess.run(["make", "-C", CSRC, "-j4", "exp"], capture_output=True, text=True)
-        if out.returncode != 0:
-            raise RuntimeError("building libunidisc_exp.so failed:\n" + out.stderr[-3000:])
-    lib = ctypes.CDLL(path)
-    lib.udm_last_error.restype = ctypes.c_char_p
-    return lib
-
-
-def call(name: str, *args):
-    """Invoke an entry point; non-zero return raises RuntimeError(udm_last_error())."""
-    lib = load()
-    rc = getattr(lib, name)(*args)
-    if rc == 3 and name in SOFT_RC3:
-        raise NotApplicable(name)
-    if rc != 0:
-        raise RuntimeError(f"{name} failed (rc={rc}): {lib.udm_last_error().decode(errors='replace')}")

@@ -25,10 +25,13 @@ MEASUREMENT at start-up rather than assumed:
                          (`kernels.gemm_set_cus`): single-round grids are cut to what fits beside the collective, leftovers split in K;
   * ``serialized``       nothing is launched inside the backward; at its end the finished ranges go out as a few large all-reduces (coalesced
                          up to ``serial_bucket_elems``) and the compute stream waits: no CU contention, communication fully exposed;
-  * ``copy_engine``      opt-in, not timed by ``auto``: the overlapped schedule with every bucket exchanged as peer-to-peer copies + one small sum kernel
-                         (``ddp_copy.py``: no CUs held); rehearsed with two ranks on one GPU only, falls back to ``overlap`` when the node cannot set it up;
-  * ``auto`` (default)   ``autotune(step_fn)`` times each of the three for a few steps on all ranks, takes all_reduce(MAX) of the times and
-                         keeps the fastest; until it has run, ``auto`` behaves as ``overlap``.
+  * ``auto`` (default)   ``autotune(step_fn)`` times each of the three for a few steps on all ranks, takes all_reduce(MAX) of the times and keeps
+                         ``overlap`` unless another schedule is at least 3 % faster for the slowest rank (a noise-level "win" must not select a schedule
+                         that costs +20 % when nothing is held); until it has run, ``auto`` behaves as ``overlap``.  The selection is bounded in wall time
+                         and every mode switch is agreed by all ranks (a rank that cannot switch leaves EVERY rank in ``overlap``: divergent schedules
+                         would deadlock the collectives).
+(A copy-engine exchange - peer-to-peer copies instead of a collective - was rehearsed in round 4 with two ranks on one GPU; it cannot be validated on this
+pool and lives under experiments/ddp_copy_engine/, outside the product.)
 RCCL's CU footprint is bounded by ``rccl_channel_env()`` (NCCL_MAX_NCHANNELS, default 32 = ``reserved_cus``; must be in the environment
 before the communicator is created).
 
@@ -47,7 +50,6 @@ from . import kernels as K
 
 
 MODES = ("overlap", "overlap_planned", "serialized")      # the schedules `auto` times
-EXTRA_MODES = ("copy_engine",)                             # opt-in: buckets exchanged by peer-to-peer copies on the copy engines (ddp_copy.py), never picked by `auto`
 DEFAULT_RCCL_CHANNELS = 32     # one channel = one workgroup = one CU; 32 is what `overlap_planned` reserves (a whole multiple of the 8 XCDs x 4 shader engines)
 
 
@@ -85,19 +87,21 @@ class BucketedGradSync:
         self.measure_exposed = False   # bench: time the compute stream spends waiting for the comm stream at the end of backward
         self._exposed: List[Tuple[torch.cuda.Event, torch.cuda.Event]] = []
         mode = os.environ.get("UDM_DDP_MODE", "auto") if mode is None else mode
-        if mode != "auto" and mode not in MODES + EXTRA_MODES:
-            raise ValueError(f"BucketedGradSync: unknown mode {mode!r} (one of {MODES + EXTRA_MODES + ('auto',)})")
+        if mode != "auto" and mode not in MODES:
+            raise ValueError(f"BucketedGradSync: unknown mode {mode!r} (one of {MODES + ('auto',)})")
         self.requested_mode = mode
         self.mode = "overlap" if mode == "auto" else mode     # what runs now; `autotune` replaces an "auto" request by the measured winner
-        self._cx = None                                        # copy_engine: the peer-buffer exchange (created on first use; None after a failed setup = RCCL path)
-        self._cx_tried = False
         self.mode_timings_ms = None                            # {mode: ms per step, max over ranks} once autotune has run
+        self.autotune_report = None                            # how the decision was taken (margin, steps, or why the selection was skipped)
         if reserved_cus is None:
             reserved_cus = int(os.environ.get("UDM_DDP_RESERVED_CUS", "0") or 0) or (int(os.environ.get("NCCL_MAX_NCHANNELS", "0") or 0) or DEFAULT_RCCL_CHANNELS)
         self.reserved_cus = (int(reserved_cus) + 31) // 32 * 32     # whole shader-engine multiples: an exact fit only works when the held CUs spread one per engine (DESIGN §5 v)
         self.serial_bucket = int(serial_bucket_elems)
         self._deferred: List[Tuple[torch.Tensor, int, int]] = []  # serialized mode: ranges finished inside the backward, reduced at its end
         self._planned = False                                      # overlap_planned: the GEMM plan is in force for the rest of this backward
+        self._in_backward = False
+        p0 = next(iter(module.parameters()), None)
+        self._agree_device = p0.device if (p0 is not None and p0.is_cuda) else "cpu"    # where the ranks' yes / no and timing tensors live (RCCL wants device tensors)
         module.grad_ready_callback = self._on_ready
         module.grad_sync_finish = self.finish
 
@@ -109,6 +113,10 @@ class BucketedGradSync:
     def _on_ready(self, flat: torch.Tensor, lo: int, hi: int):
         if not self.active or not self.enabled or self._unsynced_passes:
             return   # local pass, or accumulated gradients: reduced after autograd has summed them (finish)
+        if not self._in_backward:       # first range of a backward: nothing of a previous one may linger (a backward that raised never reached finish())
+            self._in_backward = True
+            self._pending, self._deferred = None, []
+            self._unplan()
         if self.mode == "serialized":   # nothing leaves inside the backward; adjacent ranges coalesce into few large messages
             if self._deferred and self._deferred[-1][0] is flat and self._deferred[-1][2] == lo and hi - self._deferred[-1][1] <= self.serial_bucket:
                 self._deferred[-1] = (flat, self._deferred[-1][1], hi)
@@ -138,9 +146,6 @@ class BucketedGradSync:
         """bf16-compress `seg` (fp32, contiguous), all-reduce, decompress in place.  GPU: on the comm stream, after what the current stream queued."""
         n = seg.numel()
         self.bytes_on_wire += n * 2
-        if seg.is_cuda and self.mode == "copy_engine" and self._copy_engine(seg.device) is not None:
-            self._cx.submit(seg)         # exchanged by the helper thread on the copy stream; joined in _join
-            return
         if seg.is_cuda:
             if self.comm_stream is None:
                 self.comm_stream = torch.cuda.Stream(device=seg.device)
@@ -158,17 +163,6 @@ class BucketedGradSync:
             dist.all_reduce(wire, op=dist.ReduceOp.SUM, group=self.pg)
             seg.copy_(wire.float())
 
-    def _copy_engine(self, device):
-        """The copy-engine exchange, set up collectively on first use; a node that cannot (no IPC, no peer access) drops every rank back to the RCCL path."""
-        if not self._cx_tried:
-            self._cx_tried = True
-            from . import ddp_copy
-
-            self._cx = ddp_copy.setup(dist.get_rank(self.pg), self.world, device, self.pg)
-        if self._cx is None:
-            self.mode = "overlap"      # (every rank: `setup` answers collectively)
-        return self._cx
-
     def _launch(self, flat: torch.Tensor, lo: int, hi: int):
         self._reduce_segment(flat[lo:hi], ("flat", lo))
         if self.mode == "overlap_planned" and not self._planned:
@@ -182,15 +176,7 @@ class BucketedGradSync:
             self._planned = False
 
     def _join(self):
-        if self._cx is not None:
-            if self.measure_exposed:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record(torch.cuda.current_stream())
-                self._cx.drain()
-                e1.record(torch.cuda.current_stream())
-                self._exposed.append((e0, e1))
-            else:
-                self._cx.drain()
+        self._in_backward = False
         if self.comm_stream is not None:
             cur = torch.cuda.current_stream()
             if self.measure_exposed:
@@ -257,7 +243,7 @@ class BucketedGradSync:
             return
         cat = torch.cat([g.reshape(-1).float() for g in grads])
         self._reduce_segment(cat, key)
-        if cat.is_cuda:
+        if cat.is_cuda and self.comm_stream is not None:   # the copy-back below reads what the comm stream writes
             torch.cuda.current_stream().wait_stream(self.comm_stream)
         off = 0
         for g in grads:
@@ -265,21 +251,45 @@ class BucketedGradSync:
             off += g.numel()
 
     def set_mode(self, mode: str):
-        if mode not in MODES + EXTRA_MODES:
-            raise ValueError(f"BucketedGradSync: unknown mode {mode!r} (one of {MODES + EXTRA_MODES})")
+        if mode not in MODES:
+            raise ValueError(f"BucketedGradSync: unknown mode {mode!r} (one of {MODES})")
         if self._pending is not None or self._deferred:
             raise RuntimeError("BucketedGradSync.set_mode inside a backward")
         self._unplan()
+        if mode != self.mode:
+            self._bufs = {}     # the other schedule's persistent wire buffers (serialized: up to 512 MB each) are not kept beside this one's
         self.mode = mode
 
-    def autotune(self, step_fn, steps: int = 2, settle: int = 1, modes=MODES, sync_device=None):
+    def _set_mode_everywhere(self, mode: str) -> bool:
+        """Collective: every rank switches to `mode`, or - if ANY rank cannot - every rank ends in "overlap" and False is returned.  Ranks in
+        different schedules issue different collective sequences: that is a deadlock, not a slowdown."""
+        ok = 1
+        try:
+            self.set_mode(mode)
+        except Exception:
+            ok = 0
+        if self.world > 1:
+            flag = torch.tensor([ok], dtype=torch.int32, device=self._agree_device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.pg)
+            ok = int(flag.item())
+        if not ok:
+            self._pending, self._deferred = None, []
+            self._unplan()
+            self._bufs = {}
+            self.mode = "overlap"
+        return bool(ok)
+
+    def autotune(self, step_fn, steps: int = 4, settle: int = 1, modes=MODES, sync_device=None, min_gain: float = 0.03, budget_s: float = 60.0):
         """Measure `settle + steps` calls of `step_fn()` (one full training step: zero_grad, forward, backward) in every mode, the same sequence on all
-        ranks; the time of a mode is the MAX over ranks of its mean step; the fastest is kept (ties: the earlier of `modes`).  Returns the table
-        {mode: ms}.  No-op unless the mode was requested as "auto" and gradient synchronisation is active."""
+        ranks; the time of a mode is the MAX over ranks of its mean step.  "overlap" (the reference DDP's schedule) is kept unless another mode is at
+        least `min_gain` faster - the selection must not flip on noise.  Bounded: one probe step is timed first and the selection is skipped (with the
+        reason in `autotune_report`) when all modes together would take more than `budget_s`.  Returns the table {mode: ms}.  No-op unless the mode was
+        requested as "auto" and gradient synchronisation is active."""
         import time
 
         if self.requested_mode != "auto" or not self.active:
             return self.mode_timings_ms
+        self._agree_device = sync_device if sync_device is not None else "cpu"
 
         def fence():
             if sync_device is not None:
@@ -289,11 +299,31 @@ class BucketedGradSync:
             if sync_device is not None:
                 torch.cuda.synchronize(sync_device)
 
-        if os.environ.get("UDM_DDP_AUTO_COPY_ENGINE") == "1" and "copy_engine" not in modes:
-            modes = tuple(modes) + ("copy_engine",)     # opt-in: let the measurement decide about the copy-engine exchange too (a failed set-up times the RCCL path again)
-        table = {}
+        def max_over_ranks(values):
+            t = torch.tensor(list(values), dtype=torch.float64, device=self._agree_device)
+            if self.world > 1:
+                dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.pg)     # every rank sees the same numbers -> the same decision
+            return t.tolist()
+
+        modes = tuple(modes)
+        base = "overlap" if "overlap" in modes else modes[0]
+        self._set_mode_everywhere(base)
+        fence()
+        t0 = time.perf_counter()
+        step_fn()
+        fence()
+        probe_s = max_over_ranks([time.perf_counter() - t0])[0]
+        need_s = probe_s * len(modes) * (settle + steps)
+        if need_s > budget_s:
+            self.autotune_report = dict(decision=base, skipped=f"timing {len(modes)} modes x {settle + steps} steps of {probe_s:.2f} s would take {need_s:.0f} s > {budget_s:.0f} s",
+                                        probe_step_s=probe_s)
+            return self.mode_timings_ms
+        table, failed = {}, []
         for m in modes:
-            self.set_mode(m)
+            if not self._set_mode_everywhere(m):
+                failed.append(m)
+                table[m] = float("inf")
+                continue
             for _ in range(settle):
                 step_fn()
             fence()
@@ -302,13 +332,18 @@ class BucketedGradSync:
                 step_fn()
             fence()
             table[m] = 1e3 * (time.perf_counter() - t0) / max(steps, 1)
-        ms = torch.tensor([table[m] for m in modes], dtype=torch.float64, device=sync_device if sync_device is not None else "cpu")
-        if self.world > 1:
-            dist.all_reduce(ms, op=dist.ReduceOp.MAX, group=self.pg)     # every rank sees the same table -> the same decision
-        ms = ms.tolist()
+        ms = max_over_ranks([table[m] for m in modes])
+        ms = [float("inf") if modes[i] in failed else ms[i] for i in range(len(modes))]
+        ib = modes.index(base)
         best = min(range(len(modes)), key=lambda i: (ms[i], i))
+        if best != ib and not (ms[best] <= (1.0 - min_gain) * ms[ib]):
+            best = ib            # a win inside the noise is no win
         self.mode_timings_ms = {m: ms[i] for i, m in enumerate(modes)}
-        self.set_mode(modes[best])
+        fastest = min(range(len(modes)), key=lambda i: (ms[i], i))
+        self.autotune_report = dict(decision=modes[best], fastest_measured=modes[fastest], gain_of_fastest_over_overlap=1.0 - ms[fastest] / ms[ib] if ms[ib] > 0 else 0.0,
+                                    min_gain=min_gain, steps_per_mode=steps, settle_steps=settle, probe_step_s=probe_s, modes_that_could_not_be_set=failed)
+        if not self._set_mode_everywhere(modes[best]):
+            self.autotune_report["decision"] = "overlap"
         return self.mode_timings_ms
 
     def exposed_ms(self, reset=True) -> float:

@@ -43,6 +43,15 @@ def _chk(t, dtype, name):
         raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
 
 
+def _chk_packed_f32(t, name, numel=None):
+    """a raw pointer goes into a device job table: the kernel reads `numel` packed fp32 values from it, whatever the tensor really is"""
+    if t is None:
+        return
+    if t.dtype != F32 or not t.is_contiguous() or (numel is not None and t.numel() != numel):
+        raise TypeError(f"{name}: expected a contiguous float32 tensor of {numel if numel is not None else 'any'} elements, got {t.dtype} {tuple(t.shape)} "
+                        f"stride {t.stride()}")
+
+
 _SCRATCH = {}
 
 
@@ -303,6 +312,8 @@ def interleaved_rope(modality, sid, img_cos, img_sin, sizes, txt_cos, txt_sin):
     import ctypes
 
     _chk(modality, torch.int64, "interleaved_rope modality"), _chk(sid, torch.int64, "interleaved_rope sid")
+    for t, nm in ((img_cos, "img_cos"), (img_sin, "img_sin"), (txt_cos, "txt_cos"), (txt_sin, "txt_sin")):
+        _chk(t, F32, f"interleaved_rope {nm}")
     B, L = modality.shape
     half = img_cos.shape[1]
     dev = modality.device
@@ -497,6 +508,8 @@ def adamw_jobs(items, device):
     buf, chunk0 = bytearray(), 0
     for p, g, m, v, e in items:
         n = p.numel()
+        for t, nm in ((p, "p"), (g, "g"), (m, "m"), (v, "v"), (e, "ema")):
+            _chk_packed_f32(t, f"adamw_jobs {nm}", n)
         buf += struct.pack("<QQQQQqq", _p(p), _p(g), _p(m), _p(v), _p(e) or 0, n, chunk0)
         chunk0 += (n + 1023) // 1024
     return torch.frombuffer(buf, dtype=torch.uint8).to(device), len(items), chunk0
@@ -516,6 +529,11 @@ def adamw_shadow_jobs(items, device):
     buf, tile0 = bytearray(), 0
     for p, g, m, v, e, w16, w16t in items:
         R, C = p.shape
+        for t, nm in ((p, "p"), (g, "g"), (m, "m"), (v, "v"), (e, "ema")):
+            _chk_packed_f32(t, f"adamw_shadow_jobs {nm}", R * C)
+        for t, nm, shp in ((w16, "w16", (R, C)), (w16t, "w16t", (C, R))):
+            if t is not None and (t.dtype != BF16 or tuple(t.shape) != shp or t.stride(1) != 1):
+                raise TypeError(f"adamw_shadow_jobs {nm}: expected bf16 {shp} with unit inner stride, got {t.dtype} {tuple(t.shape)} stride {t.stride()}")
         tiles_c = (C + 63) // 64
         buf += struct.pack("<QQQQQQQqqiiii", _p(p), _p(g), _p(m), _p(v), _p(e) or 0, _p(w16) or 0, _p(w16t) or 0, w16.stride(0) if w16 is not None else 0,
                            w16t.stride(0) if w16t is not None else 0, R, C, tile0, tiles_c)
