@@ -127,3 +127,13 @@ def load():
     lib.udm_abi_version.argtypes = []
     _lib = lib
     return lib
+
+
+def call(name: str, *args):
+    """Invoke an entry point; non-zero return raises RuntimeError(udm_last_error())."""
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc == 3 and name in SOFT_RC3:
+        raise NotApplicable(name)
+    if rc != 0:
+        raise RuntimeError(f"{name} failed (rc={rc}): {lib.udm_last_error().decode(errors='replace')}")
