@@ -531,9 +531,9 @@ def adamw_shadow_jobs(items, device):
         R, C = p.shape
         for t, nm in ((p, "p"), (g, "g"), (m, "m"), (v, "v"), (e, "ema")):
             _chk_packed_f32(t, f"adamw_shadow_jobs {nm}", R * C)
-        for t, nm, shp in ((w16, "w16", (R, C)), (w16t, "w16t", (C, R))):
-            if t is not None and (t.dtype != BF16 or tuple(t.shape) != shp or t.stride(1) != 1):
-                raise TypeError(f"adamw_shadow_jobs {nm}: expected bf16 {shp} with unit inner stride, got {t.dtype} {tuple(t.shape)} stride {t.stride()}")
+        for t, nm, shp in ((w16, "w16", (R, C)), (w16t, "w16t", (C, R))):   # (shadows may be padded to whole GEMM tiles: at least the parameter's extent)
+            if t is not None and (t.dtype != BF16 or t.dim() != 2 or t.shape[0] < shp[0] or t.shape[1] < shp[1] or t.stride(1) != 1):
+                raise TypeError(f"adamw_shadow_jobs {nm}: expected bf16 of at least {shp} with unit inner stride, got {t.dtype} {tuple(t.shape)} stride {t.stride()}")
         tiles_c = (C + 63) // 64
         buf += struct.pack("<QQQQQQQqqiiii", _p(p), _p(g), _p(m), _p(v), _p(e) or 0, _p(w16) or 0, _p(w16t) or 0, w16.stride(0) if w16 is not None else 0,
                            w16t.stride(0) if w16t is not None else 0, R, C, tile0, tiles_c)
