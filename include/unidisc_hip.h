@@ -157,6 +157,8 @@ int udm_attention_fwd(const void* q, const void* k, const void* v, void* o, floa
 int udm_attention_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse, float* delta, void* dq, void* dk,
                       void* dv, const int64_t* sample_ids, const int32_t* doc_ranges, int64_t B, int64_t H, int64_t L, int64_t D, int64_t q_stride, int64_t k_stride, int64_t v_stride,
                       int64_t o_stride, int64_t do_stride, int64_t dq_stride, int64_t dk_stride, int64_t dv_stride, int64_t flags, hipStream_t stream);
+/* delta: caller's fp32 scratch of 3 B H L floats (rowsum(dO O) of the dQ pass, then - with UDM_ATTN_Q_PRESCALED - the negated lse and delta the dK/dV pass
+ * starts its score accumulators from). */
 /* flags: UDM_ATTN_Q_PRESCALED = q holds bf16(q log2(e) / sqrt(D)) (udm_qknorm_rope_fwd with that q_scale): the kernels skip the per-score multiply, dq is
  * the gradient wrt that stored q (udm_qknorm_rope_bwd with the same q_scale), lse is unchanged.  The forward at head dim 128 without sample_ids,
  * L % 256 == 0, L >= 512, (B H) % 8 == 0 then runs the persistent 64-queries-per-wave kernel (csrc/attention_fwd64.hip). */

@@ -318,7 +318,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
     for (int e = 0; e < 8; ++e) delta_q += (float)of[e] * (float)dof[ks][e];
   }
   delta_q += __shfl_xor(delta_q, 32, 64);
-  if (q_ok && hi == 0) const_cast<float*>(a.delta)[sidx] = delta_q;
+  if (q_ok && hi == 0) {
+    float* dl = const_cast<float*>(a.delta);
+    dl[sidx] = delta_q;
+    if (a.q_prescaled) {   // negated copies for the wave-specialised dK/dV kernel, whose score chains start from them (attention_dkv_ws.hip): delta | -lse | -delta
+      const long plane = (long)a.B * a.H * a.L;
+      dl[plane + sidx] = -lse_q;
+      dl[2 * plane + sidx] = -delta_q;
+    }
+  }
   const float c = a.scale_log2;
   // (as in the forward kernel: the compiler's wait for these global loads must sit before the loop, not behind the inline-asm refills)
 #pragma unroll

@@ -47,6 +47,7 @@ struct Ctx {
   const bf16_t* qb16; const bf16_t* ob16; long q_stride, do_stride;   // ragged-step path
   int L, nsub, wave, lane;
   float c;
+  float lse_pad;                                  // what a query row past L gets as its (possibly negated) lse: +inf, or -inf in the pre-scaled form - p = 0 either way
   uint32_t offq[2], offo[2];                      // accum wave's DMA pieces: byte offset of (row, swizzled slot) inside a step
   uint32_t xoff[8];                               // LDS byte addresses (stage 0): row fragments, k-step m
   uint32_t zoff1[4], zoff2[4];                    // LDS byte addresses (stage 0): transposing reads, d block i, rows +0 / +8
@@ -109,20 +110,23 @@ __device__ __forceinline__ void top(const Ctx& x, char* smem, int j, int jm) {
   stamp<TIMELINE>(x, j, 1);
   if (ROLE == 1 && j + 1 + PD < x.nsub) issue_sub(x, smem, j + 1 + PD, (jm + 1 + PD) % NST);
   if (ROLE == 0 && x.wave == 0 && j + 1 < x.nsub && (j + 2) * SUB > x.L && x.lane >= x.L - (j + 1) * SUB && x.lane < 32)   // ragged last step (read at iteration j+1)
-    *reinterpret_cast<float*>(smem + LD_OFF + ((jm + 1) % NST) * 256 + x.lane * 4) = INFINITY;
+    *reinterpret_cast<float*>(smem + LD_OFF + ((jm + 1) % NST) * 256 + x.lane * 4) = x.lse_pad;
   stamp<TIMELINE>(x, j, 2);
 }
 
 // score wave, iteration j.  JM = j mod NST as a compile-time constant (ring stages and exchange parity become immediate offsets),
 // or -1: derive them at run time (head / tail iterations).
-template <bool TIMELINE, int JM, bool HX, bool HY>
+// PRE (q pre-scaled by log2(e) / sqrt(D): UDM_ATTN_Q_PRESCALED, the engine's form): the ring holds -lse | -delta (negated copies the dQ kernel writes) and the
+// score chains of X(j+1) START from them - the C operand of their first MFMA - so that the accumulators are s - lse and dp - delta as they leave the matrix
+// pipe: Y(j) is exp2 + multiply + pack per score instead of fma + subtract + exp2 + multiply + pack (the score wave is bound by its instruction issue).
+template <bool TIMELINE, int JM, bool HX, bool HY, bool PRE>
 __device__ __forceinline__ void score_step(const Ctx& x, char* smem, int j, const bf16x8_t (&kf)[KS], const bf16x8_t (&vf)[KS], const f32x16_t& s_in,
                                            const f32x16_t& dp_in, f32x16_t& s_out, f32x16_t& dp_out) {
   const int jm = (JM >= 0) ? JM : ((j + NST) % NST);
   top<TIMELINE, 0>(x, smem, j, jm);
   const uint32_t qx = ((jm + 1) % NST) * STG, ldy = x.ldoff + jm * 256;
   f32x4_t l4[4], d4[4];
-  if (HY) {
+  if (HY && !PRE) {
 #pragma unroll
     for (int rg = 0; rg < 4; ++rg) {
       l4[rg] = lds_ld<f32x4_t>(ldy + 32 * rg);
@@ -135,8 +139,18 @@ __device__ __forceinline__ void score_step(const Ctx& x, char* smem, int j, cons
     bf16x8_t xq[8], xo[8];
     auto x_read = [&](int m) { xq[m] = lds_ld<bf16x8_t>(x.xoff[m] + qx); xo[m] = lds_ld<bf16x8_t>(x.xoff[m] + qx + TQ); };
     f32x16_t s, dp;
+    if (PRE) {   // -lse | -delta of step j+1 (landed with its Q / dO rows)
+      const uint32_t ldx = x.ldoff + ((jm + 1) % NST) * 256;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+      for (int rg = 0; rg < 4; ++rg) {
+        const f32x4_t nl = lds_ld<f32x4_t>(ldx + 32 * rg), nd = lds_ld<f32x4_t>(ldx + 128 + 32 * rg);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { s[4 * rg + e] = nl[e]; dp[4 * rg + e] = nd[e]; }
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+    }
 #pragma unroll
     for (int m = 0; m < 4; ++m) x_read(m);
     __builtin_amdgcn_sched_barrier(0);
@@ -154,9 +168,9 @@ __device__ __forceinline__ void score_step(const Ctx& x, char* smem, int j, cons
     // Y(j) on the s/dp of the previous iteration, batched by operation (element-serial order is a chain of dependent VALU latencies)
     float t[16], u[16], p[16], ds[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) t[r] = s_in[r] * x.c - l4[r >> 2][r & 3];
+    for (int r = 0; r < 16; ++r) t[r] = PRE ? s_in[r] : s_in[r] * x.c - l4[r >> 2][r & 3];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) u[r] = dp_in[r] - d4[r >> 2][r & 3];
+    for (int r = 0; r < 16; ++r) u[r] = PRE ? dp_in[r] : dp_in[r] - d4[r >> 2][r & 3];
 #pragma unroll
     for (int r = 0; r < 16; ++r) p[r] = __builtin_amdgcn_exp2f(t[r]);
 #pragma unroll
@@ -210,7 +224,7 @@ __device__ __forceinline__ void accum_step(const Ctx& x, char* smem, int j, f32x
 }
 }  // namespace dkvw
 
-template <bool TIMELINE>
+template <bool TIMELINE, bool PRE = false>
 __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_ws_kernel(AttnArgs a) {
   using namespace dkvw;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -241,7 +255,10 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_ws_kernel(AttnArgs a) {
   x.qbase = reinterpret_cast<const char*>(x.qb16); x.dobase = reinterpret_cast<const char*>(x.ob16);
   x.q_stride = a.q_stride; x.do_stride = a.do_stride;
   x.qstep = (long)SUB * a.q_stride * 2; x.ostep = (long)SUB * a.do_stride * 2;
-  x.ldp = (lane < 32 ? a.lse : a.delta) + sbase + q_lo + l31;
+  // PRE: the negated copies sit behind delta in the caller's scratch: delta | -lse | -delta, B H L floats each (written by the dQ kernel)
+  const long plane = (long)a.B * a.H * a.L;
+  x.ldp = (PRE ? (lane < 32 ? a.delta + plane : a.delta + 2 * plane) : (lane < 32 ? a.lse : a.delta)) + sbase + q_lo + l31;
+  x.lse_pad = PRE ? -INFINITY : INFINITY;
   x.L = q_n; x.nsub = (q_n + SUB - 1) / SUB; x.wave = wave; x.lane = lane; x.c = a.scale_log2;
   {
 #pragma unroll
@@ -277,10 +294,10 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_ws_kernel(AttnArgs a) {
     f32x16_t sA, dpA, sB, dpB;   // ping-pong: odd iterations read A / write B, even iterations read B / write A
 #pragma unroll
     for (int r = 0; r < 16; ++r) { sA[r] = 0.f; dpA[r] = 0.f; sB[r] = 0.f; dpB[r] = 0.f; }
-    score_step<TIMELINE, -1, true, false>(x, smem, -1, kf, vf, sA, dpA, sB, dpB);   // j = -1: X(0)
+    score_step<TIMELINE, -1, true, false, PRE>(x, smem, -1, kf, vf, sA, dpA, sB, dpB);   // j = -1: X(0)
     int j = 0;
-#define UDM_WS_EVEN(JM) score_step<TIMELINE, JM, true, true>(x, smem, j, kf, vf, sB, dpB, sA, dpA)
-#define UDM_WS_ODD(JM) score_step<TIMELINE, JM, true, true>(x, smem, j, kf, vf, sA, dpA, sB, dpB)
+#define UDM_WS_EVEN(JM) score_step<TIMELINE, JM, true, true, PRE>(x, smem, j, kf, vf, sB, dpB, sA, dpA)
+#define UDM_WS_ODD(JM) score_step<TIMELINE, JM, true, true, PRE>(x, smem, j, kf, vf, sA, dpA, sB, dpB)
     for (; j + 5 <= nsub - 2;) {
       UDM_WS_EVEN(0); ++j; UDM_WS_ODD(1); ++j; UDM_WS_EVEN(2); ++j; UDM_WS_ODD(3); ++j; UDM_WS_EVEN(4); ++j; UDM_WS_ODD(5); ++j;
     }
@@ -292,9 +309,9 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_ws_kernel(AttnArgs a) {
 #undef UDM_WS_EVEN
 #undef UDM_WS_ODD
     // j = nsub-1: Y only;  j = nsub: barrier only
-    if (j & 1) score_step<TIMELINE, -1, false, true>(x, smem, j, kf, vf, sA, dpA, sB, dpB);
-    else score_step<TIMELINE, -1, false, true>(x, smem, j, kf, vf, sB, dpB, sA, dpA);
-    score_step<TIMELINE, -1, false, false>(x, smem, j + 1, kf, vf, sA, dpA, sB, dpB);
+    if (j & 1) score_step<TIMELINE, -1, false, true, PRE>(x, smem, j, kf, vf, sA, dpA, sB, dpB);
+    else score_step<TIMELINE, -1, false, true, PRE>(x, smem, j, kf, vf, sB, dpB, sA, dpA);
+    score_step<TIMELINE, -1, false, false, PRE>(x, smem, j + 1, kf, vf, sA, dpA, sB, dpB);
   } else {
     f32x16_t dkT[DB], dvT[DB];
 #pragma unroll
@@ -377,6 +394,13 @@ void udm_launch_attn_bwd_dkv_ws(const void* args, hipStream_t stream) {
       (void)hipFree(buf);
       return;
     }
+  }
+  static const int pre_on = [] { const char* e = getenv("UDM_DKV_PRE"); return e ? atoi(e) : 1; }();   // A/B switch: 0 = the plain arithmetic also for pre-scaled q
+  if (a.q_prescaled && pre_on) {   // the engine's form: score chains start from -lse / -delta (see score_step)
+    static bool once_p = false;
+    if (!once_p) { (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_ws_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES); once_p = true; }
+    hipLaunchKernelGGL((attn_bwd_dkv_ws_kernel<false, true>), grid, dim3(512), LDS_BYTES, stream, a);
+    return;
   }
   hipLaunchKernelGGL(attn_bwd_dkv_ws_kernel<false>, grid, dim3(512), LDS_BYTES, stream, a);
 }

@@ -714,7 +714,7 @@ def attention_fwd(qkr, qkv, B, L, H, D, sample_ids=None, doc_ranges=None, q_pres
 def attention_bwd(qkr, qkv, o, do, lse, dqkr, dqkv, B, L, H, D, sample_ids=None, doc_ranges=None, q_prescaled=False):
     """Writes dq|dk (wrt the stored rotated q, k) into dqkr [M,2d] and dv into dqkv[:, 2d:3d]."""
     d = H * D
-    delta = torch.empty((B, H, L), dtype=F32, device=qkr.device)
+    delta = torch.empty((3, B, H, L), dtype=F32, device=qkr.device)   # delta | -lse | -delta (include/unidisc_hip.h)
     q_ptr, k_ptr, v_ptr = qkr.data_ptr(), qkr.data_ptr() + 2 * d, qkv.data_ptr() + 4 * d
     dq_ptr, dk_ptr, dv_ptr = dqkr.data_ptr(), dqkr.data_ptr() + 2 * d, dqkv.data_ptr() + 4 * d
     _lib.call("udm_attention_bwd", q_ptr, k_ptr, v_ptr, _p(o), _p(do), _p(lse), _p(delta), dq_ptr, dk_ptr, dv_ptr, _p(sample_ids), _p(doc_ranges), B, H, L, D, 2 * d,
@@ -733,7 +733,7 @@ def attention_fwd_generic(q, k, v, B, L, H, D, sample_ids=None, doc_ranges=None,
 def attention_bwd_generic(q, k, v, o, do, lse, B, L, H, D, sample_ids=None, doc_ranges=None, q_prescaled=False):
     d = H * D
     dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
-    delta = torch.empty((B, H, L), dtype=F32, device=q.device)
+    delta = torch.empty((3, B, H, L), dtype=F32, device=q.device)
     _lib.call("udm_attention_bwd", _p(q), _p(k), _p(v), _p(o), _p(do), _p(lse), _p(delta), _p(dq), _p(dk), _p(dv), _p(sample_ids), _p(doc_ranges), B, H, L, D, d, d, d, d,
               d, d, d, d, 1 if q_prescaled else 0, _s())
     return dq, dk, dv
