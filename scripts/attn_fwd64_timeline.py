@@ -1,5 +1,5 @@
 """Cycle timeline of the persistent 64-queries-per-wave attention forward (library built with `make -C unidisc_amd/csrc UDM_FWD64_ABL=16`):
-stamps of the LAST block every workgroup processed (s_memtime; index map in csrc/asmgen/attn_fwd64.py::stamp call sites)."""
+stamps of the LAST unit (whole or half block) every workgroup processed, indexed by workgroup (s_memtime; index map in csrc/asmgen/attn_fwd64.py::stamp call sites)."""
 import json, os, sys
 import numpy as np
 import torch
@@ -14,7 +14,8 @@ qkr[:, :d] *= K.attention_q_scale(D)
 qkr = qkr.to(torch.bfloat16)
 qkv = torch.randn(M, 3 * d, device="cuda", generator=g).to(torch.bfloat16)
 nblk = B * H * (L // 256)
-tl = torch.zeros(nblk, 4, 64, dtype=torch.int32, device="cuda")
+grid = min(nblk, torch.cuda.get_device_properties(0).multi_processor_count // 8 * 8)
+tl = torch.zeros(grid, 4, 64, dtype=torch.int32, device="cuda")
 for _ in range(3):
     K.attention_fwd(qkr, qkv, B, L, H, D, q_prescaled=True)
 torch.cuda.synchronize()
@@ -26,14 +27,14 @@ t = tl.cpu().numpy().astype(np.int64) & 0xFFFFFFFF
 names = {0: "entry", 1: "entry:issued", 2: "entry:drained", 3: "blk:start", 4: "blk:waited", 5: "blk:K0frags", 6: "blk:ready", 40: "epi:start", 41: "epi:end", 42: "done"}
 for tag in range(8):
     names[8 + 3 * tag], names[9 + 3 * tag], names[10 + 3 * tag] = f"t{tag}:top", f"t{tag}:A", f"t{tag}:B"
-for last_bid in (nblk - 1, nblk - 3, 300, 256 + 5):   # workgroups that ended on these blocks (3 blocks: ids >= 512; 2 blocks: 256..511)
+for last_bid in (0, 5, grid // 2 + 3, grid - 1):   # workgroup ids
     for wave in (0, 3):
         row = t[last_bid, wave]
         if row[0] == 0:
             continue
-        order = sorted((int(row[i]), names.get(i, str(i))) for i in range(64) if row[i])
+        order = sorted((int(row[i]), names.get(i, str(i))) for i in range(62) if row[i])
         t0 = order[0][0]
-        print(f"last block {last_bid} wave {wave}: total {order[-1][0] - t0} cycles")
+        print(f"workgroup {last_bid} wave {wave}: total {order[-1][0] - t0} cycles")
         prev = t0
         line = []
         for c, n in order:

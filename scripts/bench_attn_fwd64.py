@@ -34,10 +34,10 @@ def timed(flag, cold, n=20):
 
 res = {}
 for rnd in range(3):
-    for flag in (True, False):
+    for flag in (1, 2, 0):
         for cold in (False, True):
             med, mn = timed(flag, cold)
-            res.setdefault(("fwd64" if flag else "8wave") + ("_cold" if cold else "_warm"), []).append((round(med, 1), round(mn, 1)))
+            res.setdefault({1: "fwd64", 2: "fwd64_whole_blocks", 0: "8wave"}[flag] + ("_cold" if cold else "_warm"), []).append((round(med, 1), round(mn, 1)))
 K.set_attention_fwd64(True)
 out = {k: dict(median_us=v, tf=round(fl / (min(x[0] for x in v) * 1e-6) / 1e12, 1)) for k, v in res.items()}
 print(json.dumps(out))

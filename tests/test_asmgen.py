@@ -30,8 +30,11 @@ def test_hazard_lint_is_clean(gen):
 
 
 @pytest.mark.parametrize("mode", ["late", "early"])
-@pytest.mark.parametrize("kw", [dict(B=1, H=8, L=512, grid=8, wg_id=0), dict(B=1, H=8, L=1024, grid=8, wg_id=3), dict(B=2, H=4, L=512, grid=8, wg_id=1, spike=True)],
-                         ids=["two_blocks", "four_blocks_three_trips", "rescale_path"])
+@pytest.mark.parametrize("kw", [dict(B=1, H=8, L=512, grid=8, wg_id=0), dict(B=1, H=8, L=1024, grid=8, wg_id=3), dict(B=2, H=4, L=512, grid=8, wg_id=1, spike=True),
+                                # the balanced walk (24 blocks on 16 workgroups: one whole block, then half (wg >> 3) & 1 of block 16 + (wg & 7)): both halves, the
+                                # rescale path inside a half block (workgroup 11 ends with rows 640..767 of head 3)
+                                dict(B=1, H=8, L=768, grid=16, wg_id=2), dict(B=1, H=8, L=768, grid=16, wg_id=11), dict(B=1, H=8, L=768, grid=16, wg_id=11, spike=True, spike_at=(3, 700, 650))],
+                         ids=["two_blocks", "four_blocks_three_trips", "rescale_path", "half_block_first_half", "half_block_second_half", "half_block_rescale"])
 def test_emulated_workgroup_matches_float64_attention(gen, kw, mode):
     _, e, prog = gen
     r = e.run(mode=mode, prog=prog, seed=11, **kw)

@@ -43,6 +43,20 @@ LDS_K0, LDS_V0 = 0, NST * K_TILE
 LDS_BYTES = LDS_V0 + NST * V_TILE
 WAVE_OUT = 16384     # epilogue staging per wave (inside the K ring)
 
+NQ = 2        # 32-query blocks per wave of the program being generated: 2 (256-query blocks) or 1 (the 128-query half blocks that balance the walk)
+SUF = ""      # label suffix of that program
+
+
+def nm():
+    """MFMAs per phase"""
+    return 16 * NQ
+
+
+def G(x):
+    """a gap index written for the 32-MFMA phases of the full program, scaled to this program's phase length"""
+    return -1 if x < 0 else min(nm() - 1, x * nm() // 32)
+
+
 V = Alloc("v", 0, 255)     # v255 is left to the compiler (the thread-id operand)
 A = Alloc("a", 0, 256)
 S_ = Alloc("s", 36, 100)
@@ -67,8 +81,8 @@ Ka = A("K", 64)
 # inputs (copied from the asm statement's operands, in this order)
 s_qb, s_kb, s_vb, s_ob, s_lseb = S_("qb", 2, 2), S_("kb", 2, 2), S_("vb", 2, 2), S_("ob", 2, 2), S_("lseb", 2, 2)
 s_qstr, s_kstr, s_vstr, s_ostr = S_("qstr"), S_("kstr"), S_("vstr"), S_("ostr")
-s_L, s_nkv, s_H, s_nt, s_mg_nt, s_mg_H, s_nblk, s_lds, s_bid, s_gstride = (S_(n) for n in ("L", "nkv", "H", "nt", "mg_nt", "mg_H", "nblk", "lds", "bid", "gstride"))
-INPUTS = ["qb", "kb", "vb", "ob", "lseb", "qstr", "kstr", "vstr", "ostr", "L", "nkv", "H", "nt", "mg_nt", "mg_H", "nblk", "lds", "bid", "gstride", "tid", "tl"]
+s_L, s_nkv, s_H, s_nt, s_mg_nt, s_mg_H, s_nfull, s_hashalf, s_lds, s_bid, s_gstride = (S_(n) for n in ("L", "nkv", "H", "nt", "mg_nt", "mg_H", "nfull", "hashalf", "lds", "bid", "gstride"))
+INPUTS = ["qb", "kb", "vb", "ob", "lseb", "qstr", "kstr", "vstr", "ostr", "L", "nkv", "H", "nt", "mg_nt", "mg_H", "nfull", "hashalf", "lds", "bid", "gstride", "tid", "tl"]
 # working
 s_wave = S_("wave")
 s_kt, s_vt = S_("kt", 2, 2), S_("vt", 2, 2)       # running tile bases of the refills
@@ -79,9 +93,13 @@ s_flag = [S_("flag0")]
 s_loop, s_ret = S_("loop"), S_("ret")
 s_t = [S_(f"t{i}") for i in range(6)]
 s_t0, s_t1 = s_t[0], s_t[1]
-s_o, s_lse = S_("o", 2, 2), S_("lse", 2, 2)                      # current block's outputs
-s_qn, s_kn, s_vn, s_on, s_lsen = S_("qn", 2, 2), S_("kn", 2, 2), S_("vn", 2, 2), S_("on", 2, 2), S_("lsen", 2, 2)   # next block
+s_qn, s_kn, s_vn = S_("qn", 2, 2), S_("kn", 2, 2), S_("vn", 2, 2)   # next block's operands (the current block's output pointers are recomputed in its epilogue)
 s_relax, s_nbid = S_("relax"), S_("nbid")
+# the walk: blocks bid, bid + grid, ... below `nfull` are whole 256-query blocks; when the remainder is exactly half a grid every workgroup finishes with ONE
+# 128-query half (see next_block_ptrs) - 640 blocks on 256 CUs are 2.5 per workgroup instead of 3 for half of them and 2 for the rest
+s_wg, s_hidx, s_hidxn, s_mode, s_moden, s_wqn = (S_(n) for n in ("wg", "hidx", "hidxn", "mode", "moden", "wqn"))
+s_o, s_lse = s_dec[0], s_dec[1]      # the epilogue's output pointers live in the decision's SGPR pairs (idle from the block's last tile on)
+s_tm = S_("tm", 2, 2)                # timeline builds: s_memtime lands here
 v_tl = R("v", 254)             # timeline builds only (ABL & 16): cycle stamps of this wave in lanes 0..61, the output pointer in lanes 62, 63
 
 
@@ -89,7 +107,7 @@ def stamp(idx):
     """timeline builds: s_memtime at a point where lgkmcnt is drained anyway -> lane idx of v_tl"""
     if not (ABL & 16):
         return []
-    return [s_memtime(s_dec[1]), s_waitcnt(lgkmcnt=0), v_writelane_b32(v_tl, s_dec[1][0], idx)]   # (the decision's SGPR pair is idle at every stamp)
+    return [s_memtime(s_tm), s_waitcnt(lgkmcnt=0), v_writelane_b32(v_tl, s_tm[0], idx)]
 
 LDS_STG = LDS_BYTES            # O staging: 4 KiB per wave behind the rings
 LDS_TOTAL = LDS_BYTES + 4 * 4096
@@ -161,7 +179,7 @@ def score_mfmas(buf):
     out = []
     for f in range(2):
         for ks in range(KS):
-            for q in range(2):
+            for q in range(NQ):
                 d = Sblk(buf, q, f)
                 out.append(v_mfma_f32_32x32x16_bf16(d, Kfr(f, ks), Qfr(q, ks), negm[q] if ks == 0 else d))
     return out
@@ -171,7 +189,7 @@ def pv_mfmas(buf):
     out = []
     for cc in range(4):
         for i in range(4):
-            for q in range(2):
+            for q in range(NQ):
                 out.append(v_mfma_f32_32x32x16_bf16(Oblk(q, i), Vfr(cc, i), Pfr(buf, q, cc), Oblk(q, i)))
     return out
 
@@ -182,7 +200,7 @@ def max_ops(buf):
     out = []
     for f in range(2):
         chains = []
-        for q in range(2):
+        for q in range(NQ):
             s = Sblk(buf, q, f)
             ops = []
             if f == 0:
@@ -195,19 +213,20 @@ def max_ops(buf):
                 y = rest.pop(0) if rest else x
                 ops.append(v_max3_f32(mx[q], mx[q], s[x], s[y]))
             chains.append(ops)
-        for x, y in zip(*chains):
-            out += [x, y]
+        for ops in zip(*chains):
+            out += list(ops)
     return out
 
 
 def decide_ops(tag):
     """cross-half maximum of the accumulators (= s - mc); the reference exponent moves iff some lane of the wave saw more than 2^8 above it (attention.hip's rule)"""
     out = []
-    out += [v_mov_b32(ta[0], mx[0]), v_mov_b32(tb[0], mx[0]), v_mov_b32(ta[1], mx[1]), v_mov_b32(tb[1], mx[1])]
-    out += [s_nop(0), v_permlane32_swap_b32(ta[0], tb[0]), v_permlane32_swap_b32(ta[1], tb[1])]
-    out += [v_max_f32(ta[0], ta[0], tb[0]), v_max_f32(ta[1], ta[1], tb[1])]
-    out += [v_cmp_gt_f32(s_dec[0], ta[0], eight), v_cmp_gt_f32(s_dec[1], ta[1], eight)]
-    out += [s_or_b64(s_dec[0], s_dec[0], s_dec[1])]          # SCC = some lane moves
+    for q in range(NQ):
+        out += [v_mov_b32(ta[q], mx[q]), v_mov_b32(tb[q], mx[q])]
+    out += [s_nop(1 if NQ == 1 else 0)] + [v_permlane32_swap_b32(ta[q], tb[q]) for q in range(NQ)]
+    out += [v_max_f32(ta[q], ta[q], tb[q]) for q in range(NQ)]
+    out += [v_cmp_gt_f32(s_dec[q], ta[q], eight) for q in range(NQ)]
+    out += [s_or_b64(s_dec[0], s_dec[0], s_dec[NQ - 1])]          # SCC = some lane moves
     out += [s_cbranch_scc1(f"L_move_{tag}"), label(f"L_moved_{tag}")]
     return out
 
@@ -218,17 +237,17 @@ def move_block(tag, buf, set_flag=True):
     phase (P(t), still being accumulated, is relative to the OLD exponent).  set_flag = False: the block's first tile (O^T = 0, l = 0)."""
     out = [label(f"L_move_{tag}"), s_nop(1)]
     d = [tmp[0], tmp[1]]
-    for q in range(2):
+    for q in range(NQ):
         out += [v_max_f32(d[q], 0, ta[q])]
-    for q in range(2):
+    for q in range(NQ):
         out += [v_sub_f32(tmp[2 + q], 0, d[q])]
-    for q in range(2):
+    for q in range(NQ):
         out += [v_exp_f32(alpha[q], tmp[2 + q])]
-    for q in range(2):
+    for q in range(NQ):
         out += [v_add_f32(mc[q], mc[q], d[q])]
-    for q in range(2):
+    for q in range(NQ):
         out += [v_mul_f32(ls[q][0], ls[q][0], alpha[q]), v_mul_f32(ls[q][1], ls[q][1], alpha[q]), v_sub_f32(tmp[2 + q], 0, mc[q])]
-    for q in range(2):
+    for q in range(NQ):
         for r in range(16):
             out += [v_mov_b32(negm[q][r], tmp[2 + q])]
         for f in range(2):
@@ -244,7 +263,7 @@ def move_block(tag, buf, set_flag=True):
 def rescale_o_block():
     """out of line, shared: O^T *= alpha (accumulators live in AGPRs: read, multiply, write back); returns through s_ret"""
     out = [label("L_rescale"), s_nop(15), s_nop(15)]
-    for q in range(2):
+    for q in range(NQ):
         for base in range(0, 64, 4):
             regs = [Oacc.sub(q * 64 + base + e, 1) for e in range(4)]
             out += [v_accvgpr_read_b32(tmp[e], regs[e]) for e in range(4)]
@@ -267,8 +286,14 @@ def softmax_group(buf, q, cc):
     return out
 
 
-GROUPS = [(q, cc) for cc in range(4) for q in range(2)]   # in the order the PV MFMAs need P
-N_EARLY = 3                                              # groups of softmax(t+1) done in phase B(t); the rest in phase A(t+1)
+def groups():
+    """softmax groups of a tile in the order the PV MFMAs need their P"""
+    return [(q, cc) for cc in range(4) for q in range(NQ)]
+
+
+def n_early():
+    """groups of softmax(t+1) done in phase B(t); the rest in phase A(t+1)"""
+    return 3 if NQ == 2 else 2
 
 
 CAP = 5.5          # issue budget behind one MFMA (single-issue slots of ~4 cycles under its 32; MI355X_MICROARCH.md: <= 5 hidden per gap)
@@ -353,10 +378,11 @@ def body(j, variant, tag, vm_wait):
 
 def q_loads(src, scratch):
     """the 16 Q fragments of the block at `src` (its first query row, head offset applied) -> Qf.  lane (query l31 of block q, half hi) reads 16 bytes
-    per k-step at (wave * 64 + q * 32 + l31) * qstr + hi * 16 + ks * 32; scratch: 4 free VGPRs"""
+    per k-step at (wave * W + q * 32 + l31) * qstr + hi * 16 + ks * 32, W = s_wqn = 64 rows per wave (32 for a half block: its q = 1 fragments
+    re-read the q = 0 rows and are never used); scratch: 4 free VGPRs"""
     t = scratch
     p = v_mbcnt_lane_id(t[0])
-    p += [v_and_b32(t[1], 31, t[0]), v_lshrrev_b32(t[2], 5, t[0]), s_lshl_b32(s_t[4], s_wave, 6), s_lshl_b32(s_t[5], s_qstr, 5)]
+    p += [v_and_b32(t[1], 31, t[0]), v_lshrrev_b32(t[2], 5, t[0]), s_mul_i32(s_t[4], s_wave, s_wqn), s_sub_u32(s_t[5], s_wqn, 32), s_mul_i32(s_t[5], s_t[5], s_qstr)]
     p += [v_add_u32(t[1], s_t[4], t[1]), v_lshlrev_b32(t[2], 4, t[2]), v_mul_lo_u32(t[1], t[1], s_qstr)]
     p += [v_add_u32(t[0], t[1], t[2]), s_nop(0), v_add_u32(t[3], s_t[5], t[0])]
     loads = [global_load_dwordx4(Qfr(q, ks), t[0] if q == 0 else t[3], src, ks * 32) for q in range(2) for ks in range(KS)]
@@ -388,37 +414,39 @@ def _body(j, variant, tag, vm_wait):
     else:
         wait_bar = [s_waitcnt(vmcnt=vm_wait), s_barrier()]
     fin = []
-    for (q, cc) in GROUPS[N_EARLY:]:
+    for (q, cc) in groups()[n_early():]:
         fin += softmax_group(cur, q, cc)
     vr = v_reads(j)
     if not last:
-        a, ca = spread(score_mfmas(nxt), [(wait_bar, 1, 1), (vr, 2, 28), (fin, -1, 31)], "phase A")
+        a, ca = spread(score_mfmas(nxt), [(wait_bar, G(1), G(1)), (vr, G(1) + 1, G(28)), (fin, -1, G(31))], "phase A")
     else:
-        a, ca = [comment("phase A (last tile: no scores)")] + fin[:16] + wait_bar + vr + fin[16:], []
+        a, ca = [comment("phase A (last tile: no scores)")] + fin[:8 * NQ] + wait_bar + vr + fin[8 * NQ:], []
     prog += a
     prog += [s_waitcnt(lgkmcnt=0)] + stamp(9 + 3 * tag)
     # ---------------- phase B
     streams = []
     if variant in ("main", "tail0", "tail1"):
-        streams.append((k_reads((j + 2) % 4), -1, 20))
+        streams.append((k_reads((j + 2) % 4), -1, G(20)))
     dma = dma_k(j) + dma_v((j + 3) % 4)
-    streams.append((dma, 1, 14 if variant == "tail2" else 31))
+    streams.append((dma, G(1), G(14) if variant == "tail2" else G(31)))
     # the next block's Q fragments: a load instruction touches 32 rows (64 cache lines) - sixteen of them back to back stalled the issue for 3.2 k cycles
     # (timeline), so they go out one per four MFMAs over the last two PV phases.  Offsets live in two registers of the S buffer whose tile is finished.
-    if variant == "tail2":
-        qa, ql = q_loads(s_qn, [Sbuf[cur][i] for i in range(4)])
-        streams.append((qa + ql[:8], 15, 31))
+    if variant == "tail2":     # (registers 60..63 of an S buffer never hold P: stale exponentials of a finished tile)
+        qa, ql = q_loads(s_qn, [Sbuf[cur][60 + i] for i in range(4)])
+        streams.append((qa + ql[:8], G(15), G(31)))
     if variant == "tail3":
-        _, ql = q_loads(s_qn, [Sbuf[nxt][i] for i in range(4)])      # (tail2's S buffer = this tile's `nxt`: never written in the last tile)
-        streams.append((ql[8:], 4, 31))
+        _, ql = q_loads(s_qn, [Sbuf[nxt][60 + i] for i in range(4)])      # (tail2's S buffer = this tile's `nxt`: never written in the last tile)
+        streams.append((ql[8:], G(4), G(31)))
+        streams.append((block_ptrs(s_bid, s_hidx if NQ == 1 else 0, o=s_o, lse=s_lse), G(1), G(31)))     # (no decision in the last tile: its SGPR pairs are free)
     if not last:
         soft = max_ops(nxt) + decide_ops(tag)
         early = []
-        for (q, cc) in GROUPS[:N_EARLY]:
+        for (q, cc) in groups()[:n_early()]:
             early += softmax_group(nxt, q, cc)
-        streams.append((soft, 1, 14))       # (the f = 0 halves of S(t+1) were finished half a phase ago; the f = 1 maxima come 16 ops later)
-        streams.append((early, 15, 31))
-    b, cb = spread(pv_mfmas(cur), streams, "phase B")
+        streams.append((soft, G(1), G(14)))       # (the f = 0 halves of S(t+1) were finished half a phase ago; the f = 1 maxima come 16 ops later)
+        streams.append((early, G(14) + 1, G(31)))
+    # (a half block has the same fragment reads, refills and half the softmax behind half the MFMAs: its PV phase is issue bound, spread evenly)
+    b, cb = spread(pv_mfmas(cur), streams, "phase B", cap=None if NQ == 2 else 8.5)
     prog += b
     if not last:
         prog += [s_waitcnt(lgkmcnt=0)] + stamp(10 + 3 * tag)
@@ -426,35 +454,51 @@ def _body(j, variant, tag, vm_wait):
     return prog, ca, cb
 
 
-def block_ptrs(bid, q, k, v, o, lse):
-    """block id -> (batch, head, query tile) -> the block's pointers (SALU only).  Needs (B H) % 8 == 0 (launcher)."""
+def block_ptrs(bid, hidx, q=None, k=None, v=None, o=None, lse=None):
+    """block id (+ 128-row half index: an SGPR, or 0) -> (batch, head, first query row) -> the pointers asked for (SALU only).  Needs (B H) % 8 == 0."""
     t0, t1, t2, t3 = s_t[0], s_t[1], s_t[2], s_t[3]
     p = [s_lshr_b32(t0, bid, 3), s_and_b32(t1, bid, 7), s_mul_hi_u32(t2, t0, s_mg_nt), s_mul_i32(t3, t2, s_nt), s_sub_u32(t0, t0, t3),   # t0 = tile
          s_lshl_b32(t2, t2, 3), s_add_u32(t2, t2, t1),                                                                                    # t2 = b H + h
          s_mul_hi_u32(t1, t2, s_mg_H), s_mul_i32(t3, t1, s_H), s_sub_u32(t3, t2, t3), s_lshl_b32(t3, t3, 8),                              # t1 = b, t3 = h * 256 bytes
          s_mul_i32(t1, t1, s_L), s_lshl_b32(t0, t0, 8)]                                                                                   # t1 = b L, t0 = tile * 256
+    if not (isinstance(hidx, int) and hidx == 0):
+        p += [s_lshl_b32(s_t[5], hidx, 7), s_add_u32(t0, t0, s_t[5])]                                                                     # + half * 128 rows
     for dst, base, stride in ((k, s_kb, s_kstr), (v, s_vb, s_vstr)):
-        p += [s_mul_i32(dst[0], t1, stride), s_mul_hi_u32(dst[1], t1, stride), s_add_u32(dst[0], dst[0], t3), s_addc_u32(dst[1], dst[1], 0),
-              s_add_u32(dst[0], dst[0], base[0]), s_addc_u32(dst[1], dst[1], base[1])]
-    p += [s_mul_i32(t2, t2, s_L), s_add_u32(t2, t2, t0), s_lshl_b32(t2, t2, 2), s_add_u32(lse[0], s_lseb[0], t2), s_addc_u32(lse[1], s_lseb[1], 0)]
+        if dst is not None:
+            p += [s_mul_i32(dst[0], t1, stride), s_mul_hi_u32(dst[1], t1, stride), s_add_u32(dst[0], dst[0], t3), s_addc_u32(dst[1], dst[1], 0),
+                  s_add_u32(dst[0], dst[0], base[0]), s_addc_u32(dst[1], dst[1], base[1])]
+    if lse is not None:
+        p += [s_mul_i32(t2, t2, s_L), s_add_u32(t2, t2, t0), s_lshl_b32(t2, t2, 2), s_add_u32(lse[0], s_lseb[0], t2), s_addc_u32(lse[1], s_lseb[1], 0)]
     p += [s_add_u32(t1, t1, t0)]
     for dst, base, stride in ((q, s_qb, s_qstr), (o, s_ob, s_ostr)):
-        p += [s_mul_i32(dst[0], t1, stride), s_mul_hi_u32(dst[1], t1, stride), s_add_u32(dst[0], dst[0], t3), s_addc_u32(dst[1], dst[1], 0),
-              s_add_u32(dst[0], dst[0], base[0]), s_addc_u32(dst[1], dst[1], base[1])]
+        if dst is not None:
+            p += [s_mul_i32(dst[0], t1, stride), s_mul_hi_u32(dst[1], t1, stride), s_add_u32(dst[0], dst[0], t3), s_addc_u32(dst[1], dst[1], 0),
+                  s_add_u32(dst[0], dst[0], base[0]), s_addc_u32(dst[1], dst[1], base[1])]
     return p
 
 
 def next_block_ptrs():
-    """s_nbid = the block after s_bid, or s_bid itself when there is none (its prefetches then re-read valid memory and are never used)"""
-    return [s_add_u32(s_nbid, s_bid, s_gstride), s_cmp_lt_u32(s_nbid, s_nblk), s_cbranch_scc1("L_has_next_%d" % next_block_ptrs.n), s_mov_b32(s_t[4], s_bid),
-            s_branch("L_np_%d" % next_block_ptrs.n), label("L_has_next_%d" % next_block_ptrs.n), s_mov_b32(s_t[4], s_nbid), label("L_np_%d" % next_block_ptrs.n)] + \
-        block_ptrs(s_t[4], s_qn, s_kn, s_vn, s_on, s_lsen)
+    """What this workgroup does after the current block (s_moden: 0 = a whole block, 1 = its 128-query half, 2 = nothing) and that block's operand pointers - the
+    current block's own when there is none (its prefetches then re-read valid memory and are never used)."""
+    p = []
+    if NQ == 1:     # a half block is always the last thing a workgroup does
+        p += [s_mov_b32(s_moden, 2), s_mov_b32(s_nbid, s_bid), s_mov_b32(s_hidxn, s_hidx), s_mov_b32(s_wqn, 32)]
+    else:
+        p += [s_mov_b32(s_hidxn, 0), s_mov_b32(s_wqn, 64), s_mov_b32(s_moden, 0),
+              s_add_u32(s_nbid, s_bid, s_gstride), s_cmp_lt_u32(s_nbid, s_nfull), s_cbranch_scc1("L_np"),
+              s_mov_b32(s_moden, 2), s_mov_b32(s_nbid, s_bid), s_cmp_eq_u32(s_hashalf, 0), s_cbranch_scc1("L_np"),
+              # workgroup 8 a + x (x = its XCD) takes half a & 1 of block nfull + 8 (a >> 1) + x: the block id stays congruent to the XCD, whose L2 then holds its K / V
+              s_mov_b32(s_moden, 1), s_mov_b32(s_wqn, 32), s_lshr_b32(s_nbid, s_wg, 4), s_lshl_b32(s_nbid, s_nbid, 3), s_and_b32(s_t[0], s_wg, 7), s_add_u32(s_nbid, s_nbid, s_t[0]),
+              s_add_u32(s_nbid, s_nbid, s_nfull), s_lshr_b32(s_hidxn, s_wg, 3), s_and_b32(s_hidxn, s_hidxn, 1),
+              label("L_np")]
+    return p + block_ptrs(s_nbid, s_hidxn, q=s_qn, k=s_kn, v=s_vn)
 
 
 def entry():
     p = [comment("---- entry: constants of the wave, first block's loads")]
     raw = lambda t: Inst(t, "raw")
-    regs = [s_qb, s_kb, s_vb, s_ob, s_lseb, s_qstr, s_kstr, s_vstr, s_ostr, s_L, s_nkv, s_H, s_nt, s_mg_nt, s_mg_H, s_nblk, s_lds, s_bid, s_gstride]
+    regs = [s_qb, s_kb, s_vb, s_ob, s_lseb, s_qstr, s_kstr, s_vstr, s_ostr, s_L, s_nkv, s_H, s_nt, s_mg_nt, s_mg_H, s_nfull, s_hashalf, s_lds, s_bid, s_gstride]
+    assert [S_.names[n] for n in INPUTS[:-2]] == regs
     for i, r in enumerate(regs):
         p += [raw(f"s_mov_b{64 if r.n == 2 else 32} {r}, %{i}")]
     tid = tmp[0]
@@ -489,9 +533,10 @@ def entry():
     p += [v_lshlrev_b32(t[3], 10, hi), v_and_b32(t[4], 15, lane_v), v_lshrrev_b32(t[4], 2, t[4]), v_lshlrev_b32(t[4], 6, t[4]), v_add_u32(t[3], t[3], t[4]),
           v_lshrrev_b32(t[4], 4, lane_v), v_and_b32(t[4], 1, t[4]), v_lshlrev_b32(t[4], 5, t[4]), v_add_u32(t[3], t[3], t[4]),
           v_and_b32(t[4], 3, lane_v), v_lshlrev_b32(t[4], 3, t[4]), v_add_u32(t[3], t[3], t[4]), v_add_u32(t[3], s_lds, t[3]), v_add_u32(vaddr, LDS_V0, t[3])]
-    p += [s_mov_b32(s_flag[0], 0), s_mov_b32(s_relax, 0), v_mov_b32(eight, 8.0)]
-    # ---- first block: its pointers, Q, and the ring as if its tiles -4 .. -1 had run: K0, K1, V0, K2, V1, K3, V2
-    p += block_ptrs(s_bid, s_qn, s_kt, s_vt, s_o, s_lse)
+    p += [s_mov_b32(s_flag[0], 0), s_mov_b32(s_relax, 0), v_mov_b32(eight, 8.0), s_mov_b32(s_wg, s_bid), s_mov_b32(s_hidx, 0), s_mov_b32(s_wqn, 64)]
+    # ---- first block (always a whole one: the launcher balances with halves only behind at least one whole block per workgroup): its pointers, Q, and the ring
+    #      as if its tiles -4 .. -1 had run: K0, K1, V0, K2, V1, K3, V2
+    p += block_ptrs(s_bid, 0, q=s_qn, k=s_kt, v=s_vt)
     if ABL & 32:   # debug: dump the first block's scalars into the LSE tensor (lane i of wave 0 stores SGPR 36 + i) and stop
         dump = v_mbcnt_lane_id(t[0])
         dump += [v_lshlrev_b32(t[1], 2, t[0]), s_lshl_b32(s_t0, s_bid, 8), s_nop(0), v_add_u32(t[1], s_t0, t[1]), v_mov_b32(t[2], 0), s_nop(1)]
@@ -515,18 +560,19 @@ def block_start():
     # the seam's loads have landed - the last Q loads are the youngest of them - only the previous block's 18 stores may still fly; fresh block: nothing does
     p += [s_cmp_eq_u32(s_relax, 1), s_cbranch_scc0("L_bs_fresh"), s_waitcnt(vmcnt=18), label("L_bs_fresh")] + stamp(4) + [s_barrier()]
     p += k_reads(0) + [s_waitcnt(lgkmcnt=0)] + stamp(5)
-    for q in range(2):
+    for q in range(NQ):
         p += [v_mov_b32(mc[q], 0)] + [v_mov_b32(negm[q][r], 0) for r in range(16)]
-    zero = [v_accvgpr_write_b32(Oacc[r], 0) for r in range(128)]
-    for q in range(2):
+    p += [s_nop(1)]
+    zero = [v_accvgpr_write_b32(Oacc[r], 0) for r in range(64 * NQ)]
+    for q in range(NQ):
         zero += [v_mov_b32(ls[q][0], 0), v_mov_b32(ls[q][1], 0)]
-    sm, _ = spread(score_mfmas(0), [(zero, 0, 31)], "S(0)")
+    sm, _ = spread(score_mfmas(0), [(zero, 0, nm() - 1)], "S(0)")
     p += sm
     p += k_reads(1)
     p += [s_nop(7)]
     # first reference exponent: the common decision with mc = 0 (scores within 2^8 of zero keep it there); nothing to rescale yet
     p += max_ops(0) + decide_ops(7)
-    for (q, cc) in GROUPS[:N_EARLY]:
+    for (q, cc) in groups()[:n_early()]:
         p += softmax_group(0, q, cc)
     p += [s_waitcnt(lgkmcnt=0)] + stamp(6)
     # trips of the four steady-state bodies: nkv / 4 - 1 (>= 1: the launcher takes L >= 512)
@@ -541,18 +587,19 @@ def epilogue():
     t = tmp
     e += [s_nop(15)]    # the last PV MFMAs have written O^T
     inv = [alpha[0], alpha[1]]
-    for q in range(2):
+    for q in range(NQ):
         e += [v_add_f32(ls[q][0], ls[q][0], ls[q][1])]
-    e += [v_mov_b32(ta[0], ls[0][0]), v_mov_b32(tb[0], ls[0][0]), v_mov_b32(ta[1], ls[1][0]), v_mov_b32(tb[1], ls[1][0])]
-    e += [s_nop(1), v_permlane32_swap_b32(ta[0], tb[0]), v_permlane32_swap_b32(ta[1], tb[1])]
-    e += [v_add_f32(ta[0], ta[0], tb[0]), v_add_f32(ta[1], ta[1], tb[1]), s_nop(0)]
-    e += [v_rcp_f32(inv[0], ta[0]), v_rcp_f32(inv[1], ta[1]), v_log_f32(tb[0], ta[0]), v_log_f32(tb[1], ta[1]), s_nop(0)]
-    e += [v_add_f32(tb[0], mc[0], tb[0]), v_add_f32(tb[1], mc[1], tb[1])]
+    for q in range(NQ):
+        e += [v_mov_b32(ta[q], ls[q][0]), v_mov_b32(tb[q], ls[q][0])]
+    e += [s_nop(1)] + [v_permlane32_swap_b32(ta[q], tb[q]) for q in range(NQ)]
+    e += [v_add_f32(ta[q], ta[q], tb[q]) for q in range(NQ)] + [s_nop(0)]
+    e += [v_rcp_f32(inv[q], ta[q]) for q in range(NQ)] + [v_log_f32(tb[q], ta[q]) for q in range(NQ)] + [s_nop(0)]
+    e += [v_add_f32(tb[q], mc[q], tb[q]) for q in range(NQ)]
     lane_v, l31, hi = mx[0], mx[1], ta[0]
     e += v_mbcnt_lane_id(lane_v)
     e += [v_and_b32(l31, 31, lane_v), v_lshrrev_b32(hi, 5, lane_v)]
-    e += [s_lshl_b32(s_t0, s_wave, 6), s_nop(0), v_add_u32(t[0], s_t0, l31), v_lshlrev_b32(t[0], 2, t[0])]
-    e += [global_store_dword(t[0], tb[0], s_lse, 0), global_store_dword(t[0], tb[1], s_lse, 128)]
+    e += [s_lshl_b32(s_t0, s_wave, 4 + NQ), s_nop(0), v_add_u32(t[0], s_t0, l31), v_lshlrev_b32(t[0], 2, t[0])]      # (a wave's rows: 32 NQ)
+    e += [global_store_dword(t[0], tb[q], s_lse, 128 * q) for q in range(NQ)]
     # staging write address: row r = l31: X = stg + r * 128 + ((r & 7) << 4) + hi * 8; slot sl = (i & 1) * 4 + rg at X ^ (sl << 4)
     xb = t[1]
     e += [s_lshl_b32(s_t0, s_wave, 12), s_add_u32(s_t0, s_t0, s_lds), s_add_u32(s_t0, s_t0, LDS_STG)]
@@ -562,16 +609,16 @@ def epilogue():
     g8, rdaddr = ta[1], t[4]
     e += [v_lshrrev_b32(g8, 3, lane_v), v_and_b32(t[2], 7, lane_v), v_xor_b32(t[3], t[2], g8), v_lshlrev_b32(t[3], 4, t[3]), v_lshlrev_b32(rdaddr, 7, g8), v_add_u32(rdaddr, rdaddr, t[3]),
           v_add_u32(rdaddr, s_t0, rdaddr)]
-    # global offsets: (wave * 64 + 8 k + (lane >> 3)) * ostr + (lane & 7) * 16   (+ q * 32 rows, + ch * 128 bytes as immediate)
+    # global offsets: (wave * 32 NQ + 8 k + (lane >> 3)) * ostr + (lane & 7) * 16   (+ q * 32 rows, + ch * 128 bytes as immediate)
     go = [negm[0][0], negm[0][1], negm[0][2], negm[0][3]]      # (the next block start rewrites the C-operand registers)
-    e += [s_lshl_b32(s_t1, s_wave, 6), s_nop(0), v_add_u32(t[3], s_t1, g8), v_mul_lo_u32(t[3], t[3], s_ostr), v_lshlrev_b32(t[2], 4, t[2]), v_add_u32(go[0], t[3], t[2])]
+    e += [s_lshl_b32(s_t1, s_wave, 4 + NQ), s_nop(0), v_add_u32(t[3], s_t1, g8), v_mul_lo_u32(t[3], t[3], s_ostr), v_lshlrev_b32(t[2], 4, t[2]), v_add_u32(go[0], t[3], t[2])]
     e += [s_lshl_b32(s_t1, s_ostr, 3), s_nop(0)]
     for k in range(1, 4):
         e += [v_add_u32(go[k], s_t1, go[k - 1])]
     e += [s_lshl_b32(s_t1, s_ostr, 5)]
     pk = Vf
     n = 0
-    for q in range(2):
+    for q in range(NQ):
         for ch in range(2):
             for i in (2 * ch, 2 * ch + 1):
                 for rg in range(4):
@@ -591,7 +638,7 @@ def epilogue():
             for k in range(4):
                 e += [global_store_dwordx4(go[k], rb.sub(k * 4, 4), s_o, ch * 128)]
             e += [s_nop(1)]
-        if q == 0:
+        if q == 0 and NQ == 2:
             for k in range(4):
                 e += [v_add_u32(go[k], s_t1, go[k])]
     e += stamp(41)
@@ -603,42 +650,62 @@ def timeline_store():
         return []
     t = tmp
     p = v_mbcnt_lane_id(t[0])
-    # [workgroup = first block id][wave][64]
-    p += [s_sub_u32(s_t[4], s_bid, 0), s_nop(0)]
+    # [workgroup][wave][64]
+    p += [s_nop(0)]
     return p + [Inst("s_nop 0", "nop", count=1)] + _tl_tail(t)
 
 
 def _tl_tail(t):
-    # first block id of this workgroup = bid mod gstride (bid only ever grows by gstride): keep it simple - the host passes a buffer indexed by the LAST block id
-    return [s_lshl_b32(s_t[4], s_bid, 2), s_add_u32(s_t[4], s_t[4], s_wave), s_lshl_b32(s_t[4], s_t[4], 8), v_lshlrev_b32(t[0], 2, t[0]), v_add_u32(t[0], s_t[4], t[0]),
+    return [s_lshl_b32(s_t[4], s_wg, 2), s_add_u32(s_t[4], s_t[4], s_wave), s_lshl_b32(s_t[4], s_t[4], 8), v_lshlrev_b32(t[0], 2, t[0]), v_add_u32(t[0], s_t[4], t[0]),
             v_readlane_b32(s_dec[0][0], v_tl, 62), v_readlane_b32(s_dec[0][1], v_tl, 63), s_nop(4), global_store_dword(t[0], v_tl, s_dec[0], 0), s_waitcnt(vmcnt=0)]
 
 
-def build():
-    next_block_ptrs.n = 0
-    prog = entry()
+def block_program(nq, suf):
+    """the program of one block - whole (nq = 2) or half (nq = 1) - from L_block to the end of its epilogue, and its out-of-line pieces; labels get `suf`"""
+    global NQ
+    NQ = nq
     counts = {}
-    prog += block_start()
+    prog = block_start()
     prog += [label("L_loop")]
     for j in range(4):
         b, ca, cb = body(j, "main", j, 12)
         prog += b
-        counts[f"main{j}"] = (ca, cb)
+        counts[f"main{j}{suf}"] = (ca, cb)
     prog += [s_sub_u32(s_loop, s_loop, 1), s_cmp_lg_u32(s_loop, 0), s_cbranch_scc1("L_loop")]
     # the block's last four tiles; in flight behind what each needs: 12, 12, 12 (stricter than the 16 possible) and, for the last one, the two refill
     # groups + the first 8 Q loads issued since V(nkv-1) = 24
     for j, (variant, vmw) in enumerate([("tail0", 12), ("tail1", 12), ("tail2", 12), ("tail3", 24)]):
         b, ca, cb = body(j, variant, 4 + j, vmw)
         prog += b
-        counts[variant] = (ca, cb)
+        counts[variant + suf] = (ca, cb)
     prog += epilogue()
-    # next block (its outputs' pointers were computed at this block's start), or out
-    prog += [s_cmp_lt_u32(s_nbid, s_nblk), s_cbranch_scc0("L_done"), s_mov_b32(s_bid, s_nbid), s_mov_b64(s_o, s_on), s_mov_b64(s_lse, s_lsen), s_mov_b32(s_relax, 1),
-             s_branch("L_block"), label("L_done"), s_waitcnt(vmcnt=0)] + stamp(42) + timeline_store() + [s_branch("L_end")]
+    side = []
     for tag in range(7):       # bodies 0-3 decide about tile t+1 in S buffer (j+1) & 1; the three tails 4-6 likewise
-        prog += move_block(tag, (tag + 1) & 1)
-    prog += move_block(7, 0, set_flag=False)
-    prog += rescale_o_block()
+        side += move_block(tag, (tag + 1) & 1)
+    side += move_block(7, 0, set_flag=False)
+    side += rescale_o_block()
+    NQ = 2
+
+    def ren(ins):
+        if ins.kind == "label":
+            return label(ins.meta["name"] + suf)
+        if ins.kind == "branch" and ins.meta["target"] not in ("L_end", "L_done", "L_block_F", "L_block_H"):
+            return {None: s_branch, 0: s_cbranch_scc0, 1: s_cbranch_scc1}[ins.meta["cond"]](ins.meta["target"] + suf)
+        return ins
+    return [ren(i) for i in prog], [ren(i) for i in side], counts
+
+
+def build():
+    """entry; whole blocks bid, bid + grid, ... < nfull; then, when the launcher says so, ONE half block; out"""
+    prog = entry()
+    full, side_f, counts = block_program(2, "_F")
+    half, side_h, counts_h = block_program(1, "_H")
+    counts.update(counts_h)
+    after = [s_cmp_eq_u32(s_moden, 2), s_cbranch_scc1("L_done"), s_mov_b32(s_bid, s_nbid), s_mov_b32(s_hidx, s_hidxn), s_mov_b32(s_relax, 1),
+             s_cmp_eq_u32(s_moden, 1), s_cbranch_scc1("L_block_H"), s_branch("L_block_F")]
+    prog += full + after + half
+    prog += [label("L_done"), s_waitcnt(vmcnt=0)] + stamp(42) + timeline_store() + [s_branch("L_end")]
+    prog += side_f + side_h
     prog += [label("L_end"), Inst("s_endpgm", "end", final=True)]
     return prog, counts
 

@@ -16,7 +16,15 @@ def magic(d):
     return (1 << 32) // d + 1
 
 
-def run(B=1, H=8, L=512, grid=8, wg_id=0, mode="late", seed=0, spike=False, prog=None):
+def walk(nblk, grid):
+    """the launcher's split (attention_fwd64.hip): whole blocks below nfull, then one half block per workgroup when the remainder is exactly half a grid"""
+    rem = nblk % grid
+    if rem * 2 == grid and nblk - rem >= grid and grid % 16 == 0:
+        return nblk - rem, 1
+    return nblk, 0
+
+
+def run(B=1, H=8, L=512, grid=8, wg_id=0, mode="late", seed=0, spike=False, prog=None, spike_at=None):
     rng = np.random.default_rng(seed)
     d = g.D
     M = B * L
@@ -30,7 +38,8 @@ def run(B=1, H=8, L=512, grid=8, wg_id=0, mode="late", seed=0, spike=False, prog
         # a key far above the rest in a LATE tile for query 70 (the mid-block rescale) and one in the first tile for query 300; orthogonal sign patterns, so that
         # each query only sees its own spike
         alt = np.where(np.arange(d) % 2 == 0, 1.0, -1.0)
-        for (b, h, key, qrow, pat) in [(0, wg_id % H, L - 100, 70, np.ones(d)), (0, wg_id % H, 3, 300, alt)]:
+        sh, q_late, q_first = spike_at or (wg_id % H, 70, 300)
+        for (b, h, key, qrow, pat) in [(0, sh, L - 100, q_late, np.ones(d)), (0, sh, 3, q_first, alt)]:
             qk[b * L + key, H * d + h * d: H * d + (h + 1) * d] = bf16_bits(6.0 * pat)
             qk[b * L + qrow, h * d:(h + 1) * d] = bf16_bits(6.0 * c * pat)
     out = np.zeros((M, H * d), np.uint16)
@@ -39,12 +48,13 @@ def run(B=1, H=8, L=512, grid=8, wg_id=0, mode="late", seed=0, spike=False, prog
     a_qk, a_qkv, a_out, a_lse = wg.add_buffer(qk), wg.add_buffer(qkv), wg.add_buffer(out), wg.add_buffer(lse)
     nt = L // 256
     nblk = B * H * nt
-    tl = np.zeros((nblk, 4, 64), np.uint32)
+    nfull, hashalf = walk(nblk, grid)
+    tl = np.zeros((grid, 4, 64), np.uint32)
     a_tl = wg.add_buffer(tl)
     if prog is None:
         prog, _ = g.build()
     vals = dict(qb=a_qk, kb=a_qk + H * d * 2, vb=a_qkv + 2 * H * d * 2, ob=a_out, lseb=a_lse, qstr=2 * H * d * 2, kstr=2 * H * d * 2, vstr=3 * H * d * 2, ostr=H * d * 2,
-                L=L, nkv=L // 64, H=H, nt=nt, mg_nt=magic(nt), mg_H=magic(H), nblk=nblk, lds=0, bid=wg_id, gstride=grid)
+                L=L, nkv=L // 64, H=H, nt=nt, mg_nt=magic(nt), mg_H=magic(H), nfull=nfull, hashalf=hashalf, lds=0, bid=wg_id, gstride=grid)
     waves = []
     for wid in range(4):
         w = isa.Wave(wg, wid)
@@ -60,11 +70,12 @@ def run(B=1, H=8, L=512, grid=8, wg_id=0, mode="late", seed=0, spike=False, prog
     # reference over the blocks this workgroup owns
     worst_o, worst_l, nb = 0.0, 0.0, 0
     touched = np.zeros((M, H), bool)
-    for bid in range(wg_id, nblk, grid):
+    units = [(bid, 0, 256) for bid in range(wg_id, nfull, grid)] + ([(nfull + 8 * (wg_id >> 4) + (wg_id & 7), 128 * ((wg_id >> 3) & 1), 128)] if hashalf else [])
+    for bid, r0, nr in units:
         j, x = bid >> 3, bid & 7
         bh, tile = (j // nt) * 8 + x, j % nt
         b, h = bh // H, bh % H
-        rows = slice(b * L + tile * 256, b * L + tile * 256 + 256)
+        rows = slice(b * L + tile * 256 + r0, b * L + tile * 256 + r0 + nr)
         q = bits_f32(qk[rows, h * d:(h + 1) * d]).astype(np.float64)
         k = bits_f32(qk[b * L:(b + 1) * L, H * d + h * d:H * d + (h + 1) * d]).astype(np.float64)
         v = bits_f32(qkv[b * L:(b + 1) * L, 2 * H * d + h * d:2 * H * d + (h + 1) * d]).astype(np.float64)
@@ -75,7 +86,7 @@ def run(B=1, H=8, L=512, grid=8, wg_id=0, mode="late", seed=0, spike=False, prog
         o_ref = (p @ v) / l
         o = bits_f32(out[rows, h * d:(h + 1) * d]).astype(np.float64)
         worst_o = max(worst_o, np.abs(o - o_ref).max() / np.abs(o_ref).max())
-        worst_l = max(worst_l, np.abs(lse[b, h, tile * 256:tile * 256 + 256] - (mrow + np.log2(l))[:, 0]).max())
+        worst_l = max(worst_l, np.abs(lse[b, h, tile * 256 + r0:tile * 256 + r0 + nr] - (mrow + np.log2(l))[:, 0]).max())
         touched[rows, h] = True
         nb += 1
     stray = 0

@@ -11,7 +11,7 @@
 namespace {
 // ABLV != 0: timing-only ablations of the tile loop (wrong results; built with `make UDM_FWD64_ABL="1 3 7 ..."`, picked by UDM_ATTN_FWD64_ABL)
 template <int ABLV>
-__global__ __launch_bounds__(256) void attn_fwd64_kernel(AttnArgs a, uint32_t nt, uint32_t mg_nt, uint32_t mg_h, uint32_t nblk) {
+__global__ __launch_bounds__(256) void attn_fwd64_kernel(AttnArgs a, uint32_t nt, uint32_t mg_nt, uint32_t mg_h, uint32_t nfull, uint32_t hashalf) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const uint32_t qstr = (uint32_t)(a.q_stride * 2), kstr = (uint32_t)(a.k_stride * 2), vstr = (uint32_t)(a.v_stride * 2), ostr = (uint32_t)(a.out_stride * 2);
   const uint32_t L = (uint32_t)a.L, nkv = (uint32_t)(a.L / 64), H = (uint32_t)a.H;
@@ -19,7 +19,7 @@ __global__ __launch_bounds__(256) void attn_fwd64_kernel(AttnArgs a, uint32_t nt
   const uint32_t bid = blockIdx.x, gstride = gridDim.x, tid = threadIdx.x;
 #define UDM_FWD64_RUN(TEXT)                                                                                                                                  \
   asm volatile(TEXT : : "s"(a.q), "s"(a.k), "s"(a.v), "s"(a.out), "s"(a.lse), "s"(qstr), "s"(kstr), "s"(vstr), "s"(ostr), "s"(L), "s"(nkv), "s"(H), "s"(nt), \
-               "s"(mg_nt), "s"(mg_h), "s"(nblk), "s"(lds), "s"(bid), "s"(gstride), "v"(tid), "s"(a.timeline)                                               \
+               "s"(mg_nt), "s"(mg_h), "s"(nfull), "s"(hashalf), "s"(lds), "s"(bid), "s"(gstride), "v"(tid), "s"(a.timeline)                              \
                : UDM_FWD64_CLOBBERS)
   if constexpr (ABLV == 0) UDM_FWD64_RUN(UDM_FWD64_ASM);
 #ifdef UDM_FWD64_ASM_ABL1
@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256) void attn_fwd64_kernel(AttnArgs a, uint32_t nt
   if constexpr (ABLV == 32) UDM_FWD64_RUN(UDM_FWD64_ASM_ABL32);   // debug: the first block's scalars into the LSE tensor
 #endif
 #ifdef UDM_FWD64_ASM_ABL16
-  if constexpr (ABLV == 16) UDM_FWD64_RUN(UDM_FWD64_ASM_ABL16);   // cycle stamps (correct results) -> a.timeline [blocks][4 waves][64] uint32
+  if constexpr (ABLV == 16) UDM_FWD64_RUN(UDM_FWD64_ASM_ABL16);   // cycle stamps (correct results) -> a.timeline [workgroups][4 waves][64] uint32
 #endif
 #undef UDM_FWD64_RUN
 }
@@ -61,7 +61,7 @@ extern "C" int udm_attention_set_fwd64_timeline(int64_t device_ptr) {   // diagn
 }
 
 extern "C" int udm_attention_set_fwd64(int enable) {   // tests / A-B measurements: 0 = the 8-wave kernel of attention.hip everywhere
-  g_fwd64 = enable ? 1 : 0;
+  g_fwd64 = enable;        // 2: without the balanced walk (whole blocks only)
   return 0;
 }
 
@@ -100,6 +100,10 @@ bool udm_launch_attn_fwd64(const void* args, hipStream_t stream) {
   static const int cus = [] { int dev = 0, n = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n / 8 * 8; }();
   const auto magic = [](long d) { return (uint32_t)((1ULL << 32) / (unsigned long long)d + 1); };   // n / d == mulhi(n, magic) for n d < 2^32
   const long grid = nblk < cus ? nblk : cus;    // persistent: one workgroup per CU walks blocks id, id + grid, ...
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), UDM_FWD64_LDS_BYTES, stream, a, (uint32_t)nt, magic(nt), magic(a.H), (uint32_t)nblk);
+  // balanced walk: when the blocks left behind the whole rounds are exactly half a grid (the headline's 640 blocks on 256 CUs), every workgroup ends with ONE
+  // 128-query half block (2.5 units each) instead of a third whole block for half of them (3 vs 2)
+  const long rem = nblk % grid;
+  const bool halves = g_fwd64 != 2 && rem * 2 == grid && nblk - rem >= grid && grid % 16 == 0;
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), UDM_FWD64_LDS_BYTES, stream, a, (uint32_t)nt, magic(nt), magic(a.H), (uint32_t)(halves ? nblk - rem : nblk), halves ? 1u : 0u);
   return true;
 }

@@ -743,9 +743,10 @@ def set_tr_read(enable: bool):
     debug_set("attention_tr_read", 1 if enable else 0)
 
 
-def set_attention_fwd64(enable: bool):
-    """A/B switch: the 64-queries-per-wave forward (csrc/attention_fwd64.hip; head dim 128, no mask, L % 256 == 0) on / off."""
-    debug_set("attention_fwd64", 1 if enable else 0)
+def set_attention_fwd64(enable):
+    """A/B switch: the 64-queries-per-wave forward (csrc/attention_fwd64.hip; head dim 128, no mask, L % 256 == 0) on / off; 2 = on, without the balanced walk
+    (whole 256-query blocks only)."""
+    debug_set("attention_fwd64", int(enable))
 
 
 # ------------------------------------------------------------------------------------------------ embedding / CE / adaLN helpers
