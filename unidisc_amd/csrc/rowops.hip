@@ -143,18 +143,44 @@ struct NormBwdArgs {
   long mod_stride;
   int M, d, L, norm_type, accumulate;
   float* ws;          // optional [gridDim.x, d] fp32: per-block dw partials (two-phase column reduction instead of deep atomic chains)
+  int bpb;            // MOD form: blocks per batch element (grid = B * bpb; a block's rows lie inside ONE batch element)
 };
 
-template <int NCH>
+// cross-wave sum of one 512-column chunk of per-lane partials through LDS: fn(column within the chunk, sum) on the 512 columns
+template <typename F>
+__device__ __forceinline__ void block_colsum512(float (*red)[64 * 8 + 8], const float (&acc)[8], int wave, int lane, F fn) {
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 8; ++k) red[wave][lane * 8 + k] = acc[k];
+  __syncthreads();
+  for (int t = threadIdx.x; t < 512; t += 256) fn(t, red[0][t] + red[1][t] + red[2][t] + red[3][t]);
+}
+
+// MOD (adaLN modulation, models/dit.py:263-304): the gradients of the per-batch-element shift / scale vectors are column sums over that element's L rows.
+// A block owns a contiguous run of rows of ONE batch element, keeps the two sums in registers and leaves with one atomic per column (round 5; before: one
+// atomic per ELEMENT onto B x d addresses - 1280 deep same-address chains, 1.3 ms per launch at M = 10 240, d = 2048 against 60 us without modulation).
+template <int NCH, bool MOD = false>
 __global__ __launch_bounds__(256) void norm_bwd_kernel(NormBwdArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const bool img_only = a.modality && (!a.any_img || *a.any_img != 0);
   float dw_acc[NCH][8];
+  float dsh_acc[MOD ? NCH : 1][8], dsc_acc[MOD ? NCH : 1][8];
 #pragma unroll
   for (int i = 0; i < NCH; ++i)
 #pragma unroll
-    for (int k = 0; k < 8; ++k) dw_acc[i][k] = 0.f;
-  for (long row = (long)blockIdx.x * ROWS_PER_BLOCK + wave; row < a.M; row += (long)gridDim.x * ROWS_PER_BLOCK) {
+    for (int k = 0; k < 8; ++k) {
+      dw_acc[i][k] = 0.f;
+      if (MOD) { dsh_acc[i][k] = 0.f; dsc_acc[i][k] = 0.f; }
+    }
+  long row = (long)blockIdx.x * ROWS_PER_BLOCK + wave, row_end = a.M, row_step = (long)gridDim.x * ROWS_PER_BLOCK;
+  if (MOD) {
+    const int bb = blockIdx.x / a.bpb, chunk = (a.L + a.bpb - 1) / a.bpb;
+    const long r0 = (long)bb * a.L + (long)(blockIdx.x % a.bpb) * chunk;
+    row = r0 + wave;
+    row_end = min((long)(bb + 1) * a.L, r0 + chunk);
+    row_step = ROWS_PER_BLOCK;
+  }
+  for (; row < row_end; row += row_step) {
     const float rs = a.rstd[row];
     const float mu = a.norm_type ? a.mean[row] : 0.f;
     const int b = (int)(row / a.L);
@@ -174,17 +200,13 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(NormBwdArgs a) {
         if (modulate) {
           float sc[8];
           load8_bf16(a.scale + (long)b * a.mod_stride + c, sc);
-          float dsh[8], dsc[8];
 #pragma unroll
           for (int k = 0; k < 8; ++k) {
-            dsh[k] = dy8[k];
-            dsc[k] = dy8[k] * xh[i][k] * w8[k];
+            if (MOD) {
+              dsh_acc[i][k] += dy8[k];
+              dsc_acc[i][k] += dy8[k] * xh[i][k] * w8[k];
+            }
             dy8[k] *= (1.f + sc[k]);
-          }
-#pragma unroll
-          for (int k = 0; k < 8; ++k) {
-            atomicAdd(a.dshift + (long)b * a.mod_stride + c + k, dsh[k]);
-            atomicAdd(a.dscale + (long)b * a.mod_stride + c + k, dsc[k]);
           }
         }
 #pragma unroll
@@ -220,17 +242,18 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(NormBwdArgs a) {
   __shared__ float red[ROWS_PER_BLOCK][64 * 8 + 8];
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < 8; ++k) red[wave][lane * 8 + k] = dw_acc[i][k];
-    __syncthreads();
-    for (int t = threadIdx.x; t < 512; t += 256) {
+    block_colsum512(red, dw_acc[i], wave, lane, [&](int t, float s) {
       const int c = i * 512 + t;
       if (c < a.d) {
-        float s = red[0][t] + red[1][t] + red[2][t] + red[3][t];
         if (a.ws) a.ws[(long)blockIdx.x * a.d + c] = s;
         else atomicAdd(a.dw + c, s);
       }
+    });
+    if (MOD) {
+      float* dsh = a.dshift + (long)(blockIdx.x / a.bpb) * a.mod_stride;
+      float* dsc = a.dscale + (long)(blockIdx.x / a.bpb) * a.mod_stride;
+      block_colsum512(red, dsh_acc[i], wave, lane, [&](int t, float s) { if (i * 512 + t < a.d && s != 0.f) atomicAdd(dsh + i * 512 + t, s); });
+      block_colsum512(red, dsc_acc[i], wave, lane, [&](int t, float s) { if (i * 512 + t < a.d && s != 0.f) atomicAdd(dsc + i * 512 + t, s); });
     }
   }
 }
@@ -406,18 +429,33 @@ struct ResidBwdArgs {
   int M, d, L, norm_type;
   float p_drop;
   uint64_t seed;
+  int bpb;                // GATED form: blocks per batch element (grid = B * bpb), see norm_bwd_kernel<.., MOD>
 };
 
-template <int NCH>
+// GATED (adaLN-Zero gate, models/dit.py:229-253): the gate's gradient is a column sum over the batch element's rows - kept in registers by a block whose rows lie
+// inside one batch element, one atomic per column per block (before: one atomic per element).
+template <int NCH, bool GATED = false>
 __global__ __launch_bounds__(256) void residual_bwd_kernel(ResidBwdArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float dw_acc[NCH][8];
+  float dg_acc[GATED ? NCH : 1][8];
 #pragma unroll
   for (int i = 0; i < NCH; ++i)
 #pragma unroll
-    for (int k = 0; k < 8; ++k) dw_acc[i][k] = 0.f;
+    for (int k = 0; k < 8; ++k) {
+      dw_acc[i][k] = 0.f;
+      if (GATED) dg_acc[i][k] = 0.f;
+    }
   const float keep_scale = 1.f / (1.f - a.p_drop);
-  for (long row = (long)blockIdx.x * ROWS_PER_BLOCK + wave; row < a.M; row += (long)gridDim.x * ROWS_PER_BLOCK) {
+  long row = (long)blockIdx.x * ROWS_PER_BLOCK + wave, row_end = a.M, row_step = (long)gridDim.x * ROWS_PER_BLOCK;
+  if (GATED) {
+    const int bb = blockIdx.x / a.bpb, chunk = (a.L + a.bpb - 1) / a.bpb;
+    const long r0 = (long)bb * a.L + (long)(blockIdx.x % a.bpb) * chunk;
+    row = r0 + wave;
+    row_end = min((long)(bb + 1) * a.L, r0 + chunk);
+    row_step = ROWS_PER_BLOCK;
+  }
+  for (; row < row_end; row += row_step) {
     const int b = (int)(row / a.L);
     const bool special = !a.modality || a.modality[row] == 1;
     const float rs = a.w_b ? a.rstd_b[row] : 1.f;
@@ -448,7 +486,8 @@ __global__ __launch_bounds__(256) void residual_bwd_kernel(ResidBwdArgs a) {
             const float dm = (a.p_drop > 0.f) ? (keep[k] ? keep_scale : 0.f) : 1.f;
             if (a.gate) {
               float nn = a.w_b ? ((a.norm_type == 0 ? rbf(nh[i][k]) : nh[i][k]) * w8[k]) : br[k];
-              atomicAdd(a.dgate + (long)b * a.mod_stride + c + k, dn[k] * nn * dm);
+              if (GATED) dg_acc[i][k] += dn[k] * nn * dm;
+              else atomicAdd(a.dgate + (long)b * a.mod_stride + c + k, dn[k] * nn * dm);
               dn[k] *= g8[k];
             }
             dn[k] *= dm;
@@ -486,21 +525,21 @@ __global__ __launch_bounds__(256) void residual_bwd_kernel(ResidBwdArgs a) {
       store8_bf16(a.dbranch + row * a.d + c, o);
     }
   }
-  if (!a.w_b) return;
+  if (!a.w_b && !(GATED && a.gate)) return;
   __shared__ float red[ROWS_PER_BLOCK][64 * 8 + 8];
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < 8; ++k) red[wave][lane * 8 + k] = dw_acc[i][k];
-    __syncthreads();
-    for (int t = threadIdx.x; t < 512; t += 256) {
-      const int c = i * 512 + t;
-      if (c < a.d) {
-        const float v = red[0][t] + red[1][t] + red[2][t] + red[3][t];
-        if (a.ws) a.ws[(long)blockIdx.x * a.d + c] = v;   // two-phase column reduction (colreduce_kernel finishes it)
-        else atomicAdd(a.dw_b + c, v);
-      }
+    if (a.w_b)
+      block_colsum512(red, dw_acc[i], wave, lane, [&](int t, float v) {
+        const int c = i * 512 + t;
+        if (c < a.d) {
+          if (a.ws) a.ws[(long)blockIdx.x * a.d + c] = v;   // two-phase column reduction (colreduce_kernel finishes it)
+          else atomicAdd(a.dw_b + c, v);
+        }
+      });
+    if (GATED && a.gate) {
+      float* dg = a.dgate + (long)(blockIdx.x / a.bpb) * a.mod_stride;
+      block_colsum512(red, dg_acc[i], wave, lane, [&](int t, float v) { if (i * 512 + t < a.d && v != 0.f) atomicAdd(dg + i * 512 + t, v); });
     }
   }
 }
@@ -1663,6 +1702,15 @@ inline int grid_rows(long M) {
 }
 inline int nch_for(long d) { return (int)((d + 511) / 512); }
 
+#define DISPATCH_NCH_MOD(nch, KERNEL, grid, stream, args)                                            \
+  switch (nch) {                                                                                     \
+    case 1: hipLaunchKernelGGL((KERNEL<1, true>), dim3(grid), dim3(256), 0, stream, args); break;   \
+    case 2: hipLaunchKernelGGL((KERNEL<2, true>), dim3(grid), dim3(256), 0, stream, args); break;   \
+    case 3: hipLaunchKernelGGL((KERNEL<3, true>), dim3(grid), dim3(256), 0, stream, args); break;   \
+    case 4: hipLaunchKernelGGL((KERNEL<4, true>), dim3(grid), dim3(256), 0, stream, args); break;   \
+    case 8: hipLaunchKernelGGL((KERNEL<8, true>), dim3(grid), dim3(256), 0, stream, args); break;   \
+    default: udm_set_error(#KERNEL ": unsupported hidden size (d <= 2048 or d == 4096, d %% 8 == 0)"); return 2; \
+  }
 #define DISPATCH_NCH(nch, KERNEL, grid, stream, args)                                          \
   switch (nch) {                                                                               \
     case 1: hipLaunchKernelGGL((KERNEL<1>), dim3(grid), dim3(256), 0, stream, args); break;   \
@@ -1695,12 +1743,19 @@ extern "C" int udm_norm_bwd(const void* dy, const float* x, const float* rstd, c
   UDM_CHECK_ARG(M > 0 && d > 0 && d % 8 == 0 && L > 0, "udm_norm_bwd: bad shape");
   UDM_CHECK_ARG(!shift || (scale && dshift && dscale), "udm_norm_bwd: modulated norm needs scale, dshift, dscale");
   NormBwdArgs a{(const bf16_t*)dy, x, rstd, mean, w, (const bf16_t*)shift, (const bf16_t*)scale, modality, any_img, dx, dw, dshift, dscale,
-                (long)mod_stride, (int)M, (int)d, (int)L, norm_type, accumulate, nullptr};
+                (long)mod_stride, (int)M, (int)d, (int)L, norm_type, accumulate, nullptr, 0};
   int nch = nch_for(d); if (nch > 4) nch = 8;
   int grid = min(grid_rows(M), d < 2048 ? 1024 : 512);   // (measured: 48.6 vs 51.6 us at d = 768 with 1024 blocks, 60.7 vs 57.9 us at d = 2048)
+  if (shift) {   // modulated: whole blocks per batch element (M = B L)
+    UDM_CHECK_ARG(M % L == 0, "udm_norm_bwd: modulated norm needs M = B * L");
+    const int B = (int)(M / L);
+    a.bpb = max(1, min(grid / B, (int)((L + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK)));
+    grid = B * a.bpb;
+  }
   if (ws && ws_elems >= (int64_t)grid * d && grid >= 64) a.ws = ws;   // short chains (few blocks) stay on atomics
-  else grid = min(grid, 512);
-  DISPATCH_NCH(nch, norm_bwd_kernel, grid, stream, a);
+  else if (!shift) grid = min(grid, 512);
+  if (shift) { DISPATCH_NCH_MOD(nch, norm_bwd_kernel, grid, stream, a); }
+  else { DISPATCH_NCH(nch, norm_bwd_kernel, grid, stream, a); }
   UDM_CHECK_LAUNCH("udm_norm_bwd");
   if (a.ws) {
     hipLaunchKernelGGL(colreduce_kernel, dim3((unsigned)((d + 63) / 64), 16), dim3(256), 0, stream, (const float*)ws, dw, grid, (int)d);
@@ -1750,7 +1805,22 @@ extern "C" int udm_residual_bwd(const float* dx, const void* branch, void* dbran
   UDM_CHECK_ARG(!w_b || (rstd_b && dw_b), "udm_residual_bwd: sandwich norm needs rstd and dw");
   UDM_CHECK_ARG(!gate || dgate, "udm_residual_bwd: gate needs dgate");
   ResidBwdArgs a{dx, (const bf16_t*)branch, (bf16_t*)dbranch, w_b, rstd_b, mean_b, (const bf16_t*)gate, modality, dw_b, nullptr, dgate, (long)mod_stride,
-                 (int)M, (int)d, (int)L, norm_type, p_drop, seed};
+                 (int)M, (int)d, (int)L, norm_type, p_drop, seed, 0};
+  if (gate) {   // gated (adaLN-Zero): whole blocks per batch element, the gate gradient's column sums in registers
+    UDM_CHECK_ARG(M % L == 0, "udm_residual_bwd: a gate needs M = B * L");
+    const int B = (int)(M / L);
+    int nch = nch_for(d); if (nch > 4) nch = 8;
+    a.bpb = max(1, min(1024 / B, (int)((L + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK)));
+    const int grid = B * a.bpb;
+    if (w_b && ws && ws_elems >= (int64_t)grid * d && grid >= 64) a.ws = ws;
+    DISPATCH_NCH_MOD(nch, residual_bwd_kernel, grid, stream, a);
+    UDM_CHECK_LAUNCH("udm_residual_bwd(gated)");
+    if (a.ws) {
+      hipLaunchKernelGGL(colreduce_kernel, dim3((unsigned)((d + 63) / 64), 16), dim3(256), 0, stream, (const float*)ws, dw_b, grid, (int)d);
+      UDM_CHECK_LAUNCH("udm_residual_bwd(colreduce)");
+    }
+    return 0;
+  }
   if (d == 2048 && (!w_b || (ws && ws_elems >= (int64_t)1024 * d))) {
     // d = 2048 still fits a wave per row (32 values per lane): no block-wide reductions; measured 41.8 us vs 52.9 us for the
     // block-per-row form without dropout, equal with dropout (Philox regeneration dominates there)
