@@ -55,3 +55,30 @@ def test_committed_header_is_current_and_declares_every_register(tmp_path, gen):
     for r in ['"v0"', '"v254"', '"a0"', '"a255"', '"s36"', '"s99"', '"vcc"', '"scc"', '"m0"', '"memory"']:
         assert r in clob, r
     assert '"v255"' not in clob
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------------
+# the K loop of the one-wave-per-SIMD GEMM (csrc/asmgen/gemm_loop.py -> gemm_loop_gen.h, used by gemm_quad.hip)
+# ---------------------------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("mode", ["late", "early"])
+@pytest.mark.parametrize("FM,K", [(5, 256), (4, 256), (5, 512)], ids=["320_rows_4_tiles", "256_rows_4_tiles", "320_rows_8_tiles"])
+def test_emulated_gemm_loop_matches_numpy(FM, K, mode):
+    import emu_gemm
+    r = emu_gemm.run(FM=FM, K=K, mode=mode, seed=3)
+    assert r["rel_err"] < 1e-6, r          # fp32 accumulation of exact bf16 products, in the kernel's own k order
+
+
+def test_gemm_loop_lint_and_header_current(tmp_path):
+    import isa
+    import gemm_loop as gl
+    out = tmp_path / "gen.h"
+    progs = gl.emit(str(out))
+    for FM, (g, prog) in progs.items():
+        assert isa.lint([i for i in prog if i.kind != "raw"]) == [], FM
+        assert g.LDS_BYTES <= 160 * 1024 and g.v_last < 192 and 4 * FM + len(g.INPUTS) + 1 <= 30     # (an asm statement takes at most 30 operands)
+    committed = open(os.path.join(os.path.dirname(ASMGEN), "gemm_loop_gen.h")).read()
+    assert committed == out.read_text(), "gemm_loop_gen.h is stale (or a diagnostic build): run `make -C unidisc_amd/csrc`"
+    for FM in (4, 5):
+        clob = re.search(rf"#define UDM_QUADLOOP_NT{FM}_CLOBBERS (.*)", committed).group(1)
+        for r in ['"v0"', f'"v{progs[FM][0].v_last}"', '"s36"', f'"s{progs[FM][0].s_last}"', '"vcc"', '"scc"', '"m0"', '"memory"']:
+            assert r in clob, (FM, r)

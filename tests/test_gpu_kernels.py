@@ -155,6 +155,30 @@ def test_gemm_tn_splitk_workspace(K, Kc, M, N):
     assert rel_err(out.cpu(), 2 * ref) < 2e-5
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,Kc,epi", [(640, 512, 256, "none"), (640, 256, 1024, "bias"), (512, 512, 512, "none"), (1024, 256, 256, "bias"), (640, 512, 320, "none")],
+                         ids=["fm5_4tiles", "fm5_bias_16tiles", "fm4_8tiles", "fm4_bias_4tiles", "odd_tile_count_keeps_cpp_loop"])
+def test_gemm_quad_asm_k_loop_is_bit_identical(K, M, N, Kc, epi):
+    """The generated asm K loop of the one-wave-per-SIMD NT GEMM (csrc/asmgen/gemm_loop.py) against the C++ K loop it replaces: same LDS image, same k order per
+    output -> the same bits; and both against the fp32 product.  Operands with padded leading dimensions."""
+    a, b = bf(rnd(M, Kc + 64, seed=700, scale=0.5)), bf(rnd(N, Kc + 128, seed=701, scale=0.5))
+    ga, gb = a.to(DEV)[:, :Kc], b.to(DEV)[:, :Kc]
+    bias = rnd(N, seed=702).to(DEV)
+    kw = dict(epilogue=K.EPI_BIAS, bias=bias) if epi == "bias" else {}
+    outs = {}
+    try:
+        K.gemm_set_quad(2)
+        for flag in (1, 0):
+            K.debug_set("gemm_quad_asm", flag)
+            outs[flag] = K.gemm_nt(ga, gb, **kw).cpu()
+    finally:
+        K.debug_set("gemm_quad_asm", -1)
+        K.gemm_set_quad(1)
+    ref = a[:, :Kc].float() @ b[:, :Kc].float().t() + (bias.cpu() if epi == "bias" else 0)
+    assert torch.equal(outs[0], outs[1])
+    assert rel_err(outs[1].float(), ref) < 4e-3      # bf16 output rounding
+
+
 @pytest.mark.parametrize("M0,M1,N,Kc", [(6144, 2048, 2048, 10240), (768, 256, 512, 1024), (256, 256, 256, 128), (2304, 768, 768, 24576)])
 @pytest.mark.parametrize("beta", [0.0, 1.0])
 def test_gemm_tn_pair_equals_two_launches(K, M0, M1, N, Kc, beta):

@@ -301,49 +301,7 @@ COST = {"trans": 1.5, "dma": 1.5, "label": 0.0, "comment": 0.0}
 
 
 def spread(mfmas, streams, note, cap=None):
-    """Merge `streams` of filler instructions into the gaps behind `mfmas` (gap g = behind MFMA g; gap -1 = ahead of the first MFMA).  A stream =
-    (instructions, first gap, last gap): its instructions go out in order, none before `first`, all of them by `last`.  Every gap is filled to the same
-    issue budget (an in-order wave cannot bank the slack of a thin gap for a fat one): the most urgent stream - remaining cost per remaining gap -
-    goes first; a stream past its last gap is flushed whatever the budget."""
-    cap = CAP if cap is None else cap
-    n = len(mfmas)
-    out = [comment(note)]
-    pos = [0] * len(streams)
-    cost = lambda ins: COST.get(ins.kind, 1.0)
-    rem = [sum(cost(i) for i in ins) for ins, _, _ in streams]
-    counts = []
-    for g in range(-1, n):
-        if g >= 0:
-            out.append(mfmas[g])
-        budget, c = cap, 0.0
-        while True:
-            best, bu = None, -1.0
-            for si, (ins, g0, g1) in enumerate(streams):
-                if pos[si] >= len(ins) or g < g0:
-                    continue
-                u = 1e9 if g >= g1 else rem[si] / (g1 - g + 1)
-                if u > bu:
-                    best, bu = si, u
-            if best is None:
-                break
-            nxt = streams[best][0][pos[best]]
-            if bu < 1e9 and budget - cost(nxt) < -0.25:
-                break
-            while True:    # an instruction that reads SCC (s_addc, s_cbranch_scc) stays glued to the one before it: another stream's SALU op in between
-                out.append(nxt)   # would feed it a foreign carry / condition
-                pos[best] += 1
-                rem[best] -= cost(nxt)
-                budget -= cost(nxt)
-                c += cost(nxt)
-                ins_b = streams[best][0]
-                if pos[best] < len(ins_b) and (("scc", 0) in ins_b[pos[best]].reads or ins_b[pos[best]].kind == "label"):
-                    nxt = ins_b[pos[best]]
-                else:
-                    break
-        counts.append(round(c, 1))
-    for si, (ins, _, _) in enumerate(streams):
-        assert pos[si] == len(ins), (note, si, pos[si], len(ins))
-    return out, counts
+    return schedule_gaps(mfmas, streams, note, CAP if cap is None else cap, COST)
 
 
 ABL = 0   # timing-only ablations (WRONG results): 1 = no softmax VALU in the loop, 2 = no fragment reads, 4 = no refills / waits / barriers, 8 = no MFMAs;

@@ -1,5 +1,6 @@
 // Error plumbing and version entry points of the C ABI (include/unidisc_hip.h).
 #include "common.h"
+#include "gemm_quad.h"
 #include "../../include/unidisc_hip.h"
 #include <stdarg.h>
 #include <stdio.h>
@@ -38,6 +39,8 @@ extern "C" int udm_debug_set(const char* key, int64_t value) {
   if (is("gemm_tile")) return udm_gemm_set_tile((int)value);
   if (is("gemm_quad")) return udm_gemm_set_quad((int)value);
   if (is("gemm_persist")) return udm_gemm_set_persist((int)value);
+  if (is("gemm_quad_timeline")) { g_quad_timeline = reinterpret_cast<unsigned*>(value); return 0; }
+  if (is("gemm_quad_asm")) { g_quad_asm = (int)value; return 0; }   // 0 = the C++ K loop of gemm_quad.hip everywhere, 1 = the generated asm loop where it exists, -1 = env
   if (is("attention_tr_read")) return udm_attention_set_tr_read((int)value);
   if (is("attention_fwd64")) return udm_attention_set_fwd64((int)value);
   if (is("attention_fwd64_timeline")) return udm_attention_set_fwd64_timeline(value);

@@ -33,9 +33,12 @@ struct QuadArgs {
   const bf16_t* B2 = nullptr;
   void* C2 = nullptr;
   long lda2 = 0, ldb2 = 0, ldc2 = 0;
+  unsigned* timeline = nullptr;   // diagnostic build of the asm K loop (make UDM_QUADLOOP=timeline)
 };
 
 extern int g_quad_mode;
+extern int g_quad_asm;
+extern unsigned* g_quad_timeline;
 int udm_gemm_cus_available();   // 256, or the cap of udm_gemm_set_cus / UDM_GEMM_CUS: rounds are counted against it
 int udm_quad_mode();   // 0 off, 1 auto (shapes that fill the chip), 2 force wherever the shape fits
 // TN (wgrad) form: does a quad tile fit (whole tiles, K % 64 == 0)?  *fm receives the tile height / 64 (3, 4 or 5).

@@ -23,6 +23,7 @@
 // everything else.  Split-K (TN, fp32 output) through a workspace like the 8-wave form.
 #include "common.h"
 #include "gemm_quad.h"
+#include "gemm_loop_gen.h"
 #include "../../include/unidisc_hip.h"
 
 #include <stdlib.h>
@@ -49,7 +50,9 @@ __device__ __forceinline__ const char* uniform_ptr(const char* ptr) {   // pin a
 // Every operand is staged and gathered by its own layout (TA / TB): NN is the NT kernel's A side next to the TN kernel's B side.
 // RAGGED (NT / NN forms): the last tile row may hang over M - its operand rows are clamped to M - 1 at the LDS-DMA source and its output rows are not stored.  A row count
 // that no whole tile height divides into one round (config E: M = 9216 = 48 x 192 -> 384 tiles, 1.5 rounds) then still runs as ONE round of 320-row tiles (29 x 8 = 232).
-template <int FM, int MODE, int EPI, bool OUT_F32, int DMA_GAP, int ABL = 0, bool RAGGED = false>
+// ASMLOOP (NT form, whole tiles, an even number >= 4 of K tiles, no split-K): the prologue and the K loop below are replaced by ONE hand-scheduled asm statement
+// (asmgen/gemm_loop.py: same LDS image, same k order per output - bit-identical accumulators; counted lgkmcnt waits per fragment, every instruction placed).
+template <int FM, int MODE, int EPI, bool OUT_F32, int DMA_GAP, int ABL = 0, bool RAGGED = false, bool ASMLOOP = false>
 __global__ __launch_bounds__(256, 1) void gemm_quad_kernel(QuadArgs p0) {
   QuadArgs p = p0;   // (the paired launch redirects the operand fields of the blocks that belong to the second problem, once, before anything reads them)
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -219,6 +222,30 @@ __global__ __launch_bounds__(256, 1) void gemm_quad_kernel(QuadArgs p0) {
   constexpr int P1 = ((K3S + DMA_GAP - 1) / DMA_GAP) < LOADS ? ((K3S + DMA_GAP - 1) / DMA_GAP) : LOADS;
   static_assert((LOADS - 1) * DMA_GAP < K3S + 2 * NMF + BND, "refills must be issued at least one k-step before the boundary that waits for them");
 
+  if constexpr (ASMLOOP) {
+    static_assert(MODE == 0 && !RAGGED && ABL == 0 && (FM == 4 || FM == 5), "the asm K loop exists for the NT form with 256- / 320-row tiles");
+    const uint32_t lda_b = (uint32_t)(p.lda * 2), ldb_b = (uint32_t)(p.ldb * 2), nk_u = (uint32_t)nk, tid_u = (uint32_t)tid;
+#ifdef UDM_QUADLOOP_TIMELINE   // diagnostic build (make UDM_QUADLOOP=timeline): [block][wave]{loop cycles, cycles in the boundary's vmcnt wait, in its barrier, nk}
+    const char* tlp = uniform_ptr(reinterpret_cast<const char*>(p.timeline) + ((size_t)blockIdx.x * 4 + wave) * 16);
+#define UDM_QUADLOOP_TL_OPERAND "s"(tlp),
+#else
+#define UDM_QUADLOOP_TL_OPERAND
+#endif
+    if constexpr (FM == 5) {
+      asm volatile(UDM_QUADLOOP_NT5_ASM
+                   : "+a"(acc[0][0]), "+a"(acc[0][1]), "+a"(acc[0][2]), "+a"(acc[0][3]), "+a"(acc[1][0]), "+a"(acc[1][1]), "+a"(acc[1][2]), "+a"(acc[1][3]),
+                     "+a"(acc[2][0]), "+a"(acc[2][1]), "+a"(acc[2][2]), "+a"(acc[2][3]), "+a"(acc[3][0]), "+a"(acc[3][1]), "+a"(acc[3][2]), "+a"(acc[3][3]),
+                     "+v"(acc[FM - 1][0]), "+v"(acc[FM - 1][1]), "+v"(acc[FM - 1][2]), "+v"(acc[FM - 1][3])
+                   : "s"(ap), "s"(bp), "s"(lda_b), "s"(ldb_b), "s"(lds0), "s"(nk_u), UDM_QUADLOOP_TL_OPERAND "v"(tid_u)
+                   : UDM_QUADLOOP_NT5_CLOBBERS);
+    } else {
+      asm volatile(UDM_QUADLOOP_NT4_ASM
+                   : "+a"(acc[0][0]), "+a"(acc[0][1]), "+a"(acc[0][2]), "+a"(acc[0][3]), "+a"(acc[1][0]), "+a"(acc[1][1]), "+a"(acc[1][2]), "+a"(acc[1][3]),
+                     "+a"(acc[2][0]), "+a"(acc[2][1]), "+a"(acc[2][2]), "+a"(acc[2][3]), "+a"(acc[3][0]), "+a"(acc[3][1]), "+a"(acc[3][2]), "+a"(acc[3][3])
+                   : "s"(ap), "s"(bp), "s"(lda_b), "s"(ldb_b), "s"(lds0), "s"(nk_u), UDM_QUADLOOP_TL_OPERAND "v"(tid_u)
+                   : UDM_QUADLOOP_NT4_CLOBBERS);
+    }
+  } else {
   // ---- prologue: tile 0 and the first part of tile 1 in flight, tile 0 landed, its first fragments in registers ----
 #pragma unroll
   for (int j = 0; j < LOADS; ++j) dma_piece(0, 0, j);
@@ -291,6 +318,7 @@ __global__ __launch_bounds__(256, 1) void gemm_quad_kernel(QuadArgs p0) {
     tile_body(t + 1, std::integral_constant<int, 1>{});
   }
   for (; t < nk; ++t) tile_body(t, std::integral_constant<int, -1>{});
+  }
   if (FM > FMA) asm volatile("s_nop 15" ::: "memory");   // inline-asm MFMA results -> first reader (wait states the compiler does not know it owes)
   __syncthreads();  // all LDS tile reads are done: the wave-private epilogue patches may overwrite stage memory
 
@@ -384,11 +412,17 @@ int launch_quad_t(const QuadArgs& a0, hipStream_t stream) {
   const size_t lds = (size_t)2 * (BM + 256) * BK * 2;
   constexpr int GAP = 2;
   auto kern = gemm_quad_kernel<FM, MODE, EPI, OUT_F32, GAP, 0, RAGGED>;
+  if constexpr (MODE == 0 && !RAGGED && (FM == 4 || FM == 5)) {
+    static const int env_asm = [] { const char* e = getenv("UDM_QUAD_ASM"); return e ? atoi(e) : 1; }();
+    const int nk = a.K / BK;
+    if ((g_quad_asm < 0 ? env_asm : g_quad_asm) && a.splitk <= 1 && nk >= 4 && nk % 2 == 0) kern = gemm_quad_kernel<FM, MODE, EPI, OUT_F32, GAP, 0, RAGGED, true>;
+  }
   if constexpr (EPI == UDM_EPI_NONE && FM >= 4 && !RAGGED) {   // timing-only ablations of the plain kernels (scripts/bench_gemm_quad.py)
     static const int abl = [] { const char* e = getenv("UDM_QUAD_ABL"); return e ? atoi(e) : 0; }();
     if (abl == 1) kern = gemm_quad_kernel<FM, MODE, EPI, OUT_F32, GAP, 1>;
     if (abl == 2) kern = gemm_quad_kernel<FM, MODE, EPI, OUT_F32, GAP, 2>;
   }
+  a.timeline = g_quad_timeline;
   static const void* attr_set = nullptr;
   if (attr_set != (const void*)kern) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -400,6 +434,8 @@ int launch_quad_t(const QuadArgs& a0, hipStream_t stream) {
 }
 }  // namespace
 
+unsigned* g_quad_timeline = nullptr;   // diagnostic builds only (udm_debug_set "gemm_quad_timeline")
+int g_quad_asm = -1;    // A/B switch (udm_debug_set "gemm_quad_asm"): -1 = env UDM_QUAD_ASM (default on), 0 = the C++ K loop everywhere
 int g_quad_mode = -1;   // -1: read UDM_GEMM_QUAD (default 1); 0 = off, 1 = where it fills the chip, 2 = wherever the shape fits (tests)
 int udm_quad_mode() {
   if (g_quad_mode < 0) {
