@@ -288,7 +288,13 @@ __global__ __launch_bounds__(256) void residual_fwd_kernel(ResidArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (long row = (long)blockIdx.x * ROWS_PER_BLOCK + wave; row < a.M; row += (long)gridDim.x * ROWS_PER_BLOCK) {
     float v[NCH][8];
+    float xin[NCH][8];   // the residual stream's row is requested together with the branch's (behind the row statistics it would wait a second memory round trip)
     float s1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = (i * 64 + lane) * 8;
+      if (c < a.d) load8_f32(a.x_in + row * a.d + c, xin[i]);
+    }
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
       const int c = (i * 64 + lane) * 8;
@@ -333,7 +339,7 @@ __global__ __launch_bounds__(256) void residual_fwd_kernel(ResidArgs a) {
     for (int i = 0; i < NCH; ++i) {
       const int c = (i * 64 + lane) * 8;
       if (c >= a.d) continue;
-      float o[8], xi[8];
+      float o[8];
       if (a.w_b) {
         float w8[8];
         load8_f32(a.w_b + c, w8);
@@ -361,9 +367,8 @@ __global__ __launch_bounds__(256) void residual_fwd_kernel(ResidArgs a) {
           for (int k = 0; k < 8; ++k) o[k] *= g8[k];
         }
       }
-      load8_f32(a.x_in + row * a.d + c, xi);
 #pragma unroll
-      for (int k = 0; k < 8; ++k) o[k] += xi[k];
+      for (int k = 0; k < 8; ++k) o[k] += xin[i][k];
       store8_f32(a.x_out + row * a.d + c, o);
 #pragma unroll
       for (int k = 0; k < 8; ++k) v[i][k] = o[k];   // the row of x_out stays in registers for the fused next norm
