@@ -39,7 +39,8 @@ typedef struct ihipStream_t* hipStream_t;
 
 const char* udm_last_error(void);
 /* Diagnostics / A-B switches, none of them needed by a caller (process-global; values as documented in csrc/capi.hip): keys "gemm_tile", "gemm_quad",
- * "gemm_persist", "attention_tr_read", "attention_fwd64", "exp" (experiment bits, 0 in production).  Returns 2 for an unknown key. */
+ * "gemm_persist", "gemm_quad_asm" (0 = the C++ K loop of the one-wave-per-SIMD GEMM everywhere), "attention_tr_read", "attention_fwd64", "exp" (experiment bits, 0 in
+ * production); diagnostic builds only: "attention_fwd64_timeline", "gemm_quad_timeline" (device pointers for cycle stamps).  Returns 2 for an unknown key. */
 int udm_debug_set(const char* key, int64_t value);
 /* Diagnostics: hold `blocks` CUs (1..128; one 160 KiB-LDS block each) until *flag != 0 (pinned host or device memory) - the stand-in for a collective's channel
  * kernels when the GEMMs' behaviour under a CU reservation is measured on one GPU. */

@@ -565,8 +565,8 @@ def _mod_inputs(B, d, n, seed):
 @pytest.mark.parametrize("d", [64, 768, 2048])
 @pytest.mark.parametrize("nt", [0, 1])
 @pytest.mark.parametrize("mode", ["plain", "mod_all", "mod_img"])
-def test_norm_fwd_bwd(K, d, nt, mode):
-    B, L = 3, 40
+@pytest.mark.parametrize("B,L", [(3, 40), (5, 37)], ids=["b3_l40", "b5_l37_ragged_row_chunks"])   # (modulated backward: a block owns a run of rows of ONE batch element)
+def test_norm_fwd_bwd(K, d, nt, mode, B, L):
     M = B * L
     x, w, dy = rnd(M, d, seed=12, scale=2.0) + 0.3, 1 + 0.1 * rnd(d, seed=13), bf(rnd(M, d, seed=14))
     mod = _mod_inputs(B, d, 6, 15) if mode != "plain" else None
@@ -592,12 +592,12 @@ def test_norm_fwd_bwd(K, d, nt, mode):
 
 
 @pytest.mark.parametrize("d", [64, 768, 2048])
-@pytest.mark.parametrize("variant", ["plain", "sandwich_rms", "sandwich_ln", "gate_all", "gate_img"])
-def test_residual_fwd_bwd(K, d, variant):
-    B, L = 2, 24
+@pytest.mark.parametrize("variant", ["plain", "sandwich_rms", "sandwich_ln", "gate_all", "gate_img", "gate_sandwich"])
+@pytest.mark.parametrize("B,L", [(2, 24), (5, 37)], ids=["b2_l24", "b5_l37_ragged_row_chunks"])
+def test_residual_fwd_bwd(K, d, variant, B, L):
     M = B * L
     x_in, br, dx = rnd(M, d, seed=17), bf(rnd(M, d, seed=18, scale=1.5)), rnd(M, d, seed=19)
-    w_b = 1 + 0.1 * rnd(d, seed=20) if variant.startswith("sandwich") else None
+    w_b = 1 + 0.1 * rnd(d, seed=20) if "sandwich" in variant else None
     nt = 1 if variant == "sandwich_ln" else 0
     mod = _mod_inputs(B, d, 6, 21) if variant.startswith("gate") else None
     gi = 5 if mod is not None else None
