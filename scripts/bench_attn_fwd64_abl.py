@@ -1,5 +1,5 @@
 """Timing-only ablations of the 64-queries-per-wave attention forward (UDM_ATTN_FWD64_ABL read once per process: this script re-runs itself per value).
-Needs a library built with `make -C unidisc_amd/csrc UDM_FWD64_ABL="1 2 3 4 5 7 9"`."""
+Needs a library built with `make -C unidisc_amd/csrc UDM_FWD64_ABL="1 3 7"`."""
 import json, os, subprocess, sys
 if len(sys.argv) > 1:
     import torch
@@ -20,7 +20,7 @@ if len(sys.argv) > 1:
     ts.sort()
     print(json.dumps({"abl": int(sys.argv[1]), "median_us": round(ts[15], 1), "min_us": round(ts[0], 1)}))
 else:
-    for abl in (0, 7, 0):   # (7 = MFMAs only; the VALU-only ablations need the address arithmetic of the Q prefetch kept: not maintained)
+    for abl in (0, 1, 3, 7, 0):   # 1 = no softmax arithmetic, 3 = also no fragment reads, 7 = MFMAs only
         env = dict(os.environ, UDM_ATTN_FWD64_ABL=str(abl))
         r = subprocess.run([sys.executable, __file__, str(abl)], env=env, capture_output=True, text=True)
         print(r.stdout.strip().splitlines()[-1] if r.stdout.strip() else r.stderr[-300:])

@@ -344,6 +344,8 @@ def q_loads(src, scratch):
     p += [v_add_u32(t[1], s_t[4], t[1]), v_lshlrev_b32(t[2], 4, t[2]), v_mul_lo_u32(t[1], t[1], s_qstr)]
     p += [v_add_u32(t[0], t[1], t[2]), s_nop(0), v_add_u32(t[3], s_t[5], t[0])]
     loads = [global_load_dwordx4(Qfr(q, ks), t[0] if q == 0 else t[3], src, ks * 32) for q in range(2) for ks in range(KS)]
+    for ins in p:
+        ins.meta["keep"] = True      # (address arithmetic: the timing-only ablation that drops the softmax's VALU work must not drop these)
     return p, loads
 
 
