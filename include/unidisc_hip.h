@@ -89,6 +89,14 @@ int udm_gemm_nn_splitk_bf16(const void* A, const void* B, void* C, int64_t M, in
  * the host side (kernels.py) runs a single-round GEMM of more than `cus` tiles as whole tile rows that fit + a split-K launch of the leftover rows; also env
  * UDM_GEMM_CUS */
 int udm_gemm_set_cus(int cus);
+/* nn.Linear backward for a SMALL batch in one launch - adaLN_modulation (models/dit.py:922-925, the final layer's :1091-1097): dY fp32 [B, out] (rounded to bf16 on load:
+ * the autocast backward's operand), X bf16 [B, in], W bf16 [out, in] (the forward's shadow): dW[out, in] = dYᵀ X (overwritten), db[out] += colsum(dY) (nullable), and the
+ * input gradient dY W either added into dX[B, in] (fp32 atomics) or - dX_parts non-null - written as udm_small_batch_linear_bwd_blocks(out) partial tiles
+ * dX_parts[tile][B][in] for the caller to sum (the conditioning vector's gradient is needed once, after the last block).  B <= 64, in <= 128 and a multiple of 8,
+ * rows of X and W 16-byte aligned. */
+int udm_small_batch_linear_bwd(const float* dY, int64_t lddy, const void* X, int64_t ldx, const void* W, int64_t ldw, float* dW, float* db, float* dX, int64_t lddx,
+                               float* dX_parts, int64_t B, int64_t out, int64_t in, hipStream_t stream);
+int udm_small_batch_linear_bwd_blocks(int64_t out);
 /* out[C,R] = in[R,C]ᵀ (bf16); optional colsum[c] += Σ_r in[r,c] (bias gradient).  Feeds the wgrad GEMMs. */
 int udm_transpose_bf16(const void* in, void* out, int64_t R, int64_t C, int64_t ld_in, int64_t ld_out, float* colsum, hipStream_t stream);
 /* fp32 master weights -> bf16 shadow (and Kᵀ-major shadow for dgrad): the per-forward autocast weight cast. */

@@ -465,6 +465,27 @@ def gemm_nt_splitk(a, b, out=None, *, N=None):
     return gemm_nt(a, b, out=out, N=N)
 
 
+SMALL_BATCH_LINEAR_MAX_B, SMALL_BATCH_LINEAR_MAX_IN = 64, 128
+
+
+def small_batch_linear_bwd_tiles(out):
+    return 3
+
+
+def small_batch_linear_bwd(dy, x, w16, dw, db, dx=None, dx_parts=None):
+    d16 = dy.bfloat16().float()
+    out = dy.shape[1]
+    dw.copy_(d16.t() @ x.float())
+    if db is not None:
+        db += d16.sum(0)
+    full = d16 @ w16[:out].float()
+    if dx_parts is not None:
+        dx_parts.zero_()
+        dx_parts[0] = full
+    else:
+        dx += full
+
+
 def colsum(x, out):
     out += x.float().sum(0)
     return out

@@ -562,6 +562,25 @@ def _mod_inputs(B, d, n, seed):
     return bf(mod)
 
 
+@pytest.mark.parametrize("B,out,inp", [(8, 12288, 128), (16, 4096, 128), (5, 100, 32), (64, 4608, 128)], ids=["adaln_1p4b", "final_layer", "ragged_tiny", "batch64"])
+def test_small_batch_linear_bwd(K, B, out, inp):
+    """adaLN_modulation's backward in one launch (udm_small_batch_linear_bwd) against the fp32 statement on the bf16-rounded operands; dX and db accumulate,
+    dW is overwritten; padded weight rows and leading dimensions."""
+    dy = rnd(B, out + 8, seed=710, scale=0.5)[:, :out]
+    x, w = bf(rnd(B, inp + 8, seed=711))[:, :inp], bf(rnd(out + 8, inp, seed=712, scale=0.3))
+    dx0, db0 = rnd(B, inp, seed=713), rnd(out, seed=714)
+    g = lambda t: t.to(DEV)
+    dw, db, dx = torch.full((out, inp), 7.0, device=DEV), g(db0.clone()), g(dx0.clone())
+    K.small_batch_linear_bwd(g(dy), g(x), g(w), dw, db, dx)
+    d16 = dy.bfloat16().float()
+    assert rel_err(dw.cpu(), d16.t() @ x.float()) < 1e-5
+    assert rel_err(db.cpu(), db0 + d16.sum(0)) < 1e-5
+    assert rel_err(dx.cpu(), dx0 + d16 @ w[:out].float()) < 1e-5
+    parts = torch.full((K.small_batch_linear_bwd_tiles(out), B, inp), float("nan"), device=DEV)
+    K.small_batch_linear_bwd(g(dy), g(x), g(w), dw, None, dx_parts=parts)      # no bias; the input gradient as partial tiles (every element written)
+    assert rel_err(parts.sum(0).cpu(), d16 @ w[:out].float()) < 1e-5
+
+
 @pytest.mark.parametrize("d", [64, 768, 2048])
 @pytest.mark.parametrize("nt", [0, 1])
 @pytest.mark.parametrize("mode", ["plain", "mod_all", "mod_img"])

@@ -33,6 +33,8 @@ PROTOTYPES = {
     "udm_debug_set": [ctypes.c_char_p, _I64],
     "udm_debug_cu_hog": [_I64, _P, _P],
     "udm_transpose_bf16": [_P, _P, _I64, _I64, _I64, _I64, _P, _P],
+    "udm_small_batch_linear_bwd": [_P, _I64, _P, _I64, _P, _I64, _P, _P, _P, _I64, _P, _I64, _I64, _I64, _P],
+    "udm_small_batch_linear_bwd_blocks": [_I64],
     "udm_cast_transpose_f32_bf16": [_P, _P, _P, _I64, _I64, _I64, _I64, _I64, _P],
     "udm_cast_transpose_multi_f32_bf16": [_P, _I64, _I64, _P],
     "udm_cast_f32_bf16": [_P, _P, _I64, _F, _P],

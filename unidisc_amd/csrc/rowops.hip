@@ -1979,6 +1979,142 @@ extern "C" int udm_qknorm_rope_bwd(const void* dqkr, const void* qkv, void* dqkv
   return 0;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Linear backward for a SMALL batch (adaLN_modulation: c [B, cond_dim] -> mod [B, 6 d], models/dit.py:922-925): dW = dY^T X, db += colsum(dY), dX += dY W in ONE
+// launch.  dY arrives fp32 (it is the atomically accumulated shift / scale / gate gradient) and is rounded to bf16 on load - the values the autocast backward
+// multiplies.  Replaces cast + two transposes + a K = B weight-gradient GEMM + an M = B, one-tile, K = 6 d input-gradient GEMM (~140 us: a single workgroup walking
+// 12 288 k) per block.  A block owns 32 output features: dW rows written whole, dX partials by atomics (B x in addresses, out / 32 adds each).
+// ---------------------------------------------------------------------------------------------
+constexpr int SBL_OB = 32, SBL_MAX_B = 64, SBL_MAX_IN = 128, SBL_MAX_BLOCKS = 128;
+__global__ __launch_bounds__(256) void small_batch_linear_bwd_kernel(const float* __restrict__ dY, long lddy, const bf16_t* __restrict__ X, long ldx, const bf16_t* __restrict__ W,
+                                                                     long ldw, float* __restrict__ dW, float* __restrict__ db, float* __restrict__ dX, long lddx,
+                                                                     float* __restrict__ dXp, int Bp, int out, int in, int chunks_per_block) {
+  __shared__ float dm[SBL_MAX_B][SBL_OB + 1];
+  __shared__ __attribute__((aligned(16))) float xs[SBL_MAX_B][SBL_MAX_IN];
+  __shared__ __attribute__((aligned(16))) float ws[SBL_OB][SBL_MAX_IN + 4];
+  const int tid = threadIdx.x;
+  const int vpr = in >> 3;   // 16-byte vectors per row of X / W (in % 8 == 0)
+  for (int v = tid; v < Bp * vpr; v += 256) {
+    float f8[8];
+    load8_bf16(X + (long)(v / vpr) * ldx + (v % vpr) * 8, f8);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) xs[v / vpr][(v % vpr) * 8 + k] = f8[k];
+  }
+  // dX partials of this block's features stay in registers over its chunks.  Thread = (batch row mod 8, 4-column group): all 256 threads work at any batch size
+  float accx[SBL_MAX_B / 8][4];
+#pragma unroll
+  for (int pss = 0; pss < SBL_MAX_B / 8; ++pss)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) accx[pss][j] = 0.f;
+  const int xb = tid >> 5, xn0 = (tid & 31) * 4;
+  for (int ch = 0; ch < chunks_per_block; ++ch) {
+    const int o0 = (blockIdx.x * chunks_per_block + ch) * SBL_OB;
+    if (o0 >= out) break;   // block-uniform
+    __syncthreads();        // (the previous chunk's readers are done with dm / ws; first pass: xs is complete)
+    for (int idx = tid; idx < Bp * SBL_OB; idx += 256) {
+      const int b = idx / SBL_OB, ol = idx % SBL_OB;
+      dm[b][ol] = (o0 + ol < out) ? rbf(dY[(long)b * lddy + o0 + ol]) : 0.f;
+    }
+    {   // this chunk's 32 weight rows: at most two 16-byte vectors per thread, both requested before either is stored
+      float f8[2][8];
+      bool have[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int v = tid + 256 * u, ol = v / vpr;
+        have[u] = v < SBL_OB * vpr;
+        if (have[u] && o0 + ol < out) load8_bf16(W + (long)(o0 + ol) * ldw + (v % vpr) * 8, f8[u]);
+        else {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) f8[u][k] = 0.f;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int v = tid + 256 * u;
+        if (have[u]) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) ws[v / vpr][(v % vpr) * 8 + k] = f8[u][k];
+        }
+      }
+    }
+    __syncthreads();
+    if (db && tid < SBL_OB && o0 + tid < out) {
+      float sacc = 0.f;
+      for (int b = 0; b < Bp; ++b) sacc += dm[b][tid];
+      db[o0 + tid] += sacc;
+    }
+    {   // dW[o, n] = sum_b dY[b, o] X[b, n]: thread = (feature ol, 16-column group); X rows read as 16-byte vectors
+      const int ol = tid >> 3, n0 = (tid & 7) * 16;
+      if (o0 + ol < out && n0 < in) {
+        float4 acc[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int b = 0; b < Bp; ++b) {
+          const float dv = dm[b][ol];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float4 xv = *reinterpret_cast<const float4*>(&xs[b][n0 + 4 * q]);   // (columns past `in` hold stale finite values: never stored)
+            acc[q].x += dv * xv.x; acc[q].y += dv * xv.y; acc[q].z += dv * xv.z; acc[q].w += dv * xv.w;
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (n0 + 4 * q < in) *reinterpret_cast<float4*>(dW + (long)(o0 + ol) * in + n0 + 4 * q) = acc[q];
+      }
+    }
+    // dX[b, n] += sum_{o in chunk} dY[b, o] W[o, n]
+    if (xn0 < in) {
+#pragma unroll
+      for (int pss = 0; pss < SBL_MAX_B / 8; ++pss) {
+        const int b = xb + 8 * pss;
+        if (b < Bp) {
+          for (int ol = 0; ol < SBL_OB; ++ol) {
+            const float dv = dm[b][ol];
+            const float4 wv = *reinterpret_cast<const float4*>(&ws[ol][xn0]);
+            accx[pss][0] += dv * wv.x; accx[pss][1] += dv * wv.y; accx[pss][2] += dv * wv.z; accx[pss][3] += dv * wv.w;
+          }
+        }
+      }
+    }
+  }
+  if (xn0 < in) {
+#pragma unroll
+    for (int pss = 0; pss < SBL_MAX_B / 8; ++pss) {
+      const int b = xb + 8 * pss;
+      if (b < Bp) {
+        if (dXp) {   // this block's partial tile, plain stores: the caller sums the tiles (no same-address atomic chains: 23 of 85 us)
+          *reinterpret_cast<float4*>(dXp + ((long)blockIdx.x * Bp + b) * in + xn0) = make_float4(accx[pss][0], accx[pss][1], accx[pss][2], accx[pss][3]);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) atomicAdd(dX + (long)b * lddx + xn0 + j, accx[pss][j]);
+        }
+      }
+    }
+  }
+}
+
+extern "C" int udm_small_batch_linear_bwd_blocks(int64_t out) {   // number of partial tiles udm_small_batch_linear_bwd writes into dX_parts for `out` features
+  const int chunks = (int)((out + SBL_OB - 1) / SBL_OB);
+  const int cpb = (chunks + SBL_MAX_BLOCKS - 1) / SBL_MAX_BLOCKS;
+  return (chunks + cpb - 1) / cpb;
+}
+
+extern "C" int udm_small_batch_linear_bwd(const float* dY, int64_t lddy, const void* X, int64_t ldx, const void* W, int64_t ldw, float* dW, float* db, float* dX,
+                                          int64_t lddx, float* dX_parts, int64_t B, int64_t out, int64_t in, hipStream_t stream) {
+  UDM_CHECK_ARG(dY && X && W && dW && (dX || dX_parts), "udm_small_batch_linear_bwd: null pointer");
+  UDM_CHECK_ARG(B > 0 && B <= SBL_MAX_B && in > 0 && in <= SBL_MAX_IN && in % 8 == 0 && out > 0,
+                "udm_small_batch_linear_bwd: B <= 64 and in_features <= 128, a multiple of 8 (got B=%ld in=%ld out=%ld)", (long)B, (long)in, (long)out);
+  UDM_CHECK_ARG(ldx % 8 == 0 && ldw % 8 == 0 && (uintptr_t)X % 16 == 0 && (uintptr_t)W % 16 == 0 && (uintptr_t)dW % 16 == 0 && (uintptr_t)dX_parts % 16 == 0,
+                "udm_small_batch_linear_bwd: X / W rows, dW and dX_parts must be 16-byte aligned");
+  const int chunks = (int)((out + SBL_OB - 1) / SBL_OB);
+  const int cpb = (chunks + SBL_MAX_BLOCKS - 1) / SBL_MAX_BLOCKS;
+  const int grid = (chunks + cpb - 1) / cpb;
+  hipLaunchKernelGGL(small_batch_linear_bwd_kernel, dim3((unsigned)grid), dim3(256), 0, stream, dY, (long)lddy, (const bf16_t*)X, (long)ldx, (const bf16_t*)W, (long)ldw, dW, db,
+                     dX, (long)lddx, dX_parts, (int)B, (int)out, (int)in, cpb);
+  UDM_CHECK_LAUNCH("udm_small_batch_linear_bwd");
+  return 0;
+}
+
 extern "C" int udm_embedding_fwd(const int64_t* ids, const float* E, const int64_t* modality, const float* Em, float* x, int64_t M, int64_t d, int64_t V,
                                  hipStream_t stream) {
   UDM_CHECK_ARG(ids && E && x, "udm_embedding_fwd: null pointer");

@@ -1065,6 +1065,11 @@ class DIT(nn.Module, _HubMixin):
         if tc:
             dc = torch.zeros((Bp, self.cond_dim), dtype=F32, device=dev)
             dmodf = torch.zeros((Bp, 2 * d), dtype=F32, device=dev)
+            # the adaLN_modulation backwards leave their input gradients as partial tiles in one buffer; summed once, where dc is consumed (`_ada_collect`)
+            self._ada_buf, self._ada_off = None, 0
+            if Bp <= K.SMALL_BATCH_LINEAR_MAX_B and self.cond_dim <= K.SMALL_BATCH_LINEAR_MAX_IN and self.cond_dim % 8 == 0:
+                tiles = K.small_batch_linear_bwd_tiles(2 * d) + self.n_blocks * K.small_batch_linear_bwd_tiles(6 * d)
+                self._ada_buf = torch.empty((tiles, Bp, self.cond_dim), dtype=F32, device=dev)
         fl = self.output_layer
         fmod = S["fmod"]
         # (compacted last block: its residual-stream gradient lives on the compacted rows until the block's attention is reached)
@@ -1219,6 +1224,7 @@ class DIT(nn.Module, _HubMixin):
             tail.append(self.img_count_embedding)
         if tc:  # c = silu(W2 silu(W0 te + b0) + b2)
             dc16 = torch.empty((Bp, self.cond_dim), dtype=BF16, device=dev)
+            self._ada_collect(dc)
             K.cast_f32_bf16(dc, dc16)
             dl2 = K.silu_bwd(S["l2"], dc16)
             ds1 = K.gemm_nt(dl2, lin["sig2"].w16t, N=lin["sig2"].inp)
@@ -1235,10 +1241,27 @@ class DIT(nn.Module, _HubMixin):
 
     def _ada_backward(self, dmod, lin: _Lin, c, dc, G):
         """adaLN_modulation backward: dmod fp32 [Bp, n*d] (atomically accumulated) -> dW, db, dc += dmod W."""
+        buf = getattr(self, "_ada_buf", None)
+        if buf is not None and lin.w16 is not None:
+            # one launch (round 5): the input gradient as a GEMM is M = Bp rows, ONE output tile, K = 6 d - a single workgroup walking 12 288 k took ~140 us per block
+            tiles = K.small_batch_linear_bwd_tiles(lin.out)
+            parts = buf[self._ada_off:self._ada_off + tiles]
+            self._ada_off += tiles
+            K.small_batch_linear_bwd(dmod, c, lin.w16, G[id(lin.weight)], G[id(lin.bias)] if lin.bias is not None else None, dx_parts=parts)
+            return
         dmod16 = torch.empty(dmod.shape, dtype=BF16, device=dmod.device)
         K.cast_f32_bf16(dmod, dmod16)
         self._wgrad(dmod16, c, lin, G)
         K.gemm_nt(dmod16, lin.w16t, out=dc, N=lin.inp, beta=1.0)
+
+
+    def _ada_collect(self, dc):
+        """dc += the partial input-gradient tiles this pass's adaLN_modulation backwards left behind"""
+        buf, off = getattr(self, "_ada_buf", None), getattr(self, "_ada_off", 0)
+        self._ada_buf, self._ada_off = None, 0
+        if buf is not None and off:
+            dc += buf[:off].sum(0)
+        return dc
 
 
 class _DitFn(torch.autograd.Function):

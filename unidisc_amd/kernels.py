@@ -433,6 +433,36 @@ def adamw_step_shadow(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, gra
               w16t.stride(0) if w16t is not None else 0, _p(ema), float(ema_decay), _s())
 
 
+SMALL_BATCH_LINEAR_MAX_B, SMALL_BATCH_LINEAR_MAX_IN = 64, 128
+
+
+def small_batch_linear_bwd_tiles(out):
+    """number of partial tiles small_batch_linear_bwd(..., dx_parts=...) writes for `out` output features"""
+    return int(_lib.load().udm_small_batch_linear_bwd_blocks(int(out)))
+
+
+def small_batch_linear_bwd(dy, x, w16, dw, db, dx=None, dx_parts=None):
+    """nn.Linear backward for a small batch in one launch (adaLN_modulation): dy fp32 [B, out] (rounded to bf16 on load), x bf16 [B, in], w16 bf16 [out, in]:
+    dw[out, in] = dy^T x (overwritten), db[out] += colsum(dy) (None: skipped); the input gradient dy w16 is added into dx[B, in] (atomics) or, with `dx_parts`
+    fp32 [small_batch_linear_bwd_tiles(out), B, in], written as partial tiles for the caller to sum.  B <= 64, in <= 128 and a multiple of 8; x / w16 rows 16-byte aligned."""
+    _chk(dy, F32, "small_batch_linear_bwd dy"), _chk(x, BF16, "small_batch_linear_bwd x"), _chk(w16, BF16, "small_batch_linear_bwd w16")
+    _chk(dw, F32, "small_batch_linear_bwd dw")
+    B, out = dy.shape
+    inp = x.shape[1]
+    if not (dw.is_contiguous() and tuple(dw.shape) == (out, inp) and w16.shape[0] >= out and w16.shape[1] == inp and x.shape[0] == B):
+        raise ValueError("small_batch_linear_bwd: inconsistent shapes")
+    if dx_parts is not None:
+        _chk(dx_parts, F32, "small_batch_linear_bwd dx_parts")
+        if not (dx_parts.is_contiguous() and tuple(dx_parts.shape) == (small_batch_linear_bwd_tiles(out), B, inp)):
+            raise ValueError("small_batch_linear_bwd: dx_parts must be contiguous [small_batch_linear_bwd_tiles(out), B, in]")
+    else:
+        _chk(dx, F32, "small_batch_linear_bwd dx")
+        if tuple(dx.shape) != (B, inp):
+            raise ValueError("small_batch_linear_bwd: dx must be [B, in]")
+    _lib.call("udm_small_batch_linear_bwd", _p(dy), dy.stride(0), _p(x), x.stride(0), _p(w16), w16.stride(0), _p(dw), _p(db), _p(dx), dx.stride(0) if dx is not None else 0,
+              _p(dx_parts), B, out, inp, _s())
+
+
 def colsum(x, out):
     """out[c] += sum_r x[r, c] (bias gradient) without writing a transpose."""
     _chk(x, BF16, "colsum")
