@@ -139,7 +139,16 @@ int udm_residual_bwd(const float* dx, const void* branch, void* dbranch, const f
  * bf16 d branch, i.e. the bias gradient of the Linear that produced the branch (mlp.2, :919).  ws: >= min(M, 1536) * 3 * d floats. */
 int udm_norm_residual_bwd(const void* dy, const float* x, const float* rstd, const float* mean, const float* w, float* dx, float* dw, int accumulate,
                           const void* branch, void* dbranch, const float* w_b, const float* rstd_b, const float* mean_b, float* dw_b, float* dbias,
-                          int64_t M, int64_t d, int norm_type, float p_drop, uint64_t seed, float* ws, int64_t ws_elems, hipStream_t stream); /* ws: optional fp32 scratch (>= 1024*d) for a two-phase dw_b reduction */
+                          int64_t M, int64_t d, int norm_type, float p_drop, uint64_t seed, float* ws, int64_t ws_elems, hipStream_t stream);
+/* The same fused pass for adaLN-Zero (time_conditioning = True; models/dit.py:263-304 modulate_fused, :229-253 bias_dropout_add_scale): the norm modulated by
+ * shift / scale [B, mod_stride] bf16 (rows with modality == 1 only when `modality` is given and *any_img != 0), the residual branch optionally gated by gate
+ * [B, mod_stride] (gate and dropout on rows with modality_r == 1 only when that map is given); dshift / dscale / dgate [B, mod_stride] fp32 += column sums over each
+ * batch element's rows (a block owns rows of one element: one atomic per column and block).  d = 2048 / 4096, M = B * L.  Any of shift / gate may be null. */
+int udm_norm_residual_bwd_ada(const void* dy, const float* x, const float* rstd, const float* mean, const float* w, float* dx, float* dw, int accumulate,
+                              const void* branch, void* dbranch, const float* w_b, const float* rstd_b, const float* mean_b, float* dw_b, float* dbias,
+                              const void* shift, const void* scale, float* dshift, float* dscale, const void* gate, float* dgate, int64_t mod_stride,
+                              const int64_t* modality, const int* any_img, const int64_t* modality_r, int64_t M, int64_t d, int64_t L, int norm_type, float p_drop,
+                              uint64_t seed, float* ws, int64_t ws_elems, hipStream_t stream); /* ws: optional fp32 scratch (>= 1024*d) for a two-phase dw_b reduction */
 
 /* ---- QK LayerNorm (models/dit.py:569-572, 680-682) + rotary (models/standalone_rotary.py:14-31, call dit.py:723-726)
  * qkv bf16 [M,3d] -> qkr bf16 [M,2d] (normalised, rotated q | k).  cos/sin fp32 [L,D/2] or per-sample [M,D/2]. */

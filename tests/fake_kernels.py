@@ -168,6 +168,20 @@ def norm_residual_bwd(dy, x, rstd, mean, w, norm_type, L, dx, dw, branch, *, acc
     return out
 
 
+def norm_residual_bwd_ada_ok(M, d, L):
+    return L > 0 and M % L == 0
+
+
+def norm_residual_bwd_ada(dy, x, rstd, mean, w, norm_type, L, dx, dw, branch, *, accumulate=True, w_b=None, rstd_b=None, mean_b=None, dw_b=None, p_drop=0.0, seed=0,
+                          dbias=None, mod_n=None, dmod_n=None, mod_idx=(0, 1), modality=None, any_img=None, mod_r=None, dmod_r=None, gate_idx=None, modality_r=None):
+    norm_bwd(dy, x, rstd, mean, w, norm_type, L, dx, dw, accumulate=accumulate, mod=mod_n, dmod=dmod_n, mod_idx=mod_idx, modality=modality, any_img=any_img)
+    out = residual_bwd(dx, branch, L, w_b=w_b, rstd=rstd_b, mean=mean_b, norm_type=norm_type, mod=mod_r, dmod=dmod_r, gate_idx=gate_idx, modality=modality_r, dw_b=dw_b,
+                       p_drop=p_drop, seed=seed)
+    if dbias is not None:
+        colsum(out, dbias)
+    return out
+
+
 @torch.enable_grad()
 def residual_bwd(dx, branch, L, *, w_b=None, rstd=None, mean=None, norm_type=NORM_RMS, mod=None, dmod=None, gate_idx=None, modality=None, dw_b=None,
                  p_drop=0.0, seed=0):

@@ -562,6 +562,52 @@ def _mod_inputs(B, d, n, seed):
     return bf(mod)
 
 
+@pytest.mark.parametrize("variant", ["mod_sandwich", "mod_img_gate_sandwich_dropout", "mod_gate_plain", "gate_only"])
+@pytest.mark.parametrize("B,L", [(3, 37), (2, 700)], ids=["b3_l37", "b2_l700_more_rows_than_blocks"])
+def test_norm_residual_bwd_ada_equals_separate_kernels(K, variant, B, L):
+    """The fused adaLN pass (modulated norm backward + gated residual-branch backward, udm_norm_residual_bwd_ada) against the two separate kernels it replaces
+    (each tested against torch above): same dx, dw, d branch, dw_b, and the same shift / scale / gate gradients up to the order of the fp32 sums."""
+    d, nt = 2048, 0
+    M = B * L
+    g = lambda t: t.to(DEV) if t is not None else None
+    x, w, dy = rnd(M, d, seed=720, scale=2.0) + 0.3, 1 + 0.1 * rnd(d, seed=721), bf(rnd(M, d, seed=722))
+    br, dx0 = bf(rnd(M, d, seed=723, scale=1.5)), rnd(M, d, seed=724)
+    mod_n, mod_r = _mod_inputs(B, d, 6, 725), _mod_inputs(B, d, 6, 726)
+    use_mod = variant != "gate_only"
+    use_gate = "gate" in variant
+    sandwich = "sandwich" in variant
+    img = "img" in variant
+    p_drop = 0.1 if "dropout" in variant else 0.0
+    modality = (torch.arange(M) % L >= L // 2).long() if img else None
+    any_img = torch.ones(1, dtype=torch.int32) if img else None
+    w_b = 1 + 0.1 * rnd(d, seed=727) if sandwich else None
+    _, rstd, _ = K.norm_fwd(g(x), g(w), nt, L)
+    _, rstd_b, _ = K.residual_fwd(g(rnd(M, d, seed=728)), g(br), L, w_b=g(w_b), norm_type=nt) if sandwich else (None, None, None)
+    kw_r = dict(w_b=g(w_b), norm_type=nt, p_drop=p_drop, seed=11)
+    # separate kernels
+    dx_a, dw_a, dwb_a = g(dx0.clone()), torch.zeros(d, device=DEV), torch.zeros(d, device=DEV) if sandwich else None
+    dmn_a, dmr_a = torch.zeros(mod_n.shape, device=DEV), torch.zeros(mod_r.shape, device=DEV)
+    K.norm_bwd(g(dy), g(x), rstd, None, g(w), nt, L, dx_a, dw_a, accumulate=True, mod=g(mod_n) if use_mod else None, dmod=dmn_a if use_mod else None, mod_idx=(3, 4),
+               modality=g(modality), any_img=g(any_img))
+    db_a = K.residual_bwd(dx_a, g(br), L, rstd=rstd_b, mean=None, mod=g(mod_r) if use_gate else None, dmod=dmr_a if use_gate else None, gate_idx=5 if use_gate else None,
+                          modality=g(modality), dw_b=dwb_a, **kw_r)
+    # fused
+    dx_f, dw_f, dwb_f = g(dx0.clone()), torch.zeros(d, device=DEV), torch.zeros(d, device=DEV) if sandwich else None
+    dmn_f, dmr_f = torch.zeros(mod_n.shape, device=DEV), torch.zeros(mod_r.shape, device=DEV)
+    db_f = K.norm_residual_bwd_ada(g(dy), g(x), rstd, None, g(w), nt, L, dx_f, dw_f, g(br), accumulate=True, w_b=g(w_b), rstd_b=rstd_b, dw_b=dwb_f, p_drop=p_drop, seed=11,
+                                   mod_n=g(mod_n) if use_mod else None, dmod_n=dmn_f if use_mod else None, mod_idx=(3, 4), modality=g(modality), any_img=g(any_img),
+                                   mod_r=g(mod_r) if use_gate else None, dmod_r=dmr_f if use_gate else None, gate_idx=5 if use_gate else None, modality_r=g(modality))
+    assert rel_err(dx_f, dx_a) < 1e-5
+    assert rel_err(db_f.float(), db_a.float()) < 1e-4      # (bf16 outputs: a block sum and a wave sum round a few elements differently)
+    assert rel_err(dw_f, dw_a) < 1e-4
+    if sandwich:
+        assert rel_err(dwb_f, dwb_a) < 1e-4
+    if use_mod:
+        assert rel_err(dmn_f, dmn_a) < 1e-4
+    if use_gate:
+        assert rel_err(dmr_f, dmr_a) < 1e-4
+
+
 @pytest.mark.parametrize("B,out,inp", [(8, 12288, 128), (16, 4096, 128), (5, 100, 32), (64, 4608, 128)], ids=["adaln_1p4b", "final_layer", "ragged_tiny", "batch64"])
 def test_small_batch_linear_bwd(K, B, out, inp):
     """adaLN_modulation's backward in one launch (udm_small_batch_linear_bwd) against the fp32 statement on the bf16-rounded operands; dX and db accumulate,

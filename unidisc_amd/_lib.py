@@ -45,6 +45,8 @@ PROTOTYPES = {
     "udm_residual_norm_fwd": [_P, _P, _P, _P, _P, _P, _P, _I64, _P, _I64, _I64, _I64, _I, _F, _F, _U64, _P, _P, _P, _P, _P],
     "udm_residual_bwd": [_P, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _P, _I64, _I64, _I64, _I, _F, _U64, _P, _I64, _P],
     "udm_norm_residual_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I, _F, _U64, _P, _I64, _P],
+    "udm_norm_residual_bwd_ada": [_P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _P, _I64, _I64, _I64, _I, _F, _U64,
+                                  _P, _I64, _P],
     "udm_qknorm_rope_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I64, _I64, _I64, _I64, _F, _F, _P],
     "udm_qknorm_rope_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _F, _P, _I64, _P],
     "udm_attention_doc_ranges": [_P, _I64, _I64, _P, _P],

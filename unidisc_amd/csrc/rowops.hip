@@ -1120,9 +1120,17 @@ struct NormResidBwdArgs {
   int M, d, norm_type;
   float p_drop;
   uint64_t seed;
+  // ADA form (adaLN-Zero, models/dit.py:263-304 modulate_fused + :229-253 bias_dropout_add_scale): the norm is modulated by shift / scale [B, mod_stride] (rows with
+  // modality == 1 only when a modality map is given and *any_img != 0), the residual branch optionally gated (gate [B, mod_stride]; gate and dropout on rows with
+  // modality_r == 1 only when that map is given).  Blocks own runs of rows of ONE batch element (grid = B * bpb).
+  const bf16_t* shift = nullptr; const bf16_t* scale = nullptr; float* dshift = nullptr; float* dscale = nullptr;
+  const bf16_t* gate = nullptr; float* dgate = nullptr;
+  long mod_stride = 0;
+  const int64_t* modality = nullptr; const int* any_img = nullptr; const int64_t* modality_r = nullptr;
+  int L = 0, bpb = 0;
 };
 
-template <int NCB>
+template <int NCB, bool ADA = false>
 __global__ __launch_bounds__(256) void norm_residual_bwd_kernel(NormResidBwdArgs a) {
   __shared__ float sm[8];
   const int tid = threadIdx.x;
@@ -1131,6 +1139,28 @@ __global__ __launch_bounds__(256) void norm_residual_bwd_kernel(NormResidBwdArgs
   for (int i = 0; i < NCB; ++i)
 #pragma unroll
     for (int k = 0; k < 8; ++k) { dwn[i][k] = 0.f; dwb[i][k] = 0.f; dbs[i][k] = 0.f; }
+  // ADA: this block's batch element, its run of rows, that element's scale / gate vectors and the three column sums a thread owns outright (block per row: a
+  // thread keeps the same 8 columns for every row - no cross-thread reduction, one atomic per column and block at the end)
+  long row_first = blockIdx.x, row_end = a.M, row_step = gridDim.x;
+  float sc8[ADA ? NCB : 1][8], gt8[ADA ? NCB : 1][8], dsh[ADA ? NCB : 1][8], dsc[ADA ? NCB : 1][8], dgt[ADA ? NCB : 1][8];
+  bool img_only = false;
+  int ada_b = 0;
+  if (ADA) {
+    ada_b = blockIdx.x / a.bpb;
+    const int chunk = (a.L + a.bpb - 1) / a.bpb;
+    row_first = (long)ada_b * a.L + (long)(blockIdx.x % a.bpb) * chunk;
+    row_end = min((long)(ada_b + 1) * a.L, row_first + chunk);
+    row_step = 1;
+    img_only = a.modality && (!a.any_img || *a.any_img != 0);
+#pragma unroll
+    for (int i = 0; i < NCB; ++i) {
+      const int c = (i * 256 + tid) * 8;
+      if (a.scale) load8_bf16(a.scale + (long)ada_b * a.mod_stride + c, sc8[i]);
+      if (a.gate) load8_bf16(a.gate + (long)ada_b * a.mod_stride + c, gt8[i]);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { dsh[i][k] = 0.f; dsc[i][k] = 0.f; dgt[i][k] = 0.f; }
+    }
+  }
   const float keep_scale = 1.f / (1.f - a.p_drop);
   float dy_n[NCB][8], x_n[NCB][8], dx_n[NCB][8], br_n[NCB][8];
   auto fetch = [&](long row) {
@@ -1145,7 +1175,8 @@ __global__ __launch_bounds__(256) void norm_residual_bwd_kernel(NormResidBwdArgs
       }
     }
   };
-  fetch(blockIdx.x);
+  auto fetch_in_range = [&](long row) { fetch(row < row_end ? row : (long)a.M); };   // (past the block's run: nothing is requested)
+  fetch_in_range(row_first);
   float w8[NCB][8], wb8[NCB][8];
 #pragma unroll
   for (int i = 0; i < NCB; ++i) {
@@ -1153,7 +1184,9 @@ __global__ __launch_bounds__(256) void norm_residual_bwd_kernel(NormResidBwdArgs
     load8_f32(a.w + c, w8[i]);
     if (a.w_b) load8_f32(a.w_b + c, wb8[i]);
   }
-  for (long row = blockIdx.x; row < a.M; row += gridDim.x) {
+  for (long row = row_first; row < row_end; row += row_step) {
+    const bool modulate = ADA && a.shift && (!img_only || a.modality[row] == 1);
+    const bool special = !ADA || !a.modality_r || a.modality_r[row] == 1;     // the row receives gate + dropout
     const float rs = a.rstd[row];
     const float mu = a.norm_type ? a.mean[row] : 0.f;
     const float rsb = a.w_b ? a.rstd_b[row] : 1.f;
@@ -1165,7 +1198,12 @@ __global__ __launch_bounds__(256) void norm_residual_bwd_kernel(NormResidBwdArgs
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         xh[i][k] = (x_n[i][k] - mu) * rs;
-        const float dyv = dy_n[i][k];
+        float dyv = dy_n[i][k];
+        if (ADA && modulate) {
+          dsh[i][k] += dyv;
+          dsc[i][k] += dyv * xh[i][k] * w8[i][k];
+          dyv *= 1.f + sc8[i][k];
+        }
         dwn[i][k] += dyv * xh[i][k];
         g[i][k] = dyv * w8[i][k];
         red[0] += g[i][k];
@@ -1173,7 +1211,7 @@ __global__ __launch_bounds__(256) void norm_residual_bwd_kernel(NormResidBwdArgs
         dxo[i][k] = a.accumulate ? dx_n[i][k] : 0.f;
         br[i][k] = br_n[i][k];
       }
-    fetch(row + gridDim.x);
+    fetch_in_range(row + row_step);
     block_sum4<2>(red, sm);
     const float s_gx = red[1] / a.d, s_g = a.norm_type ? red[0] / a.d : 0.f;
     float nh[NCB][8], g2[NCB][8];
@@ -1187,16 +1225,34 @@ __global__ __launch_bounds__(256) void norm_residual_bwd_kernel(NormResidBwdArgs
       float dn[8];
 #pragma unroll
       for (int k = 0; k < 8; ++k) dn[k] = dxo[i][k];
-      if (a.p_drop > 0.f) {
-        bool keep[8];
-        dropout_keep8(a.seed, (uint64_t)row * a.d + c, a.p_drop, keep);
+      if (a.w_b) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) dn[k] *= keep[k] ? keep_scale : 0.f;
+        for (int k = 0; k < 8; ++k) nh[i][k] = (br[i][k] - mub) * rsb;
+      }
+      if (special) {
+        float dm8[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) dm8[k] = 1.f;
+        if (a.p_drop > 0.f) {
+          bool keep[8];
+          dropout_keep8(a.seed, (uint64_t)row * a.d + c, a.p_drop, keep);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) dm8[k] = keep[k] ? keep_scale : 0.f;
+        }
+        if (ADA && a.gate) {   // the gate's gradient sees the branch as the forward gated it: (sandwich-)normalised, after dropout
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const float nn = a.w_b ? ((a.norm_type == 0 ? rbf(nh[i][k]) : nh[i][k]) * wb8[i][k]) : br[i][k];
+            dgt[i][k] += dn[k] * nn * dm8[k];
+            dn[k] *= gt8[i][k];
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) dn[k] *= dm8[k];
       }
       if (a.w_b) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-          nh[i][k] = (br[i][k] - mub) * rsb;
           const float nr = (a.norm_type == 0) ? rbf(nh[i][k]) : nh[i][k];
           dwb[i][k] += dn[k] * nr;
           g2[i][k] = dn[k] * wb8[i][k];
@@ -1233,7 +1289,30 @@ __global__ __launch_bounds__(256) void norm_residual_bwd_kernel(NormResidBwdArgs
     store8_f32(a.ws + ((long)blockIdx.x * 3) * a.d + c, dwn[i]);
     if (a.w_b) store8_f32(a.ws + ((long)blockIdx.x * 3 + 1) * a.d + c, dwb[i]);
     if (a.dbias) store8_f32(a.ws + ((long)blockIdx.x * 3 + 2) * a.d + c, dbs[i]);
+    if (ADA) {   // second workspace region [grid][3][d]: the block's shift / scale / gate column sums; ada_reduce_kernel adds each batch element's blocks into dmod
+      float* w2 = a.ws + (long)gridDim.x * 3 * a.d;   // (one atomic per column and block here - 4.7 M atomics in 96-deep chains - cost as much as the pass itself)
+      if (a.shift) {
+        store8_f32(w2 + ((long)blockIdx.x * 3) * a.d + c, dsh[i]);
+        store8_f32(w2 + ((long)blockIdx.x * 3 + 1) * a.d + c, dsc[i]);
+      }
+      if (a.gate) store8_f32(w2 + ((long)blockIdx.x * 3 + 2) * a.d + c, dgt[i]);
+    }
   }
+}
+
+// out_k[b][c] += sum over the bpb blocks of batch element b of ws2[block][k][c]  (k = 0 shift, 1 scale, 2 gate; a null target is skipped).  grid (ceil(d / 256), B, 3)
+__global__ __launch_bounds__(256) void ada_reduce_kernel(const float* __restrict__ ws2, float* dshift, float* dscale, float* dgate, long mod_stride, int bpb, int d) {
+  const int c = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y, k = blockIdx.z;
+  float* out = k == 0 ? dshift : (k == 1 ? dscale : dgate);
+  if (!out || c >= d) return;
+  const float* p = ws2 + ((long)b * bpb * 3 + k) * d + c;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int j = 0;
+  for (; j + 3 < bpb; j += 4) {
+    s0 += p[(long)j * 3 * d]; s1 += p[(long)(j + 1) * 3 * d]; s2 += p[(long)(j + 2) * 3 * d]; s3 += p[(long)(j + 3) * 3 * d];
+  }
+  for (; j < bpb; ++j) s0 += p[(long)j * 3 * d];
+  out[(long)b * mod_stride + c] += (s0 + s1) + (s2 + s3);
 }
 
 // The same fused pass for narrow rows (d <= 2048, e.g. UniDisc-S d = 768): a WAVE per row (lane owns 8 columns of each 512-column chunk), no block-wide
@@ -1888,6 +1967,37 @@ extern "C" int udm_norm_residual_bwd(const void* dy, const float* x, const float
   UDM_CHECK_LAUNCH("udm_norm_residual_bwd");
   hipLaunchKernelGGL(colreduce3_kernel, dim3((unsigned)((d + 63) / 64), 16, 3), dim3(256), 0, stream, (const float*)ws, dw, w_b ? dw_b : nullptr, dbias, grid, (int)d);
   UDM_CHECK_LAUNCH("udm_norm_residual_bwd(colreduce)");
+  return 0;
+}
+
+// the fused pass with adaLN-Zero modulation of the norm and / or a gated residual branch (d = 2048 / 4096: the block-per-row form)
+extern "C" int udm_norm_residual_bwd_ada(const void* dy, const float* x, const float* rstd, const float* mean, const float* w, float* dx, float* dw, int accumulate,
+                                         const void* branch, void* dbranch, const float* w_b, const float* rstd_b, const float* mean_b, float* dw_b, float* dbias,
+                                         const void* shift, const void* scale, float* dshift, float* dscale, const void* gate, float* dgate, int64_t mod_stride,
+                                         const int64_t* modality, const int* any_img, const int64_t* modality_r, int64_t M, int64_t d, int64_t L, int norm_type,
+                                         float p_drop, uint64_t seed, float* ws, int64_t ws_elems, hipStream_t stream) {
+  UDM_CHECK_ARG(dy && x && rstd && w && dx && dw && branch && dbranch && ws, "udm_norm_residual_bwd_ada: null pointer");
+  UDM_CHECK_ARG(M > 0 && L > 0 && M % L == 0 && (d == 2048 || d == 4096), "udm_norm_residual_bwd_ada: d = 2048 / 4096 and M = B * L (got M=%ld L=%ld d=%ld)", (long)M, (long)L, (long)d);
+  UDM_CHECK_ARG(norm_type == 0 || mean, "udm_norm_residual_bwd_ada: LayerNorm needs the saved mean");
+  UDM_CHECK_ARG(!w_b || (rstd_b && dw_b && (norm_type == 0 || mean_b)), "udm_norm_residual_bwd_ada: sandwich norm needs rstd_b, dw_b (and mean_b for LayerNorm)");
+  UDM_CHECK_ARG(!shift || (scale && dshift && dscale), "udm_norm_residual_bwd_ada: a modulated norm needs scale, dshift, dscale");
+  UDM_CHECK_ARG(!gate || dgate, "udm_norm_residual_bwd_ada: a gate needs dgate");
+  const int B = (int)(M / L);
+  const int bpb = max(1, min(768 / B, (int)L));
+  const int grid = B * bpb;
+  UDM_CHECK_ARG(ws_elems >= (int64_t)grid * 6 * d, "udm_norm_residual_bwd_ada: workspace too small (need %ld floats)", (long)grid * 6 * d);
+  NormResidBwdArgs a{(const bf16_t*)dy, x, rstd, mean, w, dx, dw, accumulate, (const bf16_t*)branch, (bf16_t*)dbranch, w_b, rstd_b, mean_b, dw_b, dbias, ws,
+                     (int)M, (int)d, norm_type, p_drop, seed};
+  a.shift = (const bf16_t*)shift; a.scale = (const bf16_t*)scale; a.dshift = dshift; a.dscale = dscale; a.gate = (const bf16_t*)gate; a.dgate = dgate;
+  a.mod_stride = (long)mod_stride; a.modality = modality; a.any_img = any_img; a.modality_r = modality_r; a.L = (int)L; a.bpb = bpb;
+  if (d == 2048) hipLaunchKernelGGL((norm_residual_bwd_kernel<1, true>), dim3(grid), dim3(256), 0, stream, a);
+  else hipLaunchKernelGGL((norm_residual_bwd_kernel<2, true>), dim3(grid), dim3(256), 0, stream, a);
+  UDM_CHECK_LAUNCH("udm_norm_residual_bwd_ada");
+  hipLaunchKernelGGL(colreduce3_kernel, dim3((unsigned)((d + 63) / 64), 16, 3), dim3(256), 0, stream, (const float*)ws, dw, w_b ? dw_b : nullptr, dbias, grid, (int)d);
+  UDM_CHECK_LAUNCH("udm_norm_residual_bwd_ada(colreduce)");
+  hipLaunchKernelGGL(ada_reduce_kernel, dim3((unsigned)((d + 255) / 256), B, 3), dim3(256), 0, stream, (const float*)(ws + (long)grid * 3 * d), shift ? dshift : nullptr,
+                     shift ? dscale : nullptr, gate ? dgate : nullptr, (long)mod_stride, bpb, (int)d);
+  UDM_CHECK_LAUNCH("udm_norm_residual_bwd_ada(ada reduce)");
   return 0;
 }
 

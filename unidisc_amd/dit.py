@@ -1079,6 +1079,8 @@ class DIT(nn.Module, _HubMixin):
         # consumes it - the final norm and each block's norm1 pair with the MLP branch of the block below them in the schedule, so a block's
         # gradient range is reported (and its activations dropped) only after that fused pass.
         pend = None
+        # adaLN-Zero (round 5): the same pairing with the modulated / gated forms of the fused pass where the kernel covers the shape (K.norm_residual_bwd_ada)
+        tc_fused = tc and not stream_compact and K.norm_residual_bwd_ada_ok(M, d, L)
         if tc:
             K.norm_bwd(dhf, S["x_final"], S["rstdf"], S["meanf"], fl.norm_final.weight.detach(), nt, L, dx, G[id(fl.norm_final.weight)], accumulate=False,
                        mod=fmod, dmod=dmodf, mod_idx=(0, 1), modality=mod_flat, any_img=any_img)
@@ -1096,9 +1098,16 @@ class DIT(nn.Module, _HubMixin):
                 if dbias is not None:
                     K.colsum(out, dbias)
                 return out
-            out = K.norm_residual_bwd(pend["dy"], pend["x"], pend["rstd"], pend["mean"], pend["w"], nt, L, dx, pend["dw"], branch, accumulate=pend["accumulate"],
-                                      w_b=kw.get("w_b"), rstd_b=kw.get("rstd"), mean_b=kw.get("mean"), dw_b=kw.get("dw_b"), p_drop=kw.get("p_drop", 0.0),
-                                      seed=kw.get("seed", 0), dbias=kw.get("dbias"))
+            if pend.get("mod") is not None or kw.get("gate_idx") is not None:   # adaLN-Zero: modulated norm and / or gated branch, still one pass per row
+                out = K.norm_residual_bwd_ada(pend["dy"], pend["x"], pend["rstd"], pend["mean"], pend["w"], nt, L, dx, pend["dw"], branch, accumulate=pend["accumulate"],
+                                              w_b=kw.get("w_b"), rstd_b=kw.get("rstd"), mean_b=kw.get("mean"), dw_b=kw.get("dw_b"), p_drop=kw.get("p_drop", 0.0),
+                                              seed=kw.get("seed", 0), dbias=kw.get("dbias"), mod_n=pend.get("mod"), dmod_n=pend.get("dmod"),
+                                              mod_idx=pend.get("mod_idx", (0, 1)), modality=mod_flat, any_img=any_img, mod_r=kw.get("mod"), dmod_r=kw.get("dmod"),
+                                              gate_idx=kw.get("gate_idx"), modality_r=kw.get("modality"))
+            else:
+                out = K.norm_residual_bwd(pend["dy"], pend["x"], pend["rstd"], pend["mean"], pend["w"], nt, L, dx, pend["dw"], branch, accumulate=pend["accumulate"],
+                                          w_b=kw.get("w_b"), rstd_b=kw.get("rstd"), mean_b=kw.get("mean"), dw_b=kw.get("dw_b"), p_drop=kw.get("p_drop", 0.0),
+                                          seed=kw.get("seed", 0), dbias=kw.get("dbias"))
             pend["done"]()
             return out
 
@@ -1112,10 +1121,11 @@ class DIT(nn.Module, _HubMixin):
             dmod = torch.zeros((Bp, 6 * d), dtype=F32, device=dev) if tc else None
             f1, f2 = lin[f"{i}.fc1"], lin[f"{i}.fc2"]
             # MLP branch
-            if tc:
-                du2 = K.residual_bwd(dx, R["u2"], L, w_b=blk.post_ff_norm.weight.detach() if sw else None, rstd=R["rstd_m"], mean=R["mean_m"], norm_type=nt,
-                                     mod=mod, dmod=dmod, gate_idx=5, modality=mod_flat, dw_b=G[id(blk.post_ff_norm.weight)] if sw else None,
-                                     p_drop=p_drop, seed=seed0 + 4 * i + 2)
+            if tc:   # (pend: the modulated norm1 of block i + 1 when the fused adaLN pass is in use)
+                du2 = branch_bwd(pend, R["u2"], w_b=blk.post_ff_norm.weight.detach() if sw else None, rstd=R["rstd_m"], mean=R["mean_m"], norm_type=nt,
+                                 mod=mod, dmod=dmod, gate_idx=5, modality=mod_flat, dw_b=G[id(blk.post_ff_norm.weight)] if sw else None,
+                                 p_drop=p_drop, seed=seed0 + 4 * i + 2)
+                pend = None
             else:
                 # (the mlp.2 bias gradient = column sums of du2 comes out of the same pass)
                 du2 = branch_bwd(pend, R["u2"], w_b=blk.post_ff_norm.weight.detach() if sw else None, rstd=R["rstd_m"], mean=R["mean_m"], norm_type=nt,
@@ -1137,7 +1147,15 @@ class DIT(nn.Module, _HubMixin):
                 self._wgrad(du1, R["h2"], f1, G, bias_done=True)
             del du1, du2
             # norm2 backward + attention branch
-            if tc:
+            if tc_fused:
+                p2 = dict(dy=dh2, x=R["x_mid"], rstd=R["rstd2"], mean=R["mean2"], w=blk.norm2.weight.detach(), dw=G[id(blk.norm2.weight)], accumulate=True,
+                          done=lambda: None, mod=mod, dmod=dmod, mod_idx=(3, 4))
+                if sw:
+                    da = branch_bwd(p2, R["a_out"], w_b=blk.pre_residual_norm.weight.detach(), rstd=R["rstd_a"], mean=R["mean_a"], norm_type=nt,
+                                    dw_b=G[id(blk.pre_residual_norm.weight)])
+                else:
+                    da = branch_bwd(p2, R["a_out"], mod=mod, dmod=dmod, gate_idx=2, p_drop=p_drop, seed=seed0 + 4 * i + 1)
+            elif tc:
                 K.norm_bwd(dh2, R["x_mid"], R["rstd2"], R["mean2"], blk.norm2.weight.detach(), nt, L, dx, G[id(blk.norm2.weight)], accumulate=True,
                            mod=mod, dmod=dmod, mod_idx=(3, 4), modality=mod_flat, any_img=any_img)
                 if sw:
@@ -1193,7 +1211,14 @@ class DIT(nn.Module, _HubMixin):
                 pair_out = None
             else:
                 self._wgrad(dqkv, R["h1"], lq, G)
-            if tc:
+            if tc_fused:   # norm1 (modulated) pairs with the gated MLP branch of block i - 1; this block's adaLN_modulation backward needs the shift / scale
+                def done_tc(i=i, blk=blk, dmod=dmod):   # gradients of that pass, so it waits for it
+                    self._ada_backward(dmod, lin[f"{i}.ada"], S["c"], dc, G)
+                    S["blocks"][i] = None
+                    self._notify(flat, list(blk.parameters()))
+                pend = dict(dy=dh1, x=R["x_in"], rstd=R["rstd1"], mean=R["mean1"], w=blk.norm1.weight.detach(), dw=G[id(blk.norm1.weight)], accumulate=True,
+                            done=done_tc, mod=mod, dmod=dmod, mod_idx=(0, 1))
+            elif tc:
                 K.norm_bwd(dh1, R["x_in"], R["rstd1"], R["mean1"], blk.norm1.weight.detach(), nt, L, dx, G[id(blk.norm1.weight)], accumulate=True,
                            mod=mod, dmod=dmod, mod_idx=(0, 1), modality=mod_flat, any_img=any_img)
                 self._ada_backward(dmod, lin[f"{i}.ada"], S["c"], dc, G)
@@ -1205,7 +1230,9 @@ class DIT(nn.Module, _HubMixin):
                     self._notify(flat, list(blk.parameters()))
                 pend = dict(dy=dh1, x=R["x_in"], rstd=R["rstd1"], mean=R["mean1"], w=blk.norm1.weight.detach(), dw=G[id(blk.norm1.weight)], accumulate=True, done=done)
         if pend is not None:   # block 0's norm1 (or the final norm of a model without blocks): nothing below it to pair with
-            K.norm_bwd(pend["dy"], pend["x"], pend["rstd"], pend["mean"], pend["w"], nt, L, dx, pend["dw"], accumulate=pend["accumulate"])
+            K.norm_bwd(pend["dy"], pend["x"], pend["rstd"], pend["mean"], pend["w"], nt, L, dx, pend["dw"], accumulate=pend["accumulate"], mod=pend.get("mod"),
+                       dmod=pend.get("dmod"), mod_idx=pend.get("mod_idx", (0, 1)), modality=mod_flat if pend.get("mod") is not None else None,
+                       any_img=any_img if pend.get("mod") is not None else None)
             pend["done"]()
 
         # ---- embeddings

@@ -678,6 +678,35 @@ def norm_residual_bwd(dy, x, rstd, mean, w, norm_type, L, dx, dw, branch, *, acc
     return out
 
 
+def norm_residual_bwd_ada_ok(M, d, L):
+    """Does the fused adaLN form (norm_residual_bwd_ada) cover this shape?  (the block-per-row kernel: d = 2048 / 4096, whole batch elements)"""
+    return d in (2048, 4096) and L > 0 and M % L == 0
+
+
+def norm_residual_bwd_ada(dy, x, rstd, mean, w, norm_type, L, dx, dw, branch, *, accumulate=True, w_b=None, rstd_b=None, mean_b=None, dw_b=None, p_drop=0.0, seed=0,
+                          dbias=None, mod_n=None, dmod_n=None, mod_idx=(0, 1), modality=None, any_img=None, mod_r=None, dmod_r=None, gate_idx=None, modality_r=None):
+    """norm_residual_bwd with adaLN-Zero: the norm modulated by chunks `mod_idx` = (shift, scale) of `mod_n` (gradients into the same chunks of `dmod_n`; image rows
+    only under `modality` / `any_img` as in norm_bwd), the residual branch gated by chunk `gate_idx` of `mod_r` (gradient into `dmod_r`; gate and dropout on rows
+    with modality_r == 1 only when given, as in residual_bwd).  Shapes must pass norm_residual_bwd_ada_ok."""
+    M, d = x.shape
+    (shift, scale), ms_n = _mod_ptrs(mod_n, mod_idx, d)
+    (dshift, dscale), _ = _mod_ptrs(dmod_n, mod_idx, d)
+    use_gate = gate_idx is not None and mod_r is not None
+    (gate,), ms_r = _mod_ptrs(mod_r if use_gate else None, (gate_idx,), d)
+    (dgate,), _ = _mod_ptrs(dmod_r if use_gate else None, (gate_idx,), d)
+    if mod_n is not None and use_gate and ms_n != ms_r:
+        raise ValueError("norm_residual_bwd_ada: the two adaLN tensors must share their row stride")
+    for m_, dm_ in ((mod_n, dmod_n), (mod_r if use_gate else None, dmod_r)):
+        if m_ is not None and (dm_ is None or dm_.stride(0) != m_.stride(0)):
+            raise ValueError("norm_residual_bwd_ada: an adaLN tensor and its gradient must share their row stride")
+    dbranch = torch.empty((M, d), dtype=BF16, device=x.device)
+    ws = _scratch(768 * 6 * d, x.device)
+    _lib.call("udm_norm_residual_bwd_ada", _p(dy), _p(x), _p(rstd), _p(mean), _p(w), _p(dx), _p(dw), 1 if accumulate else 0, _p(branch), _p(dbranch), _p(w_b), _p(rstd_b),
+              _p(mean_b), _p(dw_b), _p(dbias), shift, scale, dshift, dscale, gate, dgate, ms_n or ms_r, _p(modality) if mod_n is not None else None,
+              _p(any_img) if mod_n is not None else None, _p(modality_r), M, d, L, norm_type, float(p_drop), int(seed), _p(ws), ws.numel(), _s())
+    return dbranch
+
+
 # ------------------------------------------------------------------------------------------------ attention
 def attention_q_scale(D):
     """log2(e) / sqrt(D): folded into the stored q by qknorm_rope_fwd(q_scale=...) on the engine's path, so that the attention kernels' scores are the base-2
