@@ -130,6 +130,12 @@ int udm_residual_fwd(const float* x_in, const void* branch, float* x_out, const 
 int udm_residual_norm_fwd(const float* x_in, const void* branch, float* x_out, const float* w_b, float* rstd_b, float* mean_b, const void* gate,
                           int64_t mod_stride, const int64_t* modality, int64_t M, int64_t d, int64_t L, int norm_type, float eps, float p_drop,
                           uint64_t seed, const float* w_next, void* h_out, float* rstd_next, float* mean_next, hipStream_t stream);
+/* ... with the next pre-norm MODULATED (adaLN-Zero, models/dit.py:263-304): h_out = norm(x_out; w_next) (1 + next_scale) + next_shift on the rows udm_norm_fwd would
+ * modulate (next_shift / next_scale bf16 [B, next_mod_stride]; next_modality / next_any_img as udm_norm_fwd's modality / any_img). */
+int udm_residual_norm_fwd_ada(const float* x_in, const void* branch, float* x_out, const float* w_b, float* rstd_b, float* mean_b, const void* gate, int64_t mod_stride,
+                              const int64_t* modality, int64_t M, int64_t d, int64_t L, int norm_type, float eps, float p_drop, uint64_t seed, const float* w_next,
+                              void* h_out, float* rstd_next, float* mean_next, const void* next_shift, const void* next_scale, int64_t next_mod_stride,
+                              const int64_t* next_modality, const int* next_any_img, hipStream_t stream);
 int udm_residual_bwd(const float* dx, const void* branch, void* dbranch, const float* w_b, const float* rstd_b, const float* mean_b, const void* gate,
                      int64_t mod_stride, const int64_t* modality, float* dw_b, float* dgate, int64_t M, int64_t d, int64_t L, int norm_type, float p_drop,
                      uint64_t seed, float* ws, int64_t ws_elems, hipStream_t stream);

@@ -150,12 +150,13 @@ def _branch(x_in, br, L, w_b, norm_type, mod, gate_idx, modality):
     return x_in + out, rstd, mean
 
 
-def residual_fwd(x_in, branch, L, *, w_b=None, norm_type=NORM_RMS, mod=None, gate_idx=None, modality=None, p_drop=0.0, seed=0, next_w=None):
+def residual_fwd(x_in, branch, L, *, w_b=None, norm_type=NORM_RMS, mod=None, gate_idx=None, modality=None, p_drop=0.0, seed=0, next_w=None, next_mod=None,
+                 next_mod_idx=(0, 1), next_modality=None, next_any_img=None):
     assert p_drop == 0.0, "fake kernels: dropout not emulated"
     out, rstd, mean = _branch(x_in, branch.float(), L, w_b, norm_type, mod.float() if mod is not None else None, gate_idx, modality)
     if next_w is None:
         return out, rstd, mean
-    return out, rstd, mean, norm_fwd(out, next_w, norm_type, L)
+    return out, rstd, mean, norm_fwd(out, next_w, norm_type, L, mod=next_mod, mod_idx=next_mod_idx, modality=next_modality, any_img=next_any_img)
 
 
 @torch.enable_grad()

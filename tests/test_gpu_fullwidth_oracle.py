@@ -58,6 +58,9 @@ FULLWIDTH = {
     "unidisc_s_12blocks_b4": (dict(_SMALL, n_blocks=12), 4, dict(loss=5e-5, nll=1.2e-3, grad_max=None, grad_med=3e-2)),
     # BASELINE configs[0]: 2-layer d = 256 text-only adaLN DiT, L = 128, vocabulary 1k (+ [MASK])
     "config_a_plumbing_b8": (dict(_PLUMB, n_blocks=2), 8, dict(loss=5e-5, nll=1e-3, grad_max=2.5e-2, grad_med=2e-2)),
+    # the same LayerNorm DiT WITHOUT time conditioning and without sandwich norms: the residual adds carry the fused next pre-norm in its LayerNorm form (round 5: the
+    # attention branch's add passed no norm type and normalised as RMS - no golden case has this combination)
+    "layernorm_no_adaln_b4": (dict(_PLUMB, n_blocks=2, time_conditioning=False), 4, dict(loss=5e-5, nll=1e-3, grad_max=2.5e-2, grad_med=2e-2)),
 }
 
 

@@ -562,6 +562,29 @@ def _mod_inputs(B, d, n, seed):
     return bf(mod)
 
 
+@pytest.mark.parametrize("d", [64, 768, 2048])
+@pytest.mark.parametrize("nt", [0, 1], ids=["rms", "layernorm"])
+@pytest.mark.parametrize("img", [False, True], ids=["all_rows", "image_rows"])
+def test_residual_with_fused_modulated_next_norm_equals_separate_kernels(K, d, img, nt):
+    """residual add + the NEXT pre-norm in its adaLN-modulated form in one pass (udm_residual_norm_fwd_ada) against residual_fwd followed by the modulated norm_fwd:
+    the same arithmetic on the same registers - bit-identical h, rstd; the adaLN tensor of the norm has its own row stride (the final layer's is 2 d wide)."""
+    B, L = 3, 37
+    M = B * L
+    g = lambda t: t.to(DEV) if t is not None else None
+    x_in, br = rnd(M, d, seed=730), bf(rnd(M, d, seed=731, scale=1.5))
+    w_b, w_n = 1 + 0.1 * rnd(d, seed=732), 1 + 0.1 * rnd(d, seed=733)
+    mod_g, mod_n = _mod_inputs(B, d, 6, 734), _mod_inputs(B, d, 2, 735)
+    modality = (torch.arange(M) % L >= L // 2).long() if img else None
+    any_img = torch.ones(1, dtype=torch.int32) if img else None
+    kw = dict(w_b=g(w_b), norm_type=nt, mod=g(mod_g), gate_idx=5, modality=g(modality), p_drop=0.1, seed=5)
+    xo_a, rstd_a, _ = K.residual_fwd(g(x_in), g(br), L, **kw)
+    h_a, rn_a, _ = K.norm_fwd(xo_a, g(w_n), nt, L, mod=g(mod_n), mod_idx=(0, 1), modality=g(modality), any_img=g(any_img))
+    xo_f, rstd_f, _, (h_f, rn_f, _) = K.residual_fwd(g(x_in), g(br), L, next_w=g(w_n), next_mod=g(mod_n), next_mod_idx=(0, 1), next_modality=g(modality),
+                                                   next_any_img=g(any_img), **kw)
+    assert torch.equal(xo_f, xo_a) and torch.equal(rstd_f, rstd_a)
+    assert torch.equal(h_f, h_a) and torch.equal(rn_f, rn_a)
+
+
 @pytest.mark.parametrize("variant", ["mod_sandwich", "mod_img_gate_sandwich_dropout", "mod_gate_plain", "gate_only"])
 @pytest.mark.parametrize("B,L", [(3, 37), (2, 700)], ids=["b3_l37", "b2_l700_more_rows_than_blocks"])
 def test_norm_residual_bwd_ada_equals_separate_kernels(K, variant, B, L):

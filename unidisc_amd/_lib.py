@@ -43,6 +43,7 @@ PROTOTYPES = {
     "udm_norm_bwd": [_P, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I, _I, _P, _I64, _P],
     "udm_residual_fwd": [_P, _P, _P, _P, _P, _P, _P, _I64, _P, _I64, _I64, _I64, _I, _F, _F, _U64, _P],
     "udm_residual_norm_fwd": [_P, _P, _P, _P, _P, _P, _P, _I64, _P, _I64, _I64, _I64, _I, _F, _F, _U64, _P, _P, _P, _P, _P],
+    "udm_residual_norm_fwd_ada": [_P, _P, _P, _P, _P, _P, _P, _I64, _P, _I64, _I64, _I64, _I, _F, _F, _U64, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _P],
     "udm_residual_bwd": [_P, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _P, _I64, _I64, _I64, _I, _F, _U64, _P, _I64, _P],
     "udm_norm_residual_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I, _F, _U64, _P, _I64, _P],
     "udm_norm_residual_bwd_ada": [_P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _P, _I64, _I64, _I64, _I, _F, _U64,

@@ -281,6 +281,8 @@ struct ResidArgs {
   bf16_t* h_out;
   float* rstd_n;
   float* mean_n;
+  // ... modulated (adaLN-Zero, models/dit.py:263-304): h_out = norm(x_out; w_n) * (1 + scale) + shift on the rows norm_fwd would modulate
+  const bf16_t* n_shift = nullptr; const bf16_t* n_scale = nullptr; long n_mod_stride = 0; const int64_t* n_modality = nullptr; const int* n_any_img = nullptr;
 };
 
 template <int NCH>
@@ -412,6 +414,13 @@ __global__ __launch_bounds__(256) void residual_fwd_kernel(ResidArgs a) {
         load8_f32(a.w_n + c, w8);
 #pragma unroll
         for (int k = 0; k < 8; ++k) o[k] = (v[i][k] - mu2) * rs2 * w8[k];
+        if (a.n_shift && (!(a.n_modality && (!a.n_any_img || *a.n_any_img != 0)) || a.n_modality[row] == 1)) {   // norm_fwd_kernel's rule and arithmetic
+          float sh[8], sc[8];
+          load8_bf16(a.n_shift + (long)b * a.n_mod_stride + c, sh);
+          load8_bf16(a.n_scale + (long)b * a.n_mod_stride + c, sc);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) o[k] = o[k] * (1.f + sc[k]) + sh[k];
+        }
         store8_bf16(a.h_out + row * a.d + c, o);
       }
     }
@@ -1845,6 +1854,27 @@ extern "C" int udm_norm_bwd(const void* dy, const float* x, const float* rstd, c
     hipLaunchKernelGGL(colreduce_kernel, dim3((unsigned)((d + 63) / 64), 16), dim3(256), 0, stream, (const float*)ws, dw, grid, (int)d);
     UDM_CHECK_LAUNCH("udm_norm_bwd(colreduce)");
   }
+  return 0;
+}
+
+// residual add + the next pre-norm WITH adaLN modulation in one pass (time_conditioning = True)
+extern "C" int udm_residual_norm_fwd_ada(const float* x_in, const void* branch, float* x_out, const float* w_b, float* rstd_b, float* mean_b, const void* gate,
+                                         int64_t mod_stride, const int64_t* modality, int64_t M, int64_t d, int64_t L, int norm_type, float eps, float p_drop,
+                                         uint64_t seed, const float* w_next, void* h_out, float* rstd_next, float* mean_next, const void* next_shift,
+                                         const void* next_scale, int64_t next_mod_stride, const int64_t* next_modality, const int* next_any_img, hipStream_t stream) {
+  UDM_CHECK_ARG(x_in && branch && x_out && w_next && h_out && rstd_next && next_shift && next_scale, "udm_residual_norm_fwd_ada: null pointer");
+  UDM_CHECK_ARG(M > 0 && d > 0 && d % 8 == 0 && L > 0, "udm_residual_norm_fwd_ada: bad shape");
+  UDM_CHECK_ARG(!w_b || rstd_b, "udm_residual_norm_fwd_ada: sandwich norm needs rstd buffer");
+  UDM_CHECK_ARG(!(w_b && norm_type) || mean_b, "udm_residual_norm_fwd_ada: sandwich LayerNorm needs mean buffer");
+  UDM_CHECK_ARG(!norm_type || mean_next, "udm_residual_norm_fwd_ada: LayerNorm needs mean_next");
+  UDM_CHECK_ARG(p_drop >= 0.f && p_drop < 1.f, "udm_residual_norm_fwd_ada: dropout p out of range");
+  ResidArgs a{x_in, (const bf16_t*)branch, x_out, w_b, rstd_b, (w_b && norm_type) ? mean_b : nullptr, (const bf16_t*)gate, modality, (long)mod_stride,
+              (int)M, (int)d, (int)L, norm_type, eps, p_drop, seed, w_next, (bf16_t*)h_out, rstd_next, norm_type ? mean_next : nullptr};
+  a.n_shift = (const bf16_t*)next_shift; a.n_scale = (const bf16_t*)next_scale; a.n_mod_stride = (long)next_mod_stride; a.n_modality = next_modality;
+  a.n_any_img = next_any_img;
+  int nch = nch_for(d); if (nch > 4) nch = 8;
+  DISPATCH_NCH(nch, residual_fwd_kernel, grid_rows(M), stream, a);
+  UDM_CHECK_LAUNCH("udm_residual_norm_fwd_ada");
   return 0;
 }
 

@@ -686,6 +686,16 @@ class DIT(nn.Module, _HubMixin):
             S.update(Bp=Bp, te=te, l1=l1, s1=s1, l2=l2, c=c, any_img=any_img)
 
         ckpt = bool(self.use_gradient_checkpointing) and save
+        ada_cache = {}
+
+        def ada_mod(i):
+            """adaLN_modulation(c) of block i (i == n_blocks: the final layer's), computed once: the residual add in front of a modulated norm needs it one block early"""
+            key = str(i) if i < self.n_blocks else "head"
+            if key not in ada_cache:
+                self._await_cast(i if i < self.n_blocks else "head")
+                a = lin[f"{key}.ada"]
+                ada_cache[key] = K.gemm_nt(S["c"], a.w16, N=a.out, epilogue=K.EPI_BIAS, bias=a.bias.detach())   # [Bp, 6d] (final layer: [Bp, 2d]) bf16
+            return ada_cache[key]
 
         def block_fwd(i, x, pre, last_rows=None, recompute=False):
             """One DiT block: x [M, d] fp32 -> (x_out, pre_out, R).  R holds what the block's backward reads.  `recompute` (activation checkpointing,
@@ -697,8 +707,7 @@ class DIT(nn.Module, _HubMixin):
             if not recompute:
                 self._await_cast(i)
             if tc:
-                a = lin[f"{i}.ada"]
-                mod = K.gemm_nt(S["c"], a.w16, N=a.out, epilogue=K.EPI_BIAS, bias=a.bias.detach())  # [Bp, 6d] bf16
+                mod = ada_mod(i)   # [Bp, 6d] bf16
                 R["mod"] = mod
             if pre is not None:  # norm1 came fused out of the previous block's MLP residual add
                 h1, rstd1, mean1 = pre
@@ -723,26 +732,28 @@ class DIT(nn.Module, _HubMixin):
             else:
                 Mb = M
             a_out = K.gemm_nt(o, lin[f"{i}.out"].w16, N=d)
-            # Without adaLN the next pre-norm is unmodulated and is fused into the residual add (x_out is normalised while in registers)
-            fuse_w2 = None if tc else blk.norm2.weight.detach()
+            # The next pre-norm is fused into the residual add (x_out is normalised while in registers) - with adaLN in its modulated form (round 5)
+            fuse_w2 = blk.norm2.weight.detach()
+            nkw2 = dict(next_mod=mod, next_mod_idx=(3, 4), next_modality=mod_flat, next_any_img=any_img) if tc else {}
             if sw:  # x = x_skip + pre_residual_norm(attn)   (dit.py:993-994; no gate, no dropout)
-                res = K.residual_fwd(x, a_out, L, w_b=blk.pre_residual_norm.weight.detach(), norm_type=nt, next_w=fuse_w2)
+                res = K.residual_fwd(x, a_out, L, w_b=blk.pre_residual_norm.weight.detach(), norm_type=nt, next_w=fuse_w2, **nkw2)
             else:   # bias_dropout_add_scale with gate_msa on every token (Attention.time_conditioning is never set: dit.py:533,884)
-                res = K.residual_fwd(x, a_out, L, mod=mod, gate_idx=2 if tc else None, p_drop=p_drop, seed=seed0 + 4 * i + 1, next_w=fuse_w2)
+                res = K.residual_fwd(x, a_out, L, norm_type=nt, mod=mod, gate_idx=2 if tc else None, p_drop=p_drop, seed=seed0 + 4 * i + 1, next_w=fuse_w2, **nkw2)
             x_mid, rstd_a, mean_a = res[:3]
-            if fuse_w2 is not None:
-                h2, rstd2, mean2 = res[3]
-            else:
-                h2, rstd2, mean2 = K.norm_fwd(x_mid, blk.norm2.weight.detach(), nt, L, mod=mod, mod_idx=(3, 4), modality=mod_flat, any_img=any_img)
+            h2, rstd2, mean2 = res[3]
             f1, f2 = lin[f"{i}.fc1"], lin[f"{i}.fc2"]
             u1 = torch.empty((Mb, 4 * d), dtype=BF16, device=dev)
             g = K.gemm_nt(h2, f1.w16, N=4 * d, epilogue=K.EPI_BIAS_GELU, bias=f1.bias.detach(), aux=u1)
             u2 = K.gemm_nt(g, f2.w16, N=d, epilogue=K.EPI_BIAS, bias=f2.bias.detach())
-            nxt_w = None
-            if not tc:  # the consumer of x_out: norm1 of the next block, or norm_final
-                nxt_w = (self.blocks[i + 1].norm1.weight if i + 1 < self.n_blocks else self.output_layer.norm_final.weight).detach()
+            # the consumer of x_out: norm1 of the next block, or norm_final (with adaLN: modulated by the NEXT block's / the final layer's adaLN output)
+            nxt_w = (self.blocks[i + 1].norm1.weight if i + 1 < self.n_blocks else self.output_layer.norm_final.weight).detach()
+            nkw = {}
+            if tc and not recompute:
+                nkw = dict(next_mod=ada_mod(i + 1), next_mod_idx=(0, 1), next_modality=mod_flat, next_any_img=any_img)
+            elif tc:      # (recomputation of ONE block in the backward: its output's norm is not needed)
+                nxt_w = None
             res = K.residual_fwd(x_mid, u2, L, w_b=blk.post_ff_norm.weight.detach() if sw else None, norm_type=nt, mod=mod,
-                                 gate_idx=5 if tc else None, modality=mod_flat if tc else None, p_drop=p_drop, seed=seed0 + 4 * i + 2, next_w=nxt_w)
+                                 gate_idx=5 if tc else None, modality=mod_flat if tc else None, p_drop=p_drop, seed=seed0 + 4 * i + 2, next_w=nxt_w, **nkw)
             x_out, rstd_m, mean_m = res[:3]
             pre = res[3] if nxt_w is not None else None
             if save:
@@ -766,8 +777,7 @@ class DIT(nn.Module, _HubMixin):
         fmod = None
         self._await_cast("head")
         if tc:
-            a = lin["head.ada"]
-            fmod = K.gemm_nt(S["c"], a.w16, N=a.out, epilogue=K.EPI_BIAS, bias=a.bias.detach())  # [Bp, 2d]
+            fmod = ada_mod(self.n_blocks)  # [Bp, 2d]
         if pre is not None:
             hf, rstdf, meanf = pre
         else:

@@ -625,9 +625,11 @@ def norm_bwd(dy, x, rstd, mean, w, norm_type, L, dx, dw, *, accumulate=True, mod
               _p(ws), ws.numel() if ws is not None else 0, _s())
 
 
-def residual_fwd(x_in, branch, L, *, w_b=None, norm_type=NORM_RMS, mod=None, gate_idx=None, modality=None, p_drop=0.0, seed=0, next_w=None):
+def residual_fwd(x_in, branch, L, *, w_b=None, norm_type=NORM_RMS, mod=None, gate_idx=None, modality=None, p_drop=0.0, seed=0, next_w=None, next_mod=None,
+                 next_mod_idx=(0, 1), next_modality=None, next_any_img=None):
     """x_out = x_in + gate * dropout(sandwich_norm(branch)).  gate = chunk gate_idx of `mod` (None: no gate).
-    next_w: weight of the (unmodulated) norm that consumes x_out next -- fused; returns (x_out, rstd, mean, (h, rstd_n, mean_n))."""
+    next_w: weight of the norm that consumes x_out next -- fused; returns (x_out, rstd, mean, (h, rstd_n, mean_n)).  next_mod: that norm is modulated by chunks
+    next_mod_idx = (shift, scale) of this adaLN tensor (image rows only under next_modality / next_any_img, as norm_fwd)."""
     M, d = x_in.shape
     x_out = torch.empty_like(x_in)
     rstd = torch.empty(M, dtype=F32, device=x_in.device) if w_b is not None else None
@@ -641,6 +643,11 @@ def residual_fwd(x_in, branch, L, *, w_b=None, norm_type=NORM_RMS, mod=None, gat
     h = torch.empty((M, d), dtype=BF16, device=x_in.device)
     rstd_n = torch.empty(M, dtype=F32, device=x_in.device)
     mean_n = torch.empty(M, dtype=F32, device=x_in.device) if norm_type == NORM_LN else None
+    if next_mod is not None:
+        (n_shift, n_scale), n_ms = _mod_ptrs(next_mod, next_mod_idx, d)
+        _lib.call("udm_residual_norm_fwd_ada", _p(x_in), _p(branch), _p(x_out), _p(w_b), _p(rstd), _p(mean), gate, ms, _p(modality), M, d, L, norm_type,
+                  eps, float(p_drop), int(seed), _p(next_w), _p(h), _p(rstd_n), _p(mean_n), n_shift, n_scale, n_ms, _p(next_modality), _p(next_any_img), _s())
+        return x_out, rstd, mean, (h, rstd_n, mean_n)
     _lib.call("udm_residual_norm_fwd", _p(x_in), _p(branch), _p(x_out), _p(w_b), _p(rstd), _p(mean), gate, ms, _p(modality), M, d, L, norm_type,
               eps, float(p_drop), int(seed), _p(next_w), _p(h), _p(rstd_n), _p(mean_n), _s())
     return x_out, rstd, mean, (h, rstd_n, mean_n)
