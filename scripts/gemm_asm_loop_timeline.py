@@ -7,7 +7,7 @@ from unidisc_amd import kernels as K
 
 M = 10240
 K.gemm_set_quad(2)
-K.debug_set("gemm_quad_asm", 1)
+K.debug_set("gemm_quad_asm", int(os.environ.get("UDM_QUAD_ASM_MODE", "1")))      # 2: the 16x16x32 statement
 g = torch.Generator(device="cuda").manual_seed(0)
 for (N, Kd, FM) in [(2048, 8192, 5), (2048, 2048, 5), (8192, 2048, 5)]:
     a = torch.randn(M, Kd, device="cuda", generator=g).bfloat16()
@@ -23,7 +23,7 @@ for (N, Kd, FM) in [(2048, 8192, 5), (2048, 2048, 5), (8192, 2048, 5)]:
     torch.cuda.synchronize()
     t = tl.cpu().numpy().astype("int64") & 0xFFFFFFFF
     nk = Kd // 64
-    mf = nk * 4 * FM * 4
+    mf = nk * 4 * FM * 4       # counted as 32x32x16 MFMAs (the 16x16x32 loop issues twice as many of half the size)
     tot, vm, bar = t[..., 0].mean(), t[..., 1].mean(), t[..., 2].mean()
     us = e0.elapsed_time(e1) * 1e3
     print(json.dumps(dict(N=N, K=Kd, launch_us=round(us, 1), loop_cycles=round(tot), cycles_per_mfma=round(tot / mf, 2), vmcnt_wait_per_tile=round(vm / (nk - 1), 1),

@@ -68,6 +68,14 @@ def test_emulated_gemm_loop_matches_numpy(FM, K, mode):
     assert r["rel_err"] < 1e-6, r          # fp32 accumulation of exact bf16 products, in the kernel's own k order
 
 
+@pytest.mark.parametrize("mode", ["late", "early"])
+def test_emulated_gemm_loop_16x16x32_form_matches_numpy(mode):
+    """the measured-and-not-shipped form of the loop on v_mfma_f32_16x16x32_bf16 (pinned accumulators, single-buffered A fragments): still generated, still correct"""
+    import emu_gemm
+    r = emu_gemm.run(FM=5, K=256, mode=mode, seed=4, mf16=True)
+    assert r["rel_err"] < 1e-6, r
+
+
 def test_gemm_loop_lint_and_header_current(tmp_path):
     import isa
     import gemm_loop as gl

@@ -4,9 +4,9 @@ import isa
 import gemm_loop as gl
 
 
-def run(FM=5, K=256, mode="late", seed=0, ld_pad=64):
+def run(FM=5, K=256, mode="late", seed=0, ld_pad=64, mf16=False):
     rng = np.random.default_rng(seed)
-    g = gl.Gemm(FM)
+    g = gl.Gemm16(FM) if mf16 else gl.Gemm(FM)
     prog = g.build() + [isa.s_endpgm()]
     BM = 64 * FM
     lda, ldb = K + ld_pad, K + 2 * ld_pad
@@ -36,6 +36,13 @@ def run(FM=5, K=256, mode="late", seed=0, ld_pad=64):
             for j in range(4):
                 acc = w.f32(g.acc(i, j))     # [16, 64]
                 for r in range(16):
+                    if mf16:   # four 16 x 16 sub-blocks of 4 registers: sub-block (ti, tj), register rr -> row ti 16 + 4 (lane >> 4) + rr, column tj 16 + (lane & 15)
+                        ti, tj, rr = r >> 3, (r >> 2) & 1, r & 3
+                        for gq in range(4):
+                            row = wm * 32 * FM + i * 32 + ti * 16 + 4 * gq + rr
+                            c0 = wn * 128 + j * 32 + tj * 16
+                            C[row, c0:c0 + 16] = acc[r, 16 * gq:16 * gq + 16]
+                        continue
                     for h in range(2):
                         row = wm * 32 * FM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h
                         C[row, wn * 128 + j * 32: wn * 128 + j * 32 + 32] = acc[r, 32 * h:32 * h + 32]
@@ -44,6 +51,7 @@ def run(FM=5, K=256, mode="late", seed=0, ld_pad=64):
 
 
 if __name__ == "__main__":
-    for FM in (5, 4):
-        for mode in ("late", "early"):
-            print(FM, mode, run(FM=FM, mode=mode), run(FM=FM, K=512, mode=mode, seed=1))
+    for mf16 in (False, True):
+        for FM in (5, 4):
+            for mode in ("late", "early"):
+                print("16x16x32" if mf16 else "32x32x16", FM, mode, run(FM=FM, mode=mode, mf16=mf16), run(FM=FM, K=512, mode=mode, seed=1, mf16=mf16))

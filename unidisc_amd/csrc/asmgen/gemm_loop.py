@@ -160,13 +160,9 @@ class Gemm:
         p += [s_mul_i32(self.s_t[0], self.s_wave, self.A_PW * 1024), s_add_u32(self.s_dsta, self.s_lds, self.s_t[0])]
         p += [s_mul_i32(self.s_t[0], self.s_wave, self.B_PW * 1024), s_add_u32(self.s_dstb, self.s_lds, self.s_t[0]), s_add_u32(self.s_dstb, self.s_dstb, self.B0)]
         # ---- fragment addresses: row (wm 32 FM + l31) resp. (wn 128 + l31) of the stage, 128-byte rows, k-slot (2 kk + hi) ^ ((l31 >> 1) & 7)
-        p += [v_lshrrev_b32(sw, 1, l31), v_and_b32(sw, 7, sw)]
         p += [s_lshr_b32(self.s_t[0], self.s_wave, 1), s_mul_i32(self.s_t[0], self.s_t[0], 32 * self.FM * 128), s_add_u32(self.s_t[0], self.s_t[0], self.s_lds)]     # wm
         p += [s_and_b32(self.s_t[1], self.s_wave, 1), s_lshl_b32(self.s_t[1], self.s_t[1], 14), s_add_u32(self.s_t[1], self.s_t[1], self.s_lds), s_add_u32(self.s_t[1], self.s_t[1], self.B0)]
-        p += [v_lshlrev_b32(t[6], 7, l31)]
-        for kk in range(4):
-            p += [v_add_u32(t[7], 2 * kk, hi), v_xor_b32(t[7], t[7], sw), v_lshlrev_b32(t[7], 4, t[7]), v_add_u32(t[7], t[7], t[6]),
-                  v_add_u32(self.addr_a[kk], self.s_t[0], t[7]), v_add_u32(self.addr_b[kk], self.s_t[1], t[7])]
+        p += self.frag_addresses(lane, l31, hi, sw, t)
         # ---- tile 0, first pieces of tile 1
         for j in range(self.LOADS):
             p += self.dma_piece(0, j)
@@ -176,9 +172,28 @@ class Gemm:
         p += [s_waitcnt(vmcnt=self.N1), s_barrier()]
         if self.timeline:
             p += [s_mov_b32(self.s_sum[0], 0), s_mov_b32(self.s_sum[1], 0), s_memtime(self.s_tm[0]), s_waitcnt(lgkmcnt=0), s_mov_b32(self.s_sum[2], self.s_tm[0][0])]
-        p += self.frag_reads(0, 0, 0)
+        p += self.first_reads()
         p += [s_sub_u32(self.s_loop, self.s_nk, 2), s_lshr_b32(self.s_loop, self.s_loop, 1)]
         return p
+
+    def timeline_store(self):
+        if not self.timeline:
+            return []
+        t = self.tmp
+        return [s_memtime(self.s_tm[0]), s_waitcnt(lgkmcnt=0), s_sub_u32(self.s_t[3], self.s_tm[0][0], self.s_sum[2]),
+                v_mov_b32(t[0], self.s_t[3]), v_mov_b32(t[1], self.s_sum[0]), v_mov_b32(t[2], self.s_sum[1]), v_mov_b32(t[3], self.s_nk), v_mov_b32(t[4], 0), s_nop(1),
+                global_store_dwordx4(t[4], R("v", t[0].idx, 4), self.s_tl, 0), s_waitcnt(vmcnt=0)]
+
+    def frag_addresses(self, lane, l31, hi, sw, t):
+        """per-lane fragment addresses (s_t[0] / s_t[1] hold the wave's A / B row bases): row l31, k-slot (2 kk + hi) ^ ((l31 >> 1) & 7) of 128-byte rows"""
+        p = [v_lshrrev_b32(sw, 1, l31), v_and_b32(sw, 7, sw), v_lshlrev_b32(t[6], 7, l31)]
+        for kk in range(4):
+            p += [v_add_u32(t[7], 2 * kk, hi), v_xor_b32(t[7], t[7], sw), v_lshlrev_b32(t[7], 4, t[7]), v_add_u32(t[7], t[7], t[6]),
+                  v_add_u32(self.addr_a[kk], self.s_t[0], t[7]), v_add_u32(self.addr_b[kk], self.s_t[1], t[7])]
+        return p
+
+    def first_reads(self):
+        return self.frag_reads(0, 0, 0)
 
     def build(self):
         """the whole statement: entry, (nk - 2) / 2 trips of two tiles, the last two tiles"""
@@ -195,11 +210,7 @@ class Gemm:
         tail, q = resolve_needs(tail, start_q)
         assert q == []
         prog += tail + [s_nop(15), s_nop(15)]      # the last MFMAs' results -> the epilogue's reads (wait states the compiler does not know it owes)
-        if self.timeline:
-            t = self.tmp
-            prog += [s_memtime(self.s_tm[0]), s_waitcnt(lgkmcnt=0), s_sub_u32(self.s_t[3], self.s_tm[0][0], self.s_sum[2]),
-                     v_mov_b32(t[0], self.s_t[3]), v_mov_b32(t[1], self.s_sum[0]), v_mov_b32(t[2], self.s_sum[1]), v_mov_b32(t[3], self.s_nk), v_mov_b32(t[4], 0), s_nop(1),
-                     global_store_dwordx4(t[4], R("v", t[0].idx, 4), self.s_tl, 0), s_waitcnt(vmcnt=0)]
+        prog += self.timeline_store()
         assert nfr <= 15
         return prog
 
@@ -229,6 +240,124 @@ class Gemm:
 
     def clobbers(self):
         return [f'"v{i}"' for i in range(self.v_last + 1)] + [f'"s{i}"' for i in range(36, self.s_last + 1)] + ['"vcc"', '"scc"', '"m0"', '"memory"']
+
+
+class Gemm16(Gemm):
+    """The same K loop on v_mfma_f32_16x16x32_bf16 (round 5: on random bf16 operands the matrix pipe sustains 2.07 PF in this form against 1.85 PF in the 32x32x16
+    form - experiments/ubench/mfma_power.hip - and the loop is power bound).  A 32 x 32 accumulator block is four 16 x 16 sub-blocks of 4 registers; the accumulators
+    are PINNED (physical-register constraints: rows 0-3 in a[0:255], row 4 in v[192:255]) so that the text can name sub-ranges.  Per 32-k step a wave reads 2 FM + 8
+    fragments of 1 KiB (the same bytes per flop as before) for 16 FM MFMAs: the B fragments double-buffered, an A fragment re-read into its own registers as soon as
+    its row's last MFMA has issued; two k-steps per K tile, the boundary at the top of the second one, all of tile t + 2's refills behind it."""
+
+    def __init__(self, FM, timeline=False):
+        Gemm.__init__(self, FM, 0, timeline)
+        V = Alloc("v", 0, 192)
+        self.V = V
+        self.fa = [V(f"fa{r}", 4) for r in range(2 * FM)]                     # single buffer: 16-row fragments of the current k-step
+        self.fb = [[V(f"fb{b}{c}", 4) for c in range(8)] for b in range(2)]
+        self.offa = [V(f"offa{j}") for j in range(self.A_PW)]
+        self.offb = [V(f"offb{j}") for j in range(self.B_PW)]
+        self.addr_a = [V(f"aa{k}") for k in range(2)]
+        self.addr_b = [V(f"ab{k}") for k in range(2)]
+        self.tmp = [V(f"t{k}") for k in range(8)]
+        self.v_last = V.next - 1
+        self.NMF = 2 * FM * 8
+        self.N1 = self.LOADS
+
+    def acc16(self, ri, cj):
+        return self.acc(ri >> 1, cj >> 1).sub((((ri & 1) * 2) + (cj & 1)) * 4, 4)
+
+    def a_read(self, st, kk2, ri):
+        return ds_read_b128(self.fa[ri], self.addr_a[kk2], st * self.A_BYTES + ri * 2048)
+
+    def b_reads(self, st, kk2, buf):
+        return [ds_read_b128(self.fb[buf][c], self.addr_b[kk2], st * self.B_BYTES + c * 2048) for c in range(8)]
+
+    def mfmas16(self, buf):
+        out = []
+        for ri in range(2 * self.FM):
+            cs = list(range(8)) if ri % 2 == 0 else list(range(7, -1, -1))     # snake: one operand changes per MFMA
+            for n, cj in enumerate(cs):
+                pre = []
+                if ri == 0:
+                    pre.append(need(self.fb[buf][cj]))
+                if n == 0:
+                    pre.append(need(self.fa[ri]))
+                d = self.acc16(ri, cj)
+                out.append(pre + [v_mfma_f32_16x16x32_bf16(d, self.fa[ri], self.fb[buf][cj], d)])
+        return out
+
+    def body(self, ST, variant):
+        prog = [comment(f"---- K tile, stage {ST}, {variant} (16x16x32)")]
+        n = self.NMF
+        for kk2 in range(2):
+            m = self.mfmas16(kk2)
+            streams = []
+            nxt_st, nxt_kk = (ST, 1) if kk2 == 0 else (ST ^ 1, 0)
+            have_next = kk2 == 0 or variant != "last"
+            if kk2 == 1 and variant != "last":
+                # boundary: every fragment of this stage is in registers (the second k-step's were requested under the first), this wave's pieces of the next tile
+                # have landed; behind the barrier the stage may be refilled and the next tile read
+                if self.timeline:
+                    z = [s_waitcnt(lgkmcnt=0)]
+                    m[0] = ([need_all(), s_memtime(self.s_tm[0])] + z + [s_waitcnt(vmcnt=0), s_memtime(self.s_tm[1])] + z + [s_barrier(), s_memtime(self.s_tm[2])] + z +
+                            [s_sub_u32(self.s_t[3], self.s_tm[1][0], self.s_tm[0][0]), s_add_u32(self.s_sum[0], self.s_sum[0], self.s_t[3]),
+                             s_sub_u32(self.s_t[3], self.s_tm[2][0], self.s_tm[1][0]), s_add_u32(self.s_sum[1], self.s_sum[1], self.s_t[3])] + m[0])
+                else:
+                    m[0] = [need_all(), s_waitcnt(vmcnt=0), s_barrier()] + m[0]
+                if variant == "loop":
+                    streams.append((self.advance_src() + [x for j in range(self.LOADS) for x in self.dma_piece(ST, j)], 0, n - 9))
+            if have_next:
+                streams.append((self.b_reads(nxt_st, nxt_kk, kk2 ^ 1), 0, n - 2))
+                for ri in range(2 * self.FM):     # an A fragment's registers are free once its row's last MFMA has issued
+                    streams.append(([self.a_read(nxt_st, nxt_kk, ri)], ri * 8 + 7, min(n - 1, ri * 8 + 15)))
+            out, _ = schedule_gaps(m, streams, f"k-step {kk2}", 2.5, COST)
+            prog += out
+        return prog
+
+    def frag_addresses(self, lane, l31, hi, sw, t):
+        """row (lane & 15) of a 16-row fragment, k-slot (4 kk2 + (lane >> 4)) ^ ((lane & 15) >> 1): 16 consecutive lanes cover all 64 banks once"""
+        r16, kg = t[1], t[2]
+        p = [v_and_b32(r16, 15, lane), v_lshrrev_b32(kg, 4, lane), v_lshrrev_b32(sw, 1, r16), v_lshlrev_b32(t[6], 7, r16)]
+        for kk2 in range(2):
+            p += [v_add_u32(t[7], 4 * kk2, kg), v_xor_b32(t[7], t[7], sw), v_lshlrev_b32(t[7], 4, t[7]), v_add_u32(t[7], t[7], t[6]),
+                  v_add_u32(self.addr_a[kk2], self.s_t[0], t[7]), v_add_u32(self.addr_b[kk2], self.s_t[1], t[7])]
+        return p
+
+    def all_first(self):
+        return self.b_reads(0, 0, 0) + [self.a_read(0, 0, ri) for ri in range(2 * self.FM)]
+
+    def first_reads(self):
+        """the first k-step's fragments, requested in the ORDER the loop's own end-of-tile prefetch uses (the counted waits of every trip assume that order)"""
+        byw = {tuple(ins.writes): ins for ins in self.all_first()}
+        return [byw[tuple(w)] for w in self.loop_queue_order]
+
+    def build(self):
+        first_input = 4 * self.FM
+        _, q0 = resolve_needs(self.body(0, "loop") + self.body(1, "loop"), [ins.writes for ins in self.all_first()])
+        self.loop_queue_order = q0        # the order in which a tile's last k-step requests the next tile's first fragments
+        prog = resolve_needs(self.entry(first_input), [])[0]
+        loop, q = resolve_needs([label("L_loop")] + self.body(0, "loop") + self.body(1, "loop"), q0)
+        assert q == q0, "the loop must leave the fragment queue as it found it"
+        prog += loop + [s_sub_u32(self.s_loop, self.s_loop, 1), s_cmp_lg_u32(self.s_loop, 0), s_cbranch_scc1("L_loop")]
+        tail, q = resolve_needs(self.body(0, "prelast") + self.body(1, "last"), q0)
+        assert q == []
+        prog += tail + [s_nop(15), s_nop(15)] + self.timeline_store()
+        return prog
+
+    def asm_text(self, prog):
+        lines = []
+        for ins in prog:
+            if ins.kind == "comment":
+                continue
+            t = ins.text
+            if ins.kind == "label":
+                t = t[:-1] + "_%=:"
+            elif ins.kind == "branch":
+                op, tgt = t.split()
+                t = f"{op} {tgt}_%="
+            lines.append(t)
+        return lines
 
 
 def need(reg):
@@ -266,7 +395,7 @@ def resolve_needs(seq, queue):
     return out, q
 
 
-def emit(path, fms=(4, 5), timeline=False):
+def emit(path, fms=(4, 5), timeline=False, mf16=False):
     with open(path, "w") as f:
         f.write("// GENERATED by asmgen/gemm_loop.py - do not edit.  Prologue + K loop of gemm_quad_kernel as one asm statement per tile height.\n")
         progs = {}
@@ -281,11 +410,20 @@ def emit(path, fms=(4, 5), timeline=False):
             for t in g.asm_text(prog):
                 f.write(f'  "{t}\\n\\t" \\\n')
             f.write('  ""\n')
+        for FM in (fms if mf16 else ()):      # measured and not shipped (`make UDM_QUADLOOP=mf16`): the same loop on v_mfma_f32_16x16x32_bf16, accumulators pinned
+            g = Gemm16(FM, timeline=timeline)
+            prog = g.build()
+            progs[(FM, 16)] = (g, prog)
+            f.write(f"#define UDM_QUADLOOP16_NT{FM}_CLOBBERS " + ", ".join(g.clobbers()) + "\n")
+            f.write(f"#define UDM_QUADLOOP16_NT{FM}_ASM \\\n")
+            for t in g.asm_text(prog):
+                f.write(f'  "{t}\\n\\t" \\\n')
+            f.write('  ""\n')
     return progs
 
 
 if __name__ == "__main__":
-    progs = emit(sys.argv[1] if len(sys.argv) > 1 else "gemm_loop_gen.h", timeline=len(sys.argv) > 2 and sys.argv[2] == "timeline")
+    progs = emit(sys.argv[1] if len(sys.argv) > 1 else "gemm_loop_gen.h", timeline="timeline" in sys.argv[2:], mf16="mf16" in sys.argv[2:])
     for FM, (g, prog) in progs.items():
         probs = lint([i for i in prog if i.kind != "raw"])
         print("FM", FM, stats(prog), "| vgprs up to", g.v_last, "sgprs up to", g.s_last)

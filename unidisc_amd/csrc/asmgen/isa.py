@@ -524,6 +524,32 @@ def v_mfma_f32_32x32x16_bf16(d, a, b, c):
                 acc_chain=(c != 0 and c.kind == d.kind and c.idx == d.idx))
 
 
+def v_mfma_f32_16x16x32_bf16(d, a, b, c):
+    """D[i][j] (16 x 16) = sum_{k < 32} A[i][k] B[k][j] + C[i][j];  A: lane (i = l & 15, k = 8 (l >> 4) + e),  B: lane (j = l & 15, k = 8 (l >> 4) + e),
+    C / D: lane (j = l & 15), register r -> i = 4 (l >> 4) + r.   c may be the constant 0."""
+    assert d.n == 4 and a.n == 4 and b.n == 4 and (c == 0 or c.n == 4)
+
+    def emu(w):
+        A = _unpack_bf16x8(w.rf(a))   # [lane, e]
+        B = _unpack_bf16x8(w.rf(b))
+        Am = np.zeros((16, 32), np.float32)
+        Bm = np.zeros((32, 16), np.float32)
+        for g in range(4):
+            Am[:, 8 * g:8 * g + 8] = A[16 * g:16 * g + 16]
+            Bm[8 * g:8 * g + 8, :] = B[16 * g:16 * g + 16].T
+        with np.errstate(all="ignore"):
+            Dm = Am.astype(np.float64) @ Bm.astype(np.float64)
+        out = np.zeros((4, 64), np.float32)
+        for g in range(4):
+            out[:, 16 * g:16 * g + 16] = Dm[4 * g:4 * g + 4, :]
+        if c != 0:
+            with np.errstate(all="ignore"):
+                out = (out.astype(np.float64) + w.f32(c).astype(np.float64)).astype(np.float32)
+        w.f32(d)[:] = out
+    return Inst(f"v_mfma_f32_16x16x32_bf16 {d}, {a}, {b}, {_imm(c)}", "mfma", reads=[a, b] + ([c] if c != 0 else []), writes=[d], emu=emu,
+                acc_chain=(c != 0 and c.kind == d.kind and c.idx == d.idx))
+
+
 # ---- LDS ------------------------------------------------------------------------------------------------------------------------
 def _lds_addrs(w, vaddr, offset):
     return (w.rf(vaddr)[0].astype(np.int64) + offset)

@@ -52,7 +52,10 @@ __device__ __forceinline__ const char* uniform_ptr(const char* ptr) {   // pin a
 // that no whole tile height divides into one round (config E: M = 9216 = 48 x 192 -> 384 tiles, 1.5 rounds) then still runs as ONE round of 320-row tiles (29 x 8 = 232).
 // ASMLOOP (NT form, whole tiles, an even number >= 4 of K tiles, no split-K): the prologue and the K loop below are replaced by ONE hand-scheduled asm statement
 // (asmgen/gemm_loop.py: same LDS image, same k order per output - bit-identical accumulators; counted lgkmcnt waits per fragment, every instruction placed).
-template <int FM, int MODE, int EPI, bool OUT_F32, int DMA_GAP, int ABL = 0, bool RAGGED = false, bool ASMLOOP = false>
+// ASMLOOP = 2: the same statement built on v_mfma_f32_16x16x32_bf16 (the matrix pipe sustains 12 % more on random operands in that form: the loop is power bound).
+// A 32 x 32 accumulator block then holds four 16 x 16 sub-blocks of 4 registers (the epilogue's patch store maps them); sums of 32 products per instruction instead
+// of 16: equal to the other loops up to fp32 rounding, not bit for bit.
+template <int FM, int MODE, int EPI, bool OUT_F32, int DMA_GAP, int ABL = 0, bool RAGGED = false, int ASMLOOP = 0>
 __global__ __launch_bounds__(256, 1) void gemm_quad_kernel(QuadArgs p0) {
   QuadArgs p = p0;   // (the paired launch redirects the operand fields of the blocks that belong to the second problem, once, before anything reads them)
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -222,7 +225,7 @@ __global__ __launch_bounds__(256, 1) void gemm_quad_kernel(QuadArgs p0) {
   constexpr int P1 = ((K3S + DMA_GAP - 1) / DMA_GAP) < LOADS ? ((K3S + DMA_GAP - 1) / DMA_GAP) : LOADS;
   static_assert((LOADS - 1) * DMA_GAP < K3S + 2 * NMF + BND, "refills must be issued at least one k-step before the boundary that waits for them");
 
-  if constexpr (ASMLOOP) {
+  if constexpr (ASMLOOP != 0) {
     static_assert(MODE == 0 && !RAGGED && ABL == 0 && (FM == 4 || FM == 5), "the asm K loop exists for the NT form with 256- / 320-row tiles");
     const uint32_t lda_b = (uint32_t)(p.lda * 2), ldb_b = (uint32_t)(p.ldb * 2), nk_u = (uint32_t)nk, tid_u = (uint32_t)tid;
 #ifdef UDM_QUADLOOP_TIMELINE   // diagnostic build (make UDM_QUADLOOP=timeline): [block][wave]{loop cycles, cycles in the boundary's vmcnt wait, in its barrier, nk}
@@ -230,6 +233,23 @@ __global__ __launch_bounds__(256, 1) void gemm_quad_kernel(QuadArgs p0) {
 #define UDM_QUADLOOP_TL_OPERAND "s"(tlp),
 #else
 #define UDM_QUADLOOP_TL_OPERAND
+#endif
+#define UDM_ACC16_ROWS_0_3                                                                                                                                  \
+  "+{a[0:15]}"(acc[0][0]), "+{a[16:31]}"(acc[0][1]), "+{a[32:47]}"(acc[0][2]), "+{a[48:63]}"(acc[0][3]), "+{a[64:79]}"(acc[1][0]), "+{a[80:95]}"(acc[1][1]),       \
+      "+{a[96:111]}"(acc[1][2]), "+{a[112:127]}"(acc[1][3]), "+{a[128:143]}"(acc[2][0]), "+{a[144:159]}"(acc[2][1]), "+{a[160:175]}"(acc[2][2]),                 \
+      "+{a[176:191]}"(acc[2][3]), "+{a[192:207]}"(acc[3][0]), "+{a[208:223]}"(acc[3][1]), "+{a[224:239]}"(acc[3][2]), "+{a[240:255]}"(acc[3][3])
+#ifdef UDM_QUADLOOP16_NT5_ASM   // (a build with `make UDM_QUADLOOP=mf16`: measured slower - 21 cycles per 16x16x32 MFMA against the pipe's 16.5 - and not shipped)
+    if constexpr (ASMLOOP == 2 && FM == 5) {
+      asm volatile(UDM_QUADLOOP16_NT5_ASM
+                   : UDM_ACC16_ROWS_0_3, "+{v[192:207]}"(acc[FM - 1][0]), "+{v[208:223]}"(acc[FM - 1][1]), "+{v[224:239]}"(acc[FM - 1][2]), "+{v[240:255]}"(acc[FM - 1][3])
+                   : "s"(ap), "s"(bp), "s"(lda_b), "s"(ldb_b), "s"(lds0), "s"(nk_u), UDM_QUADLOOP_TL_OPERAND "v"(tid_u)
+                   : UDM_QUADLOOP16_NT5_CLOBBERS);
+    } else if constexpr (ASMLOOP == 2) {
+      asm volatile(UDM_QUADLOOP16_NT4_ASM
+                   : UDM_ACC16_ROWS_0_3
+                   : "s"(ap), "s"(bp), "s"(lda_b), "s"(ldb_b), "s"(lds0), "s"(nk_u), UDM_QUADLOOP_TL_OPERAND "v"(tid_u)
+                   : UDM_QUADLOOP16_NT4_CLOBBERS);
+    } else
 #endif
     if constexpr (FM == 5) {
       asm volatile(UDM_QUADLOOP_NT5_ASM
@@ -342,7 +362,11 @@ __global__ __launch_bounds__(256, 1) void gemm_quad_kernel(QuadArgs p0) {
     for (int j = 0; j < FN; ++j) {
       float* patch = patch0 + ((i * FN + j) & 1) * 1024;
 #pragma clang loop unroll(full)
-      for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * hi) * 32 + l31] = acc[i][j][r];
+      for (int r = 0; r < 16; ++r) {
+        if constexpr (ASMLOOP == 2)   // sub-block (r >> 3, (r >> 2) & 1), register r & 3 of a 16 x 16 tile: row 4 (lane >> 4) + (r & 3), column lane & 15
+          patch[((r >> 3) * 16 + 4 * (lane >> 4) + (r & 3)) * 32 + ((r >> 2) & 1) * 16 + (lane & 15)] = acc[i][j][r];
+        else patch[((r & 3) + 8 * (r >> 2) + 4 * hi) * 32 + l31] = acc[i][j][r];
+      }
       const int gn = col0 + wn * 128 + j * 32 + ec;
       const int gm0 = row0 + wm * 32 * FM + i * 32 + er;
       float4 v[4];
@@ -415,7 +439,13 @@ int launch_quad_t(const QuadArgs& a0, hipStream_t stream) {
   if constexpr (MODE == 0 && !RAGGED && (FM == 4 || FM == 5)) {
     static const int env_asm = [] { const char* e = getenv("UDM_QUAD_ASM"); return e ? atoi(e) : 1; }();
     const int nk = a.K / BK;
-    if ((g_quad_asm < 0 ? env_asm : g_quad_asm) && a.splitk <= 1 && nk >= 4 && nk % 2 == 0) kern = gemm_quad_kernel<FM, MODE, EPI, OUT_F32, GAP, 0, RAGGED, true>;
+    const int mode = g_quad_asm < 0 ? env_asm : g_quad_asm;      // 1 = the 32x32x16 statement, 2 = the 16x16x32 statement
+    if (mode && a.splitk <= 1 && nk >= 4 && nk % 2 == 0) {
+      kern = gemm_quad_kernel<FM, MODE, EPI, OUT_F32, GAP, 0, RAGGED, 1>;
+#ifdef UDM_QUADLOOP16_NT5_ASM
+      if (mode == 2) kern = gemm_quad_kernel<FM, MODE, EPI, OUT_F32, GAP, 0, RAGGED, 2>;
+#endif
+    }
   }
   if constexpr (EPI == UDM_EPI_NONE && FM >= 4 && !RAGGED) {   // timing-only ablations of the plain kernels (scripts/bench_gemm_quad.py)
     static const int abl = [] { const char* e = getenv("UDM_QUAD_ABL"); return e ? atoi(e) : 0; }();
