@@ -24,6 +24,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_BF16_DENSE_TFLOPS = 2500.0  # MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA (AMD's 5 PF figure is 2:1 sparse)
+SUSTAINED_MFMA_RANDOM_BF16_TFLOPS = 1830.0   # back-to-back MFMAs on random normal bf16 operands, all 256 CUs (measured: profiles/r05_mfma_power.log)
 PEAK_HBM_TBS = 8.0               # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (about 6.3 TB/s achievable with a plain copy)
 
 WORKLOADS = {
@@ -522,7 +523,10 @@ def main():
                               "frac": ach / PEAK_BF16_DENSE_TFLOPS, "traffic": traffic, "traffic_source": traffic_src, "launches": gs["launches"],
                               "launches_in_timed_region": gs["launches_seen"], "timing": f"HIP events around 1 launch in {timer.sample} (seeded pick) inside the timed region",
                               "avg_launch_ms": gs["total_ms"] / gs["launches"],
-                              "share_of_step_time": gs["total_ms"] * (gs["launches_seen"] / gs["launches"]) * 1e-3 / dt}
+                              "share_of_step_time": gs["total_ms"] * (gs["launches_seen"] / gs["launches"]) * 1e-3 / dt,
+                              # context, not the contract's peak: what a bare v_mfma_f32_32x32x16_bf16 stream SUSTAINS on this part (power-limited clock), measured by
+                              # experiments/ubench/mfma_power.hip (profiles/r05_mfma_power.log; 1.78-1.88 PF over the pool's boxes); 2.36-2.41 PF on all-zero operands
+                              "sustained_mfma_random_bf16_tflops": SUSTAINED_MFMA_RANDOM_BF16_TFLOPS, "frac_of_sustained": ach / SUSTAINED_MFMA_RANDOM_BF16_TFLOPS}
     result["rccl_world"] = world if (world > 1 and os.environ.get("UDM_DIST_BACKEND", "nccl") == "nccl") else (1 if world == 1 else 0)   # ranks joined over RCCL (0: gloo rehearsal)
     if sync is not None:
         result["allreduce_bytes_per_step"] = (sync.bytes_on_wire - wire0) // args.steps
