@@ -24,7 +24,6 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_BF16_DENSE_TFLOPS = 2500.0  # MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA (AMD's 5 PF figure is 2:1 sparse)
-SUSTAINED_MFMA_RANDOM_BF16_TFLOPS = 1830.0   # back-to-back MFMAs on random normal bf16 operands, all 256 CUs (measured: profiles/r05_mfma_power.log)
 PEAK_HBM_TBS = 8.0               # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (about 6.3 TB/s achievable with a plain copy)
 
 WORKLOADS = {
@@ -61,6 +60,19 @@ def pmc_traffic(kernel_prefix):
         return (sum(v["launches"] * v["hbm_bytes_per_launch"] for v in rows) / n if n else None), os.path.relpath(files[-1], ROOT)
     except Exception:
         return None, None
+
+
+def sustained_mfma_reference():
+    """Context for `roofline` (NOT its peak): what a bare v_mfma_f32_32x32x16_bf16 stream sustains on random bf16 operands on this part, read from the committed
+    run of experiments/ubench/mfma_power.hip (the mean of its "random bf16" 32x32x16 rows) - a number measured on ANOTHER box of the pool, so the line names
+    the file it came from.  (None, None) when no such log is committed."""
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*mfma_power.log")))
+    if not files:
+        return None, None
+    vals = [float(m.group(1)) for ln in open(files[-1]) if ln.startswith("random bf16,") and "16x16x32" not in ln for m in [re.search(r"-> (\d+) TF", ln)] if m]
+    return (sum(vals) / len(vals), os.path.relpath(files[-1], ROOT)) if vals else (None, None)
 
 
 def flops_per_token(n_blocks, d, V, L_att):
@@ -382,6 +394,7 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: workload's)")
     ap.add_argument("--dropout", type=float, default=0.1, help="model.dropout (reference extra_large.yaml: 0.1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-any-world", action="store_true", help="also time the CPU comparator on rank 0 of an N > 1 run (after every rank left the process group)")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--time-every", type=int, default=16, help="bracket 1 GEMM launch in this many with HIP events inside the timed region (1 = all: costs ~1.7 ms/step)")
     ap.add_argument("--hog-cus", type=int, default=0, help="diagnostics: hold this many CUs with a spinning kernel for the whole run (stand-in for RCCL's channel kernels; "
@@ -518,6 +531,7 @@ def main():
     if gs:
         ach = gs["flops"] / (gs["total_ms"] * 1e-3) / 1e12
         traffic, traffic_src = pmc_traffic("gemm_") if args.workload == "unidisc-1.4b-l1280" else (None, None)
+        sustained, sustained_src = sustained_mfma_reference()
         result["roofline"] = {"bound": "mfma", "kernel": "GEMM family (udm_gemm_nt_bf16 / udm_gemm_tn_bf16 / udm_gemm_nn_bf16 and the split-K forms)", "achieved": ach,
                               "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s",
                               "frac": ach / PEAK_BF16_DENSE_TFLOPS, "traffic": traffic, "traffic_source": traffic_src, "launches": gs["launches"],
@@ -526,7 +540,9 @@ def main():
                               "share_of_step_time": gs["total_ms"] * (gs["launches_seen"] / gs["launches"]) * 1e-3 / dt,
                               # context, not the contract's peak: what a bare v_mfma_f32_32x32x16_bf16 stream SUSTAINS on this part (power-limited clock), measured by
                               # experiments/ubench/mfma_power.hip (profiles/r05_mfma_power.log; 1.78-1.88 PF over the pool's boxes); 2.36-2.41 PF on all-zero operands
-                              "sustained_mfma_random_bf16_tflops": SUSTAINED_MFMA_RANDOM_BF16_TFLOPS, "frac_of_sustained": ach / SUSTAINED_MFMA_RANDOM_BF16_TFLOPS}
+                              # the constant is READ from that committed log (another box of the pool), not measured in this run: its source travels with it
+                              "sustained_mfma_random_bf16_tflops": sustained, "sustained_mfma_source": sustained_src,
+                              "frac_of_sustained": (ach / sustained) if sustained else None}
     result["rccl_world"] = world if (world > 1 and os.environ.get("UDM_DIST_BACKEND", "nccl") == "nccl") else (1 if world == 1 else 0)   # ranks joined over RCCL (0: gloo rehearsal)
     if sync is not None:
         result["allreduce_bytes_per_step"] = (sync.bytes_on_wire - wire0) // args.steps
@@ -572,18 +588,23 @@ def main():
         result["executed_mfma_flops_per_step"] = ex
         result["executed_mfma_utilization"] = ex / (dt / args.steps) / (PEAK_BF16_DENSE_TFLOPS * 1e12)
     if world > 1:
-        dist.barrier()     # (rank 0 alone times the CPU comparator below: the other ranks are done)
-    if rank == 0 and not args.no_cpu_baseline:     # every world size and every workload: north_star wants the CPU path timed "in the same run"
+        # Every rank leaves the process group BEFORE rank 0's CPU comparator (round 6): a 30 s host-only leg must not sit between the peers' communicator
+        # teardown and rank 0's.  The contract times the CPU path "on rank 0 at N = 1 only"; `--cpu-baseline-any-world` adds it to an N > 1 line (rehearsals).
+        dist.barrier()
+        torch.cuda.synchronize()
+        dist.destroy_process_group()
+    want_cpu = not args.no_cpu_baseline and (world == 1 or args.cpu_baseline_any_world)
+    if rank == 0 and want_cpu:
         try:
             result["cpu_baseline"] = cpu_baseline(args.workload, cfg, diff, seed)
             if world == 1 and "packed" not in w:
                 result["cpu_baseline"]["legs"] = cpu_baseline_legs(seed)
         except Exception as e:  # the GPU number stands on its own; say why the comparator is missing
             result["cpu_baseline"] = {"value": None, "unit": "tokens/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {type(e).__name__}: {e}"}
+    elif rank == 0 and world > 1:
+        result["cpu_baseline"] = None      # measured by the N = 1 line of the same command (contract: rank 0 at N = 1 only)
     if rank == 0:
-        print(json.dumps(result))
-    if world > 1:
-        dist.destroy_process_group()
+        print(json.dumps(result), flush=True)
 
 
 if __name__ == "__main__":

@@ -9,9 +9,10 @@ timeout 600 python scripts/bench_attn_fwd64.py 2>/dev/null | tail -1 > gpurun_ou
 timeout 600 python scripts/bench_attn_bwd.py 2>/dev/null | tail -1 > gpurun_out/r05_attn_bwd.json
 timeout 600 python scripts/bench_residual_dropout.py 2>/dev/null | tail -1 > gpurun_out/r05_residual_dropout.json
 timeout 600 python scripts/bench_qknorm_rope.py 2>/dev/null | tail -1 > gpurun_out/r05_qknorm_rope.json
-touch unidisc_amd/csrc/asmgen/gemm_loop.py; make -C unidisc_amd/csrc UDM_QUADLOOP=timeline > /dev/null 2>&1
+trap "make -C unidisc_amd/csrc regen all > /dev/null 2>&1" EXIT   # whatever happens below, the tree ends on the shipped build
+make -C unidisc_amd/csrc regen all UDM_QUADLOOP=timeline > /dev/null 2>&1
 timeout 600 python scripts/gemm_asm_loop_timeline.py 2>/dev/null | grep "^{" > gpurun_out/r05_gemm_asm_loop_timeline.json
-touch unidisc_amd/csrc/asmgen/gemm_loop.py unidisc_amd/csrc/asmgen/attn_fwd64.py; make -C unidisc_amd/csrc UDM_FWD64_ABL=16 > /dev/null 2>&1
+make -C unidisc_amd/csrc regen all UDM_FWD64_ABL=16 > /dev/null 2>&1
 timeout 600 python scripts/attn_fwd64_timeline.py 2>/dev/null | grep -v amdgpu.ids > gpurun_out/r05_attn_fwd64_timeline.log
-touch unidisc_amd/csrc/asmgen/attn_fwd64.py; make -C unidisc_amd/csrc > /dev/null 2>&1
+make -C unidisc_amd/csrc regen all > /dev/null 2>&1
 head -20 gpurun_out/r05_mfma_power.log; cat gpurun_out/r05_gemm_asm_loop_timeline.json; cut -c1-600 gpurun_out/r05_attn_fwd64_ab.json; cat gpurun_out/r05_attn_bwd.json

@@ -27,6 +27,12 @@ def test_header_symbols_exported(lib):
     assert declared == bound, (declared - bound, bound - declared)
     for name in declared:
         assert hasattr(lib, name), name
+    # ... and the converse (round 6): the dynamic symbol table holds no `udm_` entry point the header does not declare (diagnostic setters have hidden visibility
+    # and are reached through udm_debug_set)
+    import subprocess
+    nm = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = {ln.split()[-1] for ln in nm.splitlines() if " T " in ln and ln.split()[-1].startswith("udm_")}
+    assert exported == declared, (sorted(exported - declared), sorted(declared - exported))
     assert lib.udm_abi_version() == _lib.ABI_VERSION == 3
 
 

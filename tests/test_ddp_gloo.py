@@ -1,4 +1,5 @@
-"""world_size-2 gloo test of the bucketed bf16 gradient all-reduce (CPU; kernels replaced by test doubles)."""
+"""world_size-2 and world_size-8 gloo tests of the bucketed bf16 gradient all-reduce (CPU; kernels replaced by test doubles).  World 8 is BASELINE configs[3]'s
+rank count (main.py:641-656): bf16(g) / 8 in bf16, bucket order, the collective mode agreement with ONE failing rank of eight, accumulate-then-sync."""
 import os
 import socket
 import sys
@@ -35,6 +36,9 @@ def _worker(rank, world, port, min_bucket, q):
     sys.path.insert(0, HERE)
     sys.path.insert(0, os.path.dirname(HERE))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    if world > 2:
+        torch.set_num_threads(1)      # eight ranks on an eight-core host
+    rtol = 1e-2 * world               # gloo sums in bf16: one rounding (2^-9 relative) per add, world - 1 adds
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         import fake_kernels
@@ -59,7 +63,7 @@ def _worker(rank, world, port, min_bucket, q):
             exp = sum((g[k].to(torch.bfloat16).float() / world).to(torch.bfloat16).float() for g in gathered)
             exp = exp.to(torch.bfloat16).float()
             err = (synced[k] - exp).abs().max().item()
-            tol = 2e-2 * exp.abs().max().item() + 1e-6   # gloo sums in bf16: one rounding per add
+            tol = rtol * exp.abs().max().item() + 1e-6
             worst = max(worst, err / (exp.abs().max().item() + 1e-12))
             ok = ok and err <= tol
         # all ranks hold identical synchronised gradients
@@ -85,7 +89,7 @@ def _worker(rank, world, port, min_bucket, q):
             exp = sum((g[k].to(torch.bfloat16).float() / world).to(torch.bfloat16).float() for g in gathered).to(torch.bfloat16).float()
             err = (acc[k] - exp).abs().max().item()
             acc_worst = max(acc_worst, err / (exp.abs().max().item() + 1e-12))
-            acc_ok = acc_ok and err <= 2e-2 * exp.abs().max().item() + 1e-6
+            acc_ok = acc_ok and err <= rtol * exp.abs().max().item() + 1e-6
         flat = torch.cat([acc[k].flatten() for k in sorted(acc)])
         ref = flat.clone()
         dist.broadcast(ref, src=0)
@@ -107,7 +111,14 @@ def _worker(rank, world, port, min_bucket, q):
             w0 = sync.bytes_on_wire
             got = _grads(diff, golden, seed=rank)
             diff.backbone.grad_sync_finish = orig_finish
-            modes_ok = modes_ok and all(torch.equal(got[k], synced[k]) for k in synced)
+            # world 2: one add per element, bit-identical whatever the message boundaries; world 8: a ring's summation ORDER depends on where an element sits in
+            # its message, and the serialized schedule coalesces ranges - equal to bf16 summation noise, and identical on every rank (checked below)
+            modes_ok = modes_ok and all(torch.equal(got[k], synced[k]) if world == 2 else
+                                        float((got[k] - synced[k]).abs().max()) <= rtol * float(synced[k].abs().max()) + 1e-6 for k in synced)
+            flat_m = torch.cat([got[k].flatten() for k in sorted(got)])
+            ref_m = flat_m.clone()
+            dist.broadcast(ref_m, src=0)
+            modes_ok = modes_ok and torch.equal(flat_m, ref_m)
             if mode == "overlap_planned":
                 plan_calls = list(fake_kernels.CUS_CALLS)
             if mode == "serialized":
@@ -160,15 +171,16 @@ def _worker(rank, world, port, min_bucket, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("min_bucket", [1, 1 << 30])
-def test_bucketed_allreduce_world2(min_bucket):
+@pytest.mark.parametrize("world,min_bucket", [(2, 1), (2, 1 << 30), (8, 1)], ids=["world2_small_buckets", "world2_one_bucket", "world8_small_buckets"])
+def test_bucketed_allreduce(world, min_bucket):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, min_bucket, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, min_bucket, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=300) for _ in procs]
+    res = [q.get(timeout=600) for _ in procs]
+    assert sorted(r[0] for r in res) == list(range(world))
     for p in procs:
         p.join(60)
         assert p.exitcode == 0

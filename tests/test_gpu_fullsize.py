@@ -40,7 +40,7 @@ def _build(bench, workload, dropout=0.0, seed=0):
     return cfg, diff
 
 
-@pytest.mark.parametrize("workload,B", [("unidisc-s-l384", 64), ("unidisc-1.4b-l1280", 8), ("unidisc-1.4b-interleaved-l4608", 1)])
+@pytest.mark.parametrize("workload,B", [("unidisc-s-l384", 64), ("unidisc-1.4b-l1280", 8), ("unidisc-1.4b-l1280-adaln", 8), ("unidisc-1.4b-interleaved-l4608", 1)])
 def test_zero_head_known_answer_and_mask_exactness(bench, workload, B):
     """Zero vocabulary head => uniform prediction over the ids SUBS leaves valid: log p(x0) = -log(Vt - 1) on masked text positions (the
     [MASK] id is excluded), -log(V - Vt) on masked image positions, exactly 0 on unmasked positions; xt == where(move, [MASK], x0) bit for bit;
@@ -70,7 +70,7 @@ def test_zero_head_known_answer_and_mask_exactness(bench, workload, B):
     assert torch.isfinite(out.loss)
 
 
-@pytest.mark.parametrize("workload,B", [("unidisc-s-l384", 64), ("unidisc-1.4b-l1280", 8)])
+@pytest.mark.parametrize("workload,B", [("unidisc-s-l384", 64), ("unidisc-1.4b-l1280", 8), ("unidisc-1.4b-l1280-adaln", 8)])
 def test_gradient_checksums(bench, workload, B):
     """Softmax minus one-hot sums to zero over the vocabulary, so the head-bias gradient sums to zero (a checksum over all masked rows and the
     whole joint vocabulary), is exactly zero at the [MASK] id, and - with modality-restricted SUBS - sums to zero over the text ids and over the

@@ -46,6 +46,13 @@ FULLWIDTH = {
     "config_c_1block_b8": (dict(_LARGE, n_blocks=1), 8, dict(loss=5e-5, nll=1e-3, grad_max=3.2e-2, grad_med=2e-2)),
     # the same width, two blocks composed (block -> block fused residual+norm), B = 2
     "config_c_2blocks_b2": (dict(_LARGE, n_blocks=2), 2, dict(loss=5e-5, nll=1e-3, grad_max=1.1e-1, grad_med=2.2e-2)),
+    # north_star's adaLN-Zero variant AT THE WIDTH ITS FUSED KERNELS EXIST FOR (round 6): `time_conditioning=True` on the same 1.4 B block
+    # (rms + qk-norm + sandwich + modality embed + multimodal_batches: image-only modulate / gate, gate_msa unused - models/dit.py:922-925, 966-984, 1015-1022,
+    # 1078-1091).  d = 2048 is where `udm_norm_residual_bwd_ada`, the deferred adaLN_modulation backward through `_ada_buf` and the "next block's adaLN one
+    # block early" forward dispatch (unidisc_amd/dit.py `tc_fused`); adaLN weights are randomised below (the reference zero-initialises them), and every
+    # `sigma_map.*` / `adaLN_modulation.*` gradient is asserted by name
+    "config_c_adaln_1block_b8": (dict(_LARGE, n_blocks=1, time_conditioning=True), 8, dict(loss=5e-5, nll=1e-3, grad_max=3.2e-2, grad_med=2e-2)),
+    "config_c_adaln_2blocks_b2": (dict(_LARGE, n_blocks=2, time_conditioning=True), 2, dict(loss=5e-5, nll=1e-3, grad_max=1.1e-1, grad_med=2.2e-2)),
     # BASELINE configs[2] at its FULL DEPTH: all 24 blocks, d = 2048, L = 1280, one and two sequences (the fp32 oracle's fwd+bwd takes ~23 s per sequence on the GPU
     # box's host).  Achieved (profiles/r05_parity_ledger.json): loss 3.5e-6 / 5.5e-6, NLL 3.7e-4 / 3.9e-4, median gradient 8.9e-3 / 9.2e-3; the worst parameter (a
     # qk-norm vector, 1.06e-1 / 1.55e-1) is additionally held to 1.5x the reference's own floor with the flash-attention rounding points (below)
@@ -163,6 +170,14 @@ def test_training_step_matches_oracle_at_full_width(name):
         fl = {k: v for v, k in floors}
         with open(os.environ["UDM_DUMP_GRAD_ERRS"] + f".{name}.json", "w") as f:
             json.dump({k: dict(ours=e, floor=fl[k], floor_flash=floor_f[k], numel=P[k].numel(), gnorm=float(P[k].grad.norm())) for e, k in errs}, f, indent=0)
+    if case.get("time_conditioning"):
+        # the conditioning path's gradients flow through the per-block column sums / the deferred adaLN_modulation backward: each one by name, not through a median
+        ada = [(e, k) for e, k in errs if k.startswith("sigma_map.") or "adaLN_modulation" in k]
+        n_ada = 4 + 2 * case["n_blocks"] + 2
+        assert len(ada) == n_ada, (len(ada), n_ada, [k for _, k in ada])
+        for e, k in ada:
+            assert float(P[k].grad.abs().max()) > 0, k
+            check(name, f"grad_relrms[{k}]", e, bound["grad_max"] if bound["grad_max"] is not None else 0.1)
     if bound["grad_max"] is not None:
         check(name, "grad_relrms_worst_param", errs[0][0], bound["grad_max"], note=errs[0][1])
     else:

@@ -655,7 +655,7 @@ int check_common(const char* name, int64_t B, int64_t H, int64_t L, int64_t D, i
 }
 }  // namespace
 
-extern "C" int udm_attention_set_tr_read(int enable) {
+extern "C" __attribute__((visibility("hidden"))) int udm_attention_set_tr_read(int enable) {
   g_use_tr = enable ? 1 : 0;
   return 0;
 }

@@ -55,12 +55,12 @@ int g_fwd64 = -1;
 unsigned long long* g_timeline = nullptr;
 }  // namespace
 
-extern "C" int udm_attention_set_fwd64_timeline(int64_t device_ptr) {   // diagnostics (a build with UDM_FWD64_ABL=16): stamps of the next launches, 0 = off
+extern "C" __attribute__((visibility("hidden"))) int udm_attention_set_fwd64_timeline(int64_t device_ptr) {   // diagnostics (a build with UDM_FWD64_ABL=16): stamps of the next launches, 0 = off
   g_timeline = reinterpret_cast<unsigned long long*>(device_ptr);
   return 0;
 }
 
-extern "C" int udm_attention_set_fwd64(int enable) {   // tests / A-B measurements: 0 = the 8-wave kernel of attention.hip everywhere
+extern "C" __attribute__((visibility("hidden"))) int udm_attention_set_fwd64(int enable) {   // tests / A-B measurements: 0 = the 8-wave kernel of attention.hip everywhere
   g_fwd64 = enable;        // 2: without the balanced walk (whole blocks only)
   return 0;
 }
@@ -71,7 +71,7 @@ bool udm_launch_attn_fwd64(const void* args, hipStream_t stream) {
   a.timeline = g_timeline;
   if (g_fwd64 < 0) { const char* e = getenv("UDM_ATTN_FWD64"); g_fwd64 = e ? atoi(e) : 1; }
   // whole 256-query blocks, at least two trips of the four-tile loop, the XCD-sequential block order of attention.hip (B H a multiple of 8)
-  if (!g_fwd64 || !a.q_prescaled || a.L % 256 != 0 || a.L < 512 || a.out_stride % 8 != 0 || (a.B * a.H) % 8 != 0) return false;
+  if (!g_fwd64 || !a.q_prescaled || a.H < 2 /* magic(1) wraps: the head divisor would read 0 */ || a.L % 256 != 0 || a.L < 512 || a.out_stride % 8 != 0 || (a.B * a.H) % 8 != 0) return false;
   if (a.q_stride * 2 * 256 >= (1L << 31) || a.k_stride * 2 * 80 >= (1L << 31) || a.v_stride * 2 * 80 >= (1L << 31) || a.out_stride * 2 * 256 >= (1L << 31)) return false;   // 32-bit lane offsets
   const long nt = a.L / 256, nblk = nt * a.B * a.H;
   if ((long)a.B * a.L >= (1L << 30) || nblk >= (1L << 24) || nt > 4096 || a.H > 4096 || (long)a.B * a.H * a.L >= (1L << 29)) return false;   // 32-bit row / lse indices, exact magic divisions

@@ -21,13 +21,14 @@ void udm_set_error(const char* fmt, ...) {
 extern "C" const char* udm_last_error(void) { return g_err; }
 extern "C" int udm_abi_version(void) { return UDM_ABI_VERSION; }
 
-// ---- diagnostics behind ONE entry point (the setters themselves live next to the state they switch and are not part of the public header) ----
-extern "C" int udm_gemm_set_tile(int tile);      // gemm.hip: force the tile family (-1 auto, 0 = 128x128 kernel, 192 / 256 / 320 = BM x 256 kernel)
-extern "C" int udm_gemm_set_quad(int mode);      // gemm.hip: one-wave-per-SIMD kernels 0 = off, 1 = auto (default; env UDM_GEMM_QUAD), 2 = wherever the shape fits
-extern "C" int udm_gemm_set_persist(int enable); // gemm.hip: 0 = one block per output tile (default 1: persistent blocks for multi-round NT shapes)
-extern "C" int udm_attention_set_tr_read(int enable);        // attention.hip: 0 = gather V^T fragments with scalar LDS reads
-extern "C" int udm_attention_set_fwd64_timeline(int64_t device_ptr);   // attention_fwd64.hip diagnostics
-extern "C" int udm_attention_set_fwd64(int enable);          // attention_fwd64.hip: 0 = the 8-wave forward also at D = 128, L % 256 == 0 (default 1; env UDM_ATTN_FWD64)
+// ---- diagnostics behind ONE entry point (the setters themselves live next to the state they switch; hidden visibility: the library exports exactly what
+// include/unidisc_hip.h declares, tests/test_capi.py checks both directions) ----
+extern "C" __attribute__((visibility("hidden"))) int udm_gemm_set_tile(int tile);      // gemm.hip: force the tile family (-1 auto, 0 = 128x128 kernel, 192 / 256 / 320 = BM x 256 kernel)
+extern "C" __attribute__((visibility("hidden"))) int udm_gemm_set_quad(int mode);      // gemm.hip: one-wave-per-SIMD kernels 0 = off, 1 = auto (default; env UDM_GEMM_QUAD), 2 = wherever the shape fits
+extern "C" __attribute__((visibility("hidden"))) int udm_gemm_set_persist(int enable); // gemm.hip: 0 = one block per output tile (default 1: persistent blocks for multi-round NT shapes)
+extern "C" __attribute__((visibility("hidden"))) int udm_attention_set_tr_read(int enable);        // attention.hip: 0 = gather V^T fragments with scalar LDS reads
+extern "C" __attribute__((visibility("hidden"))) int udm_attention_set_fwd64_timeline(int64_t device_ptr);   // attention_fwd64.hip diagnostics
+extern "C" __attribute__((visibility("hidden"))) int udm_attention_set_fwd64(int enable);          // attention_fwd64.hip: 0 = the 8-wave forward also at D = 128, L % 256 == 0 (default 1; env UDM_ATTN_FWD64)
 
 namespace { int g_exp = [] { const char* e = getenv("UDM_EXP"); return e ? atoi(e) : 0; }(); }
 int udm_exp_flags() { return g_exp; }

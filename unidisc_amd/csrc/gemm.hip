@@ -1139,7 +1139,7 @@ extern "C" int udm_gemm_tn_splitk_bf16(const void* A, const void* B, void* C, in
   return 0;
 }
 
-extern "C" int udm_gemm_set_tile(int tile) {
+extern "C" __attribute__((visibility("hidden"))) int udm_gemm_set_tile(int tile) {
   UDM_CHECK_ARG(tile == -1 || tile == 0 || tile == 192 || tile == 256 || tile == 320, "udm_gemm_set_tile: tile must be -1 (auto), 0, 192, 256 or 320");
   g_force_tile = tile;
   return 0;
@@ -1325,13 +1325,13 @@ extern "C" int udm_gemm_set_cus(int cus) {   // 0 = all CUs; otherwise the persi
   return 0;
 }
 
-extern "C" int udm_gemm_set_quad(int mode) {   // diagnostics / tests: 0 = 8-wave kernels only, 1 = auto (default), 2 = quad wherever the shape fits
+extern "C" __attribute__((visibility("hidden"))) int udm_gemm_set_quad(int mode) {   // diagnostics / tests: 0 = 8-wave kernels only, 1 = auto (default), 2 = quad wherever the shape fits
   UDM_CHECK_ARG(mode >= 0 && mode <= 2, "udm_gemm_set_quad: mode must be 0, 1 or 2");
   g_quad_mode = mode;
   return 0;
 }
 
-extern "C" int udm_gemm_set_persist(int enable) {   // diagnostics / tests: 0 = one block per output tile everywhere
+extern "C" __attribute__((visibility("hidden"))) int udm_gemm_set_persist(int enable) {   // diagnostics / tests: 0 = one block per output tile everywhere
   g_gemm_persist = enable ? 1 : 0;
   return 0;
 }

@@ -257,7 +257,12 @@ class BucketedGradSync:
             raise RuntimeError("BucketedGradSync.set_mode inside a backward")
         self._unplan()
         if mode != self.mode:
-            self._bufs = {}     # the other schedule's persistent wire buffers (serialized: up to 512 MB each) are not kept beside this one's
+            # the other schedule's persistent wire buffers (serialized: up to 512 MB each) are not kept beside this one's.  They were allocated on the compute
+            # stream and are used on the comm stream: the compute stream waits for whatever the comm stream still has queued on them before the caching
+            # allocator may hand that memory to a compute-stream kernel (today every caller has joined already; this makes the drop safe by itself)
+            if self._bufs and self.comm_stream is not None:
+                torch.cuda.current_stream().wait_stream(self.comm_stream)
+            self._bufs = {}
         self.mode = mode
 
     def _set_mode_everywhere(self, mode: str) -> bool:
@@ -289,7 +294,8 @@ class BucketedGradSync:
 
         if self.requested_mode != "auto" or not self.active:
             return self.mode_timings_ms
-        self._agree_device = sync_device if sync_device is not None else "cpu"
+        if sync_device is not None:     # (None keeps the device inferred from the parameters in __init__: an RCCL group cannot reduce a CPU tensor)
+            self._agree_device = sync_device
 
         def fence():
             if sync_device is not None:

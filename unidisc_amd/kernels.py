@@ -685,9 +685,12 @@ def norm_residual_bwd(dy, x, rstd, mean, w, norm_type, L, dx, dw, branch, *, acc
     return out
 
 
+_ADA_GRID_ROWS = 768     # partial-sum rows of udm_norm_residual_bwd_ada's workspace (rowops.hip: grid = B * max(1, min(768 / B, L)))
+
+
 def norm_residual_bwd_ada_ok(M, d, L):
     """Does the fused adaLN form (norm_residual_bwd_ada) cover this shape?  (the block-per-row kernel: d = 2048 / 4096, whole batch elements)"""
-    return d in (2048, 4096) and L > 0 and M % L == 0
+    return d in (2048, 4096) and L > 0 and M % L == 0 and M // L <= _ADA_GRID_ROWS   # (the launch is B x min(768 / B, L) blocks over a 768 x 6 x d workspace)
 
 
 def norm_residual_bwd_ada(dy, x, rstd, mean, w, norm_type, L, dx, dw, branch, *, accumulate=True, w_b=None, rstd_b=None, mean_b=None, dw_b=None, p_drop=0.0, seed=0,
@@ -707,7 +710,7 @@ def norm_residual_bwd_ada(dy, x, rstd, mean, w, norm_type, L, dx, dw, branch, *,
         if m_ is not None and (dm_ is None or dm_.stride(0) != m_.stride(0)):
             raise ValueError("norm_residual_bwd_ada: an adaLN tensor and its gradient must share their row stride")
     dbranch = torch.empty((M, d), dtype=BF16, device=x.device)
-    ws = _scratch(768 * 6 * d, x.device)
+    ws = _scratch(_ADA_GRID_ROWS * 6 * d, x.device)
     _lib.call("udm_norm_residual_bwd_ada", _p(dy), _p(x), _p(rstd), _p(mean), _p(w), _p(dx), _p(dw), 1 if accumulate else 0, _p(branch), _p(dbranch), _p(w_b), _p(rstd_b),
               _p(mean_b), _p(dw_b), _p(dbias), shift, scale, dshift, dscale, gate, dgate, ms_n or ms_r, _p(modality) if mod_n is not None else None,
               _p(any_img) if mod_n is not None else None, _p(modality_r), M, d, L, norm_type, float(p_drop), int(seed), _p(ws), ws.numel(), _s())
