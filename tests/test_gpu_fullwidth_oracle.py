@@ -53,13 +53,13 @@ FULLWIDTH = {
     # `sigma_map.*` / `adaLN_modulation.*` gradient is asserted by name
     "config_c_adaln_1block_b8": (dict(_LARGE, n_blocks=1, time_conditioning=True), 8, dict(loss=5e-5, nll=1e-3, grad_max=3.2e-2, grad_med=2e-2)),
     "config_c_adaln_2blocks_b2": (dict(_LARGE, n_blocks=2, time_conditioning=True), 2, dict(loss=5e-5, nll=1e-3, grad_max=1.1e-1, grad_med=2.2e-2)),
-    # BASELINE configs[2] at its FULL DEPTH: all 24 blocks, d = 2048, L = 1280, one and two sequences (the fp32 oracle's fwd+bwd takes ~23 s per sequence on the GPU
+    # BASELINE configs[2] at its FULL DEPTH: all 24 blocks, d = 2048, L = 1280, two sequences (the fp32 oracle's fwd+bwd takes ~23 s per sequence on the GPU
     # box's host).  Achieved (profiles/r05_parity_ledger.json): loss 3.5e-6 / 5.5e-6, NLL 3.7e-4 / 3.9e-4, median gradient 8.9e-3 / 9.2e-3; the worst parameter (a
     # qk-norm vector, 1.06e-1 / 1.55e-1) is additionally held to 1.5x the reference's own floor with the flash-attention rounding points (below)
     # grad_max (round 4): <= 2x the recorded worst parameter (1.55e-1 / 1.05e-1 in profiles/r05_parity_ledger.json), on top of the 1.5x-of-floor assertion
     # grad_max = None (round 5): at this depth the worst parameter's absolute error (0.10 - 0.16) says nothing - an absolute bound of 0.25 would
     # hide a regression of 60 % - the assertions that bind are the ratios to the reference's own flash-rounding floor below (worst <= 1.5x, every parameter <= 2x)
-    "config_c_24blocks_b1": (dict(_LARGE, n_blocks=24), 1, dict(loss=5e-5, nll=1.2e-3, grad_max=None, grad_med=2.7e-2)),
+    # (`config_c_24blocks_b1` ran here until round 5: the two-sequence case below subsumes it, and the suite has a time budget - VERDICT r5 item 8)
     "config_c_24blocks_b2": (dict(_LARGE, n_blocks=24), 2, dict(loss=5e-5, nll=1.2e-3, grad_max=None, grad_med=2.7e-2)),
     # BASELINE configs[1]: UniDisc-S, all 12 blocks, L = 128 + 256
     "unidisc_s_12blocks_b4": (dict(_SMALL, n_blocks=12), 4, dict(loss=5e-5, nll=1.2e-3, grad_max=None, grad_med=3e-2)),
@@ -111,13 +111,12 @@ def test_training_step_matches_oracle_at_full_width(name):
     ob = O.update_batch(ocfg, {k: v.clone() for k, v in batch.items()})
     o32 = O.compute_loss(ocfg, P, bufs, ob, torch.Generator().manual_seed(123))
     o32.loss.backward()
-    P16 = {k: v.detach().clone().requires_grad_() for k, v in P.items()}
-    o16 = O.compute_loss(ocfg, P16, bufs, ob, torch.Generator().manual_seed(123), bf16=True)   # the reference's own bf16 numerics: the noise floor
-    o16.loss.backward()
-    # ... and with the rounding points INSIDE the reference's flash-attention backward as well (P, dS in bf16; delta from the stored bf16 O): tensor-boundary
-    # rounding alone runs that backward in fp32 and understates the noise of dq / dk, i.e. of exactly the qk-norm vectors that are the worst parameters here
+    # the reference's own bf16 numerics = the noise floor: ONE emulated pass (round 6; two before) with the autocast rounding points AND the rounding points INSIDE
+    # the reference's flash-attention backward (P, dS in bf16; delta from the stored bf16 O) - tensor-boundary rounding alone runs that backward in fp32 and
+    # understates the noise of dq / dk, i.e. of exactly the qk-norm vectors that are the worst parameters here (round 2 finding)
     P16f = {k: v.detach().clone().requires_grad_() for k, v in P.items()}
-    O.compute_loss(ocfg, P16f, bufs, ob, torch.Generator().manual_seed(123), bf16=True, flash_rounding=True).loss.backward()
+    o16 = O.compute_loss(ocfg, P16f, bufs, ob, torch.Generator().manual_seed(123), bf16=True, flash_rounding=True)
+    o16.loss.backward()
 
     torch.manual_seed(123)
     out = diff.training_step({k: v.clone() for k, v in batch.items()}, 1)
@@ -151,12 +150,10 @@ def test_training_step_matches_oracle_at_full_width(name):
             continue
         errs.append((_rel(p.grad.cpu(), P[k].grad), k))
     errs.sort(reverse=True)
-    floors = sorted(((_rel(P16[k].grad, P[k].grad), k) for k in P if P[k].grad is not None), reverse=True)
-    record(name, "ref_bf16_vs_fp32_grad_relrms_worst_param", floors[0][0], note=floors[0][1])
-    record(name, "ref_bf16_vs_fp32_grad_relrms_median_param", floors[len(floors) // 2][0])
     floor_f = {k: _rel(P16f[k].grad, P[k].grad) for k in P if P[k].grad is not None}
     ff = sorted(((v, k) for k, v in floor_f.items()), reverse=True)
     record(name, "ref_bf16_flash_rounding_vs_fp32_grad_relrms_worst_param", ff[0][0], note=ff[0][1])
+    record(name, "ref_bf16_flash_rounding_vs_fp32_grad_relrms_median_param", ff[len(ff) // 2][0])
     record(name, "ref_bf16_flash_rounding_vs_fp32_grad_relrms_same_param_as_ours", floor_f[errs[0][1]], note=errs[0][1])
     ratios = sorted(((e / max(floor_f[k], 1e-12), k) for e, k in errs), reverse=True)
     # VERDICT r02 (weak 1): the worst parameter - always a qk-norm vector, a column sum of dq / dk with heavy cancellation - must sit within 1.5x the reference's
@@ -167,9 +164,8 @@ def test_training_step_matches_oracle_at_full_width(name):
     record(name, "grad_err_over_flash_rounding_floor_median_ratio", ratios[len(ratios) // 2][0])
     if os.environ.get("UDM_DUMP_GRAD_ERRS"):   # per-parameter table (ours, boundary-rounding floor, flash-rounding floor) for diagnosis
         import json
-        fl = {k: v for v, k in floors}
         with open(os.environ["UDM_DUMP_GRAD_ERRS"] + f".{name}.json", "w") as f:
-            json.dump({k: dict(ours=e, floor=fl[k], floor_flash=floor_f[k], numel=P[k].numel(), gnorm=float(P[k].grad.norm())) for e, k in errs}, f, indent=0)
+            json.dump({k: dict(ours=e, floor_flash=floor_f[k], numel=P[k].numel(), gnorm=float(P[k].grad.norm())) for e, k in errs}, f, indent=0)
     if case.get("time_conditioning"):
         # the conditioning path's gradients flow through the per-block column sums / the deferred adaLN_modulation backward: each one by name, not through a median
         ada = [(e, k) for e, k in errs if k.startswith("sigma_map.") or "adaLN_modulation" in k]
@@ -177,7 +173,7 @@ def test_training_step_matches_oracle_at_full_width(name):
         assert len(ada) == n_ada, (len(ada), n_ada, [k for _, k in ada])
         for e, k in ada:
             assert float(P[k].grad.abs().max()) > 0, k
-            check(name, f"grad_relrms[{k}]", e, bound["grad_max"] if bound["grad_max"] is not None else 0.1)
+            check(name, f"grad_relrms[{k}]", e, 2.4e-2)      # achieved 4.0e-3 .. 7.8e-3 at d = 2048 (profiles/r06_parity_ledger.json)
     if bound["grad_max"] is not None:
         check(name, "grad_relrms_worst_param", errs[0][0], bound["grad_max"], note=errs[0][1])
     else:

@@ -412,6 +412,17 @@ def v_fma_f32(dst, a, b, c, neg_c=False):
     return _valu("v_fma_f32", "valu", dst, [a, b, c], fn, text=text)
 
 
+def v_pk_mul_f32(dst, a, b):
+    """dst[0:1] = a[0:1] * b[0:1] (two fp32 products per instruction; even-aligned register pairs)"""
+    assert dst.n == 2 and a.n == 2 and b.n == 2 and dst.idx % 2 == 0 and a.idx % 2 == 0 and b.idx % 2 == 0
+
+    def emu(w):
+        with np.errstate(all="ignore"):
+            res = (w.f32(a) * w.f32(b)).astype(np.float32)
+        w.f32(dst)[:] = res
+    return Inst(f"v_pk_mul_f32 {dst}, {a}, {b}", "valu", reads=[a, b], writes=[dst], emu=emu)
+
+
 def v_exp_f32(dst, a):
     return _valu("v_exp_f32", "trans", dst, [a], lambda w, a: np.exp2(_f(w.vsrc_f(a))).astype(np.float32))
 
@@ -483,6 +494,21 @@ def v_readlane_b32(sdst, a, lane):
 
 def v_readfirstlane_b32(sdst, a):
     return Inst(f"v_readfirstlane_b32 {sdst}, {a}", "readlane", reads=[a], writes=[sdst], emu=lambda w: w.sset(sdst, int(w.rf(a)[0][0])))
+
+
+def s_load_dwords(sdst, sbase, offset):
+    """s_load_dwordx{2,4,8,16}: sdst.n dwords from the 64-bit address in sbase + offset (scalar memory: out of order among themselves - wait lgkmcnt(0))"""
+    assert sdst.n in (2, 4, 8, 16) and sdst.idx % min(sdst.n, 4) == 0 and offset % 4 == 0
+
+    def emu(w):
+        flat, off = w.wg.gmem(w.sget64(sbase) + offset, 4 * sdst.n)
+        vals = flat[off:off + 4 * sdst.n].view(np.uint32).copy()
+
+        def commit():
+            w.s[sdst.idx:sdst.idx + sdst.n] = vals
+        w.s[sdst.idx:sdst.idx + sdst.n] = POISON
+        w.lgq.append(commit)
+    return Inst(f"s_load_dwordx{sdst.n} {sdst}, {sbase}, {hex(offset)}", "smem", reads=[sbase], writes=[sdst], emu=emu)
 
 
 # ---- MFMA -----------------------------------------------------------------------------------------------------------------------
@@ -625,6 +651,26 @@ def global_load_lds_dwordx4(voff, sbase, offset=0):
         else:
             w.vmq.append(commit)
     return Inst(f"global_load_lds_dwordx4 {voff}, {sbase} offset:{offset}", "dma", reads=[voff, sbase, M0], emu=emu)
+
+
+def global_load_lds_dword(voff, sbase, offset=0):
+    """LDS-DMA, 4 bytes per lane: lane i reads a dword at sbase + voff[i] + offset and lands at LDS byte M0 + 4 i."""
+    assert -4096 <= offset < 4096
+
+    def emu(w):
+        addrs = w.sget64(sbase) + w.rf(voff)[0].astype(np.int64) + offset
+        dst = int(w.m0)
+        assert dst % 4 == 0 and dst + 256 <= w.wg.lds.size
+
+        def commit(addrs=addrs, dst=dst):
+            data = w.wg.gread(addrs, 4)
+            w.wg.lds[dst:dst + 256] = data.reshape(-1)
+        if w.wg.mode == "early":
+            commit()
+            w.vmq.append(lambda: None)
+        else:
+            w.vmq.append(commit)
+    return Inst(f"global_load_lds_dword {voff}, {sbase} offset:{offset}", "dma", reads=[voff, sbase, M0], emu=emu)
 
 
 def global_load_dwordx4(dst, voff, sbase, offset=0):
