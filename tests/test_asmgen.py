@@ -90,3 +90,49 @@ def test_gemm_loop_lint_and_header_current(tmp_path):
         clob = re.search(rf"#define UDM_QUADLOOP_NT{FM}_CLOBBERS (.*)", committed).group(1)
         for r in ['"v0"', f'"v{progs[FM][0].v_last}"', '"s36"', f'"s{progs[FM][0].s_last}"', '"vcc"', '"scc"', '"m0"', '"memory"']:
             assert r in clob, (FM, r)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------------
+# the dK / dV pass of the attention backward (csrc/asmgen/attn_dkv64.py -> attention_dkv64_gen.h, used by attention_dkv64.hip)
+# ---------------------------------------------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def gen_dkv():
+    import attn_dkv64 as g
+    import emu_dkv64 as e
+    prog, _ = g.build()
+    return g, e, prog
+
+
+def test_dkv64_hazard_lint_and_budgets(gen_dkv):
+    g, _, prog = gen_dkv
+    import isa
+    assert isa.lint([i for i in prog if i.kind != "raw"], mfma_states=4) == []
+    assert g.S_.next <= 100 and g.V.next <= 255 and g.A.next <= 256
+    assert g.LDS_TOTAL <= 160 * 1024
+    assert (g.NST - 1) * g.STG + g.TILE + 6 * g.PIECE + 3 * 256 + 8 < 65536        # every fragment address is a 16-bit immediate behind ONE base register
+
+
+@pytest.mark.parametrize("mode", ["late", "early"])
+@pytest.mark.parametrize("kw", [dict(B=1, H=8, L=512, grid=8, wg_id=0), dict(B=1, H=8, L=1024, grid=8, wg_id=3), dict(B=2, H=4, L=512, grid=8, wg_id=5),
+                                # the balanced walk (24 blocks on 16 workgroups: one whole block, then half (wg >> 3) & 1 of block 16 + (wg & 7)): both halves
+                                dict(B=1, H=8, L=768, grid=16, wg_id=2), dict(B=1, H=8, L=768, grid=16, wg_id=11)],
+                         ids=["two_blocks", "four_blocks_three_trips", "two_batches", "half_block_first_half", "half_block_second_half"])
+def test_emulated_dkv64_workgroup_matches_float64_backward(gen_dkv, kw, mode):
+    _, e, prog = gen_dkv
+    r = e.run(mode=mode, prog=prog, seed=11, **kw)
+    assert r["blocks"] >= 2 and r["stray_writes"] == 0
+    assert r["dk_rel"] < 4e-3 and r["dv_rel"] < 4e-3, r      # bf16 output rounding + bf16 P / dS
+
+
+def test_dkv64_committed_header_is_current(tmp_path, gen_dkv):
+    g, _, _ = gen_dkv
+    out = tmp_path / "gen.h"
+    g.emit(str(out))
+    committed = open(os.path.join(os.path.dirname(ASMGEN), "attention_dkv64_gen.h")).read()
+    fresh = out.read_text()
+    cut = lambda s: s[:s.index("#define UDM_DKV64_ASM_ABL")] if "#define UDM_DKV64_ASM_ABL" in s else s
+    assert cut(committed) == cut(fresh), "attention_dkv64_gen.h is stale: run `make -C unidisc_amd/csrc regen`"
+    clob = re.search(r"#define UDM_DKV64_CLOBBERS (.*)", committed).group(1)
+    for r in ['"v0"', '"v254"', '"a0"', '"a255"', '"s36"', '"s99"', '"vcc"', '"scc"', '"m0"', '"memory"']:
+        assert r in clob, r
+    assert '"v255"' not in clob

@@ -291,6 +291,10 @@ def s_mov_b32(dst, a):
     return Inst(f"s_mov_b32 {dst}, {_imm(a)}", "salu", reads=[a], writes=[dst], emu=lambda w: w.sset(dst, w.sget(a)))
 
 
+def s_cselect_b32(dst, a, b):
+    return Inst(f"s_cselect_b32 {dst}, {_imm(a)}, {_imm(b)}", "salu", reads=[a, b, SCC], writes=[dst], emu=lambda w: w.sset(dst, w.sget(a) if w.scc else w.sget(b)))
+
+
 def s_mov_b64(dst, a):
     def emu(w):
         if isinstance(a, R):
@@ -765,9 +769,11 @@ def _need(wk, rk, is_chain):
     return 0
 
 
-def lint(prog, window=24):
+def lint(prog, window=24, mfma_states=1):
     """Straight-line hazard check (branches are ignored: call it per basic block or on streams whose branch targets begin with an
-    s_nop pad).  Returns a list of problem strings."""
+    s_nop pad).  Returns a list of problem strings.  `mfma_states`: wait states an intervening MFMA is counted as (default 1 = like any instruction; an 8-pass
+    MFMA behind another MFMA cannot issue before the matrix pipe has taken the first one, i.e. it really is worth 8: generators whose dependent VALU work
+    follows a few MFMAs behind its producer pass 4)."""
     problems = []
     real = [ins for ins in prog if ins.kind not in ("comment", "label")]
     # SCC is one bit every SALU compare / add / shift overwrites: a reader (s_addc, s_cbranch_scc, s_cselect) must sit directly behind its writer
@@ -792,7 +798,7 @@ def lint(prog, window=24):
                     if dist < need:
                         problems.append(f"[{i}] {ins.text}  <- [{j}] {prev.text}: {reg[0]}{reg[1]} needs {need} wait states, has {dist}")
                     break
-            dist += prev.meta.get("count", 1) if prev.kind == "nop" else 1
+            dist += prev.meta.get("count", 1) if prev.kind == "nop" else (mfma_states if prev.kind == "mfma" else 1)
     return problems
 
 

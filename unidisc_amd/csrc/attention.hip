@@ -626,6 +626,7 @@ void launch_bwd(const AttnArgs& a, hipStream_t s) {
   static bool once = false;
   if (!once) { set_lds(kq, lds_q); set_lds(kk, lds_k); once = true; }
   hipLaunchKernelGGL(kq, gq, dim3(256), lds_q, s, a);
+  if (D == 128 && !SID && TR && a.q_prescaled && udm_launch_attn_bwd_dkv64(&a, s)) return;   // the one-wave-per-SIMD, 64-keys-per-wave kernel (round 6)
   if (D == 128 && !SID && TR && g_dkv_ws) udm_launch_attn_bwd_dkv_ws(&a, s);
   else if (D == 128 && SID && TR && g_dkv_ws && a.doc_ranges) {
     // packed documents: key blocks that lie inside one document and whose query span is exactly that document go to the wave-specialised

@@ -30,6 +30,9 @@ extern "C" __attribute__((visibility("hidden"))) int udm_attention_set_tr_read(i
 extern "C" __attribute__((visibility("hidden"))) int udm_attention_set_fwd64_timeline(int64_t device_ptr);   // attention_fwd64.hip diagnostics
 extern "C" __attribute__((visibility("hidden"))) int udm_attention_set_fwd64(int enable);          // attention_fwd64.hip: 0 = the 8-wave forward also at D = 128, L % 256 == 0 (default 1; env UDM_ATTN_FWD64)
 
+void udm_attention_set_dkv64(int enable);                                     // attention_dkv64.hip: 0 = the wave-specialised dK / dV kernel everywhere, 2 = without the balanced walk
+void udm_attention_set_dkv64_timeline(int64_t device_ptr);
+
 namespace { int g_exp = [] { const char* e = getenv("UDM_EXP"); return e ? atoi(e) : 0; }(); }
 int udm_exp_flags() { return g_exp; }
 
@@ -45,6 +48,8 @@ extern "C" int udm_debug_set(const char* key, int64_t value) {
   if (is("attention_tr_read")) return udm_attention_set_tr_read((int)value);
   if (is("attention_fwd64")) return udm_attention_set_fwd64((int)value);
   if (is("attention_fwd64_timeline")) return udm_attention_set_fwd64_timeline(value);
+  if (is("attention_dkv64")) { udm_attention_set_dkv64((int)value); return 0; }
+  if (is("attention_dkv64_timeline")) { udm_attention_set_dkv64_timeline(value); return 0; }
   udm_set_error("udm_debug_set: unknown key '%s'", key);
   return 2;
 }

@@ -818,6 +818,12 @@ def set_attention_fwd64(enable):
     debug_set("attention_fwd64", int(enable))
 
 
+def set_attention_dkv64(enable):
+    """A/B switch: the 64-keys-per-wave dK / dV pass (csrc/attention_dkv64.hip; head dim 128, no mask, L % 256 == 0, q pre-scaled) on / off; 2 = on, without the
+    balanced walk (whole 256-key blocks only).  Off = the wave-specialised 8-wave kernel of attention_dkv_ws.hip."""
+    debug_set("attention_dkv64", int(enable))
+
+
 # ------------------------------------------------------------------------------------------------ embedding / CE / adaLN helpers
 def embedding_fwd(ids, E, modality=None, Em=None):
     M = ids.numel()
