@@ -331,7 +331,7 @@ def body(j, variant):
                 G.m[g] = v_mfma_f32_32x32x16_bf16(acc, slot(16 + c2 * 4 + i), dSfr(f, c2), 0 if (variant == "head" and c2 == 0) else acc)
                 g += 1
     # ---------------- G0: wait + barrier, dO row fragments, softmax
-    G.put(0, stamp(8 + j) if variant == "main" else [])
+    G.pre += stamp((8 if variant in ("main", "head") else 12) + j)       # timeline builds: the top of the step (drains the LDS queue: the queue state stays the loop's)
     G.put(0, [s_waitcnt(vmcnt=5)] if not last else [s_waitcnt(vmcnt=5)])
     G.put(1, [s_barrier()])
     for ks in range(n_pref(), KS):
