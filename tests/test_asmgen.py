@@ -136,3 +136,48 @@ def test_dkv64_committed_header_is_current(tmp_path, gen_dkv):
     for r in ['"v0"', '"v254"', '"a0"', '"a255"', '"s36"', '"s99"', '"vcc"', '"scc"', '"m0"', '"memory"']:
         assert r in clob, r
     assert '"v255"' not in clob
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------------
+# the dQ pass of the attention backward (csrc/asmgen/attn_dq64.py -> attention_dq64_gen.h, used by attention_dq64.hip)
+# ---------------------------------------------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def gen_dq():
+    import attn_dq64 as g
+    import emu_dq64 as e
+    prog, _ = g.build()
+    return g, e, prog
+
+
+def test_dq64_hazard_lint_and_budgets(gen_dq):
+    g, _, prog = gen_dq
+    import isa
+    assert isa.lint([i for i in prog if i.kind != "raw"], mfma_states=4) == []
+    assert g.S_.next <= 100 and g.V.next <= 255 and g.A.next <= 256
+    assert g.LDS_TOTAL <= 160 * 1024
+    assert (g.NST - 1) * g.STG + g.TILE + 6 * g.PIECE + 3 * 256 + 8 < 65536
+
+
+@pytest.mark.parametrize("mode", ["late", "early"])
+@pytest.mark.parametrize("kw", [dict(B=1, H=8, L=512, grid=8, wg_id=0), dict(B=1, H=8, L=1024, grid=8, wg_id=3), dict(B=2, H=4, L=512, grid=8, wg_id=5),
+                                dict(B=1, H=8, L=768, grid=16, wg_id=2), dict(B=1, H=8, L=768, grid=16, wg_id=11)],
+                         ids=["two_blocks", "four_blocks_three_trips", "two_batches", "half_block_first_half", "half_block_second_half"])
+def test_emulated_dq64_workgroup_matches_float64_backward(gen_dq, kw, mode):
+    """dQ of every block the workgroup walks, and the planes delta | -lse | -delta it leaves behind for the dK / dV pass (fp32: to rounding)"""
+    _, e, prog = gen_dq
+    r = e.run(mode=mode, prog=prog, seed=11, **kw)
+    assert r["blocks"] >= 2 and r["stray_writes"] == 0
+    assert r["dq_rel"] < 4e-3 and r["planes_err"] < 2e-6, r
+
+
+def test_dq64_committed_header_is_current(tmp_path, gen_dq):
+    g, _, _ = gen_dq
+    out = tmp_path / "gen.h"
+    g.emit(str(out))
+    committed = open(os.path.join(os.path.dirname(ASMGEN), "attention_dq64_gen.h")).read()
+    fresh = out.read_text()
+    cut = lambda s: s[:s.index("#define UDM_DQ64_ASM_ABL")] if "#define UDM_DQ64_ASM_ABL" in s else s
+    assert cut(committed) == cut(fresh), "attention_dq64_gen.h is stale: run `make -C unidisc_amd/csrc regen`"
+    clob = re.search(r"#define UDM_DQ64_CLOBBERS (.*)", committed).group(1)
+    for r in ['"v0"', '"v254"', '"a0"', '"a255"', '"s36"', '"s99"', '"vcc"', '"scc"', '"m0"', '"memory"']:
+        assert r in clob, r

@@ -427,6 +427,16 @@ def v_pk_mul_f32(dst, a, b):
     return Inst(f"v_pk_mul_f32 {dst}, {a}, {b}", "valu", reads=[a, b], writes=[dst], emu=emu)
 
 
+def v_dot2c_f32_bf16(dst, a, b):
+    """dst += a.bf16[0] * b.bf16[0] + a.bf16[1] * b.bf16[1]   (fp32 accumulate)"""
+    def fn(w, d, a, b):
+        ua, ub = w.vsrc_u(a), w.vsrc_u(b)
+        lo = _bf16_to_f32(ua & 0xFFFF).astype(np.float64) * _bf16_to_f32(ub & 0xFFFF).astype(np.float64)
+        hi = _bf16_to_f32(ua >> 16).astype(np.float64) * _bf16_to_f32(ub >> 16).astype(np.float64)
+        return (w.f32(d)[0].astype(np.float64) + lo + hi).astype(np.float32)
+    return _valu("v_dot2c_f32_bf16", "valu", dst, [dst, a, b], fn, text=f"v_dot2c_f32_bf16 {dst}, {_imm(a)}, {_imm(b)}")
+
+
 def v_exp_f32(dst, a):
     return _valu("v_exp_f32", "trans", dst, [a], lambda w, a: np.exp2(_f(w.vsrc_f(a))).astype(np.float32))
 
@@ -689,6 +699,20 @@ def global_load_dwordx4(dst, voff, sbase, offset=0):
             w.rf(dst)[:] = data.view(np.uint32).reshape(64, 4).T
         w.vmq.append(commit)
     return Inst(f"global_load_dwordx4 {dst}, {voff}, {sbase} offset:{offset}", "vmem_ld", reads=[voff, sbase], writes=[dst], emu=emu)
+
+
+def global_load_dword(dst, voff, sbase, offset=0):
+    assert -4096 <= offset < 4096 and dst.n == 1
+
+    def emu(w):
+        addrs = w.sget64(sbase) + w.rf(voff)[0].astype(np.int64) + offset
+        w.rf(dst)[:] = POISON
+
+        def commit(addrs=addrs):
+            data = w.wg.gread(addrs, 4)
+            w.rf(dst)[:] = data.view(np.uint32).reshape(64, 1).T
+        w.vmq.append(commit)
+    return Inst(f"global_load_dword {dst}, {voff}, {sbase} offset:{offset}", "vmem_ld", reads=[voff, sbase], writes=[dst], emu=emu)
 
 
 def _gstore(op, n):

@@ -625,7 +625,8 @@ void launch_bwd(const AttnArgs& a, hipStream_t s) {
   auto kk = attn_bwd_dkv_kernel<D, SID, TR, 3, W>;
   static bool once = false;
   if (!once) { set_lds(kq, lds_q); set_lds(kk, lds_k); once = true; }
-  hipLaunchKernelGGL(kq, gq, dim3(256), lds_q, s, a);
+  // D = 128, no mask, L % 256 == 0, q pre-scaled: both passes as generated one-wave-per-SIMD programs (round 6: attention_dq64.hip, attention_dkv64.hip)
+  if (!(D == 128 && !SID && TR && a.q_prescaled && udm_launch_attn_bwd_dq64(&a, s))) hipLaunchKernelGGL(kq, gq, dim3(256), lds_q, s, a);
   if (D == 128 && !SID && TR && a.q_prescaled && udm_launch_attn_bwd_dkv64(&a, s)) return;   // the one-wave-per-SIMD, 64-keys-per-wave kernel (round 6)
   if (D == 128 && !SID && TR && g_dkv_ws) udm_launch_attn_bwd_dkv_ws(&a, s);
   else if (D == 128 && SID && TR && g_dkv_ws && a.doc_ranges) {

@@ -248,5 +248,6 @@ __device__ __forceinline__ void store_rows_via_lds_d128(char* wave_lds, const f3
 
 // dK/dV kernel for head dim 128 without a document mask (attention_dkv_ws.hip); grid = ceil(L / 128) * B * H blocks of 512 threads
 void udm_launch_attn_bwd_dkv_ws(const void* args, hipStream_t stream);
+bool udm_launch_attn_bwd_dq64(const void* args, hipStream_t stream);    // attention_dq64.hip: dQ (+ delta and the planes) at D = 128, no mask, L % 256 == 0, q pre-scaled (false = shape not taken)
 bool udm_launch_attn_bwd_dkv64(const void* args, hipStream_t stream);   // attention_dkv64.hip: dK / dV at D = 128, no mask, L % 256 == 0, q pre-scaled (false = shape not taken)
 bool udm_launch_attn_fwd64(const void* args, hipStream_t stream);      // attention_fwd64.hip: forward at D = 128, no mask, L % 256 == 0 (false = shape not taken)

@@ -32,6 +32,8 @@ extern "C" __attribute__((visibility("hidden"))) int udm_attention_set_fwd64(int
 
 void udm_attention_set_dkv64(int enable);                                     // attention_dkv64.hip: 0 = the wave-specialised dK / dV kernel everywhere, 2 = without the balanced walk
 void udm_attention_set_dkv64_timeline(int64_t device_ptr);
+void udm_attention_set_dq64(int enable);                                      // attention_dq64.hip: 0 = attn_bwd_dq_kernel everywhere, 2 = without the balanced walk
+void udm_attention_set_dq64_timeline(int64_t device_ptr);
 
 namespace { int g_exp = [] { const char* e = getenv("UDM_EXP"); return e ? atoi(e) : 0; }(); }
 int udm_exp_flags() { return g_exp; }
@@ -49,6 +51,8 @@ extern "C" int udm_debug_set(const char* key, int64_t value) {
   if (is("attention_fwd64")) return udm_attention_set_fwd64((int)value);
   if (is("attention_fwd64_timeline")) return udm_attention_set_fwd64_timeline(value);
   if (is("attention_dkv64")) { udm_attention_set_dkv64((int)value); return 0; }
+  if (is("attention_dq64")) { udm_attention_set_dq64((int)value); return 0; }
+  if (is("attention_dq64_timeline")) { udm_attention_set_dq64_timeline(value); return 0; }
   if (is("attention_dkv64_timeline")) { udm_attention_set_dkv64_timeline(value); return 0; }
   udm_set_error("udm_debug_set: unknown key '%s'", key);
   return 2;

@@ -818,6 +818,12 @@ def set_attention_fwd64(enable):
     debug_set("attention_fwd64", int(enable))
 
 
+def set_attention_dq64(enable):
+    """A/B switch: the 64-queries-per-wave dQ pass (csrc/attention_dq64.hip; head dim 128, no mask, L % 256 == 0, q pre-scaled) on / off; 2 = on, without the balanced
+    walk.  Off = attn_bwd_dq_kernel (8 waves, two workgroups per CU)."""
+    debug_set("attention_dq64", int(enable))
+
+
 def set_attention_dkv64(enable):
     """A/B switch: the 64-keys-per-wave dK / dV pass (csrc/attention_dkv64.hip; head dim 128, no mask, L % 256 == 0, q pre-scaled) on / off; 2 = on, without the
     balanced walk (whole 256-key blocks only).  Off = the wave-specialised 8-wave kernel of attention_dkv_ws.hip."""
