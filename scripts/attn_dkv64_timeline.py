@@ -22,10 +22,11 @@ tl = torch.zeros(grid, 4, 64, dtype=torch.int32, device="cuda")
 for _ in range(3):
     K.attention_bwd(qkr, qkv, o, do, lse, dqkr, dqkv, B, L, H, D, q_prescaled=True)
 torch.cuda.synchronize()
-K.debug_set("attention_dkv64_timeline", tl.data_ptr())
+WHICH = os.environ.get("UDM_TL", "dkv64")      # dkv64 | dq64 (library built with UDM_DKV64_ABL=16 / UDM_DQ64_ABL=16)
+K.debug_set(f"attention_{WHICH}_timeline", tl.data_ptr())
 K.attention_bwd(qkr, qkv, o, do, lse, dqkr, dqkv, B, L, H, D, q_prescaled=True)
 torch.cuda.synchronize()
-K.debug_set("attention_dkv64_timeline", 0)
+K.debug_set(f"attention_{WHICH}_timeline", 0)
 t = tl.cpu().numpy().astype(np.int64) & 0xFFFFFFFF
 names = {0: "entry", 1: "entry:issued", 3: "blk:start", 4: "blk:waited", 40: "epi:start", 41: "epi:end", 42: "done"}
 for j in range(4):

@@ -135,7 +135,7 @@ def _abl(prog):
     out = []
     for ins in prog:
         k = ins.kind
-        if (ABL & 1) and k in ("valu", "trans") and not ins.meta.get("keep"):
+        if (ABL & 1) and k in ("valu", "trans", "dot") and not ins.meta.get("keep"):
             continue
         if (ABL & 2) and k == "lds_rd":
             continue
@@ -406,6 +406,7 @@ def block_start():
     for q in range(NQ):
         for r in range(32):
             p += [v_accvgpr_read_b32(dPb[2 + (r & 1)], dOf[q * 32 + r]), v_dot2c_f32_bf16(dlt[q], Sb[32 * q + r], dPb[2 + (r & 1)])]
+    p += [s_nop(3)]          # (DOT write -> a different VALU instruction reading it: 3 wait states)
     for q in range(NQ):
         p += [v_mov_b32(sw[q], dlt[q])]
     p += [s_nop(1)] + [v_permlane32_swap_b32(dlt[q], sw[q]) for q in range(NQ)]
@@ -427,7 +428,7 @@ def block_start():
         for r in range(16):
             p += [v_mov_b32(negl[16 * q + r], nl[q]), v_mov_b32(negd[16 * q + r], nd[q])]
     for ins in p:
-        if ins.kind in ("valu", "trans"):
+        if ins.kind in ("valu", "trans", "dot"):
             ins.meta["keep"] = True
     p += [s_nop(1)]
     # ---- S(0) into buffer 0 (its registers held the O rows of q = 0: consumed above), then the first V fragments of step 0

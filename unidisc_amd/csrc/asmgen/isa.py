@@ -434,7 +434,9 @@ def v_dot2c_f32_bf16(dst, a, b):
         lo = _bf16_to_f32(ua & 0xFFFF).astype(np.float64) * _bf16_to_f32(ub & 0xFFFF).astype(np.float64)
         hi = _bf16_to_f32(ua >> 16).astype(np.float64) * _bf16_to_f32(ub >> 16).astype(np.float64)
         return (w.f32(d)[0].astype(np.float64) + lo + hi).astype(np.float32)
-    return _valu("v_dot2c_f32_bf16", "valu", dst, [dst, a, b], fn, text=f"v_dot2c_f32_bf16 {dst}, {_imm(a)}, {_imm(b)}")
+    # kind "dot": gfx940+ needs 3 wait states between a DOT instruction's write and any OTHER kind of VALU instruction that reads it (a chain of the same DOT opcode
+    # accumulating into its own destination needs none) - the GPU read a stale accumulator one product short when a v_mov followed the last v_dot2c directly
+    return _valu("v_dot2c_f32_bf16", "dot", dst, [dst, a, b], fn, text=f"v_dot2c_f32_bf16 {dst}, {_imm(a)}, {_imm(b)}")
 
 
 def v_exp_f32(dst, a):
@@ -774,6 +776,8 @@ def run_workgroup(prog, wg, waves, max_steps=10_000_000):
 # (writer kind, reader kind) -> instructions that must lie between them (each intervening instruction counts one wait state, s_nop N
 # counts N + 1).  Conservative: MFMA results are given 16 states although the 8-pass form needs 12.
 def _need(wk, rk, is_chain):
+    if wk == "dot":
+        return 0 if rk == "dot" else 4
     if wk == "mfma":
         if rk == "mfma":
             return 0 if is_chain else 16
