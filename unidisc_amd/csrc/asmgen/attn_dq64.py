@@ -31,8 +31,14 @@ PIECE = 1040
 TILE = 8 * PIECE              # 32 rows
 STG = 2 * TILE                # K tile | V tile
 LDS_RING = NST * STG
-WAVE_STG = 8192               # epilogue staging per wave: 32 query rows x 256 bytes
-LDS_TOTAL = LDS_RING + 4 * WAVE_STG
+# Behind the ring: ONE area of two tiles per wave.  The next block's Q rows, then its dO rows, then its O rows pass through it as LDS-DMA pieces (coalesced 256-byte
+# rows; a direct fragment load touches 32 cache lines per instruction and stalled the issue ~200 cycles each: 50 of them cost 12 k cycles per block, first timeline)
+# and are picked up as row fragments; the epilogue stages dQ through its first 8 KiB while the O rows of q = 0 wait in the rest.
+A_BASE = LDS_RING
+AREA = 2 * TILE
+O0_OFF = TILE                 # (the epilogue stages through [0, 8192), the O rows of q = 1 arrive in [0, TILE))
+assert O0_OFF + TILE <= AREA and O0_OFF >= 8192
+LDS_TOTAL = LDS_RING + 4 * AREA
 
 # ---- the kernel's parameter block (kernarg segment; attention_dq64.hip declares the same struct): dword offsets
 P_K, P_V, P_KSTR, P_VSTR, P_L, P_NSTEPS, P_H, P_NT, P_MG_NT, P_MG_H, P_NFULL, P_HASHALF, P_GSTRIDE, P_PLANEB = 0, 2, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15
@@ -52,8 +58,10 @@ negl, negd = V("negl", 32), V("negd", 32)
 Fq = V("Fq", 32)
 qaddr, taddr = V("qaddr"), V("taddr")
 dk, dv = V("dk", 2), V("dv", 2)
-roff = V("roff", 3)           # per-lane row offsets of the block whose operands are being loaded: q, dO, o
-loff = V("loff")              # ... and row * 4 (lse, the planes)
+aaddr = V("aaddr")            # row-fragment base inside this wave's staging area
+lr, lcs = V("lr"), V("lcs")   # LDS-DMA lane constants: row of the piece (lane >> 2) & 3, byte (4 (lane >> 4) + (lane & 3)) * 16 inside the row
+da = V("da", 4)               # LDS-DMA source offsets of the operand being staged: pieces 4 g + j
+loff = V("loff")              # (lane & 31) * 4: lse, the planes
 tmp = V("tmp", 4)
 dQT, Qf, dOf = A("dQ", 128), A("Q", 64), A("dO", 64)
 
@@ -289,37 +297,51 @@ def stream_ptrs(bid, hidx, k, v):
     return p + ptr(k, s_t[1], s_kb, s_kstr) + ptr(v, s_t[1], s_vb, s_vstr)
 
 
-def qo_loads(bid, hidx, is_half):
-    """Q / dO fragments of the block (bid, hidx) -> Qf / dOf, its O rows -> the S buffers (q -> buffer q), its lse -> tmp[q]: parameters into s_T, per-lane row offsets,
-    the loads as units.  is_half: an SGPR that is 1 when the block is a 128-query half (a wave then owns 32 queries and its q = 1 loads re-read the q = 0 rows), or a bool."""
-    pre = [s_load_dwords(s_T.sub(0, 8), s_par, 4 * P_Q), s_load_dwords(s_T.sub(8, 4), s_par, 4 * P_QSTR), s_waitcnt(lgkmcnt=0)]
+def seam_ptrs(bid, hidx, is_half):
+    """the operand bases of block (bid, hidx) AT THIS WAVE'S FIRST ROW into s_T: [0:1] q, [2:3] dO, [4:5] o, [6:7] lse, [8] qstr, [9] dostr, [10] ostr.
+    is_half: an SGPR that is 1 when the block is a 128-query half (a wave then owns 32 queries), or a bool."""
+    p = [s_load_dwords(s_T.sub(0, 8), s_par, 4 * P_Q), s_load_dwords(s_T.sub(8, 4), s_par, 4 * P_QSTR), s_waitcnt(lgkmcnt=0)]
     qb, dob, ob, lseb = (s_T.sub(2 * i, 2) for i in range(4))
     qstr, dostr, ostr = s_T[8], s_T[9], s_T[10]
     if isinstance(is_half, bool):
-        pre += [s_mov_b32(s_wq, 32 if is_half else 64)]
+        p += [s_mov_b32(s_wq, 32 if is_half else 64)]
     else:
-        pre += [s_lshl_b32(s_wq, is_half, 5), s_sub_u32(s_wq, 64, s_wq)]
-    pre += block_coords(bid, hidx)
-    pre += [s_add_u32(s_t[1], s_t[1], s_t[0])]                      # first query row of the block (global row index)
-    pre += ptr_inplace(qb, s_t[1], qstr) + ptr_inplace(dob, s_t[1], dostr) + ptr_inplace(ob, s_t[1], ostr)
-    # lse: + (bh L + row in sequence) * 4
-    pre += [s_mul_i32(s_t[2], s_t[2], s_L), s_add_u32(s_t[2], s_t[2], s_t[0]), s_lshl_b32(s_t[2], s_t[2], 2), s_add_u32(lseb[0], lseb[0], s_t[2]), s_addc_u32(lseb[1], lseb[1], 0)]
-    lane = v_mbcnt_lane_id(tmp[2])
-    pre += lane + [v_and_b32(tmp[3], 31, tmp[2]), v_lshrrev_b32(tmp[2], 5, tmp[2]), v_lshlrev_b32(tmp[2], 4, tmp[2]), s_mul_i32(s_t[0], s_wave, s_wq), s_nop(0),
-                   v_add_u32(tmp[3], s_t[0], tmp[3]),
-                   v_mul_lo_u32(roff[0], tmp[3], qstr), v_mul_lo_u32(roff[1], tmp[3], dostr), v_mul_lo_u32(roff[2], tmp[3], ostr), v_lshlrev_b32(loff, 2, tmp[3]),
-                   v_add_u32(roff[0], roff[0], tmp[2]), v_add_u32(roff[1], roff[1], tmp[2]), v_add_u32(roff[2], roff[2], tmp[2])]
+        p += [s_lshl_b32(s_wq, is_half, 5), s_sub_u32(s_wq, 64, s_wq)]
+    p += block_coords(bid, hidx)
+    p += [s_mul_i32(s_t[4], s_wave, s_wq), s_add_u32(s_t[0], s_t[0], s_t[4]), s_add_u32(s_t[1], s_t[1], s_t[0])]      # t0: row in the sequence, t1: global row
+    p += ptr_inplace(qb, s_t[1], qstr) + ptr_inplace(dob, s_t[1], dostr) + ptr_inplace(ob, s_t[1], ostr)
+    p += [s_mul_i32(s_t[2], s_t[2], s_L), s_add_u32(s_t[2], s_t[2], s_t[0]), s_lshl_b32(s_t[2], s_t[2], 2), s_add_u32(lseb[0], lseb[0], s_t[2]), s_addc_u32(lseb[1], lseb[1], 0)]
+    for ins in p:
+        ins.meta["keep"] = True
+    return p
+
+
+def stage_dma(base, stride, area_off, ntiles, rewind=False):
+    """`ntiles` x 32 rows from `base` (advanced past them) into this wave's staging area at `area_off`, as units: piece 4 g + j = rows 16 g + 4 j .. + 3.
+    Uses t0 (LDS destination), t1 (16 rows in bytes) until its last unit has been issued.  rewind (the program of whole blocks staging for a block that may be a
+    half, s_wq = 32): the second tile re-reads the first tile's rows instead of running past the wave's 32."""
+    pre = [s_lshl_b32(s_t[1], stride, 2), v_mul_lo_u32(da[0], lr, stride), v_add_u32(da[0], da[0], lcs)]
+    pre += [v_add_u32(da[j], s_t[1], da[j - 1]) for j in range(1, 4)]
+    pre += [s_mul_i32(s_t[0], s_wave, AREA), s_add_u32(s_t[0], s_t[0], s_lds), s_add_u32(s_t[0], s_t[0], A_BASE + area_off), s_lshl_b32(s_t[1], stride, 4)]
     for ins in pre:
         ins.meta["keep"] = True
-    # q = 1: + 32 rows (whole blocks), + 0 rows (half blocks: re-read)
-    def step(base, stride):
-        return [s_sub_u32(s_t[0], s_wq, 32), s_mul_i32(s_t[1], s_t[0], stride), s_add_u32(base[0], base[0], s_t[1]), s_addc_u32(base[1], base[1], 0)]
-    lq = [[[global_load_dwordx4(Qfr(q, ks), roff[0], qb, ks * 32)] for ks in range(KS)] for q in range(2)]
-    ldo = [[[global_load_dwordx4(dOfr(q, ks), roff[1], dob, ks * 32)] for ks in range(KS)] for q in range(2)]
-    lo = [[[global_load_dwordx4(Sblk(q, 0).sub(0, 16).sub(0, 4) if False else Sb.sub(32 * q + 4 * ks, 4), roff[2], ob, ks * 32)] for ks in range(KS)] for q in range(2)]
-    llse = [[global_load_dword(tmp[q], loff, lseb, 0)] for q in range(2)]
-    lstep = [s_sub_u32(s_t[0], s_wq, 32), s_lshl_b32(s_t[0], s_t[0], 2), s_add_u32(lseb[0], lseb[0], s_t[0]), s_addc_u32(lseb[1], lseb[1], 0)]
-    return pre, dict(q=lq, do=ldo, o=lo, lse=llse, step_q=step(qb, qstr), step_do=step(dob, dostr), step_o=step(ob, ostr), step_lse=lstep)
+    units = [pre]
+    for g in range(2 * ntiles):
+        for j in range(4):
+            units.append([s_add_u32(M0, s_t[0], (4 * g + j) * PIECE), s_nop(0), global_load_lds_dwordx4(da[j], base)])
+        units.append([s_add_u32(base[0], base[0], s_t[1]), s_addc_u32(base[1], base[1], 0)])
+        if rewind and ntiles == 2 and g == 1:
+            units.append([s_sub_u32(s_t[2], 64, s_wq), s_mul_i32(s_t[2], s_t[2], stride), s_sub_u32(base[0], base[0], s_t[2]), s_subb_u32(base[1], base[1], 0)])
+    return units
+
+
+def stage_reads(dst, area_off, ntiles):
+    """the staged rows as row fragments: dst(q, ks) <- lane (row l & 31 of tile q, 8 columns 16 ks + 8 (l >> 5) ..)"""
+    return [[ds_read_b128(dst(q, ks), aaddr, area_off + q * TILE + (ks >> 1) * 256 + (ks & 1) * 32)] for q in range(ntiles) for ks in range(KS)]
+
+
+def lse_loads():
+    return [[global_load_dword(tmp[q], loff, s_T.sub(6, 2), 128 * q)] for q in range(NQ)]
 
 
 def next_block_choice():
@@ -337,16 +359,6 @@ def next_block_choice():
 
 
 INPUTS = ["par", "bid", "lds", "tid"]
-
-
-def all_loads(ld):
-    """every load of a block's operands, in an order that respects the scalar base steps: q = 0 of everything, the steps, q = 1"""
-    seq = []
-    for q in range(2):
-        if q == 1:
-            seq += [ld["step_q"], ld["step_do"], ld["step_o"], ld["step_lse"]]
-        seq += ld["q"][q] + ld["do"][q] + ld["o"][q] + [ld["lse"][q]]
-    return seq
 
 
 def entry():
@@ -375,37 +387,69 @@ def entry():
     p += [v_mul_lo_u32(t[3], hi, s_t[0]), v_and_b32(t[4], 15, lane_v), v_lshrrev_b32(t[4], 2, t[4]), v_lshlrev_b32(t[4], 6, t[4]), v_add_u32(t[3], t[3], t[4]),
           v_lshrrev_b32(t[4], 4, lane_v), v_and_b32(t[4], 1, t[4]), v_lshlrev_b32(t[4], 5, t[4]), v_add_u32(t[3], t[3], t[4]),
           v_and_b32(t[4], 3, lane_v), v_lshlrev_b32(t[4], 3, t[4]), v_add_u32(t[3], t[3], t[4]), v_add_u32(taddr, s_lds, t[3])]
+    # staging: lane constants of the LDS-DMA pieces, the fragment base inside this wave's area, (lane & 31) * 4
+    p += [v_lshrrev_b32(lr, 2, lane_v), v_and_b32(lr, 3, lr), v_lshrrev_b32(lcs, 4, lane_v), v_lshlrev_b32(lcs, 2, lcs), v_and_b32(t[5], 3, lane_v), v_add_u32(lcs, lcs, t[5]),
+          v_lshlrev_b32(lcs, 4, lcs), s_mul_i32(s_t[0], s_wave, AREA), s_add_u32(s_t[0], s_t[0], A_BASE), s_nop(0), v_add_u32(aaddr, s_t[0], qaddr), v_lshlrev_b32(loff, 2, l31)]
     p += [s_mov_b32(s_wg, s_bid), s_mov_b32(s_hidx, 0)]
     for ins in p:
         ins.meta["keep"] = True
     p += stream_ptrs(s_bid, 0, s_kt, s_vt)
-    pre, ld = qo_loads(s_bid, 0, False)
-    p += pre
-    for u in all_loads(ld):
+    # ---- the first block (always a whole one): Q and dO through the staging area into their registers, the O rows of q = 0 parked behind the epilogue's part of the
+    #      area (the block start stages those of q = 1), lse, the ring's first three steps
+    p += seam_ptrs(s_bid, 0, False)
+    for u in stage_dma(s_T.sub(0, 2), s_T[8], 0, 2):
         p += u
-    for s in range(PD):
-        for u in dma_step(s):
+    p += [s_waitcnt(vmcnt=0)]
+    for u in stage_reads(Qfr, 0, 2):
+        p += u
+    p += [s_waitcnt(lgkmcnt=0)]
+    for u in stage_dma(s_T.sub(2, 2), s_T[9], 0, 2):
+        p += u
+    for u in lse_loads():
+        p += u
+    for s_ in range(PD):
+        for u in dma_step(s_):
             p += u
+    p += [s_waitcnt(vmcnt=0)]
+    for u in stage_reads(dOfr, 0, 2):
+        p += u
+    p += [s_waitcnt(lgkmcnt=0)]
+    for u in stage_dma(s_T.sub(4, 2), s_T[10], O0_OFF, 1):
+        p += u
     p += stamp(1)
     return p
 
 
+def delta_math(q):
+    """dlt[q] = this lane's half of rowsum(dO * O) of its query in block q (the O rows sit in the S registers 32 q .. 32 q + 31)"""
+    p = [v_mov_b32(dPb[q], 0)]
+    for r in range(32):
+        p += [v_accvgpr_read_b32(dPb[2 + (r & 1)], dOf[q * 32 + r]), v_dot2c_f32_bf16(dPb[q], Sb[32 * q + r], dPb[2 + (r & 1)])]
+    return p
+
+
 def block_start():
-    """per block: what comes next; everything in flight has landed (previous stores, this block's Q / dO / O / lse, the ring's first steps); delta and the planes;
-    the C operands; the S(0) group"""
+    """per block: the O rows of q = 1 into the staging area; what comes next; everything older has landed (previous stores, the ring's first steps, the O rows of
+    q = 0, lse); delta and the planes; the C operands; the S(0) group"""
     nm = 8 * NQ
     p = [comment("---- block start"), label("L_block")] + stamp(3)
+    if NQ == 2:
+        for u in stage_dma(s_T.sub(4, 2), s_T[10], 0, 1):
+            p += u
     p += next_block_choice()
-    p += [s_waitcnt(vmcnt=0), s_barrier()] + stamp(4)
+    p += [s_waitcnt(vmcnt=8 if NQ == 2 else 0), s_barrier()] + stamp(4)
     p += [s_lshr_b32(s_loop, s_nsteps, 2), s_sub_u32(s_loop, s_loop, 1)]
-    # ---- delta = rowsum(dO * O): a lane holds 64 of its query's 128 columns (the other half sits in lane + 32); the O rows are in the S buffers (q -> buffer q)
+    # ---- delta = rowsum(dO * O): a lane holds 64 of its query's 128 columns (the other half sits in lane + 32)
     dlt = [dPb[0], dPb[1]]
     sw = [dPb[4], dPb[5]]
-    for q in range(NQ):
-        p += [v_mov_b32(dlt[q], 0)]
-    for q in range(NQ):
-        for r in range(32):
-            p += [v_accvgpr_read_b32(dPb[2 + (r & 1)], dOf[q * 32 + r]), v_dot2c_f32_bf16(dlt[q], Sb[32 * q + r], dPb[2 + (r & 1)])]
+    for u in stage_reads(lambda q, ks: Sb.sub(4 * ks, 4), O0_OFF, 1):
+        p += u
+    p += [s_waitcnt(lgkmcnt=0)] + delta_math(0)
+    if NQ == 2:
+        p += [s_waitcnt(vmcnt=0)]
+        for u in stage_reads(lambda q, ks: Sb.sub(32 + 4 * ks, 4), 0, 1):
+            p += u
+        p += [s_waitcnt(lgkmcnt=0)] + delta_math(1)
     p += [s_nop(3)]          # (DOT write -> a different VALU instruction reading it: 3 wait states)
     for q in range(NQ):
         p += [v_mov_b32(sw[q], dlt[q])]
@@ -418,7 +462,8 @@ def block_start():
     p += [s_load_dwords(s_T.sub(12, 2), s_par, 4 * P_DELTA), s_waitcnt(lgkmcnt=0)]
     p += block_coords(s_bid, s_hidx if NQ == 1 else 0)
     pl = s_T.sub(12, 2)
-    p += [s_mul_i32(s_t[2], s_t[2], s_L), s_add_u32(s_t[2], s_t[2], s_t[0]), s_lshl_b32(s_t[2], s_t[2], 2), s_add_u32(pl[0], pl[0], s_t[2]), s_addc_u32(pl[1], pl[1], 0)]
+    p += [s_mul_i32(s_t[2], s_t[2], s_L), s_add_u32(s_t[2], s_t[2], s_t[0]), s_mul_i32(s_t[4], s_wave, 32 * NQ), s_add_u32(s_t[2], s_t[2], s_t[4]), s_lshl_b32(s_t[2], s_t[2], 2),
+          s_add_u32(pl[0], pl[0], s_t[2]), s_addc_u32(pl[1], pl[1], 0)]
     for k_, vals in enumerate((dlt, nl, nd)):
         if k_:
             p += [s_add_u32(pl[0], pl[0], s_planeB), s_addc_u32(pl[1], pl[1], 0)]
@@ -442,13 +487,13 @@ def epilogue():
     """dQ^T -> bf16, scaled by ln 2 (the un-folding of the pre-scaled q), 32 query rows x 128 columns at a time through this wave's 8 KiB of staging, whole 256-byte rows"""
     e = [comment("---- epilogue")] + stamp(40)
     e += [s_nop(15), s_nop(15)]
-    e += [s_load_dwords(s_T.sub(8, 4), s_par, 4 * P_DQ), s_waitcnt(lgkmcnt=0)]
-    dq, dqstr, scale = s_T.sub(8, 2), s_T[10], s_T[11]
+    e += [s_load_dwords(s_T.sub(12, 4), s_par, 4 * P_DQ), s_waitcnt(lgkmcnt=0)]
+    dq, dqstr, scale = s_T.sub(12, 2), s_T[14], s_T[15]
     t = [Fq[i] for i in range(8)]
     lane_v, l31, hi, xw, rd = t[0], t[1], t[2], t[3], t[4]
     e += v_mbcnt_lane_id(lane_v)
     e += [v_and_b32(l31, 31, lane_v), v_lshrrev_b32(hi, 5, lane_v)]
-    e += [s_lshl_b32(s_t[0], s_wave, 13), s_add_u32(s_t[0], s_t[0], s_lds), s_add_u32(s_t[0], s_t[0], LDS_RING)]
+    e += [s_mul_i32(s_t[0], s_wave, AREA), s_add_u32(s_t[0], s_t[0], s_lds), s_add_u32(s_t[0], s_t[0], A_BASE)]     # (the first 8 KiB of this wave's area)
     e += [v_lshlrev_b32(xw, 8, l31), v_lshlrev_b32(t[5], 3, hi), v_add_u32(xw, xw, t[5]), v_and_b32(t[5], 15, l31), v_lshlrev_b32(t[5], 4, t[5]), v_add_u32(xw, xw, t[5]),
           v_add_u32(xw, s_t[0], xw)]
     g4, s15 = t[5], t[6]
@@ -524,24 +569,28 @@ def block_program(nq, suf):
     prog += [s_sub_u32(s_loop, s_loop, 1), s_cmp_lg_u32(s_loop, 0), s_cbranch_scc1("L_loop")]
     for j in range(4):
         G = body(j, f"tail{j}")
-        if j == 3:
-            # the next block's operands under the last step: Q registers are free from the start (their last reader was S(nsteps - 1)), dO registers after the dP group,
-            # S buffer 0 from the start, S buffer 1 after the dS arithmetic (this step's scores live there)
-            if NQ == 1:
-                pre, ld = qo_loads(s_nbid, s_hidxn, True)
-                G.pre = pre + G.pre
+        post = []
+        if j == 2:
+            # the next block's operand bases, its Q rows on their way into the staging area (picked up at the top of the last step, when the Q registers are free)
+            if NQ == 1:      # (a half block is the last thing a workgroup does: its "next" block is itself, a half)
+                G.pre = seam_ptrs(s_nbid, s_hidxn, True) + G.pre
             else:
-                pre, ld = qo_loads(s_nbid, s_hidxn, s_t[5])
-                G.pre = [s_cmp_eq_u32(s_moden, 1), s_cselect_b32(s_t[5], 1, 0)] + pre + G.pre
-            early = ld["q"][0] + ld["o"][0] + [ld["lse"][0]] + [ld["step_q"], ld["step_lse"]] + ld["q"][1] + [ld["lse"][1]]
-            late = ld["do"][0] + [ld["step_do"], ld["step_o"]] + ld["do"][1] + ld["o"][1]
-            G.spread(early, 2, nm - 2)
-            G.spread(late, nm, 2 * nm - 2)
+                G.pre = [s_cmp_eq_u32(s_moden, 1), s_cselect_b32(s_t[5], 1, 0)] + seam_ptrs(s_nbid, s_hidxn, s_t[5]) + G.pre
+            G.spread(stage_dma(s_T.sub(0, 2), s_T[8], 0, NQ, rewind=True), 2 * nm + 1, 3 * nm - 1)
+        if j == 3:
+            # Q rows -> Q registers (their last reader was S(nsteps - 1)); then the dO rows through the same area -> dO registers behind the last dP group (end of
+            # the step); then the O rows of q = 0 behind the part of the area the epilogue stages through
+            G.pre = [s_waitcnt(vmcnt=0)] + G.pre
+            G.spread(stage_reads(Qfr, 0, NQ), 0, 5 if NQ == 2 else 2)
+            G.put(6 if NQ == 2 else 3, [s_waitcnt(lgkmcnt=0)])
+            G.spread(stage_dma(s_T.sub(2, 2), s_T[9], 0, NQ, rewind=True) + lse_loads(), 6 if NQ == 2 else 3, 2 * nm - 2)
+            post = [s_waitcnt(vmcnt=0)] + [x for u in stage_reads(dOfr, 0, NQ) for x in u] + [s_waitcnt(lgkmcnt=0)]
+            post += [x for u in stage_dma(s_T.sub(4, 2), s_T[10], O0_OFF, 1) for x in u]
         b, pe = finish(G.flat(f"step tail{j}"), pend)
         if j < 3:
             assert pe == pend, (j, pe, pend)
         else:
-            b += [s_waitcnt(lgkmcnt=0)]
+            b += [s_waitcnt(lgkmcnt=0)] + post
         prog += b
         counts[f"tail{j}{suf}"] = G.costs()
     prog += epilogue()

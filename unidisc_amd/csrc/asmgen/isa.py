@@ -287,6 +287,14 @@ def s_addc_u32(dst, a, b):
     return Inst(f"s_addc_u32 {dst}, {_imm(a)}, {_imm(b)}", "salu", reads=[a, b, SCC], writes=[dst, SCC], emu=emu)
 
 
+def s_subb_u32(dst, a, b):
+    def emu(w):
+        t = w.sget(a) - w.sget(b) - w.scc
+        w.sset(dst, t)
+        w.scc = int(t < 0)
+    return Inst(f"s_subb_u32 {dst}, {_imm(a)}, {_imm(b)}", "salu", reads=[a, b, SCC], writes=[dst, SCC], emu=emu)
+
+
 def s_mov_b32(dst, a):
     return Inst(f"s_mov_b32 {dst}, {_imm(a)}", "salu", reads=[a], writes=[dst], emu=lambda w: w.sset(dst, w.sget(a)))
 
