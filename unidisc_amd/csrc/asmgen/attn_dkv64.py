@@ -44,8 +44,12 @@ TILE = 8 * PIECE              # 32 rows
 STG = 2 * TILE                # Q tile | dO tile
 LD_BASE = NST * STG           # [NST][-lse 32 f32 | -delta 32 f32]
 LDS_RING = LD_BASE + NST * 256
-WAVE_STG = 8192               # epilogue staging per wave: 32 key rows x 256 bytes
-LDS_TOTAL = LDS_RING + 4 * WAVE_STG
+# Behind the ring: ONE area of two tiles per wave.  The next block's K rows, then its V rows pass through it as LDS-DMA pieces (coalesced 256-byte rows; a direct
+# fragment load touches 32 cache lines per instruction and stalled the issue ~200 cycles each: 32 of them cost 7 k cycles per block, first timeline) and are picked up
+# as row fragments; the epilogue stages dK / dV through its first 8 KiB.
+A_BASE = LDS_RING
+AREA = 2 * TILE
+LDS_TOTAL = LDS_RING + 4 * AREA
 
 # ---- the kernel's parameter block (kernarg segment; attention_dkv64.hip declares the same struct): dword offsets
 P_Q, P_DO, P_NLSE, P_QSTR, P_DOSTR, P_L, P_NSTEPS, P_H, P_NT, P_MG_NT, P_MG_H, P_NFULL, P_HASHALF, P_GSTRIDE, P_PLANEB = 0, 2, 4, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17
@@ -65,8 +69,9 @@ Fq = V("Fq", 32)
 qaddr, taddr, laddr = V("qaddr"), V("taddr"), V("laddr")
 dq, do_ = V("dq", 2), V("do", 2)
 dl = V("dl")
-koff, voff = V("koff"), V("voff")
-tmp = V("tmp", 4)
+aaddr = V("aaddr")            # row-fragment base inside this wave's staging area
+da = V("da", 4)               # LDS-DMA source offsets of the operand being staged: pieces 4 g + j (also scratch of the entry: the thread id arrives in da[3])
+tmp = da
 dKT, dVT = A("dK", 128), A("dV", 128)
 
 # persistent parameters: dwords 0 .. 17 of the block, loaded by two s_load into s36 .. s53 (in this order)
@@ -356,7 +361,7 @@ def body(j, variant):
         G.spread(d0 + d1, 19, 36)
     else:
         G.spread(d0, 10, 14)
-        G.spread(d1, 15, 19)
+        G.spread(d1, 15, 18)
     # ---------------- G2: refill of step t + 3, the -lse(t+1) C operands, the first Q(t+1) row fragments
     if variant == "tail1":
         G.put(2 * nm, [s_mov_b64(s_qt, s_qn), s_mov_b64(s_dot, s_don), s_mov_b64(s_lt, s_ltn)])
@@ -402,39 +407,49 @@ def stream_ptrs(bid, hidx, q, do, lt):
     return p
 
 
-def kv_loads(bid, hidx, wk_is_half):
-    """K / V fragments of the block (bid, hidx) -> Kf / Vf: parameters into s_T, pointers into t-registers, per-lane row offsets, the loads (units, one per load).
-    wk_is_half: an SGPR that is 1 when the block is a 128-key half (a wave then owns 32 keys and its f = 1 loads re-read the f = 0 rows), or a Python bool."""
-    pre = [s_load_dwords(s_T.sub(0, 4), s_par, 4 * P_K), s_load_dwords(s_T.sub(4, 2), s_par, 4 * P_KSTR), s_waitcnt(lgkmcnt=0)]
+def seam_ptrs(bid, hidx, is_half):
+    """the K / V bases of block (bid, hidx) AT THIS WAVE'S FIRST KEY ROW into s_T: [0:1] k, [2:3] v, [4] kstr, [5] vstr.
+    is_half: an SGPR that is 1 when the block is a 128-key half (a wave then owns 32 keys), or a bool."""
+    p = [s_load_dwords(s_T.sub(0, 4), s_par, 4 * P_K), s_load_dwords(s_T.sub(4, 2), s_par, 4 * P_KSTR), s_waitcnt(lgkmcnt=0)]
     k, v, kstr, vstr = s_T.sub(0, 2), s_T.sub(2, 2), s_T[4], s_T[5]
-    if isinstance(wk_is_half, bool):
-        pre += [s_mov_b32(s_wk, 32 if wk_is_half else 64)]
+    if isinstance(is_half, bool):
+        p += [s_mov_b32(s_wk, 32 if is_half else 64)]
     else:
-        pre += [s_lshl_b32(s_wk, wk_is_half, 5), s_sub_u32(s_wk, 64, s_wk)]
-    pre += block_coords(bid, hidx)
-    pre += [s_add_u32(s_t[1], s_t[1], s_t[0])]                      # first key row of the block
-    kp, vp = s_T.sub(6, 2), R("s", s_t[4].idx, 2)
-    assert s_t[4].idx % 2 == 0
-    pre += ptr(kp, s_t[1], k, kstr) + ptr(vp, s_t[1], v, vstr)
-    # per-lane: (wave * wk + l31) * stride + hi * 16
-    lane = v_mbcnt_lane_id(tmp[0])
-    pre += lane + [v_and_b32(tmp[1], 31, tmp[0]), v_lshrrev_b32(tmp[2], 5, tmp[0]), v_lshlrev_b32(tmp[2], 4, tmp[2]), s_mul_i32(s_t[0], s_wave, s_wk), s_nop(0),
-                   v_add_u32(tmp[1], s_t[0], tmp[1]), v_mul_lo_u32(koff, tmp[1], kstr), v_mul_lo_u32(voff, tmp[1], vstr),
-                   v_add_u32(koff, koff, tmp[2]), v_add_u32(voff, voff, tmp[2])]
+        p += [s_lshl_b32(s_wk, is_half, 5), s_sub_u32(s_wk, 64, s_wk)]
+    p += block_coords(bid, hidx)
+    p += [s_mul_i32(s_t[4], s_wave, s_wk), s_add_u32(s_t[1], s_t[1], s_t[0]), s_add_u32(s_t[1], s_t[1], s_t[4])]      # this wave's first key row (global row index)
+    for base, stride in ((k, kstr), (v, vstr)):
+        p += [s_mul_i32(s_t[4], s_t[1], stride), s_mul_hi_u32(s_t[5], s_t[1], stride), s_add_u32(s_t[4], s_t[4], s_t[3]), s_addc_u32(s_t[5], s_t[5], 0),
+              s_add_u32(base[0], base[0], s_t[4]), s_addc_u32(base[1], base[1], s_t[5])]
+    for ins in p:
+        ins.meta["keep"] = True
+    return p
+
+
+def stage_dma(base, stride, ntiles, rewind=False):
+    """`ntiles` x 32 rows from `base` (advanced past them) into this wave's staging area, as units: piece 4 g + j = rows 16 g + 4 j .. + 3; lane i of a piece reads row
+    (i >> 2) & 3, 16 bytes at (4 (i >> 4) + (i & 3)) * 16.  Uses t0 (LDS destination), t1 (16 rows in bytes) until its last unit has been issued.  rewind (the program
+    of whole blocks staging for a block that may be a half, s_wk = 32): the second tile re-reads the first tile's rows instead of running past the wave's 32."""
+    pre = v_mbcnt_lane_id(da[3])
+    pre += [v_lshrrev_b32(da[2], 2, da[3]), v_and_b32(da[2], 3, da[2]), v_lshrrev_b32(da[1], 4, da[3]), v_lshlrev_b32(da[1], 2, da[1]), v_and_b32(da[3], 3, da[3]),
+            v_add_u32(da[1], da[1], da[3]), v_lshlrev_b32(da[1], 4, da[1]), v_mul_lo_u32(da[0], da[2], stride), v_add_u32(da[0], da[0], da[1]), s_lshl_b32(s_t[1], stride, 2)]
+    pre += [v_add_u32(da[j], s_t[1], da[j - 1]) for j in range(1, 4)]
+    pre += [s_mul_i32(s_t[0], s_wave, AREA), s_add_u32(s_t[0], s_t[0], s_lds), s_add_u32(s_t[0], s_t[0], A_BASE), s_lshl_b32(s_t[1], stride, 4)]
     for ins in pre:
         ins.meta["keep"] = True
-    units = []
-    # f = 1: + 32 rows (whole blocks), + 0 rows (half blocks: re-read)
-    step_k = [s_sub_u32(s_t[0], s_wk, 32), s_mul_i32(s_t[1], s_t[0], kstr), s_mul_i32(s_t[0], s_t[0], vstr),
-              s_add_u32(kp[0], kp[0], s_t[1]), s_addc_u32(kp[1], kp[1], 0), s_add_u32(vp[0], vp[0], s_t[0]), s_addc_u32(vp[1], vp[1], 0)]
-    for f in range(2):
-        if f == 1:
-            units.append(step_k)
-        for ks in range(KS):
-            units.append([global_load_dwordx4(Kfr(f, ks), koff, kp, ks * 32)])
-        for ks in range(KS):
-            units.append([global_load_dwordx4(Vfr(f, ks), voff, vp, ks * 32)])
-    return pre, units
+    units = [pre]
+    for g in range(2 * ntiles):
+        for j in range(4):
+            units.append([s_add_u32(M0, s_t[0], (4 * g + j) * PIECE), s_nop(0), global_load_lds_dwordx4(da[j], base)])
+        units.append([s_add_u32(base[0], base[0], s_t[1]), s_addc_u32(base[1], base[1], 0)])
+        if rewind and ntiles == 2 and g == 1:
+            units.append([s_sub_u32(s_t[2], 64, s_wk), s_mul_i32(s_t[2], s_t[2], stride), s_sub_u32(base[0], base[0], s_t[2]), s_subb_u32(base[1], base[1], 0)])
+    return units
+
+
+def stage_reads(dst, ntiles):
+    """the staged rows as row fragments: dst(f, ks) <- lane (row l & 31 of tile f, 8 columns 16 ks + 8 (l >> 5) ..)"""
+    return [[ds_read_b128(dst(f, ks), aaddr, f * TILE + (ks >> 1) * 256 + (ks & 1) * 32)] for f in range(ntiles) for ks in range(KS)]
 
 
 def next_block_choice():
@@ -493,18 +508,28 @@ def entry():
           v_and_b32(t[4], 3, lane_v), v_lshlrev_b32(t[4], 3, t[4]), v_add_u32(t[3], t[3], t[4]), v_add_u32(taddr, s_lds, t[3])]
     #   -lse / -delta: lds + LD_BASE + hi * 16
     p += [v_lshlrev_b32(t[3], 4, hi), v_add_u32(t[3], s_lds, t[3]), v_add_u32(laddr, LD_BASE, t[3])]
+    p += [s_mul_i32(s_t[0], s_wave, AREA), s_add_u32(s_t[0], s_t[0], A_BASE), s_nop(0), v_add_u32(aaddr, s_t[0], qaddr)]     # the fragment base inside this wave's area
     p += [s_mov_b32(s_wg, s_bid), s_mov_b32(s_hidx, 0)]
     for ins in p:
         ins.meta["keep"] = True
-    # ---- the first block (always a whole one): its K / V, its first three steps
+    # ---- the first block (always a whole one): K and V through the staging area into their registers, its first three steps
     p += stream_ptrs(s_bid, 0, s_qt, s_dot, s_lt)
-    pre, units = kv_loads(s_bid, 0, False)
-    p += pre
-    for u in units:
+    p += seam_ptrs(s_bid, 0, False)
+    for u in stage_dma(s_T.sub(0, 2), s_T[4], 2):
         p += u
     for s in range(PD):
         for u in dma_step(s):
             p += u
+    p += [s_waitcnt(vmcnt=3 * 5)]
+    for u in stage_reads(Kfr, 2):
+        p += u
+    p += [s_waitcnt(lgkmcnt=0)]
+    for u in stage_dma(s_T.sub(2, 2), s_T[5], 2):
+        p += u
+    p += [s_waitcnt(vmcnt=0)]
+    for u in stage_reads(Vfr, 2):
+        p += u
+    p += [s_waitcnt(lgkmcnt=0)]
     p += stamp(1)
     return p
 
@@ -541,7 +566,7 @@ def epilogue():
     e += v_mbcnt_lane_id(lane_v)
     e += [v_and_b32(l31, 31, lane_v), v_lshrrev_b32(hi, 5, lane_v)]
     # staging write: row = l31: stg + row * 256 + ((slot ^ (row & 15)) << 4) + hi * 8, slot = 4 i + rg  ->  X = stg + row * 256 + hi * 8, XOR term (row & 15) << 4
-    e += [s_lshl_b32(s_t[0], s_wave, 13), s_add_u32(s_t[0], s_t[0], s_lds), s_add_u32(s_t[0], s_t[0], LDS_RING)]
+    e += [s_mul_i32(s_t[0], s_wave, AREA), s_add_u32(s_t[0], s_t[0], s_lds), s_add_u32(s_t[0], s_t[0], A_BASE)]     # (the first 8 KiB of this wave's area)
     e += [v_lshlrev_b32(xw, 8, l31), v_lshlrev_b32(t[5], 3, hi), v_add_u32(xw, xw, t[5]), v_and_b32(t[5], 15, l31), v_lshlrev_b32(t[5], 4, t[5]), v_add_u32(xw, xw, t[5]),
           v_add_u32(xw, s_t[0], xw)]
     # (slot s at X ^ (s << 4): the row's XOR term sits in bits 4..7 of X already, stg and row * 256 are multiples of 256)
@@ -630,36 +655,26 @@ def block_program(nf, suf):
     prog += [s_sub_u32(s_loop, s_loop, 1), s_cmp_lg_u32(s_loop, 0), s_cbranch_scc1("L_loop")]
     for j in range(4):
         G = body(j, f"tail{j}")
-        if j == 3:
-            # the next block's K / V fragments under the last step: K registers are free from the start (their last reader was S(nsteps - 1)), V registers after dP
-            # (a half block is the last thing a workgroup does: its "next" block is itself, a half)
-            if NF == 1:
-                pre, units = kv_loads(s_nbid, s_hidxn, True)
-                G.pre = pre + G.pre
+        post = []
+        if j == 2:
+            # the next block's K / V bases, its K rows on their way into the staging area (picked up at the top of the last step, when the K registers are free)
+            if NF == 1:      # (a half block is the last thing a workgroup does: its "next" block is itself, a half)
+                G.pre = seam_ptrs(s_nbid, s_hidxn, True) + G.pre
             else:
-                pre, units = kv_loads(s_nbid, s_hidxn, s_t[5])
-                G.pre = [s_cmp_eq_u32(s_moden, 1), s_cselect_b32(s_t[5], 1, 0)] + pre + G.pre
-            kk = [u for u in units if len(u) == 1 and u[0].kind == "vmem_ld" and Kf.idx <= u[0].writes[0][1] < Kf.idx + 64]
-            vv = [u for u in units if len(u) == 1 and u[0].kind == "vmem_ld" and Vf.idx <= u[0].writes[0][1] < Vf.idx + 64]
-            stepu = [u for u in units if not (len(u) == 1 and u[0].kind == "vmem_ld")]
-            assert len(kk) == 16 and len(vv) == 16 and len(stepu) == 1
-            # order that respects the bases: K f0, V f0 (after the dP group), step, K f1, V f1
-            seq = kk[:8] + vv[:8] + stepu + kk[8:] + vv[8:]
-            # V(f = 0) loads may not start before the dP group has issued its last MFMA (index nm - 1)
-            first_v = len(kk[:8])
-            lo = 2
-            hi_ = 3 * nm - 2
-            ngap = hi_ - lo + 1
-            for k, u in enumerate(seq):
-                gpos = lo + (k * ngap) // len(seq)
-                if k >= first_v:
-                    gpos = max(gpos, nm + 1)
-                G.put(gpos, u)
+                G.pre = [s_cmp_eq_u32(s_moden, 1), s_cselect_b32(s_t[5], 1, 0)] + seam_ptrs(s_nbid, s_hidxn, s_t[5]) + G.pre
+            G.spread(stage_dma(s_T.sub(0, 2), s_T[4], NF, rewind=True), 2 * nm + 2, 4 * nm - 1)
+        if j == 3:
+            # K rows -> K registers (their last reader was S(nsteps - 1)); then the V rows through the same area -> V registers behind the last dP group (end of the step)
+            G.pre = [s_waitcnt(vmcnt=0)] + G.pre
+            G.spread(stage_reads(Kfr, NF), 0, 5 if NF == 2 else 2)
+            G.put(6 if NF == 2 else 3, [s_waitcnt(lgkmcnt=0)])
+            G.spread(stage_dma(s_T.sub(2, 2), s_T[5], NF, rewind=True), 6 if NF == 2 else 3, 2 * nm - 1)
+            post = [s_waitcnt(vmcnt=0)] + [x for u in stage_reads(Vfr, NF) for x in u] + [s_waitcnt(lgkmcnt=0)]
         b, pe = finish(G.flat(f"step tail{j}"), pend)
         if j < 3:
             assert pe == pend, (j, pe, pend)
         else:
-            b += [s_waitcnt(lgkmcnt=0)]
+            b += [s_waitcnt(lgkmcnt=0)] + post
         prog += b
         counts[f"tail{j}{suf}"] = G.costs()
     prog += epilogue()
