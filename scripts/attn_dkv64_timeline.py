@@ -31,6 +31,9 @@ t = tl.cpu().numpy().astype(np.int64) & 0xFFFFFFFF
 names = {0: "entry", 1: "entry:issued", 3: "blk:start", 4: "blk:waited", 40: "epi:start", 41: "epi:end", 42: "done"}
 for j in range(4):
     names[8 + j], names[12 + j] = f"main{j}", f"tail{j}"
+for k in list(names):
+    if 3 <= k < 42:
+        names[k + 16] = "H:" + names[k]        # the half-block program's stamps
 out = {}
 for wgid in (0, 5, grid // 2 + 3, grid - 1):
     for wave in (0, 3):

@@ -99,8 +99,11 @@ v_tl = R("v", 254)
 
 
 def stamp(idx):
+    """timeline builds: s_memtime -> lane idx of v_tl (the half-block program's stamps of the block sit 16 lanes behind the whole-block program's: both stay readable)"""
     if not (ABL & 16):
         return []
+    if 3 <= idx < 42 and NF == 1:
+        idx += 16
     return [s_memtime(s_tm), s_waitcnt(lgkmcnt=0), v_writelane_b32(v_tl, s_tm[0], idx)]
 
 
