@@ -169,12 +169,13 @@ def n_pref():
     return (LA() + NQ - 1) // NQ
 
 
-def exp_units(buf):
+def exp_units(buf, c2):
+    """exp2 of the 16-key chunk c2 of S in `buf` (in place).  Chunk 0 of S(t+1) runs under the dQ group of step t - right behind the S(t+1) MFMAs - chunk 1 under the dP
+    group of step t+1: 32 quarter-rate instructions under ONE 16-MFMA group saturate the VALU (first timeline: 40.6 cycles per MFMA against the dK / dV program's 36.5)"""
     u = []
-    for c2 in range(2):
-        for q in range(NQ):
-            s = Sblk(buf, q)
-            u += [[v_exp_f32(s[8 * c2 + e], s[8 * c2 + e])] for e in range(8)]
+    for q in range(NQ):
+        s = Sblk(buf, q)
+        u += [[v_exp_f32(s[8 * c2 + e], s[8 * c2 + e])] for e in range(8)]
     return u
 
 
@@ -237,7 +238,7 @@ def body(j, variant):
     G.put(1, [s_barrier()])
     for ks in range(n_pref(), KS):
         G.put(ks * NQ - LA(), row_frag(ks, VT, ks))
-    G.spread(exp_units(bt), 0, nm - 1)
+    G.spread(exp_units(bt, 1), 0, nm - 1)
     d0, d1 = ds_units(bt)
     if not last:
         s_group(G, nm, stn, bn)
@@ -253,6 +254,7 @@ def body(j, variant):
         if variant == "tail1":
             G.put(2 * nm, [s_mov_b64(s_kt, s_kn), s_mov_b64(s_vt, s_vn)])
         G.spread(dma_step(rst), 2 * nm + 1, 2 * nm + (10 if NQ == 2 else 5))
+        G.spread(exp_units(bn, 0), 2 * nm + (4 if NQ == 2 else 5), 3 * nm - 1)      # (S(t+1)'s last MFMA is index 2 nm - 1: >= 16 wait states behind it)
         for n, u in enumerate(v_prefetch(stn)):
             G.put(3 * nm + n * NQ - LA(), u)
     else:
@@ -482,7 +484,7 @@ def block_start():
     # ---- S(0) into buffer 0 (its registers held the O rows of q = 0: consumed above), then the first V fragments of step 0
     G = Gaps(nm)
     s_group(G, 0, 0, 0)
-    post = [x for u in v_prefetch(0) for x in u] + [s_nop(15)]      # (the first step's exp2 follows the S(0) MFMAs directly)
+    post = [x for u in v_prefetch(0) for x in u] + [s_nop(15)] + [x for u in exp_units(0, 0) for x in u]      # (chunk 0 of S(0): what a step's dQ group does for the next)
     return p, G, post
 
 
