@@ -46,10 +46,12 @@ LD_BASE = NST * STG           # [NST][-lse 32 f32 | -delta 32 f32]
 LDS_RING = LD_BASE + NST * 256
 # Behind the ring: ONE area of two tiles per wave.  The next block's K rows, then its V rows pass through it as LDS-DMA pieces (coalesced 256-byte rows; a direct
 # fragment load touches 32 cache lines per instruction and stalled the issue ~200 cycles each: 32 of them cost 7 k cycles per block, first timeline) and are picked up
-# as row fragments; the epilogue stages dK / dV through its first 8 KiB.
+# as row fragments (the V rows under the next block's S(0) group: their LDS-DMA has the whole epilogue to land).
 A_BASE = LDS_RING
 AREA = 2 * TILE
-LDS_TOTAL = LDS_RING + 4 * AREA
+E_BASE = A_BASE + 4 * AREA    # epilogue staging: 4 KiB per wave (32 rows x 64 columns at a time) - NOT inside the area: the next block's V rows wait there through the epilogue
+E_STG = 4096
+LDS_TOTAL = E_BASE + 4 * E_STG
 
 # ---- the kernel's parameter block (kernarg segment; attention_dkv64.hip declares the same struct): dword offsets
 P_Q, P_DO, P_NLSE, P_QSTR, P_DOSTR, P_L, P_NSTEPS, P_H, P_NT, P_MG_NT, P_MG_H, P_NFULL, P_HASHALF, P_GSTRIDE, P_PLANEB = 0, 2, 4, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17
@@ -529,10 +531,7 @@ def entry():
     p += [s_waitcnt(lgkmcnt=0)]
     for u in stage_dma(s_T.sub(2, 2), s_T[5], 2):
         p += u
-    p += [s_waitcnt(vmcnt=0)]
-    for u in stage_reads(Vfr, 2):
-        p += u
-    p += [s_waitcnt(lgkmcnt=0)]
+    p += [s_waitcnt(vmcnt=0)]       # (once per workgroup: the block start's counted wait assumes nothing but stores behind what it needs)
     p += stamp(1)
     return p
 
@@ -542,7 +541,9 @@ def block_start():
     nm = 8 * NF
     p = [comment("---- block start"), label("L_block")] + stamp(3)
     p += next_block_choice()
-    p += [s_waitcnt(vmcnt=0), s_barrier()] + stamp(4)
+    # everything older than the previous block's stores (8 per 32-row block and output) has landed: the next steps of the ring, the V rows; a workgroup's first block
+    # finds the queue drained by the entry
+    p += [s_waitcnt(vmcnt=16 * NF), s_barrier()] + stamp(4)
     # trips through the four steady-state steps: nsteps / 4 - 1 (>= 1: the launcher takes L >= 256)
     p += [s_lshr_b32(s_loop, s_nsteps, 2), s_sub_u32(s_loop, s_loop, 1)]
     pre = []
@@ -554,63 +555,79 @@ def block_start():
     s_group(G, 0, 0)
     # (s_group indexes its gaps from the group's first MFMA: the fragments before gap 0 are the prefetched ones)
     G.pre = pre + G.pre
+    # the V rows (staged under the previous block's last step, or by the entry) -> V registers: first read by the dP group of step 0.  Issued ahead of the group's last
+    # Q fragment, so that the wait for that fragment drains them (the LDS queue at the loop's entry stays the loop's)
+    G.spread(stage_reads(Vfr, NF), 0, (2 * 7 - LA() - 1) if NF == 2 else (7 - LA() - 1))
     return p, G
 
 
+def epi_addresses(t, e_base, xb, rdaddr, gos, strides, rows_per_wave, sregs=None):
+    """Addresses of the row-store epilogue (shared with attn_dq64.py).  A wave holds X^T of 32 rows (lane & 31 = row, registers walk the columns); it goes out 64 columns
+    at a time through 4 KiB of LDS owned by the wave (rows of 128 bytes, 16-byte slots XOR-ed with the row) as whole 128-byte row segments.
+    t: 6 scratch VGPRs; xb: write base (slot sl at xb ^ (sl << 4)); rdaddr: read-back base (instruction k at + k * 1024: rows 8 k + (lane >> 3), slot lane & 7);
+    gos[n][k]: global offsets of output n, rows wave * rows_per_wave + 8 k + (lane >> 3) (+ (lane & 7) * 16).  Uses s_t[0 .. 2].
+    sregs: (s_t, s_wave, s_lds) of the calling generator (default: this module's)."""
+    s_t, s_wave, s_lds = sregs if sregs is not None else (globals()["s_t"], globals()["s_wave"], globals()["s_lds"])
+    lane_v, l31, hi, g8 = t[0], t[1], t[2], t[3]
+    e = v_mbcnt_lane_id(lane_v)
+    e += [v_and_b32(l31, 31, lane_v), v_lshrrev_b32(hi, 5, lane_v)]
+    e += [s_lshl_b32(s_t[0], s_wave, 12), s_add_u32(s_t[0], s_t[0], s_lds), s_add_u32(s_t[0], s_t[0], e_base)]
+    e += [v_lshlrev_b32(xb, 7, l31), v_and_b32(t[4], 7, l31), v_lshlrev_b32(t[4], 4, t[4]), v_add_u32(xb, xb, t[4]), v_lshlrev_b32(t[4], 3, hi), v_add_u32(xb, xb, t[4]),
+          v_add_u32(xb, s_t[0], xb)]
+    e += [v_lshrrev_b32(g8, 3, lane_v), v_and_b32(t[4], 7, lane_v), v_xor_b32(t[5], t[4], g8), v_lshlrev_b32(t[5], 4, t[5]), v_lshlrev_b32(rdaddr, 7, g8), v_add_u32(rdaddr, rdaddr, t[5]),
+          v_add_u32(rdaddr, s_t[0], rdaddr)]
+    e += [s_mul_i32(s_t[1], s_wave, rows_per_wave), s_nop(0), v_add_u32(t[5], s_t[1], g8), v_lshlrev_b32(t[4], 4, t[4])]
+    for go, stride in zip(gos, strides):
+        e += [v_mul_lo_u32(go[0], t[5], stride), v_add_u32(go[0], go[0], t[4]), s_lshl_b32(s_t[2], stride, 3), s_nop(0)]
+        e += [v_add_u32(go[k], s_t[2], go[k - 1]) for k in range(1, 4)]
+    return e
+
+
+def epi_block(acc, scale, vals, pk, ta, xb, rdaddr, rb, go, base):
+    """one 32-row x 128-column block: acc(i) = the 16 accumulator registers of column group i; scale: an SGPR or None; vals: 4, pk: 2 (an even pair), ta: 2, rb: 16 VGPRs"""
+    e = []
+    n = 0
+    for ch in range(2):
+        for i in (2 * ch, 2 * ch + 1):
+            for rg in range(4):
+                o = acc(i)
+                e += [v_accvgpr_read_b32(vals[k], o[rg * 4 + k]) for k in range(4)]
+                if scale is not None:
+                    e += [v_mul_f32(vals[k], scale, vals[k]) for k in range(4)]
+                e += [v_cvt_pk_bf16_f32(pk[0], vals[0], vals[1]), v_cvt_pk_bf16_f32(pk[1], vals[2], vals[3])]
+                e += [v_xor_b32(ta[n & 1], ((i & 1) * 4 + rg) << 4, xb), ds_write_b64(ta[n & 1], R("v", pk[0].idx, 2), 0)]
+                n += 1
+        for k in range(4):
+            e += [ds_read_b128(rb.sub(k * 4, 4), rdaddr, k * 1024)]
+        e += [s_waitcnt(lgkmcnt=0)]
+        for k in range(4):
+            e += [global_store_dwordx4(go[k], rb.sub(k * 4, 4), base, ch * 128)]
+        e += [s_nop(1)]
+    return e
+
+
 def epilogue():
-    """dK^T, dV^T -> bf16 (dK scaled by ln 2: the un-folding of the pre-scaled q), 32 key rows x 128 columns at a time through this wave's 8 KiB of staging (rows of 256 bytes,
-    16-byte slots XOR-ed with the row), stored as whole 256-byte rows.  The ring is NOT touched: it already holds the next block's first steps."""
+    """dK^T, dV^T -> bf16 (dK scaled by ln 2: the un-folding of the pre-scaled q), stored as whole 128-byte row segments (epi_addresses / epi_block).  Neither the ring (it
+    holds the next block's first steps) nor the staging area (the next block's V rows) is touched."""
     e = [comment("---- epilogue")] + stamp(40)
     e += [s_nop(15), s_nop(15)]
     e += [s_load_dwords(s_T, s_par, 4 * P_DK), s_waitcnt(lgkmcnt=0)]
     dk, dv, dkstr, dvstr, scale = s_T.sub(0, 2), s_T.sub(2, 2), s_T[4], s_T[5], s_T[6]
-    t = [Fq[i] for i in range(8)]
-    lane_v, l31, hi, xw, rd = t[0], t[1], t[2], t[3], t[4]
-    e += v_mbcnt_lane_id(lane_v)
-    e += [v_and_b32(l31, 31, lane_v), v_lshrrev_b32(hi, 5, lane_v)]
-    # staging write: row = l31: stg + row * 256 + ((slot ^ (row & 15)) << 4) + hi * 8, slot = 4 i + rg  ->  X = stg + row * 256 + hi * 8, XOR term (row & 15) << 4
-    e += [s_mul_i32(s_t[0], s_wave, AREA), s_add_u32(s_t[0], s_t[0], s_lds), s_add_u32(s_t[0], s_t[0], A_BASE)]     # (the first 8 KiB of this wave's area)
-    e += [v_lshlrev_b32(xw, 8, l31), v_lshlrev_b32(t[5], 3, hi), v_add_u32(xw, xw, t[5]), v_and_b32(t[5], 15, l31), v_lshlrev_b32(t[5], 4, t[5]), v_add_u32(xw, xw, t[5]),
-          v_add_u32(xw, s_t[0], xw)]
-    # (slot s at X ^ (s << 4): the row's XOR term sits in bits 4..7 of X already, stg and row * 256 are multiples of 256)
-    # read-back: instruction p reads rows 4 p + (lane >> 4), slot lane & 15: stg + row * 256 + (((lane & 15) ^ (row & 15)) << 4)
-    g4, s15 = t[5], t[6]
-    e += [v_lshrrev_b32(g4, 4, lane_v), v_and_b32(s15, 15, lane_v)]
-    rdaddr = [Sb[i] for i in range(8)]
-    goff = [[Sb[8 + i] for i in range(8)], [Sb[16 + i] for i in range(8)]]
-    for p_ in range(8):
-        e += [v_add_u32(t[7], 4 * p_, g4), v_and_b32(rd, 15, t[7]), v_xor_b32(rd, rd, s15), v_lshlrev_b32(rd, 4, rd), v_lshlrev_b32(rdaddr[p_], 8, t[7]), v_add_u32(rdaddr[p_], rdaddr[p_], rd),
-              v_add_u32(rdaddr[p_], s_t[0], rdaddr[p_])]
-        # global: (wave * wk + f * 32 + row) * stride + slot * 16   (the f * 32 rows go into the scalar base)
-        e += [s_mul_i32(s_t[1], s_wave, 32 * NF), s_nop(0), v_add_u32(t[7], s_t[1], t[7]), v_lshlrev_b32(rd, 4, s15),
-              v_mul_lo_u32(goff[0][p_], t[7], dkstr), v_mul_lo_u32(goff[1][p_], t[7], dvstr), v_add_u32(goff[0][p_], goff[0][p_], rd), v_add_u32(goff[1][p_], goff[1][p_], rd)]
-    # output bases of the block
+    t = [Fq[i] for i in range(6)]
+    xb, rdaddr = Fq[6], Fq[7]
+    gos = [[Fq[8 + i] for i in range(4)], [Fq[12 + i] for i in range(4)]]
+    ta = [Fq[16], Fq[17]]
+    vals = [dPb[i] for i in range(4)]
+    pk = [dPb[4 + i] for i in range(2)]
+    rb = dPb.sub(8, 16)
+    e += epi_addresses(t, E_BASE, xb, rdaddr, gos, [dkstr, dvstr], 32 * NF)
     e += block_coords(s_bid, s_hidx if NF == 1 else 0)
     e += [s_add_u32(s_t[1], s_t[1], s_t[0])]
     ok, ov = s_qn, s_don      # (recomputed by the next block start)
     e += ptr(ok, s_t[1], dk, dkstr) + ptr(ov, s_t[1], dv, dvstr)
-    vals = [dPb[i] for i in range(4)]
-    pk = [dPb[4 + i] for i in range(2)]
-    rb = dPb.sub(8, 16)
     for which, (acc_of, base, stride, sc) in enumerate(((dKblk, ok, dkstr, scale), (dVblk, ov, dvstr, None))):
         for f in range(NF):
-            n = 0
-            for i in range(4):
-                for rg in range(4):
-                    o = acc_of(f, i)
-                    e += [v_accvgpr_read_b32(vals[k], o[rg * 4 + k]) for k in range(4)]
-                    if sc is not None:
-                        e += [v_mul_f32(vals[k], sc, vals[k]) for k in range(4)]
-                    e += [v_cvt_pk_bf16_f32(pk[0], vals[0], vals[1]), v_cvt_pk_bf16_f32(pk[1], vals[2], vals[3])]
-                    e += [v_xor_b32(t[7], (i * 4 + rg) << 4, xw), ds_write_b64(t[7], R("v", pk[0].idx, 2), 0)]
-                    n += 1
-            for half in range(2):
-                for k in range(4):
-                    e += [ds_read_b128(rb.sub(k * 4, 4), rdaddr[half * 4 + k], 0)]
-                e += [s_waitcnt(lgkmcnt=0)]
-                for k in range(4):
-                    e += [global_store_dwordx4(goff[which][half * 4 + k], rb.sub(k * 4, 4), base, 0)]
-                e += [s_nop(1)]
+            e += epi_block(lambda i, f=f, acc_of=acc_of: acc_of(f, i), sc, vals, pk, ta, xb, rdaddr, rb, gos[which], base)
             if f == 0 and NF == 2:   # the f = 1 key rows: + 32 rows
                 e += [s_lshl_b32(s_t[2], stride, 5), s_add_u32(base[0], base[0], s_t[2]), s_addc_u32(base[1], base[1], 0)]
     e += stamp(41)
@@ -667,12 +684,12 @@ def block_program(nf, suf):
                 G.pre = [s_cmp_eq_u32(s_moden, 1), s_cselect_b32(s_t[5], 1, 0)] + seam_ptrs(s_nbid, s_hidxn, s_t[5]) + G.pre
             G.spread(stage_dma(s_T.sub(0, 2), s_T[4], NF, rewind=True), 2 * nm + 2, 4 * nm - 1)
         if j == 3:
-            # K rows -> K registers (their last reader was S(nsteps - 1)); then the V rows through the same area -> V registers behind the last dP group (end of the step)
+            # K rows -> K registers (their last reader was S(nsteps - 1)); then the V rows into the same area
             G.pre = [s_waitcnt(vmcnt=0)] + G.pre
             G.spread(stage_reads(Kfr, NF), 0, 5 if NF == 2 else 2)
             G.put(6 if NF == 2 else 3, [s_waitcnt(lgkmcnt=0)])
             G.spread(stage_dma(s_T.sub(2, 2), s_T[5], NF, rewind=True), 6 if NF == 2 else 3, 2 * nm - 1)
-            post = [s_waitcnt(vmcnt=0)] + [x for u in stage_reads(Vfr, NF) for x in u] + [s_waitcnt(lgkmcnt=0)]
+            # (the V rows are picked up under the next block's S(0) group: block_start)
         b, pe = finish(G.flat(f"step tail{j}"), pend)
         if j < 3:
             assert pe == pend, (j, pe, pend)

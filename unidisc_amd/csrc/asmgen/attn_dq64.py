@@ -23,7 +23,7 @@ Step t (32 keys, 48 MFMAs, ONE barrier):
 LDS ring, persistence, balanced walk (128-query half blocks, NQ = 1), counted waits (`auto_waits`), lint and emulation: as in attn_dkv64.py."""
 import sys
 from isa import *   # noqa: F401,F403
-from attn_dkv64 import Gaps, auto_waits
+from attn_dkv64 import Gaps, auto_waits, epi_addresses as _epi_addresses, epi_block
 
 D, KS = 128, 8
 NST, PD = 4, 3
@@ -33,12 +33,13 @@ STG = 2 * TILE                # K tile | V tile
 LDS_RING = NST * STG
 # Behind the ring: ONE area of two tiles per wave.  The next block's Q rows, then its dO rows, then its O rows pass through it as LDS-DMA pieces (coalesced 256-byte
 # rows; a direct fragment load touches 32 cache lines per instruction and stalled the issue ~200 cycles each: 50 of them cost 12 k cycles per block, first timeline)
-# and are picked up as row fragments; the epilogue stages dQ through its first 8 KiB while the O rows of q = 0 wait in the rest.
+# and are picked up as row fragments, each a step or more after its DMA went out: Q rows leave under the third-last step and are read under the second-last (behind
+# the block's last S group), dO rows leave under the last step and are read at its end, O rows fly through the epilogue and are read by the next block start.
 A_BASE = LDS_RING
 AREA = 2 * TILE
-O0_OFF = TILE                 # (the epilogue stages through [0, 8192), the O rows of q = 1 arrive in [0, TILE))
-assert O0_OFF + TILE <= AREA and O0_OFF >= 8192
-LDS_TOTAL = LDS_RING + 4 * AREA
+E_BASE = A_BASE + 4 * AREA    # epilogue staging: 4 KiB per wave (attn_dkv64.epi_block), not inside the area
+E_STG = 4096
+LDS_TOTAL = E_BASE + 4 * E_STG
 
 # ---- the kernel's parameter block (kernarg segment; attention_dq64.hip declares the same struct): dword offsets
 P_K, P_V, P_KSTR, P_VSTR, P_L, P_NSTEPS, P_H, P_NT, P_MG_NT, P_MG_H, P_NFULL, P_HASHALF, P_GSTRIDE, P_PLANEB = 0, 2, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15
@@ -234,7 +235,7 @@ def body(j, variant):
                 G.m[g] = v_mfma_f32_32x32x16_bf16(acc, slot(16 + c2 * 4 + i), dSfr(q, c2), 0 if (variant == "head" and c2 == 0) else acc)
                 g += 1
     G.pre += stamp((8 if variant in ("main", "head") else 12) + j)
-    G.put(0, [s_waitcnt(vmcnt=4)])
+    G.put(0, [s_waitcnt(vmcnt=4 + 8 * NQ if variant == "tail2" else 4)])      # (tail2: the Q rows' LDS-DMA of the previous step is in the queue behind the ring's)
     G.put(1, [s_barrier()])
     for ks in range(n_pref(), KS):
         G.put(ks * NQ - LA(), row_frag(ks, VT, ks))
@@ -264,7 +265,7 @@ def body(j, variant):
             for i in range(4):
                 n = 16 + c2 * 4 + i
                 G.put(max(0, (n - 8) * NQ - LA()), tr_frag(n, KT, i, c2))
-        G.spread(dma_step(rst), nm + 1, nm + (10 if NQ == 2 else 5))
+        G.spread(dma_step(rst), nm + 2, nm + (11 if NQ == 2 else 6))      # (behind the dO rows' LDS-DMA: the step's closing wait counts these four)
     return G
 
 
@@ -399,12 +400,14 @@ def entry():
     for ins in p:
         ins.meta["keep"] = True
     p += stream_ptrs(s_bid, 0, s_kt, s_vt)
-    # ---- the first block (always a whole one): Q and dO through the staging area into their registers, the O rows of q = 0 parked behind the epilogue's part of the
-    #      area (the block start stages those of q = 1), lse, the ring's first three steps
+    # ---- the first block (always a whole one): Q, dO and O through the staging area one after the other, lse, the ring's first three steps
     p += seam_ptrs(s_bid, 0, False)
     for u in stage_dma(s_T.sub(0, 2), s_T[8], 0, 2):
         p += u
-    p += [s_waitcnt(vmcnt=0)]
+    for s_ in range(PD):
+        for u in dma_step(s_):
+            p += u
+    p += [s_waitcnt(vmcnt=4 * PD)]
     for u in stage_reads(Qfr, 0, 2):
         p += u
     p += [s_waitcnt(lgkmcnt=0)]
@@ -412,15 +415,13 @@ def entry():
         p += u
     for u in lse_loads():
         p += u
-    for s_ in range(PD):
-        for u in dma_step(s_):
-            p += u
     p += [s_waitcnt(vmcnt=0)]
     for u in stage_reads(dOfr, 0, 2):
         p += u
     p += [s_waitcnt(lgkmcnt=0)]
-    for u in stage_dma(s_T.sub(4, 2), s_T[10], O0_OFF, 1):
+    for u in stage_dma(s_T.sub(4, 2), s_T[10], 0, 2):
         p += u
+    p += [s_waitcnt(vmcnt=0)]       # (once per workgroup: the block start's counted wait assumes nothing but stores behind what it needs)
     p += stamp(1)
     return p
 
@@ -434,27 +435,23 @@ def delta_math(q):
 
 
 def block_start():
-    """per block: the O rows of q = 1 into the staging area; what comes next; everything older has landed (previous stores, the ring's first steps, the O rows of
-    q = 0, lse); delta and the planes; the C operands; the S(0) group"""
+    """per block: what comes next; everything but the previous block's stores has landed (the ring's first steps, the O rows, lse); delta and the planes; the C operands;
+    the S(0) group"""
     nm = 8 * NQ
     p = [comment("---- block start"), label("L_block")] + stamp(3)
-    if NQ == 2:
-        for u in stage_dma(s_T.sub(4, 2), s_T[10], 0, 1):
-            p += u
     p += next_block_choice()
-    p += [s_waitcnt(vmcnt=8 if NQ == 2 else 0), s_barrier()] + stamp(4)
+    # everything older than the previous block's stores (8 per 32-row block) has landed: the ring's next steps, the O rows, lse; a workgroup's first block finds the
+    # queue drained by the entry
+    p += [s_waitcnt(vmcnt=8 * NQ), s_barrier()] + stamp(4)
     p += [s_lshr_b32(s_loop, s_nsteps, 2), s_sub_u32(s_loop, s_loop, 1)]
-    # ---- delta = rowsum(dO * O): a lane holds 64 of its query's 128 columns (the other half sits in lane + 32)
+    # ---- delta = rowsum(dO * O): a lane holds 64 of its query's 128 columns (the other half sits in lane + 32); the O rows wait in the staging area
     dlt = [dPb[0], dPb[1]]
     sw = [dPb[4], dPb[5]]
-    for u in stage_reads(lambda q, ks: Sb.sub(4 * ks, 4), O0_OFF, 1):
+    for u in stage_reads(lambda q, ks: Sb.sub(32 * q + 4 * ks, 4), 0, NQ):
         p += u
-    p += [s_waitcnt(lgkmcnt=0)] + delta_math(0)
-    if NQ == 2:
-        p += [s_waitcnt(vmcnt=0)]
-        for u in stage_reads(lambda q, ks: Sb.sub(32 + 4 * ks, 4), 0, 1):
-            p += u
-        p += [s_waitcnt(lgkmcnt=0)] + delta_math(1)
+    p += [s_waitcnt(lgkmcnt=0)]
+    for q in range(NQ):
+        p += delta_math(q)
     p += [s_nop(3)]          # (DOT write -> a different VALU instruction reading it: 3 wait states)
     for q in range(NQ):
         p += [v_mov_b32(sw[q], dlt[q])]
@@ -489,49 +486,26 @@ def block_start():
 
 
 def epilogue():
-    """dQ^T -> bf16, scaled by ln 2 (the un-folding of the pre-scaled q), 32 query rows x 128 columns at a time through this wave's 8 KiB of staging, whole 256-byte rows"""
+    """dQ^T -> bf16, scaled by ln 2 (the un-folding of the pre-scaled q), stored as whole 128-byte row segments (attn_dkv64.epi_addresses / epi_block); neither the ring
+    nor the staging area (the next block's O rows are landing there) is touched"""
     e = [comment("---- epilogue")] + stamp(40)
     e += [s_nop(15), s_nop(15)]
     e += [s_load_dwords(s_T.sub(12, 4), s_par, 4 * P_DQ), s_waitcnt(lgkmcnt=0)]
     dq, dqstr, scale = s_T.sub(12, 2), s_T[14], s_T[15]
-    t = [Fq[i] for i in range(8)]
-    lane_v, l31, hi, xw, rd = t[0], t[1], t[2], t[3], t[4]
-    e += v_mbcnt_lane_id(lane_v)
-    e += [v_and_b32(l31, 31, lane_v), v_lshrrev_b32(hi, 5, lane_v)]
-    e += [s_mul_i32(s_t[0], s_wave, AREA), s_add_u32(s_t[0], s_t[0], s_lds), s_add_u32(s_t[0], s_t[0], A_BASE)]     # (the first 8 KiB of this wave's area)
-    e += [v_lshlrev_b32(xw, 8, l31), v_lshlrev_b32(t[5], 3, hi), v_add_u32(xw, xw, t[5]), v_and_b32(t[5], 15, l31), v_lshlrev_b32(t[5], 4, t[5]), v_add_u32(xw, xw, t[5]),
-          v_add_u32(xw, s_t[0], xw)]
-    g4, s15 = t[5], t[6]
-    e += [v_lshrrev_b32(g4, 4, lane_v), v_and_b32(s15, 15, lane_v)]
-    rdaddr = [negl[i] for i in range(8)]
-    goff = [negl[8 + i] for i in range(8)]
-    e += [s_mul_i32(s_t[1], s_wave, 32 * NQ)]
-    for p_ in range(8):
-        e += [v_add_u32(t[7], 4 * p_, g4), v_and_b32(rd, 15, t[7]), v_xor_b32(rd, rd, s15), v_lshlrev_b32(rd, 4, rd), v_lshlrev_b32(rdaddr[p_], 8, t[7]), v_add_u32(rdaddr[p_], rdaddr[p_], rd),
-              v_add_u32(rdaddr[p_], s_t[0], rdaddr[p_])]
-        e += [v_add_u32(t[7], s_t[1], t[7]), v_lshlrev_b32(rd, 4, s15), v_mul_lo_u32(goff[p_], t[7], dqstr), v_add_u32(goff[p_], goff[p_], rd)]
+    t = [Fq[i] for i in range(6)]
+    xb, rdaddr = Fq[6], Fq[7]
+    go = [Fq[8 + i] for i in range(4)]
+    ta = [Fq[16], Fq[17]]
+    vals = [dPb[i] for i in range(4)]
+    pk = [dPb[4 + i] for i in range(2)]
+    rb = dPb.sub(8, 16)
+    e += _epi_addresses(t, E_BASE, xb, rdaddr, [go], [dqstr], 32 * NQ, sregs=(s_t, s_wave, s_lds))
     e += block_coords(s_bid, s_hidx if NQ == 1 else 0)
     e += [s_add_u32(s_t[1], s_t[1], s_t[0])]
     out = s_kn          # (recomputed by the next block start)
     e += ptr(out, s_t[1], dq, dqstr)
-    vals = [dPb[i] for i in range(4)]
-    pk = [dPb[4 + i] for i in range(2)]
-    rb = dPb.sub(8, 16)
     for q in range(NQ):
-        for i in range(4):
-            for rg in range(4):
-                o = dQblk(q, i)
-                e += [v_accvgpr_read_b32(vals[k], o[rg * 4 + k]) for k in range(4)]
-                e += [v_mul_f32(vals[k], scale, vals[k]) for k in range(4)]
-                e += [v_cvt_pk_bf16_f32(pk[0], vals[0], vals[1]), v_cvt_pk_bf16_f32(pk[1], vals[2], vals[3])]
-                e += [v_xor_b32(t[7], (i * 4 + rg) << 4, xw), ds_write_b64(t[7], R("v", pk[0].idx, 2), 0)]
-        for half in range(2):
-            for k in range(4):
-                e += [ds_read_b128(rb.sub(k * 4, 4), rdaddr[half * 4 + k], 0)]
-            e += [s_waitcnt(lgkmcnt=0)]
-            for k in range(4):
-                e += [global_store_dwordx4(goff[half * 4 + k], rb.sub(k * 4, 4), out, 0)]
-            e += [s_nop(1)]
+        e += epi_block(lambda i, q=q: dQblk(q, i), scale, vals, pk, ta, xb, rdaddr, rb, go, out)
         if q == 0 and NQ == 2:
             e += [s_lshl_b32(s_t[2], dqstr, 5), s_add_u32(out[0], out[0], s_t[2]), s_addc_u32(out[1], out[1], 0)]
     e += stamp(41)
@@ -572,29 +546,33 @@ def block_program(nq, suf):
         prog += b
         counts[f"main{j}{suf}"] = G.costs()
     prog += [s_sub_u32(s_loop, s_loop, 1), s_cmp_lg_u32(s_loop, 0), s_cbranch_scc1("L_loop")]
+    cur = pend
     for j in range(4):
         G = body(j, f"tail{j}")
         post = []
-        if j == 2:
-            # the next block's operand bases, its Q rows on their way into the staging area (picked up at the top of the last step, when the Q registers are free)
+        if j == 1:
+            # the next block's operand bases; its Q rows leave for the staging area (behind the ring's refill of this step)
             if NQ == 1:      # (a half block is the last thing a workgroup does: its "next" block is itself, a half)
                 G.pre = seam_ptrs(s_nbid, s_hidxn, True) + G.pre
             else:
                 G.pre = [s_cmp_eq_u32(s_moden, 1), s_cselect_b32(s_t[5], 1, 0)] + seam_ptrs(s_nbid, s_hidxn, s_t[5]) + G.pre
-            G.spread(stage_dma(s_T.sub(0, 2), s_T[8], 0, NQ, rewind=True), 2 * nm + 1, 3 * nm - 1)
+            G.spread(stage_dma(s_T.sub(0, 2), s_T[8], 0, NQ, rewind=True), 2 * nm + (11 if NQ == 2 else 6), 3 * nm - 1)
+        if j == 2:
+            # Q rows -> Q registers, behind the block's last S group (their last reader) and this step's refill of the ring (4 LDS-DMAs younger than the rows')
+            G.put(2 * nm + (11 if NQ == 2 else 6), [s_waitcnt(vmcnt=4)])
+            G.spread(stage_reads(Qfr, 0, NQ), 2 * nm + (11 if NQ == 2 else 6), 3 * nm - 1)
         if j == 3:
-            # Q rows -> Q registers (their last reader was S(nsteps - 1)); then the dO rows through the same area -> dO registers behind the last dP group (end of
-            # the step); then the O rows of q = 0 behind the part of the area the epilogue stages through
-            G.pre = [s_waitcnt(vmcnt=0)] + G.pre
-            G.spread(stage_reads(Qfr, 0, NQ), 0, 5 if NQ == 2 else 2)
-            G.put(6 if NQ == 2 else 3, [s_waitcnt(lgkmcnt=0)])
-            G.spread(stage_dma(s_T.sub(2, 2), s_T[9], 0, NQ, rewind=True) + lse_loads(), 6 if NQ == 2 else 3, 2 * nm - 2)
-            post = [s_waitcnt(vmcnt=0)] + [x for u in stage_reads(dOfr, 0, NQ) for x in u] + [s_waitcnt(lgkmcnt=0)]
-            post += [x for u in stage_dma(s_T.sub(4, 2), s_T[10], O0_OFF, 1) for x in u]
-        b, pe = finish(G.flat(f"step tail{j}"), pend)
-        if j < 3:
+            # dO rows leave (the Q rows have been read: drained first), lse; at the end of the step, behind the last dP group, dO rows -> dO registers and the O rows leave:
+            # they have the epilogue to land
+            G.put(1, [s_waitcnt(lgkmcnt=0)])
+            G.spread(stage_dma(s_T.sub(2, 2), s_T[9], 0, NQ, rewind=True) + lse_loads(), 1, nm)
+            post = [s_waitcnt(vmcnt=4)] + [x for u in stage_reads(dOfr, 0, NQ) for x in u] + [s_waitcnt(lgkmcnt=0)]
+            post += [x for u in stage_dma(s_T.sub(4, 2), s_T[10], 0, NQ, rewind=True) for x in u]
+        b, pe = finish(G.flat(f"step tail{j}"), cur)
+        if j < 2:
             assert pe == pend, (j, pe, pend)
-        else:
+        cur = pe        # (tail2 ends with the Q rows' reads in the queue: tail3 drains them before the dO rows' LDS-DMA goes out)
+        if j == 3:
             b += [s_waitcnt(lgkmcnt=0)] + post
         prog += b
         counts[f"tail{j}{suf}"] = G.costs()
