@@ -342,7 +342,7 @@ def body(j, variant):
                 g += 1
     # ---------------- G0: wait + barrier, dO row fragments, softmax
     G.pre += stamp((8 if variant in ("main", "head") else 12) + j)       # timeline builds: the top of the step (drains the LDS queue: the queue state stays the loop's)
-    G.put(0, [s_waitcnt(vmcnt=5)] if not last else [s_waitcnt(vmcnt=5)])
+    G.put(0, [s_waitcnt(vmcnt=5 + 8 * NF if variant == "tail2" else 5)])      # (tail2: the K rows' LDS-DMA of the previous step is in the queue behind the ring's)
     G.put(1, [s_barrier()])
     for ks in range(n_pref(), KS):
         G.put(ks * NF - LA(), row_frag(ks, OT, ks))
@@ -676,16 +676,17 @@ def block_program(nf, suf):
     for j in range(4):
         G = body(j, f"tail{j}")
         post = []
-        if j == 2:
-            # the next block's K / V bases, its K rows on their way into the staging area (picked up at the top of the last step, when the K registers are free)
+        if j == 1:
+            # the next block's K / V bases, its K rows on their way into the staging area TWO steps before they are picked up (at the top of the last step, when the K
+            # registers are free): an LDS-DMA issued one step ahead was still in flight (timeline: the wait at the top of the last step cost 2-3 k cycles)
             if NF == 1:      # (a half block is the last thing a workgroup does: its "next" block is itself, a half)
                 G.pre = seam_ptrs(s_nbid, s_hidxn, True) + G.pre
             else:
                 G.pre = [s_cmp_eq_u32(s_moden, 1), s_cselect_b32(s_t[5], 1, 0)] + seam_ptrs(s_nbid, s_hidxn, s_t[5]) + G.pre
-            G.spread(stage_dma(s_T.sub(0, 2), s_T[4], NF, rewind=True), 2 * nm + 2, 4 * nm - 1)
+            G.spread(stage_dma(s_T.sub(0, 2), s_T[4], NF, rewind=True), 3 * nm, 4 * nm - 1)      # (behind the step's own refill of the ring)
         if j == 3:
             # K rows -> K registers (their last reader was S(nsteps - 1)); then the V rows into the same area
-            G.pre = [s_waitcnt(vmcnt=0)] + G.pre
+            G.pre = [s_waitcnt(vmcnt=5)] + G.pre          # (everything but the previous step's refill of the ring)
             G.spread(stage_reads(Kfr, NF), 0, 5 if NF == 2 else 2)
             G.put(6 if NF == 2 else 3, [s_waitcnt(lgkmcnt=0)])
             G.spread(stage_dma(s_T.sub(2, 2), s_T[5], NF, rewind=True), 6 if NF == 2 else 3, 2 * nm - 1)
