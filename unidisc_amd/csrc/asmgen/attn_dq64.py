@@ -55,12 +55,7 @@ S_ = Alloc("s", 36, 100)
 
 Sb = V("S", 64, 2)
 dPb = V("dP", 32, 2)
-negd = V("negd", 32)
-# An MFMA that takes an A / B operand from an AccVGPR is slower than one fed from ArchVGPRs (timing-only experiment, profiles/r06_attn_dq64_agpr_operand_experiment.log: all
-# 32 resident B fragments aliased into VGPRs -> the backward 20 us per layer faster).  So the registers the VALU never touches trade places: the -lse C operand lives in
-# AGPRs (the S accumulators are initialised from it with v_accvgpr_read ahead of their chain's first MFMA) and as many Q / dO fragments as fit move to VGPRs.
-NVF = 19                      # resident fragments (of the 32: index q * 16 + 2 * ks + {0: Q, 1: dO}... see frag_index) held in VGPRs
-QV = V("QV", 4 * NVF)
+negl, negd = V("negl", 32), V("negd", 32)
 Fq = V("Fq", 32)
 qaddr, taddr = V("qaddr"), V("taddr")
 dk, dv = V("dk", 2), V("dv", 2)
@@ -69,9 +64,7 @@ lr, lcs = V("lr"), V("lcs")   # LDS-DMA lane constants: row of the piece (lane >
 da = V("da", 4)               # LDS-DMA source offsets of the operand being staged: pieces 4 g + j
 loff = V("loff")              # (lane & 31) * 4: lse, the planes
 tmp = V("tmp", 4)
-dQT = A("dQ", 128)
-QA = A("QA", 4 * (32 - NVF))  # the resident fragments that stay in AGPRs
-negl_a = A("negl", 32)        # -lse of the lane's queries, [q][16]
+dQT, Qf, dOf = A("dQ", 128), A("Q", 64), A("dO", 64)
 
 s_kb, s_vb = S_("kb", 2, 4), S_("vb", 2, 2)
 s_kstr, s_vstr, s_L, s_nsteps, s_H, s_nt, s_mg_nt, s_mg_H, s_nfull, s_hashalf, s_gstride, s_planeB = (S_(n) for n in (
@@ -123,28 +116,12 @@ def dQblk(q, i):
     return dQT.sub((q * 4 + i) * 16, 16)
 
 
-def frag_index(which, q, ks):
-    """position of a resident fragment in the VGPR-first order: the fragments of both operands interleaved, so that every MFMA group gets its share of VGPR-fed MFMAs"""
-    return (q * KS + ks) * 2 + which
-
-
-def _resident(which, q, ks):
-    n = frag_index(which, q, ks)
-    return QV.sub(4 * n, 4) if n < NVF else QA.sub(4 * (n - NVF), 4)
-
-
 def Qfr(q, ks):
-    return _resident(0, q, ks)
+    return Qf.sub((q * KS + ks) * 4, 4)
 
 
 def dOfr(q, ks):
-    return _resident(1, q, ks)
-
-
-def dO_reg(q, r):
-    """register r (0 .. 31) of the dO fragments of block q, as a single register (the delta arithmetic walks them)"""
-    f = dOfr(q, r // 4)
-    return f[r % 4]
+    return dOf.sub((q * KS + ks) * 4, 4)
 
 
 def row_frag(n, tile, ks):
@@ -217,18 +194,13 @@ def ds_units(buf):
     return halves
 
 
-def s_init(buf):
-    """the S accumulators of `buf` start from -lse (kept in AGPRs): the chain's first MFMA accumulates like the rest"""
-    return [[v_accvgpr_read_b32(Sblk(buf, q)[r], negl_a[16 * q + r])] for q in range(NQ) for r in range(16)]
-
-
 def s_group(G, g0, stage_next, buf_next):
-    """the S(t+1) group at MFMA index g0: MFMAs and the K(t+1) row fragments that are not prefetched (the accumulators were initialised by s_init a group earlier)"""
+    """the S(t+1) group at MFMA index g0: MFMAs and the K(t+1) row fragments that are not prefetched"""
     g = g0
     for ks in range(KS):
         for q in range(NQ):
             d = Sblk(buf_next, q)
-            G.m[g] = v_mfma_f32_32x32x16_bf16(d, slot(8 + ks), Qfr(q, ks), d)
+            G.m[g] = v_mfma_f32_32x32x16_bf16(d, slot(8 + ks), Qfr(q, ks), negl.sub(16 * q, 16) if ks == 0 else d)
             g += 1
     for ks in range(KS):        # (at a block start the first of them land ahead of the group's first MFMA: gap -1)
         G.put(max(-1, g0 + ks * NQ - LA()), row_frag(8 + ks, stage_next * STG, ks))
@@ -268,8 +240,6 @@ def body(j, variant):
     for ks in range(n_pref(), KS):
         G.put(ks * NQ - LA(), row_frag(ks, VT, ks))
     G.spread(exp_units(bt, 1), 0, nm - 1)
-    if not last:
-        G.spread(s_init(bn), 0, nm - 3)      # (S(t+1)'s registers are free: S(t-1) was consumed a step ago)
     d0, d1 = ds_units(bt)
     if not last:
         s_group(G, nm, stn, bn)
@@ -460,11 +430,7 @@ def delta_math(q):
     """dlt[q] = this lane's half of rowsum(dO * O) of its query in block q (the O rows sit in the S registers 32 q .. 32 q + 31)"""
     p = [v_mov_b32(dPb[q], 0)]
     for r in range(32):
-        src = dO_reg(q, r)
-        if src.kind == "a":
-            p += [v_accvgpr_read_b32(dPb[2 + (r & 1)], src), v_dot2c_f32_bf16(dPb[q], Sb[32 * q + r], dPb[2 + (r & 1)])]
-        else:
-            p += [v_dot2c_f32_bf16(dPb[q], Sb[32 * q + r], src)]
+        p += [v_accvgpr_read_b32(dPb[2 + (r & 1)], dOf[q * 32 + r]), v_dot2c_f32_bf16(dPb[q], Sb[32 * q + r], dPb[2 + (r & 1)])]
     return p
 
 
@@ -507,11 +473,11 @@ def block_start():
             p += [global_store_dword(loff, vals[q], pl, 128 * q)]
     for q in range(NQ):
         for r in range(16):
-            p += [v_accvgpr_write_b32(negl_a[16 * q + r], nl[q]), v_mov_b32(negd[16 * q + r], nd[q])]
+            p += [v_mov_b32(negl[16 * q + r], nl[q]), v_mov_b32(negd[16 * q + r], nd[q])]
     for ins in p:
         if ins.kind in ("valu", "trans", "dot"):
             ins.meta["keep"] = True
-    p += [s_nop(1)] + [x for u in s_init(0) for x in u] + [s_nop(1)]
+    p += [s_nop(1)]
     # ---- S(0) into buffer 0 (its registers held the O rows of q = 0: consumed above), then the first V fragments of step 0
     G = Gaps(nm)
     s_group(G, 0, 0, 0)
