@@ -39,8 +39,8 @@ typedef struct ihipStream_t* hipStream_t;
 
 const char* udm_last_error(void);
 /* Diagnostics / A-B switches, none of them needed by a caller (process-global; values as documented in csrc/capi.hip): keys "gemm_tile", "gemm_quad",
- * "gemm_persist", "gemm_quad_asm" (0 = the C++ K loop of the one-wave-per-SIMD GEMM everywhere), "attention_tr_read", "attention_fwd64", "exp" (experiment bits, 0 in
- * production); diagnostic builds only: "attention_fwd64_timeline", "gemm_quad_timeline" (device pointers for cycle stamps).  Returns 2 for an unknown key. */
+ * "gemm_persist", "gemm_quad_asm" (0 = the C++ K loop of the one-wave-per-SIMD GEMM everywhere), "attention_tr_read", "attention_fwd64", "attention_dq64", "attention_dkv64" (0 = the 8-wave backward kernels everywhere, 2 = the generated programs without the balanced walk), "exp" (experiment bits, 0 in
+ * production); diagnostic builds only: "attention_fwd64_timeline", "attention_dq64_timeline", "attention_dkv64_timeline", "gemm_quad_timeline" (device pointers for cycle stamps).  Returns 2 for an unknown key. */
 int udm_debug_set(const char* key, int64_t value);
 /* Diagnostics: hold `blocks` CUs (1..128; one 160 KiB-LDS block each) until *flag != 0 (pinned host or device memory) - the stand-in for a collective's channel
  * kernels when the GEMMs' behaviour under a CU reservation is measured on one GPU. */
@@ -185,7 +185,8 @@ int udm_attention_bwd(const void* q, const void* k, const void* v, const void* o
  * starts its score accumulators from). */
 /* flags: UDM_ATTN_Q_PRESCALED = q holds bf16(q log2(e) / sqrt(D)) (udm_qknorm_rope_fwd with that q_scale): the kernels skip the per-score multiply, dq is
  * the gradient wrt that stored q (udm_qknorm_rope_bwd with the same q_scale), lse is unchanged.  The forward at head dim 128 without sample_ids,
- * L % 256 == 0, L >= 512, (B H) % 8 == 0 then runs the persistent 64-queries-per-wave kernel (csrc/attention_fwd64.hip). */
+ * L % 256 == 0, L >= 512, H >= 2, (B H) % 8 == 0 then runs the persistent 64-queries-per-wave kernel (csrc/attention_fwd64.hip), and the backward its two generated
+ * counterparts (csrc/attention_dq64.hip: dQ + delta + the planes; csrc/attention_dkv64.hip: dK / dV; 16-byte aligned row strides). */
 #define UDM_ATTN_Q_PRESCALED 1
 
 /* ---- embeddings: EmbeddingLayer models/dit.py:1036-1043 (+modality embedding :1402-1411) ------------- */
