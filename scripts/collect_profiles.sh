@@ -1,6 +1,6 @@
 #!/bin/bash
 # copy the round's artifacts from gpurun_out/ (scratch) to profiles/ (tracked).  Usage: bash scripts/collect_profiles.sh r03
-TAG=${1:-r05}
+TAG=${1:-r06}
 cp gpurun_out/gputests_$TAG.log profiles/${TAG}_gputests.log
 cp gpurun_out/parity_ledger_$TAG.json profiles/${TAG}_parity_ledger.json
 for f in gpurun_out/graderrs_$TAG.*.json; do n=$(basename $f | sed "s/graderrs_$TAG\.//"); cp $f profiles/${TAG}_grad_errors_$n; done

@@ -3,7 +3,7 @@
 # RCCL world-1 check), the bench workloads (headline with the CPU baseline; config E with bf16 and fp8 attention; UniDisc-S), the rocprofv3 kernel-trace
 # summaries of all three workloads and the two PMC passes (HBM traffic, MFMA utilisation) of the headline command, the CU-reservation measurement.
 # Usage: bash scripts/gpu_round_artifacts.sh r03     (outputs under gpurun_out/, copied to profiles/ by scripts/collect_profiles.sh)
-TAG=${1:-r05}; export TAG; R=${GRAFT_REPO_ROOT:-$(pwd)}; mkdir -p $R/gpurun_out; export TMPDIR=/tmp
+TAG=${1:-r06}; export TAG; R=${GRAFT_REPO_ROOT:-$(pwd)}; mkdir -p $R/gpurun_out; export TMPDIR=/tmp
 cd $R
 [ -n "$SKIP_TESTS" ] || UDM_DUMP_GRAD_ERRS=gpurun_out/graderrs_$TAG UDM_LEDGER=gpurun_out/parity_ledger_$TAG.json timeout 2400 python -m pytest tests -m gpu -q -p no:cacheprovider --timeout 1500 2>&1 | tail -15 > gpurun_out/gputests_$TAG.log
 timeout 900 python bench.py --steps 25 --warmup 5 > gpurun_out/bench_1.4b_b8_$TAG.json 2> gpurun_out/bench_1.4b_b8_$TAG.err

@@ -92,3 +92,22 @@ def test_dkv64_engine_layout_and_untouched_neighbours(K):
     assert _rel(a[:, d:].float(), dk_r) < 8e-3 and _rel(av[:, 2 * d:].float(), dv_r) < 8e-3
     assert _rel(a[:, d:].float(), b[:, d:].float()) < 5e-3 and _rel(av[:, 2 * d:].float(), bv[:, 2 * d:].float()) < 5e-3
     assert _rel(a[:, :d].float(), dq_r) < 8e-3 and _rel(a[:, :d].float(), b[:, :d].float()) < 5e-3
+
+
+def test_generated_attention_programs_respect_the_cu_plan(K):
+    """While a collective holds CUs (`udm_gemm_set_cus`, the data-parallel schedule `overlap_planned`) the persistent grids of the forward and of both backward passes shrink
+    to the CUs that are left (224 here: 640 blocks no longer split into whole rounds + halves) - same blocks, same arithmetic: bit-identical results."""
+    B, H, L, D, dev = 8, 16, 1280, 128, "cuda"
+    g = torch.Generator(device=dev).manual_seed(3)
+    q, k, v, do = ((1.2 * torch.randn(B * L, H * D, device=dev, generator=g)) for _ in range(4))
+    q, k, v, do = (q * K.attention_q_scale(D)).to(BF16), k.to(BF16), v.to(BF16), do.to(BF16)
+    outs = []
+    for cus in (0, 224):
+        K.gemm_set_cus(cus)
+        try:
+            o, lse = K.attention_fwd_generic(q, k, v, B, L, H, D, q_prescaled=True)
+            outs.append((o, lse) + K.attention_bwd_generic(q, k, v, o, do, lse, B, L, H, D, q_prescaled=True))
+        finally:
+            K.gemm_set_cus(0)
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)

@@ -4,6 +4,7 @@
 // hazards and executed on a CPU emulator by tests/test_asmgen.py before it ships).  This file only computes the block's scalars and launches.
 // Replaces flash_attn_qkvpacked_func (reference models/dit.py:843) on the headline path; attention.hip keeps every other shape.
 #include "attention_common.h"
+#include "gemm_quad.h"
 #include "attention_fwd64_gen.h"
 
 #include <stdlib.h>
@@ -97,7 +98,11 @@ bool udm_launch_attn_fwd64(const void* args, hipStream_t stream) {
   }
   static const void* attr_set = nullptr;
   if (attr_set != (const void*)kern) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, UDM_FWD64_LDS_BYTES); attr_set = (const void*)kern; }
-  static const int cus = [] { int dev = 0, n = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n / 8 * 8; }();
+  static const int dev_cus = [] { int dev = 0, n = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n / 8 * 8; }();
+  // a persistent workgroup needs a whole CU: while a collective's channel kernels hold CUs (udm_gemm_set_cus, the data-parallel schedule `overlap_planned`) the grid is
+  // what is left - a workgroup that finds no CU would start its whole walk only when another has finished its own
+  const int plan_cus = udm_gemm_cus_available() / 8 * 8;
+  const int cus = plan_cus >= 8 && plan_cus < dev_cus ? plan_cus : dev_cus;
   const auto magic = [](long d) { return (uint32_t)((1ULL << 32) / (unsigned long long)d + 1); };   // n / d == mulhi(n, magic) for n d < 2^32
   const long grid = nblk < cus ? nblk : cus;    // persistent: one workgroup per CU walks blocks id, id + grid, ...
   // balanced walk: when the blocks left behind the whole rounds are exactly half a grid (the headline's 640 blocks on 256 CUs), every workgroup ends with ONE
