@@ -15,7 +15,7 @@ Registers of a wave:
     v[128:191]  S and dP of ONE 32-query step, [f][16] each (VGPRs: the VALU reads them)
     v[192:207]  P as packed bf16, [f][16-query chunk][4]
     v[208:239]  a ring of eight 4-register fragment slots: every LDS fragment is read ~7 MFMAs before its first use and dies two MFMAs later
-    v[240:253]  addresses, LDS-DMA offsets
+    v[240:252]  addresses, LDS-DMA offsets (ring and staging area)
 
 LDS: a ring of four stages = 32-query steps, each a Q tile and a dO tile in the piece layout of attn_fwd64.py (4-row pieces of 1040 bytes, [64-byte column chunk]
 [row][64 bytes] inside a piece): the row fragments (`ds_read_b128`) and the transposed fragments (`ds_read_b64_tr_b16`) of the same tile are both conflict-free and
@@ -28,9 +28,11 @@ Step t of the loop (64 MFMAs, ONE barrier, no double buffering of S / dP):
     G3  16 MFMAs S(t+1)         under them: the -delta(t+1) C operands into the dP registers
 Every VALU stage sits a full group behind the MFMAs that produce its input and a full group ahead of those that consume its output.
 
-PERSISTENT like the forward: a workgroup walks blocks id, id + grid, ... of its XCD; the last three steps of a block refill the ring with the NEXT block's first steps,
-the next block's K / V fragments are loaded under the last step's MFMAs; when the blocks behind the whole rounds are half a grid every workgroup ends with one
-128-key half block (a wave owns one 32-key block: the NF = 1 program).
+PERSISTENT like the forward: a workgroup walks blocks id, id + grid, ... of its XCD; the last three steps of a block refill the ring with the NEXT block's first steps; when
+the blocks behind the whole rounds are half a grid every workgroup ends with one 128-key half block (a wave owns one 32-key block: the NF = 1 program).  The next block's K / V
+rows do not come as fragment loads (lane = row: 32 cache lines per instruction, ~200 cycles of a lone wave each) but as coalesced LDS-DMA pieces into a per-wave staging area
+behind the ring: K rows leave two steps before the block ends and are read into the K registers at the top of its last step, V rows follow through the same area and are read
+under the next block's S(0) group; dK / dV leave through 4 KiB of LDS per wave as whole 128-byte row segments (epi_addresses / epi_block, shared with attn_dq64.py).
 
 `s_waitcnt lgkmcnt` is not written by hand: `auto_waits` walks a straight-line piece, tracks the LDS queue and puts the counted wait in front of the first reader of
 every fragment; `isa.lint` checks the software-visible hazards and tests/test_asmgen.py executes the stream on the CPU emulator (late and early memory)."""

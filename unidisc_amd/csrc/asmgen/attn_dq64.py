@@ -20,7 +20,9 @@ Step t (32 keys, 48 MFMAs, ONE barrier):
     G0  16 MFMAs dP(t)       under them: exp2 of S(t)
     G1  16 MFMAs S(t+1)      under them: dS(t) = P dP, packed in place
     G2  16 MFMAs dQ^T += ..  under them: the LDS-DMA of step t + 3
-LDS ring, persistence, balanced walk (128-query half blocks, NQ = 1), counted waits (`auto_waits`), lint and emulation: as in attn_dkv64.py."""
+The first 16-key chunk of S(t+1) is exponentiated under the dQ group of step t, the second under the dP group of step t+1.
+LDS ring, persistence, balanced walk (128-query half blocks, NQ = 1), the per-wave staging area for the next block's Q / dO / O rows, the row-store epilogue, counted waits
+(`auto_waits`), lint and emulation: as in attn_dkv64.py."""
 import sys
 from isa import *   # noqa: F401,F403
 from attn_dkv64 import Gaps, auto_waits, epi_addresses as _epi_addresses, epi_block
