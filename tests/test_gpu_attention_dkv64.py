@@ -96,18 +96,22 @@ def test_dkv64_engine_layout_and_untouched_neighbours(K):
 
 def test_generated_attention_programs_respect_the_cu_plan(K):
     """While a collective holds CUs (`udm_gemm_set_cus`, the data-parallel schedule `overlap_planned`) the persistent grids of the forward and of both backward passes shrink
-    to the CUs that are left (224 here: 640 blocks no longer split into whole rounds + halves) - same blocks, same arithmetic: bit-identical results."""
+    to the CUs that are left (224 here: 640 blocks no longer split into whole rounds + halves) - same blocks, same arithmetic."""
     B, H, L, D, dev = 8, 16, 1280, 128, "cuda"
     g = torch.Generator(device=dev).manual_seed(3)
     q, k, v, do = ((1.2 * torch.randn(B * L, H * D, device=dev, generator=g)) for _ in range(4))
     q, k, v, do = (q * K.attention_q_scale(D)).to(BF16), k.to(BF16), v.to(BF16), do.to(BF16)
+    o, lse = K.attention_fwd_generic(q, k, v, B, L, H, D, q_prescaled=True)
     outs = []
     for cus in (0, 224):
         K.gemm_set_cus(cus)
         try:
-            o, lse = K.attention_fwd_generic(q, k, v, B, L, H, D, q_prescaled=True)
-            outs.append((o, lse) + K.attention_bwd_generic(q, k, v, o, do, lse, B, L, H, D, q_prescaled=True))
+            o_c, lse_c = K.attention_fwd_generic(q, k, v, B, L, H, D, q_prescaled=True)
+            outs.append((o_c, lse_c) + K.attention_bwd_generic(q, k, v, o, do, lse, B, L, H, D, q_prescaled=True))
         finally:
             K.gemm_set_cus(0)
-    for a, b in zip(*outs):
+    (o0, l0, *g0), (o1, l1, *g1) = outs
+    # the forward's half blocks (grid 256) and whole blocks (grid 224) take their lazy-rescale decisions per wave of 32 / 64 queries: equal to bf16 rounding, not bit for bit
+    assert _rel(o1.float(), o0.float()) < 2.5e-3 and (l1 - l0).abs().max() < 1e-4
+    for a, b in zip(g0, g1):      # the backward passes have no data-dependent decisions: the same o / lse in, the same bits out
         assert torch.equal(a, b)
