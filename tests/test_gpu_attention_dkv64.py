@@ -33,7 +33,8 @@ def _rel(a, b):
     return float((a.double() - b.double()).norm() / b.double().norm())
 
 
-@pytest.mark.parametrize("B,H,L", [(1, 8, 512), (2, 4, 768), (1, 8, 1024), (3, 8, 1280), (8, 16, 1280), (1, 16, 2048), (2, 24, 512), (2, 3, 512), (8, 1, 512), (1, 8, 256)])
+@pytest.mark.parametrize("B,H,L", [(1, 8, 512), (2, 4, 768), (1, 8, 1024), (3, 8, 1280), (8, 16, 1280), (1, 16, 2048), (2, 24, 512), (2, 3, 512), (8, 1, 512), (1, 8, 256),
+                                   (1, 24, 4096), (4, 8, 512)])     # 384 blocks of 16 tiles: whole rounds + halves with another tile count; 64 blocks: fewer than CUs
 def test_dkv64_matches_reference_and_8wave_kernel(K, B, H, L):
     D, dev = 128, "cuda"
     g = torch.Generator(device=dev).manual_seed(B * 1000 + L)
